@@ -1,0 +1,147 @@
+"""Synthetic checkpoints and inputs for the ReGenNet sampling hot path.
+
+No trained checkpoint, dataset or SMPL-X asset exists in the build environment,
+so tests and bench.py use a deterministic synthetic checkpoint emitted with the *reference's*
+state_dict key names and shapes (model/cmdm.py:53-105 in the reference), and synthetic actor
+motions laid out like `ccollate` produces them (data_loaders/tensors.py:57-94): `cmotion`
+[B, 56, 6, T] = 55 SMPL-X joints in rot6d + one translation row [tx,ty,tz,0,0,0]
+(data_loaders/a2m/dataset.py:175-181).
+
+Everything here is NumPy (PCG64) so it is reproducible on any box without the reference.
+"""
+import numpy as np
+
+# Named configurations mirroring BASELINE.json `configs`.
+CONFIGS = {
+    # NTU120-AS shipped config: README.md:96 + utils/parser_util.py defaults + utils/model_util.py:66-72
+    "ntu": dict(dataset="ntu", njoints=56, nfeats=6, num_frames=60, latent_dim=512, ff_size=1024,
+                num_heads=4, layers=8, cm_mode="concat", cond_mode="no_cond", cond_mask_prob=0.0,
+                num_actions=26),
+    "ntu_action": dict(dataset="ntu", njoints=56, nfeats=6, num_frames=60, latent_dim=512, ff_size=1024,
+                       num_heads=4, layers=8, cm_mode="concat", cond_mode="action", cond_mask_prob=0.1,
+                       num_actions=26),
+    "chi3d": dict(dataset="chi3d", njoints=56, nfeats=6, num_frames=150, latent_dim=512, ff_size=1024,
+                  num_heads=4, layers=8, cm_mode="concat", cond_mode="action", cond_mask_prob=0.1,
+                  num_actions=8),
+    "text150": dict(dataset="chi3d", njoints=56, nfeats=6, num_frames=150, latent_dim=512, ff_size=1024,
+                    num_heads=4, layers=8, cm_mode="concat", cond_mode="text", cond_mask_prob=0.1,
+                    num_actions=1),
+    # small configs the oracle / reference finish in milliseconds
+    "tiny": dict(dataset="ntu", njoints=5, nfeats=6, num_frames=8, latent_dim=64, ff_size=128,
+                 num_heads=4, layers=2, cm_mode="concat", cond_mode="action", cond_mask_prob=0.1,
+                 num_actions=3),
+    "tiny_add": dict(dataset="ntu", njoints=5, nfeats=6, num_frames=8, latent_dim=64, ff_size=128,
+                     num_heads=4, layers=2, cm_mode="add", cond_mode="no_cond", cond_mask_prob=0.0,
+                     num_actions=1),
+    "tiny_text": dict(dataset="ntu", njoints=5, nfeats=6, num_frames=11, latent_dim=64, ff_size=128,
+                      num_heads=2, layers=2, cm_mode="concat", cond_mode="text", cond_mask_prob=0.1,
+                      num_actions=1),
+}
+
+
+def get_config(name, **overrides):
+    cfg = dict(CONFIGS[name])
+    cfg.update(overrides)
+    return cfg
+
+
+def positional_table(d_model, max_len=5000):
+    """Sinusoid table [max_len, 1, d] exactly as PositionalEncoding builds it (model/cmdm.py:269-276):
+    fp32 arithmetic throughout (torch.arange(...).float(), torch.exp, torch.sin/cos on fp32)."""
+    position = np.arange(0, max_len, dtype=np.float32)[:, None]
+    div_term = np.exp(np.arange(0, d_model, 2, dtype=np.float32) * np.float32(-np.log(10000.0) / d_model))
+    div_term = div_term.astype(np.float32)
+    pe = np.zeros((max_len, d_model), dtype=np.float32)
+    ang = (position * div_term).astype(np.float32)
+    pe[:, 0::2] = np.sin(ang)
+    pe[:, 1::2] = np.cos(ang)
+    return pe[:, None, :]
+
+
+def make_state_dict(cfg, seed=0):
+    """Deterministic synthetic checkpoint: dict key -> float32 ndarray, reference key names.
+
+    Linear weights ~ N(0, gain^2/fan_in); q/k projections get a larger gain so the causal softmax is
+    far from uniform; LayerNorm gamma ~ 1+0.1N, beta ~ 0.1N; biases ~ 0.02..0.1 N.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    d, ff, L = cfg["latent_dim"], cfg["ff_size"], cfg["layers"]
+    F = cfg["njoints"] * cfg["nfeats"]
+    sd = {}
+
+    def lin(prefix, out_f, in_f, gain=1.0, bias_std=0.05):
+        sd[prefix + ".weight"] = (rng.standard_normal((out_f, in_f)) * (gain / np.sqrt(in_f))).astype(np.float32)
+        sd[prefix + ".bias"] = (rng.standard_normal(out_f) * bias_std).astype(np.float32)
+
+    lin("input_process.poseEmbedding", d, F)
+    lin("cmo_process.poseEmbedding", d, F)
+    if cfg["cm_mode"] == "concat":
+        lin("fuse_process", d, 2 * d, gain=1.4)
+    pe = positional_table(d)
+    sd["sequence_pos_encoder.pe"] = pe
+    sd["embed_timestep.sequence_pos_encoder.pe"] = pe.copy()
+    lin("embed_timestep.time_embed.0", d, d, gain=1.5)
+    lin("embed_timestep.time_embed.2", d, d, gain=1.5)
+    for l in range(L):
+        p = f"seqTransDecoder.layers.{l}."
+        w = rng.standard_normal((3 * d, d)) / np.sqrt(d)
+        w[: 2 * d] *= 2.5  # q,k gain -> peaky attention
+        sd[p + "self_attn.in_proj_weight"] = w.astype(np.float32)
+        sd[p + "self_attn.in_proj_bias"] = (rng.standard_normal(3 * d) * 0.05).astype(np.float32)
+        lin(p + "self_attn.out_proj", d, d)
+        sd[p + "multihead_attn.in_proj_weight"] = (rng.standard_normal((3 * d, d)) / np.sqrt(d)).astype(np.float32)
+        sd[p + "multihead_attn.in_proj_bias"] = (rng.standard_normal(3 * d) * 0.05).astype(np.float32)
+        lin(p + "multihead_attn.out_proj", d, d)
+        lin(p + "linear1", ff, d, gain=1.2)
+        lin(p + "linear2", d, ff, gain=1.2)
+        for n in ("norm1", "norm2", "norm3"):
+            sd[p + n + ".weight"] = (1.0 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+            sd[p + n + ".bias"] = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    if "text" in cfg["cond_mode"]:
+        lin("embed_text", d, cfg.get("clip_dim", 512))
+    if "action" in cfg["cond_mode"]:
+        sd["embed_action.action_embedding"] = rng.standard_normal((cfg["num_actions"], d)).astype(np.float32)
+    lin("output_process.poseFinal", F, d, gain=1.0)
+    return sd
+
+
+def _random_rot6d(rng, shape):
+    """rot6d (first two rows of a rotation matrix, row-major) of uniformly random rotations."""
+    q = rng.standard_normal(shape + (4,))
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    r0 = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1)
+    r1 = np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1)
+    return np.concatenate([r0, r1], -1)
+
+
+def make_cmotion(cfg, batch, seed=1):
+    """Actor motion [B, njoints, 6, T] fp32: rot6d joints + last row = translation [tx,ty,tz,0,0,0]."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    J, T = cfg["njoints"], cfg["num_frames"]
+    assert cfg["nfeats"] == 6
+    rot = _random_rot6d(rng, (batch, T, J - 1))                   # [B,T,J-1,6]
+    tr = np.zeros((batch, T, 1, 6))
+    tr[..., 0, :3] = rng.uniform(-1, 1, (batch, T, 3))
+    cm = np.concatenate([rot, tr], axis=2)                          # [B,T,J,6]
+    return np.ascontiguousarray(cm.transpose(0, 2, 3, 1)).astype(np.float32)
+
+
+def make_noise_tape(cfg, batch, steps, seed=10):
+    """[steps+1, B, J, 6, T] fp32 N(0,1): entry 0 is x_T, entry k the k-th per-step draw."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    shape = (steps + 1, batch, cfg["njoints"], cfg["nfeats"], cfg["num_frames"])
+    return rng.standard_normal(shape, dtype=np.float32)
+
+
+def make_actions(cfg, batch, seed=2):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.integers(0, max(cfg["num_actions"], 1), (batch, 1)).astype(np.int64)
+
+
+def make_text_features(cfg, batch, seed=3):
+    """Stand-in for CLIP ViT-B/32 text features [B, 512] (CLIP itself is out of scope)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    f = rng.standard_normal((batch, cfg.get("clip_dim", 512)))
+    f /= np.linalg.norm(f, axis=-1, keepdims=True)
+    return f.astype(np.float32)

@@ -1,0 +1,209 @@
+"""Generate golden vectors by RUNNING THE REFERENCE (CPU) in the build container.
+
+    python tests/golden/make_golden.py [--only NAME] [--skip-long]
+
+Imports /root/reference through tests/golden/_ref_import.py (stub clip/timm/smplx), loads the
+build's synthetic checkpoint (regennet_amd.synth, reference key names -> proves key/shape
+compatibility), injects a recorded noise tape in the reference's own draw order and records
+outputs of the reference's `CMDM.forward`, `ClassifierFreeSampleModel.forward`,
+`SpacedDiffusion.p_sample_loop` / `ddim_sample_loop`, `space_timesteps` and the schedule tables.
+
+Only DATA is written (tests/golden/*.npz): inputs are re-derivable from the recorded seeds via
+regennet_amd.synth (a digest of every input is stored to detect drift). Nothing from the
+reference's source travels.
+"""
+import argparse
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+
+import _ref_import  # noqa: E402
+from regennet_amd import synth  # noqa: E402
+
+
+def digest(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def sd_digest(sd):
+    return digest(*[sd[k] for k in sorted(sd)])
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def gen_schedules():
+    _ref_import.install()
+    from diffusion import gaussian_diffusion as gd
+    from diffusion.respace import SpacedDiffusion, space_timesteps
+    out = {}
+    for resp in ["", "ddim100", "100", "ddim50", "50", "ddim5", "ddim20", "20", "10", "250,250,300", "10,15,20"]:
+        n = 300 if resp == "10,15,20" else 1000
+        s = space_timesteps(n, resp or [n])
+        out["space__" + resp.replace(",", "_")] = np.array(sorted(s), dtype=np.int64)
+    for sched in ["cosine", "linear"]:
+        betas = gd.get_named_beta_schedule(sched, 1000, 1.0)
+        for resp in ["", "ddim100", "50"]:
+            d = SpacedDiffusion(use_timesteps=space_timesteps(1000, resp or [1000]), betas=betas,
+                                model_mean_type=gd.ModelMeanType.START_X,
+                                model_var_type=gd.ModelVarType.FIXED_SMALL, loss_type=gd.LossType.MSE)
+            tag = f"{sched}__{resp}"
+            out[f"map__{tag}"] = np.array(d.timestep_map, dtype=np.int64)
+            for k in ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+                      "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+                      "posterior_mean_coef1", "posterior_mean_coef2"]:
+                out[f"{k}__{tag}"] = np.asarray(getattr(d, k), dtype=np.float64)
+    save("schedules", **out)
+
+
+def make_y(cfg, B, guided, scale=2.5):
+    y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1))}
+    if "action" in cfg["cond_mode"]:
+        y["action"] = torch.from_numpy(synth.make_actions(cfg, B, seed=2))
+    if "text" in cfg["cond_mode"]:
+        y["text"] = ["synthetic"] * B
+        y["text_features"] = torch.from_numpy(synth.make_text_features(cfg, B, seed=3))
+    if guided:
+        y["scale"] = torch.ones(B) * scale
+    return y
+
+
+def build(cfg, resp, sd):
+    model, diffusion = _ref_import.build_reference(cfg, sd, resp)
+    if "text" in cfg["cond_mode"]:
+        # CLIP is out of scope: the text encoder output is an INPUT
+        holder = {}
+        model.encode_text = lambda raw_text: holder["feat"]
+        model._feat_holder = holder
+    return model, diffusion
+
+
+def gen_forward(name, cfg_name, B, ts, guided=False, **over):
+    cfg = synth.get_config(cfg_name, **over)
+    sd = synth.make_state_dict(cfg, seed=0)
+    model, _ = build(cfg, "", sd)
+    y = make_y(cfg, B, guided)
+    if "text" in cfg["cond_mode"]:
+        model._feat_holder["feat"] = y["text_features"]
+    x = torch.from_numpy(synth.make_noise_tape(cfg, B, 0, seed=11)[0])
+    if guided:
+        from model.cfg_sampler import ClassifierFreeSampleModel
+        fmodel = ClassifierFreeSampleModel(model)
+    else:
+        fmodel = model
+    outs = []
+    with torch.no_grad():
+        for t in ts:
+            outs.append(fmodel(x, torch.tensor([t] * B), y=y).numpy())
+    save(name, cfg_name=cfg_name, over=repr(over), B=B, ts=np.array(ts), guided=guided,
+         out=np.stack(outs), sd_digest=sd_digest(sd), in_digest=digest(x.numpy(), y["cmotion"].numpy()))
+
+
+def gen_loop(name, cfg_name, B, resp, mode, guided=False, keep_trace=False, **over):
+    cfg = synth.get_config(cfg_name, **over)
+    sd = synth.make_state_dict(cfg, seed=0)
+    model, diffusion = build(cfg, resp, sd)
+    S = diffusion.num_timesteps
+    y = make_y(cfg, B, guided)
+    if "text" in cfg["cond_mode"]:
+        model._feat_holder["feat"] = y["text_features"]
+    tape = synth.make_noise_tape(cfg, B, S, seed=10)
+    if guided:
+        from model.cfg_sampler import ClassifierFreeSampleModel
+        fmodel = ClassifierFreeSampleModel(model)
+    else:
+        fmodel = model
+    shape = (B, cfg["njoints"], cfg["nfeats"], cfg["num_frames"])
+    fn = diffusion.p_sample_loop_progressive if mode == "ddpm" else diffusion.ddim_sample_loop_progressive
+    x0s, xs, seen_t = [], [], []
+    # record the timestep indices the model is actually called with (bit-exact requirement)
+    orig_forward = model.forward
+
+    def spy(x, timesteps, y=None):
+        seen_t.append(timesteps.clone().numpy())
+        return orig_forward(x, timesteps, y)
+
+    model.forward = spy
+    t0 = time.time()
+    with _ref_import.NoiseTape(tape) as nt:
+        for out in fn(fmodel, shape, clip_denoised=False, model_kwargs={"y": y}):
+            if keep_trace:
+                x0s.append(out["pred_xstart"].numpy().copy())
+                xs.append(out["sample"].numpy().copy())
+            final = out["sample"]
+        assert nt.pos == S + 1, (nt.pos, S)
+    dt = time.time() - t0
+    print(f"{name}: reference {mode} S={S} B={B} took {dt:.1f}s")
+    kw = dict(cfg_name=cfg_name, over=repr(over), B=B, resp=resp, mode=mode, guided=guided, S=S,
+              final=final.numpy(), model_t=np.stack(seen_t)[:, 0], ref_seconds=dt,
+              sd_digest=sd_digest(sd), in_digest=digest(tape[0], tape[-1], y["cmotion"].numpy()))
+    if keep_trace:
+        kw["x0"] = np.stack(x0s)
+        kw["x"] = np.stack(xs)
+    save(name, **kw)
+
+
+def gen_post():
+    """next-1/next-2 rows: rotation_6d_to_matrix and the cgenerate.py:142 smoothing."""
+    _ref_import.install()
+    from scipy.ndimage import gaussian_filter1d
+    import utils.rotation_conversions as rc
+    rng = np.random.Generator(np.random.PCG64(5))
+    d6 = rng.standard_normal((4, 7, 6)).astype(np.float32)
+    mats = rc.rotation_6d_to_matrix(torch.from_numpy(d6)).numpy()
+    x = rng.standard_normal((2, 5, 6, 13)).astype(np.float32)
+    gf = gaussian_filter1d(x, sigma=1, axis=-1)
+    x3 = rng.standard_normal((1, 2, 6, 3)).astype(np.float32)   # T smaller than the 4-tap radius
+    gf3 = gaussian_filter1d(x3, sigma=1, axis=-1)
+    save("postproc", d6=d6, mats=mats, x=x, gf=gf, x3=x3, gf3=gf3)
+
+
+JOBS = {
+    "schedules": gen_schedules,
+    "postproc": gen_post,
+    "tiny_fwd": lambda: gen_forward("tiny_fwd", "tiny", 3, [0, 1, 500, 999]),
+    "tiny_fwd_cfg": lambda: gen_forward("tiny_fwd_cfg", "tiny", 3, [0, 700], guided=True),
+    "tiny_add_fwd": lambda: gen_forward("tiny_add_fwd", "tiny_add", 2, [3, 999]),
+    "tiny_etd_fwd": lambda: gen_forward("tiny_etd_fwd", "tiny", 2, [10, 999], emb_trans_dec=True),
+    "tiny_text_fwd_cfg": lambda: gen_forward("tiny_text_fwd_cfg", "tiny_text", 3, [0, 321], guided=True),
+    "tiny_ddpm10": lambda: gen_loop("tiny_ddpm10", "tiny", 2, "10", "ddpm", keep_trace=True),
+    "tiny_ddim10_cfg": lambda: gen_loop("tiny_ddim10_cfg", "tiny", 2, "ddim10", "ddim", guided=True, keep_trace=True),
+    "tiny_add_ddpm1000": lambda: gen_loop("tiny_add_ddpm1000", "tiny_add", 2, "", "ddpm"),
+    "tiny_text_ddim20_cfg": lambda: gen_loop("tiny_text_ddim20_cfg", "tiny_text", 3, "ddim20", "ddim", guided=True),
+    "ntu_fwd": lambda: gen_forward("ntu_fwd", "ntu", 2, [0, 500, 999]),
+    "ntu_action_fwd_cfg": lambda: gen_forward("ntu_action_fwd_cfg", "ntu_action", 2, [0, 990], guided=True),
+    "ntu_ddpm50": lambda: gen_loop("ntu_ddpm50", "ntu", 2, "50", "ddpm"),
+    "ntu_action_ddim100_cfg": lambda: gen_loop("ntu_action_ddim100_cfg", "ntu_action", 2, "ddim100", "ddim", guided=True),
+    "chi3d_fwd": lambda: gen_forward("chi3d_fwd", "chi3d", 2, [0, 999]),
+    "text150_ddim50_cfg": lambda: gen_loop("text150_ddim50_cfg", "text150", 2, "ddim50", "ddim", guided=True),
+    # long: the headline configuration (1000-step DDPM), B=2
+    "ntu_ddpm1000": lambda: gen_loop("ntu_ddpm1000", "ntu", 2, "", "ddpm"),
+}
+LONG = {"ntu_ddpm1000"}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--skip-long", action="store_true")
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    for k, fn in JOBS.items():
+        if a.only and k not in a.only.split(","):
+            continue
+        if a.skip_long and k in LONG:
+            continue
+        fn()

@@ -1,0 +1,90 @@
+"""CPU: pin the oracle (oracle/regennet_oracle.py) against vectors recorded from the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import regennet_oracle as orc
+from tests.helpers import fixture_inputs
+
+FWD = ["tiny_fwd", "tiny_fwd_cfg", "tiny_add_fwd", "tiny_etd_fwd", "tiny_text_fwd_cfg", "ntu_fwd",
+       "ntu_action_fwd_cfg", "chi3d_fwd"]
+LOOPS = ["tiny_ddpm10", "tiny_ddim10_cfg", "tiny_add_ddpm1000", "tiny_text_ddim20_cfg", "ntu_ddpm50"]
+
+
+def _ty(y):
+    return {k: torch.from_numpy(v) for k, v in y.items()}
+
+
+@pytest.mark.parametrize("name", FWD)
+def test_denoiser_forward_matches_reference(golden, name):
+    g = golden(name)
+    cfg, sd, y, x = fixture_inputs(g, loop=False)
+    f = orc.cfg_forward if bool(g["guided"]) else orc.cmdm_forward
+    with torch.no_grad():
+        for i, t in enumerate(g["ts"]):
+            out = f(sd, cfg, torch.from_numpy(x), torch.tensor([int(t)] * x.shape[0]), _ty(y)).numpy()
+            np.testing.assert_allclose(out, g["out"][i], atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("name", LOOPS)
+def test_sampling_loop_matches_reference(golden, name):
+    g = golden(name)
+    cfg, sd, y, tape = fixture_inputs(g, loop=True)
+    sched = orc.make_schedule("cosine", str(g["resp"]))
+    # bit-exact timestep indices handed to the denoiser (respace.py:124-129)
+    assert np.array_equal(np.array(sched[0])[::-1], g["model_t"][:: (2 if bool(g["guided"]) else 1)])
+    trace = {}
+    out = orc.sample_loop(sd, cfg, sched, tape, _ty(y), mode=str(g["mode"]), guided=bool(g["guided"]), trace=trace)
+    np.testing.assert_allclose(out.numpy(), g["final"], atol=1e-4, rtol=0)
+    if "x0" in g:
+        np.testing.assert_allclose(torch.stack(trace["x0"]).numpy(), g["x0"], atol=1e-4, rtol=0)
+        np.testing.assert_allclose(torch.stack(trace["x"]).numpy(), g["x"], atol=1e-4, rtol=0)
+
+
+def test_schedule_tables_and_respacing_match_reference(golden):
+    g = golden("schedules")
+    for key in g.files:
+        kind, _, tag = key.partition("__")
+        if kind == "space":
+            resp = tag.replace("_", ",") if tag and tag[0].isdigit() else tag
+            n = 300 if resp == "10,15,20" else 1000
+            assert sorted(orc.space_timesteps(n, resp or [n])) == g[key].tolist(), key
+        elif kind == "map":
+            sched, _, resp = tag.partition("__")
+            tmap, _ = orc.make_schedule(sched, resp)
+            assert tmap == g[key].tolist()
+        else:
+            sched, _, resp = tag.partition("__")
+            _, tb = orc.make_schedule(sched, resp)
+            assert np.array_equal(tb[kind], g[key]), key   # fp64 bit-exact
+
+
+def test_schedule_known_answers():
+    """KATs recorded in SURVEY.md §8a (a1/a2/a3)."""
+    b = orc.get_named_beta_schedule("cosine", 1000)
+    assert b[0] == pytest.approx(4.12842248e-05, rel=1e-8) and b[500] == pytest.approx(3.15569144e-03, rel=1e-8)
+    assert b[998] == pytest.approx(7.49999393e-01, rel=1e-8) and b[999] == 0.999
+    tb = orc.diffusion_tables(b)
+    assert tb["alphas_cumprod"][500] == pytest.approx(4.92285172e-01, rel=1e-8)
+    assert tb["alphas_cumprod"][999] == pytest.approx(2.42876691e-09, rel=1e-7)
+    assert tb["posterior_variance"][0] == 0 and tb["posterior_variance"][1] == pytest.approx(2.17894961e-05, rel=1e-8)
+    assert tb["posterior_log_variance_clipped"][0] == tb["posterior_log_variance_clipped"][1] == pytest.approx(-10.73408253, rel=1e-8)
+    assert tb["posterior_mean_coef1"][0] == 1 and tb["posterior_mean_coef2"][0] == 0
+    assert sorted(orc.space_timesteps(1000, "ddim100")) == list(range(0, 1000, 10))
+    assert sorted(orc.space_timesteps(1000, "ddim5")) == [0, 200, 400, 600, 800]
+    s100 = sorted(orc.space_timesteps(1000, "100"))
+    assert s100[:2] == [0, 10] and s100[-3:] == [979, 989, 999]
+    with pytest.raises(ValueError):
+        orc.space_timesteps(1000, "250,250,500")     # respace.py:47
+    with pytest.raises(ValueError):
+        orc.space_timesteps(1000, "ddim999")          # respace.py:36
+    with pytest.raises(NotImplementedError):
+        orc.get_named_beta_schedule("sqrt", 10)      # gaussian_diffusion.py:45
+
+
+def test_postproc_rows_match_reference(golden):
+    g = golden("postproc")
+    m = orc.rotation_6d_to_matrix(torch.from_numpy(g["d6"])).numpy()
+    np.testing.assert_allclose(m, g["mats"], atol=1e-6)
+    np.testing.assert_allclose(orc.gaussian_filter1d_lastaxis(g["x"]), g["gf"], atol=1e-6)
+    np.testing.assert_allclose(orc.gaussian_filter1d_lastaxis(g["x3"]), g["gf3"], atol=1e-6)
