@@ -1,0 +1,154 @@
+/*
+ * regennet_hip.h — C-ABI of libregennet_hip.so: the MI355X (gfx950) implementation of ReGenNet's
+ * diffusion-sampling hot path. Plain C types only; device memory is passed as raw
+ * pointers (e.g. torch.Tensor.data_ptr()), streams as hipStream_t cast to void*.
+ *
+ * The reference has no FFI of its own (it is pure Python/PyTorch); every entry point below states
+ * the reference interface (file:line under the upstream repo) whose arithmetic it replaces. The
+ * reference-side binding a maintainer would add is shown in INTEGRATION.md; the in-tree binding is
+ * regennet_amd/_lib.py (ctypes).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative rgn_status; rgn_last_error() gives text.
+ *   - no exceptions cross the boundary; a handle is NOT thread-safe (one handle per device/stream).
+ *   - "x" tensors are fp32 [B, njoints, nfeats, T] contiguous — the reference's boundary layout
+ *     (model/cmdm.py:173-177); timesteps are int64 like the reference's `t` tensors.
+ */
+#ifndef REGENNET_HIP_H
+#define REGENNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rgn_ctx* rgn_handle;
+
+typedef enum {
+    RGN_OK = 0,
+    RGN_ERR_INVALID_ARG = -1,    /* bad pointer / size / enum                                   */
+    RGN_ERR_BAD_KEY = -2,        /* unexpected state_dict key (utils/model_util.py:7)           */
+    RGN_ERR_BAD_SHAPE = -3,      /* tensor shape does not match the configuration               */
+    RGN_ERR_MISSING_KEY = -4,    /* finalize: a required key was never loaded (model_util.py:8) */
+    RGN_ERR_STATE = -5,          /* call order violated (e.g. sample before set_schedule)       */
+    RGN_ERR_HIP = -6,            /* HIP runtime error (text in rgn_last_error)                  */
+    RGN_ERR_UNSUPPORTED = -7     /* configuration outside the hot path (e.g. arch != online)    */
+} rgn_status;
+
+enum { RGN_CM_ADD = 0, RGN_CM_CONCAT = 1 };                 /* --cm_mode, model/cmdm.py:207-211  */
+enum { RGN_COND_NONE = 0, RGN_COND_ACTION = 1, RGN_COND_TEXT = 2 }; /* cond_mode, model_util.py:25-30 */
+enum { RGN_PREC_F32 = 0,      /* fp32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products     */
+       RGN_PREC_BF16X3 = 1,   /* split-bf16: a*b ~ ah*bh + ah*bl + al*bh on bf16 MFMA, fp32 accum  */
+       RGN_PREC_BF16 = 2 };   /* plain bf16 MFMA inputs (fastest; outside the 1e-3 parity bound)   */
+enum { RGN_SAMPLER_DDPM = 0,  /* GaussianDiffusion.p_sample   diffusion/gaussian_diffusion.py:508  */
+       RGN_SAMPLER_DDIM = 1 };/* GaussianDiffusion.ddim_sample diffusion/gaussian_diffusion.py:744 */
+enum { RGN_FLAG_UNCOND = 1,   /* y['uncond']=True  (model/cmdm.py:181, mask_cond :129-137)         */
+       RGN_FLAG_GUIDED = 2 }; /* ClassifierFreeSampleModel.forward (model/cfg_sampler.py:24-31)    */
+
+/* Mirrors the keyword arguments `CMDM(**get_model_args(args, data))` receives for arch='online'
+ * (utils/model_util.py:20-72; model/cmdm.py:13-16). */
+typedef struct {
+    int32_t njoints;        /* 56 for SMPL-X (model_util.py:45-46)                     */
+    int32_t nfeats;         /* 6 for rot6d (model_util.py:47-48)                       */
+    int32_t num_frames;     /* T: 60 ntu / 150 chi3d (model_util.py:61-64)             */
+    int32_t latent_dim;     /* d, --latent_dim (parser_util.py:126)                    */
+    int32_t ff_size;        /* 1024 (model_util.py:69)                                 */
+    int32_t num_heads;      /* 4 (model_util.py:69)                                    */
+    int32_t num_layers;     /* --layers                                                */
+    int32_t cm_mode;        /* RGN_CM_*                                                */
+    int32_t cond_mode;      /* RGN_COND_*                                              */
+    int32_t num_actions;    /* rows of embed_action.action_embedding (cmdm.py:361)     */
+    int32_t clip_dim;       /* 512 (cmdm.py:15)                                        */
+    int32_t emb_trans_dec;  /* --emb_trans_dec (cmdm.py:212-215,224-225)               */
+    int32_t wo_pos_emb;     /* --wo_pos_emb (cmdm.py:217)                              */
+    int32_t max_batch;      /* largest B any later call will use                       */
+    int32_t precision;      /* RGN_PREC_*                                              */
+    int32_t device;         /* HIP device ordinal                                      */
+} rgn_config;
+
+/* Per-timestep fp64 tables of the (re-spaced) diffusion, each of length S, exactly the attributes
+ * GaussianDiffusion.__init__ builds (diffusion/gaussian_diffusion.py:172-209) after
+ * SpacedDiffusion.__init__ re-derived the betas (diffusion/respace.py:73-87). */
+typedef struct {
+    int32_t S;                              /* num_timesteps after respacing                         */
+    const int64_t* timestep_map;            /* respace.py:75,85 — ORIGINAL index of each kept step   */
+    const double* posterior_mean_coef1;     /* gaussian_diffusion.py:199-201                          */
+    const double* posterior_mean_coef2;     /* :202-206                                               */
+    const double* model_log_variance;       /* FIXED_SMALL: posterior_log_variance_clipped (:360-363);
+                                               FIXED_LARGE: log(append(post_var[1], betas[1:])) (:352-357) */
+    const double* sqrt_recip_alphas_cumprod;    /* :184                                              */
+    const double* sqrt_recipm1_alphas_cumprod;  /* :185                                              */
+    const double* alphas_cumprod;               /* :174                                              */
+    const double* alphas_cumprod_prev;          /* :175                                              */
+} rgn_schedule;
+
+/* Lifetime. Replaces: CMDM.__init__ (model/cmdm.py:13-111) + model.to(dev()) (sample/cgenerate.py:82). */
+int rgn_create(const rgn_config* cfg, rgn_handle* out);
+int rgn_destroy(rgn_handle h);
+/* Text of the most recent error on `h` (or of the last failed rgn_create when h == NULL). */
+const char* rgn_last_error(rgn_handle h);
+
+/* Checkpoint ingestion, keyed by the reference's state_dict names. Replaces
+ * load_model_wo_clip / nn.Module.load_state_dict(strict=False) (utils/model_util.py:5-8):
+ * an unexpected key -> RGN_ERR_BAD_KEY; keys starting with "clip_model." are accepted and ignored.
+ * `host` is caller-owned fp32 host memory, copied during the call. */
+int rgn_load_weight(rgn_handle h, const char* ref_key, const float* host, const int64_t* shape, int32_t ndim);
+/* Checks that no required key is missing (model_util.py:8), folds/packs weights for the kernels and
+ * uploads them. Must be called once before any compute entry point. */
+int rgn_finalize_weights(rgn_handle h);
+/* One flat device buffer holds every packed weight so multi-GPU start-up is ONE RCCL broadcast
+ * (replaces utils/dist_util.py:54-83 sync_params / load_state_dict). */
+int rgn_weight_blob(rgn_handle h, void** dev_ptr, uint64_t* nbytes);
+
+/* Replaces SpacedDiffusion.__init__ + _WrappedModel timestep mapping (diffusion/respace.py:64-129)
+ * and the per-step _extract_into_tensor gathers (gaussian_diffusion.py:1604-1617). */
+int rgn_set_schedule(rgn_handle h, const rgn_schedule* s);
+
+/* Binds model_kwargs['y'] for subsequent denoise/sample calls (data_loaders/tensors.py:57-94):
+ * cmotion_dev fp32 [B,njoints,nfeats,T]; action_dev int64 [B] (y['action'][:,0]) or NULL;
+ * text_feat_dev fp32 [B,clip_dim] = CLIP text features (encode_text output, cmdm.py:153-166) or NULL;
+ * scale_dev fp32 [B] (y['scale'], cfg_sampler.py:31) or NULL. Hoists cmo_process(cmotion) and its
+ * fuse_process half out of the step loop (model/cmdm.py:202,207-211). Inputs are read, never written. */
+int rgn_set_condition(rgn_handle h, int32_t B, const float* cmotion_dev, const int64_t* action_dev,
+                      const float* text_feat_dev, const float* scale_dev, void* stream);
+
+/* One denoiser evaluation: out = CMDM.forward(x, t, y) (model/cmdm.py:173-252), or with
+ * RGN_FLAG_GUIDED the ClassifierFreeSampleModel combination (model/cfg_sampler.py:24-31).
+ * t_dev: int64 [B] ORIGINAL timestep indices (what _WrappedModel passes on, respace.py:124-129). */
+int rgn_denoise(rgn_handle h, const float* x_dev, const int64_t* t_dev, int32_t flags, float* out_dev, void* stream);
+
+/* Steps i = first_index, first_index-1, ..., first_index-count+1 of the sampling loop
+ * (p_sample_loop_progressive gaussian_diffusion.py:711-742 / ddim :979-1005) applied in place to
+ * x_dev [B,njoints,nfeats,T]:  x <- sampler(x, model(x, map[i]), noise_i).
+ *   noise_dev : fp32 [count, B,njoints,nfeats,T], the per-step draws th.randn_like(x)
+ *               (gaussian_diffusion.py:544,785) in loop order; NULL -> on-device Philox4x32-10
+ *               keyed by (seed, global sample index = sample_offset + b, step i, element).
+ *   x0_dev    : optional fp32 output, pred_xstart of the LAST executed step (NULL to skip).
+ *   use_graph : replay a captured hipGraph of one step instead of launching kernels one by one.
+ *   clip_denoised : clamp pred_xstart to [-1,1] (process_xstart, gaussian_diffusion.py:366-372). */
+int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, float* x_dev,
+                     const float* noise_dev, uint64_t seed, uint64_t sample_offset,
+                     int32_t first_index, int32_t count, float* x0_dev, int32_t use_graph,
+                     int32_t clip_denoised, void* stream);
+
+/* Fills x_dev [B,njoints,nfeats,T] with N(0,1) from the same Philox stream (x_T, gaussian_diffusion.py:706). */
+int rgn_randn(rgn_handle h, float* x_dev, int32_t B, uint64_t seed, uint64_t sample_offset, void* stream);
+
+/* Post-processing rows next to the path:
+ * rot6d -> rotation matrices, Gram-Schmidt (utils/rotation_conversions.py:513-534): d6 [n,6] -> [n,3,3] */
+int rgn_rot6d_to_matrix(rgn_handle h, const float* d6_dev, float* mat_dev, int64_t n, void* stream);
+/* scipy.ndimage.gaussian_filter1d(x, sigma, axis=-1, mode='reflect') on device (sample/cgenerate.py:142):
+ * x [rows, T] -> out [rows, T] */
+int rgn_gaussian_filter1d(rgn_handle h, const float* x_dev, float* out_dev, int64_t rows, int32_t T,
+                          float sigma, void* stream);
+
+/* Introspection for bench/profiling: name and accumulated HIP-event time (ms) + launch count of the
+ * internal kernel classes since the last reset; timing is only collected when enabled. */
+int rgn_profile_enable(rgn_handle h, int32_t on);
+int rgn_profile_query(rgn_handle h, int32_t idx, const char** name, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REGENNET_HIP_H */

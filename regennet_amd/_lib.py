@@ -1,0 +1,191 @@
+"""ctypes binding of libregennet_hip.so (C-ABI: include/regennet_hip.h).
+
+The product path has NO CPU fallback: if the HIP library has not been built
+(`python -c "import __graft_entry__ as g; g.build()"`) importing this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libregennet_hip.so")
+
+RGN_OK = 0
+ERR_NAMES = {-1: "INVALID_ARG", -2: "BAD_KEY", -3: "BAD_SHAPE", -4: "MISSING_KEY", -5: "STATE", -6: "HIP", -7: "UNSUPPORTED"}
+CM = {"add": 0, "concat": 1}
+COND = {"no_cond": 0, "action": 1, "text": 2}
+PREC = {"f32": 0, "bf16x3": 1, "bf16": 2}
+SAMPLER = {"ddpm": 0, "ddim": 1}
+FLAG_UNCOND, FLAG_GUIDED = 1, 2
+
+
+class RgnError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"regennet_hip error {code} ({ERR_NAMES.get(code, '?')}): {msg}")
+        self.code = code
+
+
+class RgnConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "njoints", "nfeats", "num_frames", "latent_dim", "ff_size", "num_heads", "num_layers", "cm_mode",
+        "cond_mode", "num_actions", "clip_dim", "emb_trans_dec", "wo_pos_emb", "max_batch", "precision", "device")]
+
+
+class RgnSchedule(C.Structure):
+    _fields_ = [("S", C.c_int32), ("timestep_map", C.POINTER(C.c_int64))] + [
+        (n, C.POINTER(C.c_double)) for n in (
+            "posterior_mean_coef1", "posterior_mean_coef2", "model_log_variance", "sqrt_recip_alphas_cumprod",
+            "sqrt_recipm1_alphas_cumprod", "alphas_cumprod", "alphas_cumprod_prev")]
+
+
+# every symbol include/regennet_hip.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64, _u64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+SYMBOLS = {
+    "rgn_create": (C.c_int, [C.POINTER(RgnConfig), C.POINTER(_vp)]),
+    "rgn_destroy": (C.c_int, [_vp]),
+    "rgn_last_error": (C.c_char_p, [_vp]),
+    "rgn_load_weight": (C.c_int, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i32]),
+    "rgn_finalize_weights": (C.c_int, [_vp]),
+    "rgn_weight_blob": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_u64)]),
+    "rgn_set_schedule": (C.c_int, [_vp, C.POINTER(RgnSchedule)]),
+    "rgn_set_condition": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "rgn_denoise": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp]),
+    "rgn_sample_range": (C.c_int, [_vp, _i32, _i32, _f32, _vp, _vp, _u64, _u64, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "rgn_randn": (C.c_int, [_vp, _vp, _i32, _u64, _u64, _vp]),
+    "rgn_rot6d_to_matrix": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "rgn_gaussian_filter1d": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "rgn_profile_enable": (C.c_int, [_vp, _i32]),
+    "rgn_profile_query": (C.c_int, [_vp, _i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and type every entry point. Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` from the repo root.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """Owns one rgn_handle. Thin, typed wrappers; tensors are torch CUDA(HIP) tensors, fp32/int64 contiguous."""
+
+    def __init__(self, cfg, max_batch, device_index, precision="f32"):
+        self.lib = load()
+        self.cfg = dict(cfg)
+        self.max_batch = int(max_batch)
+        self.precision = precision
+        rc = RgnConfig(
+            njoints=cfg["njoints"], nfeats=cfg["nfeats"], num_frames=cfg["num_frames"], latent_dim=cfg["latent_dim"],
+            ff_size=cfg["ff_size"], num_heads=cfg["num_heads"], num_layers=cfg["layers"], cm_mode=CM[cfg["cm_mode"]],
+            cond_mode=COND[cfg["cond_mode"]], num_actions=int(cfg.get("num_actions", 1)), clip_dim=int(cfg.get("clip_dim", 512)),
+            emb_trans_dec=int(bool(cfg.get("emb_trans_dec", False))), wo_pos_emb=int(bool(cfg.get("wo_pos_emb", False))),
+            max_batch=self.max_batch, precision=PREC[precision], device=int(device_index))
+        h = C.c_void_p()
+        code = self.lib.rgn_create(C.byref(rc), C.byref(h))
+        if code != RGN_OK:
+            raise RgnError(code, (self.lib.rgn_last_error(None) or b"").decode())
+        self.h = h
+        self.schedule_id = None
+        self.cond_key = None
+
+    def _ck(self, code):
+        if code != RGN_OK:
+            raise RgnError(code, (self.lib.rgn_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rgn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights -------------------------------------------------------------------------------
+    def load_weight(self, key, array):
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        shape = (C.c_int64 * a.ndim)(*a.shape)
+        self._ck(self.lib.rgn_load_weight(self.h, key.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+
+    def finalize(self):
+        self._ck(self.lib.rgn_finalize_weights(self.h))
+
+    def weight_blob(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._ck(self.lib.rgn_weight_blob(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    # ---- schedule / condition ----------------------------------------------------------------------
+    def set_schedule(self, timestep_map, tables, sched_id=None):
+        keep = []
+
+        def dptr(name):
+            a = np.ascontiguousarray(tables[name], dtype=np.float64)
+            keep.append(a)
+            return a.ctypes.data_as(C.POINTER(C.c_double))
+
+        tm = np.ascontiguousarray(timestep_map, dtype=np.int64)
+        s = RgnSchedule(S=len(tm), timestep_map=tm.ctypes.data_as(C.POINTER(C.c_int64)),
+                        posterior_mean_coef1=dptr("posterior_mean_coef1"), posterior_mean_coef2=dptr("posterior_mean_coef2"),
+                        model_log_variance=dptr("model_log_variance"),
+                        sqrt_recip_alphas_cumprod=dptr("sqrt_recip_alphas_cumprod"),
+                        sqrt_recipm1_alphas_cumprod=dptr("sqrt_recipm1_alphas_cumprod"),
+                        alphas_cumprod=dptr("alphas_cumprod"), alphas_cumprod_prev=dptr("alphas_cumprod_prev"))
+        self._ck(self.lib.rgn_set_schedule(self.h, C.byref(s)))
+        self.schedule_id = sched_id
+
+    def set_condition(self, B, cmotion, action, text_feat, scale, stream):
+        self._ck(self.lib.rgn_set_condition(self.h, int(B), _ptr(cmotion), _ptr(action), _ptr(text_feat), _ptr(scale),
+                                            C.c_void_p(stream)))
+
+    # ---- compute -----------------------------------------------------------------------------------
+    def denoise(self, x, t, flags, out, stream):
+        self._ck(self.lib.rgn_denoise(self.h, _ptr(x), _ptr(t), int(flags), _ptr(out), C.c_void_p(stream)))
+
+    def sample_range(self, sampler, guided, eta, x, noise, seed, sample_offset, first_index, count, x0_out, use_graph,
+                     clip_denoised, stream):
+        self._ck(self.lib.rgn_sample_range(self.h, SAMPLER[sampler], int(bool(guided)), float(eta), _ptr(x), _ptr(noise),
+                                           int(seed) & (2 ** 64 - 1), int(sample_offset), int(first_index), int(count),
+                                           _ptr(x0_out), int(bool(use_graph)), int(bool(clip_denoised)), C.c_void_p(stream)))
+
+    def randn(self, x, B, seed, sample_offset, stream):
+        self._ck(self.lib.rgn_randn(self.h, _ptr(x), int(B), int(seed) & (2 ** 64 - 1), int(sample_offset), C.c_void_p(stream)))
+
+    def rot6d_to_matrix(self, d6, mat, n, stream):
+        self._ck(self.lib.rgn_rot6d_to_matrix(self.h, _ptr(d6), _ptr(mat), int(n), C.c_void_p(stream)))
+
+    def gaussian_filter1d(self, x, out, rows, T, sigma, stream):
+        self._ck(self.lib.rgn_gaussian_filter1d(self.h, _ptr(x), _ptr(out), int(rows), int(T), float(sigma), C.c_void_p(stream)))
+
+    def profile_enable(self, on):
+        self._ck(self.lib.rgn_profile_enable(self.h, int(bool(on))))
+
+    def profile_query(self):
+        out = {}
+        for i in range(16):
+            name, ms, n = C.c_char_p(), C.c_double(), C.c_int64()
+            code = self.lib.rgn_profile_query(self.h, i, C.byref(name), C.byref(ms), C.byref(n))
+            if code != RGN_OK:
+                break
+            out[name.value.decode()] = (ms.value, n.value)
+        return out

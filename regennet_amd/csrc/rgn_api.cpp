@@ -1,0 +1,829 @@
+// Host side of libregennet_hip.so: the C-ABI declared in include/regennet_hip.h.
+// Owns the packed weight blob, the activation workspace, the per-step coefficient tables, the
+// step orchestration (one denoiser evaluation + sampler update = ~45 kernel launches) and its
+// hipGraph capture. All arithmetic on tensors happens in rgn_kernels.hip.
+#include "../../include/regennet_hip.h"
+#include "rgn_internal.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace rgn;
+
+namespace {
+
+std::string g_create_error;
+
+struct HostTensor {
+    std::vector<float> v;
+    std::vector<int64_t> shape;
+};
+
+struct Lin {  // one packed nn.Linear: offsets (bytes) into the weight blob
+    size_t w = 0, hi = 0, lo = 0, b = 0;
+    int N = 0, K = 0, Kp = 0;
+    bool has_bias = false;
+};
+
+struct LayerW {
+    Lin qkv, out, ff1, ff2;
+    size_t ln[6];  // g1,b1,g2,b2,g3,b3
+};
+
+struct ProfEv {
+    int kc;
+    hipEvent_t a, b;
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// round-to-nearest-even fp32 -> bf16 bits
+inline uint16_t f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf2f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+}  // namespace
+
+struct rgn_ctx {
+    rgn_config cfg{};
+    std::string err;
+    std::map<std::string, std::vector<int64_t>> expected;  // key -> shape (pe: shape[0] free)
+    std::map<std::string, HostTensor> sd;
+    bool finalized = false, have_sched = false, have_cond = false;
+    int F = 0, d = 0, Tq = 0, etd = 0, L = 0, H = 0, ff = 0, pe_len = 0;
+
+    // packed weights
+    std::vector<char> hblob;
+    char* dblob = nullptr;
+    size_t blob_bytes = 0;
+    Lin lin_x, lin_c, lin_t0, lin_t2, lin_g, lin_out, lin_text;
+    std::vector<LayerW> layers;
+    size_t off_pe = 0, off_action = 0, off_bt = 0;
+
+    // workspace
+    float *xin = nullptr, *cmo_in = nullptr, *c0 = nullptr, *h = nullptr, *tmp = nullptr, *qkv = nullptr, *att = nullptr,
+          *ffn = nullptr, *x0tok = nullptr, *pe_rows = nullptr, *emb1 = nullptr, *emb = nullptr, *call = nullptr,
+          *condemb = nullptr, *scale = nullptr;
+    StepCoef* d_tab = nullptr;
+    int* d_step = nullptr;
+    SampleParams* d_sp = nullptr;
+    std::vector<void*> allocs;
+
+    // schedule (host copies)
+    int S = 0;
+    std::vector<int64_t> tmap;
+    std::vector<double> coef1, coef2, logvar, srecip, srecipm1, ac, acp;
+    float tab_eta = -1.f;
+    bool tab_valid = false;
+
+    // bound condition
+    int B = 0;
+    bool cond_has_scale = false;
+
+    // graphs: key = B | guided<<20 | sampler<<21
+    std::map<uint64_t, hipGraphExec_t> graphs;
+
+    // profiling
+    bool prof = false;
+    std::vector<ProfEv> prof_ev;
+    double prof_ms[KC_COUNT] = {0};
+    int64_t prof_n[KC_COUNT] = {0};
+
+    int fail(int code, const std::string& m) {
+        err = m;
+        return code;
+    }
+    template <typename T>
+    T* dp(size_t off) const { return reinterpret_cast<T*>(dblob + off); }
+};
+
+namespace {
+
+const char* kclass_names[KC_COUNT] = {"gemm_mfma", "attention", "layernorm", "embed", "update", "misc"};
+
+#define RGN_HIP(h, expr)                                                                                    \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess)                                                                               \
+            return (h)->fail(RGN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+    } while (0)
+
+// Launch wrapper: optional HIP-event bracketing per kernel class (eager mode only).
+#define RGN_LAUNCH(h, KCLS, stream, call)                                        \
+    do {                                                                         \
+        ProfEv _pe{};                                                            \
+        const bool _p = (h)->prof;                                               \
+        if (_p) {                                                                \
+            _pe.kc = (KCLS);                                                     \
+            (void)hipEventCreate(&_pe.a);                                        \
+            (void)hipEventCreate(&_pe.b);                                        \
+            (void)hipEventRecord(_pe.a, (stream));                               \
+        }                                                                        \
+        RGN_HIP(h, call);                                                        \
+        if (_p) {                                                                \
+            (void)hipEventRecord(_pe.b, (stream));                               \
+            (h)->prof_ev.push_back(_pe);                                         \
+        }                                                                        \
+    } while (0)
+
+void build_expected(rgn_ctx* c) {
+    const int64_t d = c->d, F = c->F, ff = c->ff;
+    auto& e = c->expected;
+    e["input_process.poseEmbedding.weight"] = {d, F};
+    e["input_process.poseEmbedding.bias"] = {d};
+    e["cmo_process.poseEmbedding.weight"] = {d, F};
+    e["cmo_process.poseEmbedding.bias"] = {d};
+    if (c->cfg.cm_mode == RGN_CM_CONCAT) {
+        e["fuse_process.weight"] = {d, 2 * d};
+        e["fuse_process.bias"] = {d};
+    }
+    e["sequence_pos_encoder.pe"] = {-1, 1, d};
+    e["embed_timestep.sequence_pos_encoder.pe"] = {-1, 1, d};
+    e["embed_timestep.time_embed.0.weight"] = {d, d};
+    e["embed_timestep.time_embed.0.bias"] = {d};
+    e["embed_timestep.time_embed.2.weight"] = {d, d};
+    e["embed_timestep.time_embed.2.bias"] = {d};
+    for (int l = 0; l < c->L; ++l) {
+        const std::string p = "seqTransDecoder.layers." + std::to_string(l) + ".";
+        for (const char* a : {"self_attn.", "multihead_attn."}) {
+            e[p + a + "in_proj_weight"] = {3 * d, d};
+            e[p + a + "in_proj_bias"] = {3 * d};
+            e[p + a + "out_proj.weight"] = {d, d};
+            e[p + a + "out_proj.bias"] = {d};
+        }
+        e[p + "linear1.weight"] = {ff, d};
+        e[p + "linear1.bias"] = {ff};
+        e[p + "linear2.weight"] = {d, ff};
+        e[p + "linear2.bias"] = {d};
+        for (const char* n : {"norm1", "norm2", "norm3"}) {
+            e[p + n + ".weight"] = {d};
+            e[p + n + ".bias"] = {d};
+        }
+    }
+    if (c->cfg.cond_mode == RGN_COND_TEXT) {
+        e["embed_text.weight"] = {d, c->cfg.clip_dim};
+        e["embed_text.bias"] = {d};
+    }
+    if (c->cfg.cond_mode == RGN_COND_ACTION) e["embed_action.action_embedding"] = {c->cfg.num_actions, d};
+    e["output_process.poseFinal.weight"] = {F, d};
+    e["output_process.poseFinal.bias"] = {F};
+}
+
+// ---- blob building --------------------------------------------------------------------------------
+size_t blob_put(rgn_ctx* c, const void* src, size_t bytes) {
+    const size_t off = align_up(c->hblob.size(), 256);
+    c->hblob.resize(off + bytes);
+    if (src) memcpy(c->hblob.data() + off, src, bytes);
+    return off;
+}
+
+// Pack W[N,K] (row-major fp32) into fp32 [N,Kp] plus bf16 hi/lo planes; bias optional.
+Lin pack_linear(rgn_ctx* c, const float* W, const float* bias, int N, int K) {
+    Lin L;
+    L.N = N;
+    L.K = K;
+    L.Kp = (int)align_up((size_t)K, 16);
+    std::vector<float> w((size_t)N * L.Kp, 0.f);
+    std::vector<uint16_t> hi((size_t)N * L.Kp, 0), lo((size_t)N * L.Kp, 0);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) {
+            const float v = W[(size_t)n * K + k];
+            const size_t o = (size_t)n * L.Kp + k;
+            w[o] = v;
+            hi[o] = f2bf(v);
+            lo[o] = f2bf(v - bf2f(hi[o]));
+        }
+    L.w = blob_put(c, w.data(), w.size() * 4);
+    L.hi = blob_put(c, hi.data(), hi.size() * 2);
+    L.lo = blob_put(c, lo.data(), lo.size() * 2);
+    if (bias) {
+        L.b = blob_put(c, bias, (size_t)N * 4);
+        L.has_bias = true;
+    }
+    return L;
+}
+
+// C[n,k] = sum_j A[n,j] * B[j,k]  in fp64 (weight folding at load time)
+void matmul64(const float* A, const float* Bm, int N, int J, int K, std::vector<double>& C) {
+    C.assign((size_t)N * K, 0.0);
+    for (int n = 0; n < N; ++n) {
+        double* cr = &C[(size_t)n * K];
+        for (int j = 0; j < J; ++j) {
+            const double a = A[(size_t)n * J + j];
+            const float* br = Bm + (size_t)j * K;
+            for (int k = 0; k < K; ++k) cr[k] += a * (double)br[k];
+        }
+    }
+}
+
+template <typename T>
+int ws_alloc(rgn_ctx* c, T** p, size_t count) {
+    void* q = nullptr;
+    RGN_HIP(c, hipMalloc(&q, count * sizeof(T) + 256));
+    c->allocs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return RGN_OK;
+}
+
+Dims make_dims(const rgn_ctx* c, int B, bool guided) {
+    Dims dm;
+    dm.B = B;
+    dm.Bm = guided ? 2 * B : B;
+    dm.T = c->cfg.num_frames;
+    dm.Tq = c->Tq;
+    dm.etd = c->etd;
+    dm.F = c->F;
+    dm.d = c->d;
+    dm.H = c->H;
+    dm.dh = c->d / c->H;
+    dm.ff = c->ff;
+    dm.L = c->L;
+    return dm;
+}
+
+GemmArgs gemm_args(const rgn_ctx* c, const Lin& L, const float* A, int lda, float* C, int ldc, int M) {
+    GemmArgs g{};
+    g.A = A;
+    g.lda = lda;
+    g.W = c->dp<float>(L.w);
+    g.Whi = c->dp<uint16_t>(L.hi);
+    g.Wlo = c->dp<uint16_t>(L.lo);
+    g.bias = L.has_bias ? c->dp<float>(L.b) : nullptr;
+    g.add = nullptr;
+    g.ldadd = 0;
+    g.add_mod = 0;
+    g.C = C;
+    g.ldc = ldc;
+    g.M = M;
+    g.N = L.N;
+    g.K = L.K;
+    g.Kp = L.Kp;
+    g.act = 0;
+    return g;
+}
+
+// One denoiser evaluation on the bound condition, ending in k_update (sampler step or plain output).
+// Everything t-dependent is read on the device (d_step / d_sp) so the sequence is graph-capturable.
+int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, hipStream_t s) {
+    const Dims dm = make_dims(c, B, guided);
+    const int prec = c->cfg.precision;
+    const int d = c->d, Ld = c->L * c->d, M = dm.Bm * dm.Tq, Mb = B * dm.Tq;
+
+    // timestep embedding (TimestepEmbedder cmdm.py:284-298) + condition embedding (cmdm.py:181-187)
+    RGN_LAUNCH(c, KC_EMBED, s, launch_gather_pe(c->dp<float>(c->off_pe), c->d_tab, c->d_step, c->d_sp, c->pe_rows, dm.Bm, B, d, s));
+    {
+        GemmArgs g = gemm_args(c, c->lin_t0, c->pe_rows, d, c->emb1, d, dm.Bm);
+        g.act = 2;
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+        g = gemm_args(c, c->lin_t2, c->emb1, d, c->emb, d, dm.Bm);
+        if (c->cfg.cond_mode != RGN_COND_NONE) {
+            g.add = (uncond && !guided) ? c->condemb + (size_t)B * d : c->condemb;
+            g.ldadd = d;
+        }
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+        // cross-attention onto the 1-token memory, all layers at once: call[b, l*d:(l+1)*d]
+        g = gemm_args(c, c->lin_g, c->emb, d, c->call, Ld, dm.Bm);
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+    }
+    // input embedding + hoisted condition part (InputProcess/fuse/pos-enc, cmdm.py:201-218)
+    {
+        GemmArgs g = gemm_args(c, c->lin_x, c->xin, c->F, c->h, d, Mb);
+        g.add = c->c0;
+        g.ldadd = d;
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+        if (guided)
+            RGN_HIP(c, hipMemcpyAsync(c->h + (size_t)Mb * d, c->h, (size_t)Mb * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (c->etd)
+            RGN_LAUNCH(c, KC_EMBED, s, launch_emb_rows(c->emb, c->dp<float>(c->off_pe), c->h, dm, c->cfg.wo_pos_emb, s));
+    }
+    for (int l = 0; l < c->L; ++l) {
+        const LayerW& w = c->layers[l];
+        GemmArgs g = gemm_args(c, w.qkv, c->h, d, c->qkv, 3 * d, M);
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+        RGN_LAUNCH(c, KC_ATTN, s, launch_attention(c->qkv, c->att, dm, s));
+        g = gemm_args(c, w.out, c->att, d, c->tmp, d, M);
+        g.add = c->h;
+        g.ldadd = d;
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+        RGN_LAUNCH(c, KC_LN, s,
+                   launch_layernorm(c->tmp, c->h, M, d, c->dp<float>(w.ln[0]), c->dp<float>(w.ln[1]), c->call + (size_t)l * d, Ld,
+                                    dm.Tq, c->dp<float>(w.ln[2]), c->dp<float>(w.ln[3]), s));
+        g = gemm_args(c, w.ff1, c->h, d, c->ffn, c->ff, M);
+        g.act = 1;
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+        g = gemm_args(c, w.ff2, c->ffn, c->ff, c->tmp, d, M);
+        g.add = c->h;
+        g.ldadd = d;
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+        RGN_LAUNCH(c, KC_LN, s,
+                   launch_layernorm(c->tmp, c->h, M, d, c->dp<float>(w.ln[4]), c->dp<float>(w.ln[5]), nullptr, 0, dm.Tq, nullptr,
+                                    nullptr, s));
+    }
+    {
+        GemmArgs g = gemm_args(c, c->lin_out, c->h, d, c->x0tok, c->F, M);
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+    }
+    RGN_LAUNCH(c, KC_UPDATE, s, launch_update(c->x0tok, c->scale, c->d_tab, c->d_step, c->d_sp, c->xin, dm, s));
+    return RGN_OK;
+}
+
+// fp32 emulation of the scalar arithmetic of p_sample / ddim_sample (gaussian_diffusion.py:544-559,
+// 771-793): every table entry is cast fp64->fp32 first (_extract_into_tensor), then combined in fp32.
+int build_step_table(rgn_ctx* c, float eta) {
+    if (c->tab_valid && c->tab_eta == eta) return RGN_OK;
+    std::vector<StepCoef> tab(c->S);
+    for (int i = 0; i < c->S; ++i) {
+        StepCoef k{};
+        const float nz = (i != 0) ? 1.f : 0.f;
+        k.c1 = (float)c->coef1[i];
+        k.c2 = (float)c->coef2[i];
+        volatile float half_lv = 0.5f * (float)c->logvar[i];
+        k.sig_ddpm = nz * expf(half_lv);
+        k.sr = (float)c->srecip[i];
+        k.srm1 = (float)c->srecipm1[i];
+        const float ab = (float)c->ac[i], abp = (float)c->acp[i];
+        volatile float r1 = (1.f - abp) / (1.f - ab);
+        volatile float r2 = 1.f - ab / abp;
+        volatile float s1 = sqrtf(r1), s2 = sqrtf(r2);
+        volatile float sig0 = eta * s1;
+        volatile float sigma = sig0 * s2;
+        k.ca = sqrtf(abp);
+        volatile float sg2 = sigma * sigma;
+        volatile float inner = 1.f - abp;
+        inner = inner - sg2;
+        k.cb = sqrtf(inner);
+        k.sig_ddim = nz * sigma;
+        k.t_model = (int32_t)c->tmap[i];
+        tab[i] = k;
+    }
+    RGN_HIP(c, hipMemcpy(c->d_tab, tab.data(), tab.size() * sizeof(StepCoef), hipMemcpyHostToDevice));
+    c->tab_eta = eta;
+    c->tab_valid = true;
+    return RGN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rgn_last_error(rgn_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int rgn_create(const rgn_config* cfg, rgn_handle* out) {
+    if (!cfg || !out) {
+        g_create_error = "rgn_create: null argument";
+        return RGN_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    auto bad = [&](int code, const std::string& m) {
+        g_create_error = m;
+        return code;
+    };
+    if (cfg->njoints <= 0 || cfg->nfeats <= 0 || cfg->num_frames <= 0 || cfg->latent_dim <= 0 || cfg->ff_size <= 0 ||
+        cfg->num_heads <= 0 || cfg->num_layers <= 0 || cfg->max_batch <= 0)
+        return bad(RGN_ERR_INVALID_ARG, "rgn_create: non-positive dimension");
+    if (cfg->latent_dim % cfg->num_heads) return bad(RGN_ERR_INVALID_ARG, "rgn_create: latent_dim % num_heads != 0");
+    if (cfg->latent_dim % 64 || cfg->latent_dim > 1024 || (cfg->latent_dim / 64 & (cfg->latent_dim / 64 - 1)))
+        return bad(RGN_ERR_UNSUPPORTED, "rgn_create: latent_dim must be 64*2^k <= 1024");
+    if (cfg->latent_dim / cfg->num_heads > 128)
+        return bad(RGN_ERR_UNSUPPORTED, "rgn_create: head dim > 128 unsupported");
+    if (cfg->cm_mode != RGN_CM_ADD && cfg->cm_mode != RGN_CM_CONCAT) return bad(RGN_ERR_INVALID_ARG, "rgn_create: cm_mode");
+    if (cfg->cond_mode < RGN_COND_NONE || cfg->cond_mode > RGN_COND_TEXT) return bad(RGN_ERR_INVALID_ARG, "rgn_create: cond_mode");
+    if (cfg->precision < RGN_PREC_F32 || cfg->precision > RGN_PREC_BF16) return bad(RGN_ERR_INVALID_ARG, "rgn_create: precision");
+    if (cfg->cond_mode == RGN_COND_ACTION && cfg->num_actions <= 0) return bad(RGN_ERR_INVALID_ARG, "rgn_create: num_actions");
+    if (cfg->cond_mode == RGN_COND_TEXT && cfg->clip_dim <= 0) return bad(RGN_ERR_INVALID_ARG, "rgn_create: clip_dim");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return bad(RGN_ERR_HIP, "rgn_create: no HIP device visible");
+    if (cfg->device < 0 || cfg->device >= ndev) return bad(RGN_ERR_INVALID_ARG, "rgn_create: device ordinal out of range");
+    if (hipSetDevice(cfg->device) != hipSuccess) return bad(RGN_ERR_HIP, "rgn_create: hipSetDevice failed");
+
+    rgn_ctx* c = new rgn_ctx();
+    c->cfg = *cfg;
+    c->F = cfg->njoints * cfg->nfeats;
+    c->d = cfg->latent_dim;
+    c->etd = cfg->emb_trans_dec ? 1 : 0;
+    c->Tq = cfg->num_frames + c->etd;
+    c->L = cfg->num_layers;
+    c->H = cfg->num_heads;
+    c->ff = cfg->ff_size;
+    build_expected(c);
+    *out = c;
+    return RGN_OK;
+}
+
+int rgn_destroy(rgn_handle h) {
+    if (!h) return RGN_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto& e : h->prof_ev) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->dblob) (void)hipFree(h->dblob);
+    delete h;
+    return RGN_OK;
+}
+
+int rgn_load_weight(rgn_handle h, const char* key, const float* host, const int64_t* shape, int32_t ndim) {
+    if (!h) return RGN_ERR_INVALID_ARG;
+    if (!key || !host || !shape || ndim <= 0) return h->fail(RGN_ERR_INVALID_ARG, "rgn_load_weight: null/empty argument");
+    if (h->finalized) return h->fail(RGN_ERR_STATE, "rgn_load_weight: weights already finalized");
+    const std::string k(key);
+    if (k.rfind("clip_model.", 0) == 0) return RGN_OK;  // accepted and ignored (model_util.py:8)
+    auto it = h->expected.find(k);
+    if (it == h->expected.end()) return h->fail(RGN_ERR_BAD_KEY, "unexpected key in state_dict: " + k);
+    const auto& es = it->second;
+    bool ok = (int)es.size() == ndim;
+    for (int i = 0; ok && i < ndim; ++i) ok = (es[i] == -1) ? (shape[i] > 0) : (es[i] == shape[i]);
+    if (!ok) {
+        std::string m = "size mismatch for " + k + ": got [";
+        for (int i = 0; i < ndim; ++i) m += std::to_string(shape[i]) + (i + 1 < ndim ? "," : "");
+        m += "], expected [";
+        for (size_t i = 0; i < es.size(); ++i) m += std::to_string(es[i]) + (i + 1 < es.size() ? "," : "");
+        return h->fail(RGN_ERR_BAD_SHAPE, m + "]");
+    }
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    HostTensor t;
+    t.v.assign(host, host + n);
+    t.shape.assign(shape, shape + ndim);
+    h->sd[k] = std::move(t);
+    return RGN_OK;
+}
+
+int rgn_finalize_weights(rgn_handle h) {
+    if (!h) return RGN_ERR_INVALID_ARG;
+    if (h->finalized) return h->fail(RGN_ERR_STATE, "rgn_finalize_weights: already finalized");
+    rgn_ctx* c = h;
+    std::string missing;
+    for (auto& kv : c->expected)
+        if (!c->sd.count(kv.first)) missing += (missing.empty() ? "" : ", ") + kv.first;
+    if (!missing.empty()) return c->fail(RGN_ERR_MISSING_KEY, "missing keys in state_dict: " + missing);
+    RGN_HIP(c, hipSetDevice(c->cfg.device));
+    auto W = [&](const std::string& k) -> const float* { return c->sd[k].v.data(); };
+    const int d = c->d, F = c->F, ff = c->ff;
+
+    // --- positional table: the buffer both modules alias; load order makes the embed_timestep key win
+    const HostTensor& pe = c->sd["embed_timestep.sequence_pos_encoder.pe"];
+    c->pe_len = (int)pe.shape[0];
+    if (c->pe_len < c->Tq) return c->fail(RGN_ERR_BAD_SHAPE, "positional table shorter than the sequence");
+    c->off_pe = blob_put(c, pe.v.data(), pe.v.size() * 4);
+
+    // --- input stage: fold fuse_process into the two pose embeddings (concat), fp64
+    {
+        std::vector<double> wx, wc;
+        std::vector<float> bconst(d), wxf((size_t)d * F), wcf((size_t)d * F);
+        const float* win = W("input_process.poseEmbedding.weight");
+        const float* wcm = W("cmo_process.poseEmbedding.weight");
+        const float* bin = W("input_process.poseEmbedding.bias");
+        const float* bcm = W("cmo_process.poseEmbedding.bias");
+        if (c->cfg.cm_mode == RGN_CM_CONCAT) {
+            const float* wf = W("fuse_process.weight");  // [d, 2d] = [Wf_x | Wf_c]
+            const float* bf = W("fuse_process.bias");
+            std::vector<float> wfx((size_t)d * d), wfc((size_t)d * d);
+            for (int n = 0; n < d; ++n)
+                for (int j = 0; j < d; ++j) {
+                    wfx[(size_t)n * d + j] = wf[(size_t)n * 2 * d + j];
+                    wfc[(size_t)n * d + j] = wf[(size_t)n * 2 * d + d + j];
+                }
+            matmul64(wfx.data(), win, d, d, F, wx);
+            matmul64(wfc.data(), wcm, d, d, F, wc);
+            for (int n = 0; n < d; ++n) {
+                double b = bf[n];
+                for (int j = 0; j < d; ++j) b += (double)wfx[(size_t)n * d + j] * bin[j] + (double)wfc[(size_t)n * d + j] * bcm[j];
+                bconst[n] = (float)b;
+            }
+            for (size_t i = 0; i < wx.size(); ++i) {
+                wxf[i] = (float)wx[i];
+                wcf[i] = (float)wc[i];
+            }
+        } else {
+            memcpy(wxf.data(), win, wxf.size() * 4);
+            memcpy(wcf.data(), wcm, wcf.size() * 4);
+            for (int n = 0; n < d; ++n) bconst[n] = (float)((double)bin[n] + (double)bcm[n]);
+        }
+        c->lin_x = pack_linear(c, wxf.data(), nullptr, d, F);
+        c->lin_c = pack_linear(c, wcf.data(), bconst.data(), d, F);
+    }
+    c->lin_t0 = pack_linear(c, W("embed_timestep.time_embed.0.weight"), W("embed_timestep.time_embed.0.bias"), d, d);
+    c->lin_t2 = pack_linear(c, W("embed_timestep.time_embed.2.weight"), W("embed_timestep.time_embed.2.bias"), d, d);
+
+    // --- layers; cross-attention folded: G_l = Wo_c * Wv_c, g_l = Wo_c * bv_c + bo_c (1-token memory)
+    std::vector<float> gall((size_t)c->L * d * d), gb((size_t)c->L * d);
+    c->layers.resize(c->L);
+    for (int l = 0; l < c->L; ++l) {
+        const std::string p = "seqTransDecoder.layers." + std::to_string(l) + ".";
+        LayerW& lw = c->layers[l];
+        lw.qkv = pack_linear(c, W(p + "self_attn.in_proj_weight"), W(p + "self_attn.in_proj_bias"), 3 * d, d);
+        lw.out = pack_linear(c, W(p + "self_attn.out_proj.weight"), W(p + "self_attn.out_proj.bias"), d, d);
+        lw.ff1 = pack_linear(c, W(p + "linear1.weight"), W(p + "linear1.bias"), ff, d);
+        lw.ff2 = pack_linear(c, W(p + "linear2.weight"), W(p + "linear2.bias"), d, ff);
+        const char* names[6] = {"norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "norm3.weight", "norm3.bias"};
+        for (int i = 0; i < 6; ++i) lw.ln[i] = blob_put(c, W(p + names[i]), (size_t)d * 4);
+        const float* wv = W(p + "multihead_attn.in_proj_weight") + (size_t)2 * d * d;
+        const float* bv = W(p + "multihead_attn.in_proj_bias") + 2 * d;
+        const float* wo = W(p + "multihead_attn.out_proj.weight");
+        const float* bo = W(p + "multihead_attn.out_proj.bias");
+        std::vector<double> G;
+        matmul64(wo, wv, d, d, d, G);
+        for (size_t i = 0; i < G.size(); ++i) gall[(size_t)l * d * d + i] = (float)G[i];
+        for (int n = 0; n < d; ++n) {
+            double b = bo[n];
+            for (int j = 0; j < d; ++j) b += (double)wo[(size_t)n * d + j] * bv[j];
+            gb[(size_t)l * d + n] = (float)b;
+        }
+    }
+    c->lin_g = pack_linear(c, gall.data(), gb.data(), c->L * d, d);
+    c->lin_out = pack_linear(c, W("output_process.poseFinal.weight"), W("output_process.poseFinal.bias"), F, d);
+    if (c->cfg.cond_mode == RGN_COND_TEXT) {
+        c->lin_text = pack_linear(c, W("embed_text.weight"), W("embed_text.bias"), d, c->cfg.clip_dim);
+        c->off_bt = c->lin_text.b;
+    }
+    if (c->cfg.cond_mode == RGN_COND_ACTION) {
+        const HostTensor& a = c->sd["embed_action.action_embedding"];
+        c->off_action = blob_put(c, a.v.data(), a.v.size() * 4);
+    }
+    c->blob_bytes = align_up(c->hblob.size(), 256);
+    c->hblob.resize(c->blob_bytes);
+    RGN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->dblob), c->blob_bytes));
+    RGN_HIP(c, hipMemcpy(c->dblob, c->hblob.data(), c->blob_bytes, hipMemcpyHostToDevice));
+    c->hblob.clear();
+    c->hblob.shrink_to_fit();
+    c->sd.clear();
+
+    // --- workspace
+    const size_t B = c->cfg.max_batch, Bm = 2 * B, M = Bm * c->Tq, Mb = B * c->Tq;
+    int rc;
+    if ((rc = ws_alloc(c, &c->xin, Mb * F))) return rc;
+    if ((rc = ws_alloc(c, &c->cmo_in, Mb * F))) return rc;
+    if ((rc = ws_alloc(c, &c->c0, Mb * d))) return rc;
+    if ((rc = ws_alloc(c, &c->h, M * d))) return rc;
+    if ((rc = ws_alloc(c, &c->tmp, M * d))) return rc;
+    if ((rc = ws_alloc(c, &c->qkv, M * 3 * d))) return rc;
+    if ((rc = ws_alloc(c, &c->att, M * d))) return rc;
+    if ((rc = ws_alloc(c, &c->ffn, M * ff))) return rc;
+    if ((rc = ws_alloc(c, &c->x0tok, M * F))) return rc;
+    if ((rc = ws_alloc(c, &c->pe_rows, Bm * d))) return rc;
+    if ((rc = ws_alloc(c, &c->emb1, Bm * d))) return rc;
+    if ((rc = ws_alloc(c, &c->emb, Bm * d))) return rc;
+    if ((rc = ws_alloc(c, &c->call, Bm * c->L * d))) return rc;
+    if ((rc = ws_alloc(c, &c->condemb, Bm * d))) return rc;
+    if ((rc = ws_alloc(c, &c->scale, B))) return rc;
+    if ((rc = ws_alloc(c, &c->d_tab, (size_t)1024))) return rc;
+    if ((rc = ws_alloc(c, &c->d_step, (size_t)4))) return rc;
+    if ((rc = ws_alloc(c, &c->d_sp, (size_t)1))) return rc;
+    RGN_HIP(c, configure_attention(c->Tq, c->d / c->H));
+    RGN_HIP(c, hipMemset(c->xin, 0, Mb * F * sizeof(float)));
+    RGN_HIP(c, hipMemset(c->cmo_in, 0, Mb * F * sizeof(float)));
+    RGN_HIP(c, hipMemset(c->d_step, 0, 4 * sizeof(int)));
+    c->finalized = true;
+    return RGN_OK;
+}
+
+int rgn_weight_blob(rgn_handle h, void** dev_ptr, uint64_t* nbytes) {
+    if (!h || !dev_ptr || !nbytes) return RGN_ERR_INVALID_ARG;
+    if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_weight_blob: weights not finalized");
+    *dev_ptr = h->dblob;
+    *nbytes = h->blob_bytes;
+    return RGN_OK;
+}
+
+int rgn_set_schedule(rgn_handle h, const rgn_schedule* s) {
+    if (!h) return RGN_ERR_INVALID_ARG;
+    if (!s || s->S <= 0 || !s->timestep_map || !s->posterior_mean_coef1 || !s->posterior_mean_coef2 || !s->model_log_variance ||
+        !s->sqrt_recip_alphas_cumprod || !s->sqrt_recipm1_alphas_cumprod || !s->alphas_cumprod || !s->alphas_cumprod_prev)
+        return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_schedule: null table or S <= 0");
+    if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_set_schedule: weights not finalized");
+    if (s->S > 1024) return h->fail(RGN_ERR_UNSUPPORTED, "rgn_set_schedule: more than 1024 steps");
+    for (int i = 0; i < s->S; ++i) {
+        if (s->timestep_map[i] < 0 || s->timestep_map[i] >= h->pe_len)
+            return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_schedule: timestep_map entry outside the positional table");
+        if (i && s->timestep_map[i] <= s->timestep_map[i - 1])
+            return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_schedule: timestep_map must be strictly increasing");
+    }
+    h->S = s->S;
+    h->tmap.assign(s->timestep_map, s->timestep_map + s->S);
+    h->coef1.assign(s->posterior_mean_coef1, s->posterior_mean_coef1 + s->S);
+    h->coef2.assign(s->posterior_mean_coef2, s->posterior_mean_coef2 + s->S);
+    h->logvar.assign(s->model_log_variance, s->model_log_variance + s->S);
+    h->srecip.assign(s->sqrt_recip_alphas_cumprod, s->sqrt_recip_alphas_cumprod + s->S);
+    h->srecipm1.assign(s->sqrt_recipm1_alphas_cumprod, s->sqrt_recipm1_alphas_cumprod + s->S);
+    h->ac.assign(s->alphas_cumprod, s->alphas_cumprod + s->S);
+    h->acp.assign(s->alphas_cumprod_prev, s->alphas_cumprod_prev + s->S);
+    h->tab_valid = false;
+    h->have_sched = true;
+    RGN_HIP(h, hipSetDevice(h->cfg.device));
+    return build_step_table(h, 0.0f);
+}
+
+int rgn_set_condition(rgn_handle h, int32_t B, const float* cmotion, const int64_t* action, const float* text_feat,
+                      const float* scale, void* stream) {
+    if (!h) return RGN_ERR_INVALID_ARG;
+    rgn_ctx* c = h;
+    if (!c->finalized) return c->fail(RGN_ERR_STATE, "rgn_set_condition: weights not finalized");
+    if (B <= 0 || B > c->cfg.max_batch) return c->fail(RGN_ERR_INVALID_ARG, "rgn_set_condition: B outside (0, max_batch]");
+    if (!cmotion) return c->fail(RGN_ERR_INVALID_ARG, "rgn_set_condition: y['cmotion'] is required (cmdm.py:189)");
+    if (c->cfg.cond_mode == RGN_COND_ACTION && !action) return c->fail(RGN_ERR_INVALID_ARG, "rgn_set_condition: y['action'] required");
+    if (c->cfg.cond_mode == RGN_COND_TEXT && !text_feat) return c->fail(RGN_ERR_INVALID_ARG, "rgn_set_condition: text features required");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    RGN_HIP(c, hipSetDevice(c->cfg.device));
+    const Dims dm = make_dims(c, B, false);
+    const int d = c->d;
+    // hoisted: c0 = cmo_process(cmotion) -> fuse half + all constant biases + positional encoding
+    RGN_LAUNCH(c, KC_UPDATE, s, launch_pack_x(cmotion, c->cmo_in, dm, s));
+    GemmArgs g = gemm_args(c, c->lin_c, c->cmo_in, c->F, c->c0, d, B * dm.Tq);
+    RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, c->cfg.precision, s));
+    if (!c->cfg.wo_pos_emb) RGN_LAUNCH(c, KC_EMBED, s, launch_add_pe(c->c0, c->dp<float>(c->off_pe), dm, s));
+    // condition embedding rows: [0,B) conditional, [B,2B) what mask_cond(force_mask=True) leaves
+    if (c->cfg.cond_mode == RGN_COND_ACTION) {
+        RGN_LAUNCH(c, KC_EMBED, s, launch_cond_rows(c->dp<float>(c->off_action), action, c->condemb, B, d, s));
+        RGN_LAUNCH(c, KC_EMBED, s, launch_fill_rows(c->condemb + (size_t)B * d, nullptr, B, d, s));
+    } else if (c->cfg.cond_mode == RGN_COND_TEXT) {
+        GemmArgs t = gemm_args(c, c->lin_text, text_feat, c->cfg.clip_dim, c->condemb, d, B);
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(t, c->cfg.precision, s));
+        RGN_LAUNCH(c, KC_EMBED, s, launch_fill_rows(c->condemb + (size_t)B * d, c->dp<float>(c->off_bt), B, d, s));  // embed_text(0) = bias
+    }
+    c->cond_has_scale = scale != nullptr;
+    if (scale) RGN_HIP(c, hipMemcpyAsync(c->scale, scale, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
+    c->B = B;
+    c->have_cond = true;
+    return RGN_OK;
+}
+
+int rgn_denoise(rgn_handle h, const float* x, const int64_t* t, int32_t flags, float* out, void* stream) {
+    if (!h) return RGN_ERR_INVALID_ARG;
+    rgn_ctx* c = h;
+    if (!c->have_cond) return c->fail(RGN_ERR_STATE, "rgn_denoise: no condition bound (rgn_set_condition)");
+    if (!x || !t || !out) return c->fail(RGN_ERR_INVALID_ARG, "rgn_denoise: null pointer");
+    const bool guided = flags & RGN_FLAG_GUIDED, uncond = flags & RGN_FLAG_UNCOND;
+    if (guided && c->cfg.cond_mode == RGN_COND_NONE)
+        return c->fail(RGN_ERR_INVALID_ARG, "rgn_denoise: guidance needs cond_mode text/action (cfg_sampler.py:26)");
+    if (guided && !c->cond_has_scale) return c->fail(RGN_ERR_STATE, "rgn_denoise: guided evaluation needs y['scale']");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    RGN_HIP(c, hipSetDevice(c->cfg.device));
+    const Dims dm = make_dims(c, c->B, guided);
+    SampleParams sp{};
+    sp.x0_out = out;
+    sp.t_ext = t;
+    sp.mode = 1;
+    sp.guided = guided;
+    RGN_HIP(c, hipMemcpyAsync(c->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
+    RGN_LAUNCH(c, KC_UPDATE, s, launch_pack_x(x, c->xin, dm, s));
+    return run_eval(c, c->B, guided, uncond, s);
+}
+
+int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, float* x, const float* noise, uint64_t seed,
+                     uint64_t sample_offset, int32_t first_index, int32_t count, float* x0_out, int32_t use_graph,
+                     int32_t clip_denoised, void* stream) {
+    if (!h) return RGN_ERR_INVALID_ARG;
+    rgn_ctx* c = h;
+    if (!c->have_sched) return c->fail(RGN_ERR_STATE, "rgn_sample_range: no schedule (rgn_set_schedule)");
+    if (!c->have_cond) return c->fail(RGN_ERR_STATE, "rgn_sample_range: no condition bound (rgn_set_condition)");
+    if (!x) return c->fail(RGN_ERR_INVALID_ARG, "rgn_sample_range: null x");
+    if (sampler != RGN_SAMPLER_DDPM && sampler != RGN_SAMPLER_DDIM) return c->fail(RGN_ERR_INVALID_ARG, "rgn_sample_range: sampler");
+    if (count <= 0 || first_index >= c->S || first_index - count + 1 < 0)
+        return c->fail(RGN_ERR_INVALID_ARG, "rgn_sample_range: step range outside [0, S)");
+    if (guided && c->cfg.cond_mode == RGN_COND_NONE)
+        return c->fail(RGN_ERR_INVALID_ARG, "rgn_sample_range: guidance needs cond_mode text/action (cfg_sampler.py:26)");
+    if (guided && !c->cond_has_scale) return c->fail(RGN_ERR_STATE, "rgn_sample_range: guided sampling needs y['scale']");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    RGN_HIP(c, hipSetDevice(c->cfg.device));
+    int rc = build_step_table(c, eta);
+    if (rc) return rc;
+    const Dims dm = make_dims(c, c->B, guided != 0);
+    SampleParams sp{};
+    sp.x = x;
+    sp.noise = noise;
+    sp.x0_out = x0_out;
+    sp.t_ext = nullptr;
+    sp.seed = seed;
+    sp.sample_offset = sample_offset;
+    sp.first_index = first_index;
+    sp.sampler = sampler;
+    sp.mode = 0;
+    sp.guided = guided != 0;
+    sp.clip = clip_denoised != 0;
+    RGN_HIP(c, hipMemcpyAsync(c->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
+    RGN_HIP(c, hipMemcpyAsync(c->d_step, &first_index, sizeof(int), hipMemcpyHostToDevice, s));
+    RGN_LAUNCH(c, KC_UPDATE, s, launch_pack_x(x, c->xin, dm, s));
+
+    hipGraphExec_t gexec = nullptr;
+    if (use_graph && !c->prof) {
+        const uint64_t key = (uint64_t)c->B | ((uint64_t)(guided != 0) << 20) | ((uint64_t)sampler << 21);
+        auto it = c->graphs.find(key);
+        if (it == c->graphs.end()) {
+            hipGraph_t graph = nullptr;
+            RGN_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            rc = run_eval(c, c->B, guided != 0, false, s);
+            if (rc == RGN_OK && launch_advance(c->d_step, s) != hipSuccess) rc = c->fail(RGN_ERR_HIP, "launch_advance");
+            hipError_t e = hipStreamEndCapture(s, &graph);
+            if (rc) {
+                if (graph) (void)hipGraphDestroy(graph);
+                return rc;
+            }
+            RGN_HIP(c, e);
+            RGN_HIP(c, hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            c->graphs[key] = gexec;
+        } else {
+            gexec = it->second;
+        }
+    }
+    for (int k = 0; k < count; ++k) {
+        if (gexec) {
+            RGN_HIP(c, hipGraphLaunch(gexec, s));
+        } else {
+            rc = run_eval(c, c->B, guided != 0, false, s);
+            if (rc) return rc;
+            RGN_LAUNCH(c, KC_MISC, s, launch_advance(c->d_step, s));
+        }
+    }
+    return RGN_OK;
+}
+
+int rgn_randn(rgn_handle h, float* x, int32_t B, uint64_t seed, uint64_t sample_offset, void* stream) {
+    if (!h) return RGN_ERR_INVALID_ARG;
+    if (!x || B <= 0) return h->fail(RGN_ERR_INVALID_ARG, "rgn_randn: null x or B <= 0");
+    RGN_HIP(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    RGN_LAUNCH(h, KC_UPDATE, s, launch_randn(x, B, h->F * h->cfg.num_frames, seed, sample_offset, s));
+    return RGN_OK;
+}
+
+int rgn_rot6d_to_matrix(rgn_handle h, const float* d6, float* mat, int64_t n, void* stream) {
+    if (!h) return RGN_ERR_INVALID_ARG;
+    if (n < 0 || (n > 0 && (!d6 || !mat))) return h->fail(RGN_ERR_INVALID_ARG, "rgn_rot6d_to_matrix: bad argument");
+    RGN_HIP(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    RGN_LAUNCH(h, KC_MISC, s, launch_rot6d(d6, mat, n, s));
+    return RGN_OK;
+}
+
+int rgn_gaussian_filter1d(rgn_handle h, const float* x, float* out, int64_t rows, int32_t T, float sigma, void* stream) {
+    if (!h) return RGN_ERR_INVALID_ARG;
+    if (rows < 0 || T <= 0 || !(sigma > 0.f) || (rows > 0 && (!x || !out)))
+        return h->fail(RGN_ERR_INVALID_ARG, "rgn_gaussian_filter1d: bad argument");
+    RGN_HIP(h, hipSetDevice(h->cfg.device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    RGN_LAUNCH(h, KC_MISC, s, launch_gauss1d(x, out, rows, T, sigma, s));
+    return RGN_OK;
+}
+
+int rgn_profile_enable(rgn_handle h, int32_t on) {
+    if (!h) return RGN_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (auto& e : h->prof_ev) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    h->prof_ev.clear();
+    for (int i = 0; i < KC_COUNT; ++i) {
+        h->prof_ms[i] = 0;
+        h->prof_n[i] = 0;
+    }
+    h->prof = on != 0;
+    return RGN_OK;
+}
+
+int rgn_profile_query(rgn_handle h, int32_t idx, const char** name, double* total_ms, int64_t* launches) {
+    if (!h) return RGN_ERR_INVALID_ARG;
+    if (idx < 0 || idx >= KC_COUNT || !name || !total_ms || !launches) return h->fail(RGN_ERR_INVALID_ARG, "rgn_profile_query: bad argument");
+    if (!h->prof_ev.empty()) {
+        (void)hipSetDevice(h->cfg.device);
+        (void)hipDeviceSynchronize();
+        for (auto& e : h->prof_ev) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+                h->prof_ms[e.kc] += ms;
+                h->prof_n[e.kc] += 1;
+            }
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+        h->prof_ev.clear();
+    }
+    *name = kclass_names[idx];
+    *total_ms = h->prof_ms[idx];
+    *launches = h->prof_n[idx];
+    return RGN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// Internal declarations shared by rgn_api.cpp (host orchestration) and rgn_kernels.hip (device code).
+// Not part of the C-ABI (that is include/regennet_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rgn {
+
+// ---- kernel classes (for per-class HIP-event timing, rgn_profile_query) -------------------------
+enum KClass : int {
+    KC_GEMM = 0,      // all MFMA GEMMs (dominant)
+    KC_ATTN,          // causal self-attention
+    KC_LN,            // residual LayerNorm kernels
+    KC_EMBED,         // pe gather / emb rows
+    KC_UPDATE,        // pack / sampler update / output transpose / philox
+    KC_MISC,
+    KC_COUNT
+};
+
+// ---- per-step scalar table (device resident; index = loop index i, S-1 .. 0) --------------------
+// All coefficients are the reference's fp64 table entries cast to fp32 exactly like
+// _extract_into_tensor does (gaussian_diffusion.py:1614), with the remaining scalar arithmetic of
+// p_sample / ddim_sample done in fp32 on the host in the reference's operation order.
+struct StepCoef {
+    float c1, c2;        // DDPM: mean = c1*x0 + c2*x      (posterior_mean_coef1/2)
+    float sig_ddpm;      // (t!=0) * exp(0.5*log_variance)
+    float sr, srm1;      // DDIM: eps = (sr*x - x0)/srm1   (sqrt_recip / sqrt_recipm1 alphas_cumprod)
+    float ca, cb;        // DDIM: mean = x0*ca + cb*eps    (sqrt(abar_prev), sqrt(1-abar_prev-sigma^2))
+    float sig_ddim;      // (t!=0) * sigma(eta)
+    int32_t t_model;     // timestep_map[i] : ORIGINAL index handed to the denoiser
+    int32_t pad[3];
+};
+
+// ---- arguments that change between rgn_sample_range calls (device resident so a captured graph
+//      of one step can be replayed with different bindings) ---------------------------------------
+struct SampleParams {
+    float* x;                 // [B,F,T] sampler state, updated in place
+    const float* noise;       // [count,B,F,T] tape or nullptr (-> Philox)
+    float* x0_out;            // optional pred_xstart [B,F,T]
+    const int64_t* t_ext;     // rgn_denoise: external timesteps [B]; nullptr inside sampling loops
+    unsigned long long seed;
+    unsigned long long sample_offset;
+    int32_t first_index;      // loop index that tape entry 0 belongs to
+    int32_t sampler;          // RGN_SAMPLER_*
+    int32_t mode;             // 0: sampler update, 1: output only (rgn_denoise)
+    int32_t guided;
+    int32_t clip;             // clamp pred_xstart to [-1,1]
+    int32_t pad;
+};
+
+struct GemmArgs {
+    const float* A; int lda;          // [M,K] row-major activations (fp32)
+    const float* W;                   // [N,Kp] row-major fp32 weights, K zero-padded to Kp (multiple of 16)
+    const uint16_t* Whi;              // [N,Kp] bf16 high parts   (BF16X3 / BF16)
+    const uint16_t* Wlo;              // [N,Kp] bf16 low parts    (BF16X3)
+    const float* bias;                // [N] or nullptr
+    const float* add; int ldadd;      // optional addend, row r uses add[(r % add_mod) * ldadd + n]
+    int add_mod;                      // 0 -> r itself
+    float* C; int ldc;
+    int M, N, K, Kp;
+    int act;                          // 0 none, 1 gelu(erf), 2 silu
+};
+
+struct Dims {
+    int B;        // motions in the bound condition
+    int Bm;       // rows of the batched evaluation (B, or 2B under guidance)
+    int T, Tq;    // frames, tokens per sample (T + emb_trans_dec)
+    int etd;      // emb_trans_dec as 0/1 (row offset of frame 0 inside a sample)
+    int F;        // njoints*nfeats
+    int d, H, dh, ff, L;
+};
+
+// ---- launchers (rgn_kernels.hip) ----------------------------------------------------------------
+hipError_t launch_gemm(const GemmArgs& g, int precision, hipStream_t s);
+hipError_t configure_attention(int Tq, int dh);
+hipError_t launch_attention(const float* qkv, float* out, const Dims& dm, hipStream_t s);
+// h_out = LN_b( LN_a(in) + addvec[row/Tq] ) when ln_b != nullptr, else LN_a(in)
+hipError_t launch_layernorm(const float* in, float* out, int M, int d, const float* ga, const float* ba,
+                            const float* addvec, int ldadd, int Tq, const float* gb, const float* bb, hipStream_t s);
+hipError_t launch_gather_pe(const float* pe, const StepCoef* tab, const int* d_step, const SampleParams* sp,
+                            float* out, int Bm, int B, int d, hipStream_t s);
+hipError_t launch_emb_rows(const float* emb, const float* pe, float* h, const Dims& dm, int wo_pos, hipStream_t s);
+hipError_t launch_add_pe(float* c0, const float* pe, const Dims& dm, hipStream_t s);
+hipError_t launch_pack_x(const float* x, float* xin, const Dims& dm, hipStream_t s);
+hipError_t launch_update(const float* x0tok, const float* scale, const StepCoef* tab, const int* d_step,
+                         const SampleParams* sp, float* xin, const Dims& dm, hipStream_t s);
+hipError_t launch_advance(int* d_step, hipStream_t s);
+hipError_t launch_cond_rows(const float* table, const int64_t* action, float* out, int B, int d, hipStream_t s);
+hipError_t launch_fill_rows(float* out, const float* row, int rows, int d, hipStream_t s);
+hipError_t launch_randn(float* x, int B, int FT, unsigned long long seed, unsigned long long sample_offset,
+                        hipStream_t s);
+hipError_t launch_rot6d(const float* d6, float* mat, long long n, hipStream_t s);
+hipError_t launch_gauss1d(const float* x, float* out, long long rows, int T, float sigma, hipStream_t s);
+
+}  // namespace rgn

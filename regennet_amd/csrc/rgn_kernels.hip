@@ -1,0 +1,569 @@
+// Device code for the ReGenNet sampling hot path on MI355X (gfx950, wave64, MFMA).
+//
+// Layouts:
+//   boundary tensors   x, cmotion, out : fp32 [B, F=njoints*nfeats, T]   (frames contiguous)
+//   token-major        xin  [B*Tq, F]   h [Bm*Tq, d]   qkv [Bm*Tq, 3d]   att [Bm*Tq, d]   ffn [Bm*Tq, ff]
+//                      row = b*Tq + etd + t  (a sample's tokens are contiguous -> attention reads one slab)
+//   weights            nn.Linear layout [N, Kp] (K contiguous, zero padded to a multiple of 16)
+//
+// Reference arithmetic replaced (file:line in the upstream repo) is cited per kernel.
+#include "rgn_internal.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace rgn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == 1) return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));  // F.gelu, exact erf
+    if (act == 2) return v / (1.0f + __expf(-v));                                  // nn.SiLU (cmdm.py:293)
+    return v;
+}
+
+// =================================================================================================
+// GEMM  C[M,N] = act( A[M,K] * W[N,K]^T + bias[N] + add[r % add_mod, N] )
+// Replaces every nn.Linear on the path (cmdm.py:61,291-295,307,337 and the in_proj/out_proj/linear1/
+// linear2 of nn.TransformerDecoderLayer constructed at cmdm.py:75-81).
+//
+// F32 precision mode: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate).
+// Block = 128x128 output tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles (64 acc VGPRs).
+// K is walked in 16-wide LDS tiles; rows are padded to 20 floats so that the 16 lanes of a
+// ds_read_b128 group (consecutive rows, 80-byte stride) fall on disjoint bank quads.
+// An 8-wide k chunk is contracted by 4 MFMAs: lanes 0-31 feed k = kc+j, lanes 32-63 feed k = kc+4+j
+// for A and B alike (any consistent permutation of the contraction index is legal).
+// =================================================================================================
+constexpr int G_BM = 128, G_BN = 128, G_BK = 16, G_LD = G_BK + 4;
+
+template <bool VEC_A>
+__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[G_BM * G_LD];
+    __shared__ __attribute__((aligned(16))) float Ws[G_BN * G_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * G_BM, n0 = blockIdx.x * G_BN;
+    const int lr = tid >> 2, lk = (tid & 3) * 4;  // staging: row (0..63, +64), k quad
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    f32x4 ra[2], rw[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + lr + 64 * i, k = k0 + lk;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < g.M) {
+                const float* p = g.A + (size_t)m * g.lda + k;
+                if (VEC_A) {
+                    if (k < g.K) v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (k + j < g.K) v[j] = p[j];
+                }
+            }
+            ra[i] = v;
+            const int n = n0 + lr + 64 * i;
+            f32x4 w = {0.f, 0.f, 0.f, 0.f};
+            if (n < g.N) w = *reinterpret_cast<const f32x4*>(g.W + (size_t)n * g.Kp + k);
+            rw[i] = w;
+        }
+    };
+    const int nk = g.Kp / G_BK;
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4*>(&As[(lr + 64 * i) * G_LD + lk]) = ra[i];
+            *reinterpret_cast<f32x4*>(&Ws[(lr + 64 * i) * G_LD + lk]) = rw[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) gload((kt + 1) * G_BK);
+#pragma unroll
+        for (int kc = 0; kc < G_BK; kc += 8) {
+            f32x4 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *reinterpret_cast<const f32x4*>(&As[(wm * 64 + t * 32 + (lane & 31)) * G_LD + kc + 4 * (lane >> 5)]);
+                b[t] = *reinterpret_cast<const f32x4*>(&Ws[(wn * 64 + t * 32 + (lane & 31)) * G_LD + kc + 4 * (lane >> 5)]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < 2; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta][j], b[tb][j], acc[ta][tb], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int n = n0 + wn * 64 + tb * 32 + (lane & 31);
+        if (n >= g.N) continue;
+        const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + wm * 64 + ta * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                if (m >= g.M) continue;
+                float v = acc[ta][tb][i] + bias;
+                if (g.add) {
+                    const int ar = g.add_mod ? (m % g.add_mod) : m;
+                    v += g.add[(size_t)ar * g.ldadd + n];
+                }
+                g.C[(size_t)m * g.ldc + n] = act_apply(v, g.act);
+            }
+        }
+    }
+}
+
+hipError_t launch_gemm(const GemmArgs& g, int precision, hipStream_t s) {
+    (void)precision;
+    dim3 grid((g.N + G_BN - 1) / G_BN, (g.M + G_BM - 1) / G_BM);
+    const bool vec = (g.lda % 4 == 0) && (g.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(k_gemm_f32<true>, grid, dim3(256), 0, s, g);
+    else
+        hipLaunchKernelGGL(k_gemm_f32<false>, grid, dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
+// =================================================================================================
+// Causal self-attention, one workgroup per (sample, head). v1: fp32 VALU, K/V slab in LDS.
+// Replaces nn.MultiheadAttention inside TransformerDecoderLayer._sa_block with the mask of
+// generate_square_subsequent_mask (cmdm.py:168-171,220-227): softmax(q k^T / sqrt(dh) + causal) v.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, float* __restrict__ out, Dims dm) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, hd = blockIdx.y;
+    const int Tq = dm.Tq, dh = dm.dh, d = dm.d, ldk = dh + 1;
+    float* Ks = smem;                       // [Tq][dh+1]
+    float* Vs = Ks + Tq * ldk;              // [Tq][dh+1]
+    float* qs = Vs + Tq * ldk;              // [4][dh]
+    float* ps = qs + 4 * dh;                // [4][Tq]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t row0 = (size_t)b * Tq;
+    for (int idx = tid; idx < Tq * dh; idx += 256) {
+        const int j = idx / dh, c = idx - j * dh;
+        const float* base = qkv + (row0 + j) * (size_t)(3 * d) + hd * dh + c;
+        Ks[j * ldk + c] = base[d];
+        Vs[j * ldk + c] = base[2 * d];
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)dh);
+    float* q = qs + wave * dh;
+    float* p = ps + wave * Tq;
+    for (int i0 = 0; i0 < Tq; i0 += 4) {   // uniform trip count: block barriers order the LDS hand-offs
+        const int i = i0 + wave;
+        const bool on = i < Tq;
+        if (on)
+            for (int c = lane; c < dh; c += 64) q[c] = qkv[(row0 + i) * (size_t)(3 * d) + hd * dh + c] * scale;
+        __syncthreads();
+        float inv = 0.f;
+        if (on) {
+            float mx = -INFINITY;
+            for (int j = lane; j <= i; j += 64) {
+                float s = 0.f;
+                const float* kr = Ks + j * ldk;
+                for (int c = 0; c < dh; ++c) s = fmaf(q[c], kr[c], s);
+                p[j] = s;
+                mx = fmaxf(mx, s);
+            }
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int j = lane; j <= i; j += 64) {
+                const float e = __expf(p[j] - mx);
+                p[j] = e;
+                sum += e;
+            }
+            inv = 1.0f / wave_sum(sum);
+        }
+        __syncthreads();
+        if (on)
+            for (int c = lane; c < dh; c += 64) {
+                float o = 0.f;
+                for (int j = 0; j <= i; ++j) o = fmaf(p[j], Vs[j * ldk + c], o);
+                out[(row0 + i) * (size_t)d + hd * dh + c] = o * inv;
+            }
+        __syncthreads();
+    }
+}
+
+static size_t attn_lds_bytes(int Tq, int dh) { return ((size_t)2 * Tq * (dh + 1) + 4 * dh + 4 * Tq) * sizeof(float); }
+// Called once at finalize (never during graph capture): allow > 64 KiB of dynamic LDS.
+hipError_t configure_attention(int Tq, int dh) {
+    const size_t lds = attn_lds_bytes(Tq, dh);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+hipError_t launch_attention(const float* qkv, float* out, const Dims& dm, hipStream_t s) {
+    hipLaunchKernelGGL(k_attention, dim3(dm.Bm, dm.H), dim3(256), attn_lds_bytes(dm.Tq, dm.dh), s, qkv, out, dm);
+    return hipGetLastError();
+}
+
+// =================================================================================================
+// Residual LayerNorm(s): one wave per token row, row held in registers.
+//   out = LN_b( LN_a(in) + addvec[row / Tq] )   or   out = LN_a(in)
+// `in` already contains residual + sublayer output (+bias) from the producing GEMM's epilogue.
+// Replaces norm1/norm2/norm3 of TransformerDecoderLayer (post-norm, eps=1e-5) and the add of the
+// 1-token cross-attention result, which is constant over the sequence.
+// =================================================================================================
+template <int VPL>
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in, float* __restrict__ out, int M, int d,
+                                                    const float* __restrict__ ga, const float* __restrict__ ba,
+                                                    const float* __restrict__ addvec, int ldadd, int Tq,
+                                                    const float* __restrict__ gb, const float* __restrict__ bb) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* x = in + (size_t)row * d;
+    float v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i] = x[lane + 64 * i];
+        s += v[i];
+    }
+    const float invd = 1.0f / (float)d;
+    float mean = wave_sum(s) * invd;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const float c = v[i] - mean;
+        q += c * c;
+    }
+    float rstd = 1.0f / sqrtf(wave_sum(q) * invd + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) v[i] = (v[i] - mean) * rstd * ga[lane + 64 * i] + ba[lane + 64 * i];
+    if (gb) {
+        const float* av = addvec + (size_t)(row / Tq) * ldadd;
+        s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            v[i] += av[lane + 64 * i];
+            s += v[i];
+        }
+        mean = wave_sum(s) * invd;
+        q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const float c = v[i] - mean;
+            q += c * c;
+        }
+        rstd = 1.0f / sqrtf(wave_sum(q) * invd + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) v[i] = (v[i] - mean) * rstd * gb[lane + 64 * i] + bb[lane + 64 * i];
+    }
+    float* y = out + (size_t)row * d;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) y[lane + 64 * i] = v[i];
+}
+
+hipError_t launch_layernorm(const float* in, float* out, int M, int d, const float* ga, const float* ba,
+                            const float* addvec, int ldadd, int Tq, const float* gb, const float* bb, hipStream_t s) {
+    dim3 grid((M + 3) / 4), block(256);
+#define RGN_LN(V) hipLaunchKernelGGL(k_layernorm<V>, grid, block, 0, s, in, out, M, d, ga, ba, addvec, ldadd, Tq, gb, bb)
+    switch (d / 64) {
+        case 1: RGN_LN(1); break;
+        case 2: RGN_LN(2); break;
+        case 4: RGN_LN(4); break;
+        case 8: RGN_LN(8); break;
+        case 16: RGN_LN(16); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef RGN_LN
+    return hipGetLastError();
+}
+
+// =================================================================================================
+// Timestep embedding input: out[r,:] = pe[t_r,:]  (TimestepEmbedder.forward gather, cmdm.py:298).
+// t_r comes from the device step table (sampling loop; bit-exact timestep_map lookup of
+// _WrappedModel.__call__, respace.py:124-129) or from external int64 timesteps (rgn_denoise).
+// =================================================================================================
+__global__ void k_gather_pe(const float* __restrict__ pe, const StepCoef* __restrict__ tab, const int* __restrict__ d_step,
+                            const SampleParams* __restrict__ sp, float* __restrict__ out, int Bm, int B, int d) {
+    const int r = blockIdx.x;
+    long long t;
+    if (sp->t_ext)
+        t = sp->t_ext[r % B];
+    else
+        t = tab[*d_step].t_model;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) out[(size_t)r * d + c] = pe[(size_t)t * d + c];
+}
+hipError_t launch_gather_pe(const float* pe, const StepCoef* tab, const int* d_step, const SampleParams* sp,
+                            float* out, int Bm, int B, int d, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_pe, dim3(Bm), dim3(d >= 256 ? 256 : 64), 0, s, pe, tab, d_step, sp, out, Bm, B, d);
+    return hipGetLastError();
+}
+
+// emb_trans_dec: token 0 of every sample is emb[b] (+ pe[0])            (cmdm.py:212-218)
+__global__ void k_emb_rows(const float* __restrict__ emb, const float* __restrict__ pe, float* __restrict__ h, Dims dm,
+                           int wo_pos) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < dm.d; c += blockDim.x)
+        h[(size_t)b * dm.Tq * dm.d + c] = emb[(size_t)b * dm.d + c] + (wo_pos ? 0.f : pe[c]);
+}
+hipError_t launch_emb_rows(const float* emb, const float* pe, float* h, const Dims& dm, int wo_pos, hipStream_t s) {
+    hipLaunchKernelGGL(k_emb_rows, dim3(dm.Bm), dim3(256), 0, s, emb, pe, h, dm, wo_pos);
+    return hipGetLastError();
+}
+
+// c0[b*Tq + j, :] += pe[j, :]   (sequence_pos_encoder, cmdm.py:278-281) — hoisted, once per condition
+__global__ void k_add_pe(float* __restrict__ c0, const float* __restrict__ pe, Dims dm) {
+    const int r = blockIdx.x, j = r % dm.Tq;
+    for (int c = threadIdx.x; c < dm.d; c += blockDim.x) c0[(size_t)r * dm.d + c] += pe[(size_t)j * dm.d + c];
+}
+hipError_t launch_add_pe(float* c0, const float* pe, const Dims& dm, hipStream_t s) {
+    hipLaunchKernelGGL(k_add_pe, dim3(dm.B * dm.Tq), dim3(256), 0, s, c0, pe, dm);
+    return hipGetLastError();
+}
+
+// =================================================================================================
+// Boundary layout <-> token-major transposes, fused with the sampler arithmetic.
+// =================================================================================================
+// InputProcess permute (cmdm.py:312): x [B,F,T] -> xin[(b*Tq+etd+t), f]; 32x32 LDS tiles, both sides coalesced.
+__global__ __launch_bounds__(256) void k_pack_x(const float* __restrict__ x, float* __restrict__ xin, Dims dm) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int f = f0 + i, t = t0 + tx;
+        tile[i][tx] = (f < dm.F && t < dm.T) ? x[((size_t)b * dm.F + f) * dm.T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, f = f0 + tx;
+        if (t < dm.T && f < dm.F) xin[((size_t)b * dm.Tq + dm.etd + t) * dm.F + f] = tile[tx][i];
+    }
+}
+hipError_t launch_pack_x(const float* x, float* xin, const Dims& dm, hipStream_t s) {
+    dim3 grid((dm.T + 31) / 32, (dm.F + 31) / 32, dm.B);
+    hipLaunchKernelGGL(k_pack_x, grid, dim3(256), 0, s, x, xin, dm);
+    return hipGetLastError();
+}
+
+// ---- Philox4x32-10 + Box-Muller: counter = (element/4, loop index, sample lo, sample hi), key = seed
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned long long sample, uint32_t stream,
+                                               uint32_t elem) {
+    uint32_t r[4];
+    philox4x32_10(elem >> 2, stream, (uint32_t)sample, (uint32_t)(sample >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const int pair = (elem >> 1) & 1;
+    const float u1 = ((r[2 * pair] >> 8) + 1u) * 5.9604644775390625e-08f;   // (0,1]
+    const float u2 = (r[2 * pair + 1] >> 8) * 5.9604644775390625e-08f;      // [0,1)
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincospif(2.0f * u2, &sn, &cs);
+    return rad * ((elem & 1) ? sn : cs);
+}
+
+__global__ void k_randn(float* __restrict__ x, int B, int FT, unsigned long long seed, unsigned long long off) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * FT) return;
+    const int b = (int)(idx / FT), e = (int)(idx - (size_t)b * FT);
+    x[idx] = philox_normal(seed, off + b, 0xFFFFFFFFu, (uint32_t)e);   // stream 0xFFFFFFFF = x_T draw
+}
+hipError_t launch_randn(float* x, int B, int FT, unsigned long long seed, unsigned long long off, hipStream_t s) {
+    const size_t n = (size_t)B * FT;
+    hipLaunchKernelGGL(k_randn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, B, FT, seed, off);
+    return hipGetLastError();
+}
+
+// Sampler update, one 32(f) x 32(t) tile per block.
+//   x0 = x0_c                                   (plain)          OutputProcess permute cmdm.py:353-354
+//   x0 = x0_u + scale_b * (x0_c - x0_u)         (guided)         cfg_sampler.py:31
+//   DDPM  x' = (c1*x0 + c2*x) + sig*eps                          gaussian_diffusion.py:265-276,559
+//   DDIM  e = (sr*x - x0)/srm1 ; x' = (x0*ca + cb*e) + sig*eps   gaussian_diffusion.py:419-423,785-793
+// Products and sums are rounded separately (no FMA contraction) to follow the reference's op order.
+// Writes the new state in boundary layout [B,F,T] and token-major xin for the next step's GEMM.
+__global__ __launch_bounds__(256) void k_update(const float* __restrict__ x0tok, const float* __restrict__ scale,
+                                                 const StepCoef* __restrict__ tab, const int* __restrict__ d_step,
+                                                 const SampleParams* __restrict__ spp, float* __restrict__ xin, Dims dm) {
+    __shared__ float tc[32][33];
+    __shared__ float tu[32][33];
+    const SampleParams sp = *spp;
+    const int b = blockIdx.z, f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const size_t half = (size_t)dm.B * dm.Tq * dm.F;
+    for (int i = ty; i < 32; i += 8) {   // token-major read, coalesced along f
+        const int t = t0 + i, f = f0 + tx;
+        float c = 0.f, u = 0.f;
+        if (t < dm.T && f < dm.F) {
+            const size_t o = ((size_t)b * dm.Tq + dm.etd + t) * dm.F + f;
+            c = x0tok[o];
+            if (sp.guided) u = x0tok[half + o];
+        }
+        tc[i][tx] = c;
+        tu[i][tx] = u;
+    }
+    __syncthreads();
+    const int step = (sp.mode == 0) ? *d_step : 0;
+    StepCoef k;
+    if (sp.mode == 0) k = tab[step];
+    const size_t FT = (size_t)dm.F * dm.T;
+    const float sc = sp.guided ? scale[b] : 0.f;
+    for (int i = ty; i < 32; i += 8) {   // boundary layout, coalesced along t
+        const int f = f0 + i, t = t0 + tx;
+        float nv = 0.f;
+        if (f < dm.F && t < dm.T) {
+            float x0 = tc[tx][i];
+            if (sp.guided) {
+                const float u = tu[tx][i];
+                x0 = __fadd_rn(u, __fmul_rn(sc, __fsub_rn(x0, u)));
+            }
+            if (sp.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+            const size_t o = (size_t)b * FT + (size_t)f * dm.T + t;
+            if (sp.x0_out) sp.x0_out[o] = x0;
+            if (sp.mode == 0) {
+                const float xv = sp.x[o];
+                float eps;
+                if (sp.noise)
+                    eps = sp.noise[(size_t)(sp.first_index - step) * dm.B * FT + o];
+                else
+                    eps = philox_normal(sp.seed, sp.sample_offset + b, (uint32_t)step, (uint32_t)(f * dm.T + t));
+                if (sp.sampler == 0) {
+                    const float mean = __fadd_rn(__fmul_rn(k.c1, x0), __fmul_rn(k.c2, xv));
+                    nv = __fadd_rn(mean, __fmul_rn(k.sig_ddpm, eps));
+                } else {
+                    const float e = __fdiv_rn(__fsub_rn(__fmul_rn(k.sr, xv), x0), k.srm1);
+                    const float mean = __fadd_rn(__fmul_rn(x0, k.ca), __fmul_rn(k.cb, e));
+                    nv = __fadd_rn(mean, __fmul_rn(k.sig_ddim, eps));
+                }
+                sp.x[o] = nv;
+            }
+        }
+        tc[tx][i] = nv;
+    }
+    if (sp.mode != 0) return;
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, f = f0 + tx;
+        if (t < dm.T && f < dm.F) xin[((size_t)b * dm.Tq + dm.etd + t) * dm.F + f] = tc[i][tx];
+    }
+}
+hipError_t launch_update(const float* x0tok, const float* scale, const StepCoef* tab, const int* d_step,
+                         const SampleParams* sp, float* xin, const Dims& dm, hipStream_t s) {
+    dim3 grid((dm.T + 31) / 32, (dm.F + 31) / 32, dm.B);
+    hipLaunchKernelGGL(k_update, grid, dim3(256), 0, s, x0tok, scale, tab, d_step, sp, xin, dm);
+    return hipGetLastError();
+}
+
+__global__ void k_advance(int* d_step) { *d_step -= 1; }
+hipError_t launch_advance(int* d_step, hipStream_t s) {
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, d_step);
+    return hipGetLastError();
+}
+
+// EmbedAction.forward (cmdm.py:363-365): out[b,:] = table[action[b],:]
+__global__ void k_cond_rows(const float* __restrict__ table, const int64_t* __restrict__ action, float* __restrict__ out,
+                            int B, int d) {
+    const int b = blockIdx.x;
+    const long long a = action[b];
+    for (int c = threadIdx.x; c < d; c += blockDim.x) out[(size_t)b * d + c] = table[(size_t)a * d + c];
+}
+hipError_t launch_cond_rows(const float* table, const int64_t* action, float* out, int B, int d, hipStream_t s) {
+    hipLaunchKernelGGL(k_cond_rows, dim3(B), dim3(256), 0, s, table, action, out, B, d);
+    return hipGetLastError();
+}
+__global__ void k_fill_rows(float* __restrict__ out, const float* __restrict__ row, int rows, int d) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) out[(size_t)r * d + c] = row ? row[c] : 0.f;
+}
+hipError_t launch_fill_rows(float* out, const float* row, int rows, int d, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_rows, dim3(rows), dim3(256), 0, s, out, row, rows, d);
+    return hipGetLastError();
+}
+
+// =================================================================================================
+// next-1 row: rotation_6d_to_matrix (utils/rotation_conversions.py:513-534) — Gram-Schmidt.
+// F.normalize semantics: v / max(||v||, 1e-12).
+// =================================================================================================
+__global__ void k_rot6d(const float* __restrict__ d6, float* __restrict__ mat, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = d6 + i * 6;
+    float a1x = p[0], a1y = p[1], a1z = p[2], a2x = p[3], a2y = p[4], a2z = p[5];
+    float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
+    const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+    const float dot = b1x * a2x + b1y * a2y + b1z * a2z;
+    float b2x = a2x - dot * b1x, b2y = a2y - dot * b1y, b2z = a2z - dot * b1z;
+    const float n2 = fmaxf(sqrtf(b2x * b2x + b2y * b2y + b2z * b2z), 1e-12f);
+    b2x /= n2; b2y /= n2; b2z /= n2;
+    float* m = mat + i * 9;
+    m[0] = b1x; m[1] = b1y; m[2] = b1z;
+    m[3] = b2x; m[4] = b2y; m[5] = b2z;
+    m[6] = b1y * b2z - b1z * b2y;
+    m[7] = b1z * b2x - b1x * b2z;
+    m[8] = b1x * b2y - b1y * b2x;
+}
+hipError_t launch_rot6d(const float* d6, float* mat, long long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rot6d, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d6, mat, n);
+    return hipGetLastError();
+}
+
+// next-2 row: scipy.ndimage.gaussian_filter1d(x, sigma, axis=-1, mode='reflect', truncate=4)
+// (sample/cgenerate.py:142). One thread per output sample; taps recomputed (<= 2*4*sigma+1 of them).
+__global__ void k_gauss1d(const float* __restrict__ x, float* __restrict__ out, long long rows, int T, float sigma,
+                          int radius) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * T) return;
+    const long long r = idx / T;
+    const int t = (int)(idx - r * T);
+    const float* xr = x + r * T;
+    double wsum = 0.0, acc = 0.0;
+    const double s2 = -0.5 / ((double)sigma * sigma);
+    const int period = 2 * T;
+    for (int j = -radius; j <= radius; ++j) {
+        const double w = exp(s2 * j * j);
+        int q = (t + j) % period;
+        if (q < 0) q += period;
+        if (q >= T) q = period - 1 - q;
+        wsum += w;
+        acc += w * (double)xr[q];
+    }
+    out[idx] = (float)(acc / wsum);
+}
+hipError_t launch_gauss1d(const float* x, float* out, long long rows, int T, float sigma, hipStream_t s) {
+    const long long n = rows * T;
+    if (n <= 0) return hipSuccess;
+    const int radius = (int)(4.0f * sigma + 0.5f);
+    hipLaunchKernelGGL(k_gauss1d, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out, rows, T, sigma, radius);
+    return hipGetLastError();
+}
+
+}  // namespace rgn

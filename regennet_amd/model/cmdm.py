@@ -1,0 +1,237 @@
+"""CMDM denoiser object for arch='online' — host-side mirror of the reference's `model/cmdm.py`.
+
+The class keeps the reference's constructor keywords, attribute names and state_dict key names
+(so `load_model_wo_clip`, `model.to(dev())`, `model.eval()`, `next(model.parameters()).device`,
+`model(x, t, y=...)` behave as callers of the reference expect), but it holds the
+parameters only as a checkpoint container: `forward` hands the tensors to libregennet_hip.so, where
+the whole evaluation (cmdm.py:173-252) runs as HIP kernels. There is no eager/CPU fallback.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+class _Pose(nn.Module):          # InputProcess / OutputProcess parameter holders (cmdm.py:301-355)
+    def __init__(self, name, fin, fout):
+        super().__init__()
+        setattr(self, name, nn.Linear(fin, fout))
+
+
+class _MHA(nn.Module):           # nn.MultiheadAttention's parameter names
+    def __init__(self, d):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = nn.Linear(d, d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+
+class _DecoderLayer(nn.Module):  # nn.TransformerDecoderLayer's parameter names
+    def __init__(self, d, ff):
+        super().__init__()
+        self.self_attn = _MHA(d)
+        self.multihead_attn = _MHA(d)
+        self.linear1 = nn.Linear(d, ff)
+        self.linear2 = nn.Linear(ff, d)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d), nn.LayerNorm(d), nn.LayerNorm(d)
+
+
+class _Decoder(nn.Module):
+    def __init__(self, d, ff, n):
+        super().__init__()
+        self.layers = nn.ModuleList([_DecoderLayer(d, ff) for _ in range(n)])
+
+
+class PositionalEncoding(nn.Module):
+    """Sinusoid table buffer `pe` [max_len,1,d] (cmdm.py:265-276)."""
+
+    def __init__(self, d_model, dropout=0.1, max_len=5000):
+        super().__init__()
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-np.log(10000.0) / d_model))
+        pe = torch.zeros(max_len, d_model)
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(1))
+
+
+class TimestepEmbedder(nn.Module):
+    def __init__(self, d, sequence_pos_encoder):
+        super().__init__()
+        self.sequence_pos_encoder = sequence_pos_encoder    # shared module -> both `pe` keys
+        self.time_embed = nn.Sequential(nn.Linear(d, d), nn.SiLU(), nn.Linear(d, d))
+
+
+class EmbedAction(nn.Module):
+    def __init__(self, num_actions, d):
+        super().__init__()
+        self.action_embedding = nn.Parameter(torch.randn(num_actions, d))
+
+
+class _Rot2xyzUnavailable:
+    """model.rot2xyz needs the `smplx` package and licensed SMPL-X assets (model/rotation2xyz.py:165);
+    post-processing is outside the hot path. Assign your own callable to use it."""
+    smpl_model = None
+
+    def __call__(self, *a, **k):
+        raise NotImplementedError(self.__doc__)
+
+
+class CMDM(nn.Module):
+    def __init__(self, modeltype, njoints, nfeats, num_actions, translation, pose_rep, glob, glob_rot,
+                 num_frames=60, latent_dim=256, ff_size=1024, num_layers=8, num_heads=4, dropout=0.1,
+                 ablation=None, activation="gelu", legacy=False, data_rep="rot6d", dataset="amass", clip_dim=512,
+                 arch="trans_enc", cm_mode="add", body_model="smpl", wo_pos_emb=False, emb_trans_dec=False,
+                 clip_version=None, **kargs):
+        super().__init__()
+        if arch != "online":
+            raise NotImplementedError(
+                f"arch={arch!r}: only the shipped 'online' decoder (cmdm.py:205-227) is on the HIP hot path; "
+                "offline/trans_enc/mlp/gru are ablation architectures (SURVEY.md §2 row 3)")
+        if activation != "gelu":
+            raise NotImplementedError("activation is hard-coded to gelu by the reference factory (model_util.py:70)")
+        if data_rep not in ("rot6d", "xyz", "hml_vec"):
+            raise ValueError(data_rep)
+        if cm_mode not in ("add", "concat"):
+            raise NotImplementedError(cm_mode)
+        self.legacy, self.modeltype = legacy, modeltype
+        self.njoints, self.nfeats, self.num_actions = njoints, nfeats, num_actions
+        self.data_rep, self.dataset, self.pose_rep = data_rep, dataset, pose_rep
+        self.glob, self.glob_rot, self.translation = glob, glob_rot, translation
+        self.latent_dim, self.ff_size, self.num_layers, self.num_heads = latent_dim, ff_size, num_layers, num_heads
+        self.dropout, self.ablation, self.activation, self.clip_dim = dropout, ablation, activation, clip_dim
+        self.action_emb = kargs.get("action_emb", None)
+        self.input_feats = njoints * nfeats
+        self.normalize_output = kargs.get("normalize_encoder_output", False)
+        self.cond_mode = kargs.get("cond_mode", "no_cond")
+        self.cond_mask_prob = kargs.get("cond_mask_prob", 0.0)
+        self.arch, self.cm_mode, self.num_frames = arch, cm_mode, num_frames
+        self.emb_trans_dec, self.wo_pos_emb, self.body_model = emb_trans_dec, wo_pos_emb, body_model
+        self.clip_version = clip_version
+        if self.cond_mode not in ("no_cond", "action", "text"):
+            raise NotImplementedError(f"cond_mode={self.cond_mode!r}")
+
+        d = latent_dim
+        self.input_process = _Pose("poseEmbedding", self.input_feats, d)
+        self.cmo_process = _Pose("poseEmbedding", self.input_feats, d)
+        self.sequence_pos_encoder = PositionalEncoding(d, dropout)
+        if cm_mode == "concat":
+            self.fuse_process = nn.Linear(2 * d, d)
+        self.seqTransDecoder = _Decoder(d, ff_size, num_layers)
+        self.embed_timestep = TimestepEmbedder(d, self.sequence_pos_encoder)
+        if self.cond_mode == "text":
+            self.embed_text = nn.Linear(clip_dim, d)
+            # CLIP ViT-B/32 (cmdm.py:116-127) is a third-party model that is not on the hot path: supply
+            # y['text_features'] [B,clip_dim] or assign `model.encode_text = callable(list[str]) -> Tensor`.
+        if self.cond_mode == "action":
+            self.embed_action = EmbedAction(num_actions, d)
+        self.output_process = _Pose("poseFinal", d, self.input_feats)
+        self.rot2xyz = _Rot2xyzUnavailable()
+
+        self.precision = os.environ.get("REGENNET_PRECISION", kargs.get("precision", "f32"))
+        self._engine = None
+        self._engine_stale = True
+        self._cond_key = None
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    # ---- nn.Module plumbing ---------------------------------------------------------------------------
+    def parameters_wo_clip(self):
+        return [p for name, p in self.named_parameters() if not name.startswith("clip_model.")]
+
+    def load_state_dict(self, state_dict, strict=True):
+        self._engine_stale = True
+        return super().load_state_dict(state_dict, strict=strict)
+
+    def _apply(self, fn, *a, **k):
+        self._engine_stale = True
+        return super()._apply(fn, *a, **k)
+
+    def encode_text(self, raw_text):
+        raise NotImplementedError(
+            "CLIP text encoding (cmdm.py:153-166) is out of scope: pass y['text_features'] [B,clip_dim] "
+            "or assign model.encode_text")
+
+    def mask_cond(self, cond, force_mask=False):
+        return torch.zeros_like(cond) if force_mask else cond   # eval-mode behaviour of cmdm.py:129-137
+
+    def generate_square_subsequent_mask(self, sz):
+        return torch.full((sz, sz), float("-inf")).triu(1)      # cmdm.py:168-171
+
+    # ---- engine management ----------------------------------------------------------------------------
+    def engine_config(self):
+        return dict(njoints=self.njoints, nfeats=self.nfeats, num_frames=self.num_frames, latent_dim=self.latent_dim,
+                    ff_size=self.ff_size, num_heads=self.num_heads, layers=self.num_layers, cm_mode=self.cm_mode,
+                    cond_mode=self.cond_mode, num_actions=self.num_actions, clip_dim=self.clip_dim,
+                    emb_trans_dec=self.emb_trans_dec, wo_pos_emb=self.wo_pos_emb)
+
+    def _get_engine(self, B):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("regennet_amd CMDM runs on an AMD GPU only: call model.to(dist_util.dev()) first "
+                               "(there is no CPU fallback; the CPU restatement lives in oracle/ as a test checker)")
+        eng = self._engine
+        if eng is None or self._engine_stale or B > eng.max_batch or eng.precision != self.precision:
+            if eng is not None:
+                torch.cuda.synchronize(dev)
+                eng.close()
+            max_b = max(B, eng.max_batch if eng is not None else 0)
+            eng = _lib.Engine(self.engine_config(), max_b, dev.index or 0, self.precision)
+            for k, v in self.state_dict().items():
+                if k.startswith("clip_model."):
+                    continue
+                eng.load_weight(k, v.detach().float().cpu().numpy())
+            eng.finalize()
+            self._engine, self._engine_stale, self._cond_key = eng, False, None
+        return eng, dev
+
+    def _rgn_bind(self, B, y, device=None, guided=False):
+        """Bind model_kwargs['y'] on the engine (idempotent for an unchanged y). Returns (engine, guided, device)."""
+        eng, dev = self._get_engine(B)
+        cm = y["cmotion"]
+        assert tuple(cm.shape) == (B, self.njoints, self.nfeats, self.num_frames), \
+            f"y['cmotion'] {tuple(cm.shape)} != {(B, self.njoints, self.nfeats, self.num_frames)}"
+        action = text = scale = None
+        if self.cond_mode == "action":
+            action = y["action"]
+        if self.cond_mode == "text":
+            text = y.get("text_features", None)
+            if text is None:
+                text = self.encode_text(y["text"])
+        if guided:
+            scale = y["scale"]
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) if t is not None else None
+                    for t in (cm, action, text, scale)) + (B,)
+        if key != self._cond_key:
+            cm = cm.to(device=dev, dtype=torch.float32).contiguous()
+            if action is not None:
+                action = action.to(device=dev).reshape(B, -1)[:, 0].to(torch.int64).contiguous()
+            if text is not None:
+                text = text.to(device=dev, dtype=torch.float32).contiguous()
+                assert tuple(text.shape) == (B, self.clip_dim)
+            if scale is not None:
+                scale = scale.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+                assert tuple(scale.shape) == (B,)
+            eng.set_condition(B, cm, action, text, scale, torch.cuda.current_stream(dev).cuda_stream)
+            self._keep = (cm, action, text, scale)   # keep device copies alive until the stream consumed them
+            self._cond_key = key
+        return eng, guided, dev
+
+    # ---- cmdm.py:173-252 -------------------------------------------------------------------------------
+    def forward(self, x, timesteps, y=None, _guided=False):
+        """x [B,njoints,nfeats,T] (x_t); timesteps [B] int; y dict with 'cmotion' (+ 'action'/'text_features',
+        'uncond', 'scale'). Returns x0_hat [B,njoints,nfeats,T] on x's device."""
+        bs, njoints, nfeats, nframes = x.shape
+        assert (njoints, nfeats, nframes) == (self.njoints, self.nfeats, self.num_frames)
+        eng, _, dev = self._rgn_bind(bs, y, guided=_guided)
+        assert tuple(timesteps.shape) == (bs,)
+        xc = x.to(device=dev, dtype=torch.float32).contiguous()
+        tc = timesteps.to(device=dev, dtype=torch.int64).contiguous()
+        out = torch.empty_like(xc)
+        flags = (_lib.FLAG_GUIDED if _guided else 0) | (_lib.FLAG_UNCOND if y.get("uncond", False) else 0)
+        eng.denoise(xc, tc, flags, out, torch.cuda.current_stream(dev).cuda_stream)
+        return out

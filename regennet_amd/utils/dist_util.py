@@ -1,0 +1,91 @@
+"""Distributed helpers — MI355X counterpart of the reference's `utils/dist_util.py`.
+
+The reference rendezvouses over mpi4py and pins 4 GPUs per node (dist_util.py:15-42). Here one process
+drives one GPU (8 per node), rendezvous comes from torchrun's environment, and the backend is
+`nccl` (= RCCL on ROCm, xGMI inside a node) or `gloo` on CPU-only hosts. Sampling shards only the
+batch axis: the single collective is ONE broadcast of the flat packed-weight buffer (replacing the
+per-tensor `sync_params`, dist_util.py:77-83) plus an optional all_gather of the outputs.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+_device = None
+
+
+def setup_dist(device=None):
+    """setup_dist() (dist_util.py:20-42): bind this process to its GPU; join the process group when launched
+    under torchrun (RANK/WORLD_SIZE/MASTER_ADDR/MASTER_PORT/LOCAL_RANK)."""
+    global _device
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        idx = local_rank % torch.cuda.device_count() if device is None else int(device)
+        torch.cuda.set_device(idx)
+        _device = torch.device(f"cuda:{idx}")
+    else:
+        _device = torch.device("cpu")
+    if world_size > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if _device.type == "cuda":
+            kw["device_id"] = _device
+        dist.init_process_group(backend="nccl" if _device.type == "cuda" else "gloo", **kw)
+    return _device
+
+
+def dev():
+    """dev() (dist_util.py:45-51)."""
+    if _device is not None:
+        return _device
+    return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+
+def world():
+    return (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+
+
+def shard_bounds(total, rank=None, world_size=None):
+    """Contiguous batch shard [lo, hi) of `total` samples for this rank."""
+    r, w = world() if rank is None else (rank, world_size)
+    base, extra = divmod(total, w)
+    lo = r * base + min(r, extra)
+    return lo, lo + base + (1 if r < extra else 0)
+
+
+def broadcast_flat(buf, src=0):
+    """Broadcast one flat tensor from `src` (the packed weight blob): one collective over xGMI."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(buf, src)
+    return buf
+
+
+def sync_params(params):
+    """dist_util.py:77-83, but as a single flattened broadcast instead of one per tensor."""
+    params = list(params)
+    if not dist.is_initialized() or dist.get_world_size() == 1 or not params:
+        return
+    flat = torch.cat([p.detach().reshape(-1) for p in params])
+    dist.broadcast(flat, 0)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            p.copy_(flat[off:off + n].view_as(p))
+            off += n
+
+
+def all_gather_samples(local, total):
+    """Gather per-rank sample shards [b_r, ...] back into [total, ...] on every rank."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    w = dist.get_world_size()
+    sizes = [shard_bounds(total, r, w) for r in range(w)]
+    mx = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    outs = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(outs, pad)
+    return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(outs, sizes)], dim=0)

@@ -1,0 +1,199 @@
+"""GPU: the HIP path (through the C-ABI) against golden vectors recorded from the reference and against
+the oracle on the same seeded inputs. Tolerance from BASELINE.json north_star: 1e-3 abs on rot6d
+(written per test); timestep indices bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import build_hip, fixture_inputs, y_to_device
+
+pytestmark = pytest.mark.gpu
+
+PRECISIONS = ["f32"]
+TOL = {"f32": 2e-4, "bf16x3": 1e-3}       # abs; both inside the 1e-3 contract
+
+FWD = ["tiny_fwd", "tiny_fwd_cfg", "tiny_add_fwd", "tiny_etd_fwd", "tiny_text_fwd_cfg", "ntu_fwd",
+       "ntu_action_fwd_cfg", "chi3d_fwd"]
+LOOPS = ["tiny_ddpm10", "tiny_ddim10_cfg", "tiny_add_ddpm1000", "tiny_text_ddim20_cfg", "ntu_ddpm50",
+         "ntu_action_ddim100_cfg", "text150_ddim50_cfg"]
+
+
+def _wrap(model, guided):
+    if not guided:
+        return model
+    from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    return ClassifierFreeSampleModel(model)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("name", FWD)
+def test_denoiser_forward(golden, name, precision):
+    g = golden(name)
+    cfg, sd, y, x = fixture_inputs(g, loop=False)
+    model, _ = build_hip(cfg, sd, precision=precision)
+    fm = _wrap(model, bool(g["guided"]))
+    yd = y_to_device(y)
+    xd = torch.from_numpy(x).cuda()
+    for i, t in enumerate(g["ts"]):
+        out = fm(xd, torch.full((x.shape[0],), int(t), dtype=torch.long, device="cuda"), y=yd)
+        assert out.shape == xd.shape and out.dtype == torch.float32 and out.is_cuda
+        err = np.abs(out.cpu().numpy() - g["out"][i]).max()
+        assert err < TOL[precision], (name, int(t), err)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("name", LOOPS)
+def test_sampling_loop(golden, name, precision):
+    g = golden(name)
+    cfg, sd, y, tape = fixture_inputs(g, loop=True)
+    model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision=precision)
+    # bit-exact timestep indices (respace.py:124-129)
+    step = 2 if bool(g["guided"]) else 1
+    assert diffusion.timestep_map[::-1] == g["model_t"][::step].tolist()
+    fm = _wrap(model, bool(g["guided"]))
+    shape = (int(g["B"]), cfg["njoints"], cfg["nfeats"], cfg["num_frames"])
+    fn = diffusion.p_sample_loop if str(g["mode"]) == "ddpm" else diffusion.ddim_sample_loop
+    out = fn(fm, shape, clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
+    err = np.abs(out.cpu().numpy() - g["final"]).max()
+    assert err < 1e-3, (name, err)
+    if "x0" in g:   # per-step trace through the progressive API
+        pfn = diffusion.p_sample_loop_progressive if str(g["mode"]) == "ddpm" else diffusion.ddim_sample_loop_progressive
+        for k, o in enumerate(pfn(fm, shape, clip_denoised=False, model_kwargs={"y": y_to_device(y)},
+                                  noise_tape=torch.from_numpy(tape))):
+            assert np.abs(o["pred_xstart"].cpu().numpy() - g["x0"][k]).max() < 1e-3
+            assert np.abs(o["sample"].cpu().numpy() - g["x"][k]).max() < 1e-3
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_headline_1000_step_ddpm(golden, precision):
+    """BASELINE configs[0]/[1] shape: NTU120-AS, 1000-step DDPM, identical noise; <= 1e-3 abs vs the reference."""
+    g = golden("ntu_ddpm1000")
+    cfg, sd, y, tape = fixture_inputs(g, loop=True)
+    model, diffusion = build_hip(cfg, sd, precision=precision)
+    assert diffusion.timestep_map == list(range(1000)) and g["model_t"].tolist() == list(range(999, -1, -1))
+    shape = (2, 56, 6, 60)
+    out = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y_to_device(y)},
+                                  noise_tape=torch.from_numpy(tape), use_graph=True)
+    err = np.abs(out.cpu().numpy() - g["final"]).max()
+    assert err < 1e-3, err
+
+
+def test_graph_replay_equals_eager(golden):
+    g = golden("ntu_ddpm50")
+    cfg, sd, y, tape = fixture_inputs(g, loop=True)
+    model, diffusion = build_hip(cfg, sd, resp="50")
+    shape = (2, 56, 6, 60)
+    kw = dict(clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
+    a = diffusion.p_sample_loop(model, shape, use_graph=False, **kw)
+    b = diffusion.p_sample_loop(model, shape, use_graph=True, **kw)
+    c = diffusion.p_sample_loop(model, shape, use_graph=True, **kw)   # replays the cached graph
+    assert torch.equal(a, b) and torch.equal(b, c)
+
+
+def test_oracle_parity_random_inputs():
+    """HIP vs oracle on fresh seeded inputs (not the golden ones), ragged batch, mid-size model."""
+    from oracle import regennet_oracle as orc
+    from regennet_amd import synth
+    cfg = synth.get_config("ntu_action", layers=3, num_frames=37)
+    sd = synth.make_state_dict(cfg, seed=7)
+    B = 5
+    model, diffusion = build_hip(cfg, sd, resp="ddim20")
+    y = {"cmotion": synth.make_cmotion(cfg, B, seed=21), "action": synth.make_actions(cfg, B, seed=22)}
+    tape = synth.make_noise_tape(cfg, B, 20, seed=23)
+    ty = {k: torch.from_numpy(v) for k, v in y.items()}
+    ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", "ddim20"), tape, ty, mode="ddim").numpy()
+    out = diffusion.ddim_sample_loop(model, (B, 56, 6, 37), clip_denoised=False, model_kwargs={"y": y_to_device(y)},
+                                     noise_tape=torch.from_numpy(tape))
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-3
+
+
+def test_philox_stream_properties():
+    """On-device N(0,1): moments, world-size invariance (sample_offset), determinism, x_T != per-step stream."""
+    from regennet_amd import synth
+    cfg = synth.get_config("ntu", layers=1)
+    sd = synth.make_state_dict(cfg, seed=0)
+    model, diffusion = build_hip(cfg, sd, resp="ddim5")
+    eng, dev = model._get_engine(8)
+    st = torch.cuda.current_stream().cuda_stream
+    a = torch.empty(8, 56, 6, 60, device="cuda")
+    eng.randn(a, 8, 1234, 0, st)
+    b = torch.empty(4, 56, 6, 60, device="cuda")
+    eng.randn(b, 4, 1234, 4, st)
+    assert torch.equal(a[4:], b)                       # shard [4,8) of an 8-batch == 4-batch at offset 4
+    c = torch.empty_like(a)
+    eng.randn(c, 8, 1235, 0, st)
+    assert not torch.equal(a, c)
+    n = a.numel()
+    assert abs(a.mean().item()) < 4 / n ** 0.5 and abs(a.var().item() - 1) < 0.02
+    assert abs((a ** 3).mean().item()) < 0.05 and abs((a ** 4).mean().item() - 3) < 0.1
+    # sampling with Philox: same seed -> same samples; sharded == unsharded
+    y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, 8)).cuda()}
+    s1 = diffusion.p_sample_loop(model, (8, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y}, seed=77)
+    s2 = diffusion.p_sample_loop(model, (8, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y}, seed=77)
+    assert torch.equal(s1, s2)
+    y2 = {"cmotion": y["cmotion"][4:].contiguous()}
+    s3 = diffusion.p_sample_loop(model, (4, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y2}, seed=77, sample_offset=4)
+    assert torch.allclose(s1[4:], s3, atol=1e-5)
+    assert torch.isfinite(s1).all()
+
+
+def test_postproc_rows(golden):
+    g = golden("postproc")
+    from regennet_amd import synth
+    cfg = synth.get_config("tiny")
+    model, _ = build_hip(cfg, synth.make_state_dict(cfg, seed=0))
+    eng, _ = model._get_engine(1)
+    st = torch.cuda.current_stream().cuda_stream
+    d6 = torch.from_numpy(g["d6"]).cuda().contiguous()
+    mat = torch.empty(d6.shape[:-1] + (3, 3), device="cuda")
+    eng.rot6d_to_matrix(d6, mat, d6.numel() // 6, st)
+    assert np.abs(mat.cpu().numpy() - g["mats"]).max() < 1e-6
+    for xk, gk in (("x", "gf"), ("x3", "gf3")):
+        x = torch.from_numpy(g[xk]).cuda().contiguous()
+        out = torch.empty_like(x)
+        eng.gaussian_filter1d(x, out, x.numel() // x.shape[-1], x.shape[-1], 1.0, st)
+        assert np.abs(out.cpu().numpy() - g[gk]).max() < 1e-6
+
+
+def test_boundary_protocol_and_errors():
+    """Model/diffusion object protocol of SURVEY.md §8b and error behaviour of the C-ABI."""
+    from regennet_amd import _lib, synth
+    from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    from regennet_amd.utils.model_util import load_model_wo_clip
+    cfg = synth.get_config("tiny")
+    sd = synth.make_state_dict(cfg, seed=0)
+    model, diffusion = build_hip(cfg, sd, resp="ddim5")
+    assert next(model.parameters()).device.type == "cuda"
+    assert (model.njoints, model.nfeats, model.data_rep, model.cond_mode) == (5, 6, "rot6d", "action")
+    assert set(model.state_dict().keys()) == set(sd.keys())
+    with pytest.raises(AssertionError):                       # unexpected key (model_util.py:7)
+        load_model_wo_clip(model, {**{k: torch.from_numpy(v) for k, v in sd.items()}, "bogus.weight": torch.zeros(1)})
+    load_model_wo_clip(model, {**{k: torch.from_numpy(v) for k, v in sd.items()}, })
+    model.to("cuda:0")
+    B = 2
+    y = y_to_device({"cmotion": synth.make_cmotion(cfg, B), "action": synth.make_actions(cfg, B)})
+    with pytest.raises(AssertionError):                       # shape mismatch
+        diffusion.p_sample_loop(model, (B, 5, 6, 9), clip_denoised=False, model_kwargs={"y": y})
+    with pytest.raises(NotImplementedError):
+        diffusion.ddim_sample_loop(model, (B, 5, 6, 8), model_kwargs={"y": y}, dump_steps=[1])
+    with pytest.raises(KeyError):                             # guided needs y['scale'] (cfg_sampler.py:31)
+        diffusion.p_sample_loop(ClassifierFreeSampleModel(model), (B, 5, 6, 8), clip_denoised=False, model_kwargs={"y": y})
+    dumped = diffusion.p_sample_loop(model, (B, 5, 6, 8), clip_denoised=False, model_kwargs={"y": y}, dump_steps=[0, 4], seed=3)
+    assert len(dumped) == 2 and dumped[0].shape == (B, 5, 6, 8)
+    clipped = diffusion.p_sample_loop(model, (B, 5, 6, 8), clip_denoised=True, model_kwargs={"y": y}, seed=3)
+    assert torch.isfinite(clipped).all()
+    # y is never mutated
+    assert set(y.keys()) == {"cmotion", "action"}
+    # raw C-ABI error codes
+    eng = _lib.Engine(cfg, 2, 0, "f32")
+    with pytest.raises(_lib.RgnError) as e:
+        eng.load_weight("not.a.key", np.zeros((1,), np.float32))
+    assert e.value.code == -2
+    with pytest.raises(_lib.RgnError) as e:
+        eng.load_weight("fuse_process.bias", np.zeros((3,), np.float32))
+    assert e.value.code == -3
+    eng.load_weight("clip_model.anything", np.zeros((3,), np.float32))   # accepted and ignored
+    with pytest.raises(_lib.RgnError) as e:
+        eng.finalize()
+    assert e.value.code == -4 and "missing keys" in str(e.value)
+    eng.close()
