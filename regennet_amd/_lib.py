@@ -71,6 +71,12 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` from the repo root.")
+    # PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7). It must be in the process BEFORE
+    # our library so that both bind to ONE HIP runtime (streams/events/pointers are shared with torch).
+    import torch  # noqa: F401
+    rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        C.CDLL(rt, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)      # AttributeError if the library does not export a declared symbol

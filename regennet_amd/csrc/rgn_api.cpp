@@ -84,6 +84,8 @@ struct rgn_ctx {
     int* d_step = nullptr;
     SampleParams* d_sp = nullptr;
     std::vector<void*> allocs;
+    hipStream_t stream = nullptr;      // all work runs here; callers' streams are joined by events
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
 
     // schedule (host copies)
     int S = 0;
@@ -141,6 +143,19 @@ const char* kclass_names[KC_COUNT] = {"gemm_mfma", "attention", "layernorm", "em
             (h)->prof_ev.push_back(_pe);                                         \
         }                                                                        \
     } while (0)
+
+// Work is enqueued on the handle's own non-blocking stream (capturable, unlike the legacy null stream
+// torch hands over by default) and ordered after / before the caller's stream with events.
+int stream_enter(rgn_ctx* c, hipStream_t user) {
+    RGN_HIP(c, hipEventRecord(c->ev_in, user));
+    RGN_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    return RGN_OK;
+}
+int stream_exit(rgn_ctx* c, hipStream_t user) {
+    RGN_HIP(c, hipEventRecord(c->ev_out, c->stream));
+    RGN_HIP(c, hipStreamWaitEvent(user, c->ev_out, 0));
+    return RGN_OK;
+}
 
 void build_expected(rgn_ctx* c) {
     const int64_t d = c->d, F = c->F, ff = c->ff;
@@ -435,6 +450,9 @@ int rgn_destroy(rgn_handle h) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
+    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+    if (h->ev_out) (void)hipEventDestroy(h->ev_out);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->dblob) (void)hipFree(h->dblob);
     delete h;
@@ -590,6 +608,9 @@ int rgn_finalize_weights(rgn_handle h) {
     if ((rc = ws_alloc(c, &c->d_step, (size_t)4))) return rc;
     if ((rc = ws_alloc(c, &c->d_sp, (size_t)1))) return rc;
     RGN_HIP(c, configure_attention(c->Tq, c->d / c->H));
+    RGN_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    RGN_HIP(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    RGN_HIP(c, hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
     RGN_HIP(c, hipMemset(c->xin, 0, Mb * F * sizeof(float)));
     RGN_HIP(c, hipMemset(c->cmo_in, 0, Mb * F * sizeof(float)));
     RGN_HIP(c, hipMemset(c->d_step, 0, 4 * sizeof(int)));
@@ -642,8 +663,10 @@ int rgn_set_condition(rgn_handle h, int32_t B, const float* cmotion, const int64
     if (!cmotion) return c->fail(RGN_ERR_INVALID_ARG, "rgn_set_condition: y['cmotion'] is required (cmdm.py:189)");
     if (c->cfg.cond_mode == RGN_COND_ACTION && !action) return c->fail(RGN_ERR_INVALID_ARG, "rgn_set_condition: y['action'] required");
     if (c->cfg.cond_mode == RGN_COND_TEXT && !text_feat) return c->fail(RGN_ERR_INVALID_ARG, "rgn_set_condition: text features required");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = c->stream;
     RGN_HIP(c, hipSetDevice(c->cfg.device));
+    int rc0 = stream_enter(c, us);
+    if (rc0) return rc0;
     const Dims dm = make_dims(c, B, false);
     const int d = c->d;
     // hoisted: c0 = cmo_process(cmotion) -> fuse half + all constant biases + positional encoding
@@ -664,7 +687,7 @@ int rgn_set_condition(rgn_handle h, int32_t B, const float* cmotion, const int64
     if (scale) RGN_HIP(c, hipMemcpyAsync(c->scale, scale, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
     c->B = B;
     c->have_cond = true;
-    return RGN_OK;
+    return stream_exit(c, us);
 }
 
 int rgn_denoise(rgn_handle h, const float* x, const int64_t* t, int32_t flags, float* out, void* stream) {
@@ -676,8 +699,10 @@ int rgn_denoise(rgn_handle h, const float* x, const int64_t* t, int32_t flags, f
     if (guided && c->cfg.cond_mode == RGN_COND_NONE)
         return c->fail(RGN_ERR_INVALID_ARG, "rgn_denoise: guidance needs cond_mode text/action (cfg_sampler.py:26)");
     if (guided && !c->cond_has_scale) return c->fail(RGN_ERR_STATE, "rgn_denoise: guided evaluation needs y['scale']");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = c->stream;
     RGN_HIP(c, hipSetDevice(c->cfg.device));
+    int rc = stream_enter(c, us);
+    if (rc) return rc;
     const Dims dm = make_dims(c, c->B, guided);
     SampleParams sp{};
     sp.x0_out = out;
@@ -686,7 +711,9 @@ int rgn_denoise(rgn_handle h, const float* x, const int64_t* t, int32_t flags, f
     sp.guided = guided;
     RGN_HIP(c, hipMemcpyAsync(c->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
     RGN_LAUNCH(c, KC_UPDATE, s, launch_pack_x(x, c->xin, dm, s));
-    return run_eval(c, c->B, guided, uncond, s);
+    rc = run_eval(c, c->B, guided, uncond, s);
+    if (rc) return rc;
+    return stream_exit(c, us);
 }
 
 int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, float* x, const float* noise, uint64_t seed,
@@ -703,10 +730,11 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
     if (guided && c->cfg.cond_mode == RGN_COND_NONE)
         return c->fail(RGN_ERR_INVALID_ARG, "rgn_sample_range: guidance needs cond_mode text/action (cfg_sampler.py:26)");
     if (guided && !c->cond_has_scale) return c->fail(RGN_ERR_STATE, "rgn_sample_range: guided sampling needs y['scale']");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = c->stream;
     RGN_HIP(c, hipSetDevice(c->cfg.device));
     int rc = build_step_table(c, eta);
     if (rc) return rc;
+    if ((rc = stream_enter(c, us))) return rc;
     const Dims dm = make_dims(c, c->B, guided != 0);
     SampleParams sp{};
     sp.x = x;
@@ -755,25 +783,31 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
             RGN_LAUNCH(c, KC_MISC, s, launch_advance(c->d_step, s));
         }
     }
-    return RGN_OK;
+    return stream_exit(c, us);
 }
 
 int rgn_randn(rgn_handle h, float* x, int32_t B, uint64_t seed, uint64_t sample_offset, void* stream) {
     if (!h) return RGN_ERR_INVALID_ARG;
     if (!x || B <= 0) return h->fail(RGN_ERR_INVALID_ARG, "rgn_randn: null x or B <= 0");
     RGN_HIP(h, hipSetDevice(h->cfg.device));
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_randn: weights not finalized");
+    hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = h->stream;
+    int rc = stream_enter(h, us);
+    if (rc) return rc;
     RGN_LAUNCH(h, KC_UPDATE, s, launch_randn(x, B, h->F * h->cfg.num_frames, seed, sample_offset, s));
-    return RGN_OK;
+    return stream_exit(h, us);
 }
 
 int rgn_rot6d_to_matrix(rgn_handle h, const float* d6, float* mat, int64_t n, void* stream) {
     if (!h) return RGN_ERR_INVALID_ARG;
     if (n < 0 || (n > 0 && (!d6 || !mat))) return h->fail(RGN_ERR_INVALID_ARG, "rgn_rot6d_to_matrix: bad argument");
     RGN_HIP(h, hipSetDevice(h->cfg.device));
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_rot6d_to_matrix: weights not finalized");
+    hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = h->stream;
+    int rc = stream_enter(h, us);
+    if (rc) return rc;
     RGN_LAUNCH(h, KC_MISC, s, launch_rot6d(d6, mat, n, s));
-    return RGN_OK;
+    return stream_exit(h, us);
 }
 
 int rgn_gaussian_filter1d(rgn_handle h, const float* x, float* out, int64_t rows, int32_t T, float sigma, void* stream) {
@@ -781,9 +815,12 @@ int rgn_gaussian_filter1d(rgn_handle h, const float* x, float* out, int64_t rows
     if (rows < 0 || T <= 0 || !(sigma > 0.f) || (rows > 0 && (!x || !out)))
         return h->fail(RGN_ERR_INVALID_ARG, "rgn_gaussian_filter1d: bad argument");
     RGN_HIP(h, hipSetDevice(h->cfg.device));
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_gaussian_filter1d: weights not finalized");
+    hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = h->stream;
+    int rc = stream_enter(h, us);
+    if (rc) return rc;
     RGN_LAUNCH(h, KC_MISC, s, launch_gauss1d(x, out, rows, T, sigma, s));
-    return RGN_OK;
+    return stream_exit(h, us);
 }
 
 int rgn_profile_enable(rgn_handle h, int32_t on) {
