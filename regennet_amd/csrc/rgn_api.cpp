@@ -213,7 +213,7 @@ Lin pack_linear(rgn_ctx* c, const float* W, const float* bias, int N, int K) {
     Lin L;
     L.N = N;
     L.K = K;
-    L.Kp = (int)align_up((size_t)K, 16);
+    L.Kp = (int)align_up((size_t)K, 32);
     std::vector<float> w((size_t)N * L.Kp, 0.f);
     std::vector<uint16_t> hi((size_t)N * L.Kp, 0), lo((size_t)N * L.Kp, 0);
     for (int n = 0; n < N; ++n)

@@ -139,14 +139,178 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// BF16X3 / BF16 precision modes: v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+//   BF16X3: every fp32 operand is split x = hi + lo (both bf16, round-to-nearest-even) and the product
+//           is formed as ah*bh + ah*bl + al*bh (the al*bl term, ~2^-18 relative, is dropped): three MFMAs
+//           per tile pair, ~2^-16 relative accuracy per product — inside the 1e-3 end-to-end tolerance
+//           where plain bf16 (2^-9) is not (SURVEY.md §7 "Precision vs. the 1e-3 abs tolerance").
+//   Weights are pre-split on the host (Whi/Wlo [N,Kp] bf16); activations stay fp32 in HBM and are
+//   split while being staged into LDS (v_cvt_pk_bf16_f32), so the residual stream never loses bits.
+// Tile 128x128x32, 4 waves (2x2), wave tile 64x64 = 2x2 MFMA tiles; LDS rows padded to 40 bf16 (80 B)
+// -> the 16 lanes of each ds_read_b128 group hit 16 disjoint bank quads.
+// Blocks are remapped so that the column tiles of one A row-block run on the same XCD (shared L2).
+// -------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int H_BM = 128, H_BN = 128, H_BK = 32, H_LD = H_BK + 8;   // bf16 elements per LDS row
+
+__device__ __forceinline__ void split_bf16(const f32x4 v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(v[j] - (float)h);
+    }
+}
+
+template <bool X3, bool VEC_A>
+__global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs g, int nbx, int nby) {
+    __shared__ __attribute__((aligned(16))) __bf16 Ah[H_BM * H_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Al[X3 ? H_BM * H_LD : 8];
+    __shared__ __attribute__((aligned(16))) __bf16 Wh[H_BN * H_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Wl[X3 ? H_BN * H_LD : 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware bijective remap: hardware places block b on XCD b%8; give each XCD a contiguous range of
+    // virtual ids (n-tile fastest) so one A row-block is fetched into a single XCD's L2.
+    const int nwg = nbx * nby, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int m0 = (vid / nbx) * H_BM, n0 = (vid % nbx) * H_BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    const int ar = tid >> 3, ak = (tid & 7) * 4;     // A staging: 8 threads x float4 cover one 32-float row
+    const int wr = tid >> 2, wk = (tid & 3) * 8;     // W staging: 4 threads x 8 bf16 cover one 32-elem row
+    f32x4 ra[4];
+    u32x4 rwh[2], rwl[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + ar + 32 * i, k = k0 + ak;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < g.M) {
+                const float* p = g.A + (size_t)m * g.lda + k;
+                if (VEC_A) {
+                    if (k < g.K) v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (k + j < g.K) v[j] = p[j];
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int n = n0 + wr + 64 * i;
+            u32x4 h = {0u, 0u, 0u, 0u}, l = {0u, 0u, 0u, 0u};
+            if (n < g.N) {
+                const size_t o = (size_t)n * g.Kp + k0 + wk;
+                h = *reinterpret_cast<const u32x4*>(g.Whi + o);
+                if (X3) l = *reinterpret_cast<const u32x4*>(g.Wlo + o);
+            }
+            rwh[i] = h;
+            rwl[i] = l;
+        }
+    };
+    const int nk = g.Kp / H_BK;
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x4 hi, lo;
+            split_bf16(ra[i], hi, lo);
+            *reinterpret_cast<bf16x4*>(&Ah[(ar + 32 * i) * H_LD + ak]) = hi;
+            if (X3) *reinterpret_cast<bf16x4*>(&Al[(ar + 32 * i) * H_LD + ak]) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<u32x4*>(&Wh[(wr + 64 * i) * H_LD + wk]) = rwh[i];
+            if (X3) *reinterpret_cast<u32x4*>(&Wl[(wr + 64 * i) * H_LD + wk]) = rwl[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) gload((kt + 1) * H_BK);
+#pragma unroll
+        for (int ks = 0; ks < H_BK; ks += 16) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ao = (wm * 64 + t * 32 + (lane & 31)) * H_LD + ks + 8 * (lane >> 5);
+                const int bo = (wn * 64 + t * 32 + (lane & 31)) * H_LD + ks + 8 * (lane >> 5);
+                ah[t] = *reinterpret_cast<const bf16x8*>(&Ah[ao]);
+                bh[t] = *reinterpret_cast<const bf16x8*>(&Wh[bo]);
+                if (X3) {
+                    al[t] = *reinterpret_cast<const bf16x8*>(&Al[ao]);
+                    bl[t] = *reinterpret_cast<const bf16x8*>(&Wl[bo]);
+                }
+            }
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) {
+                    if (X3) {   // small terms first, then the leading product
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ta], bh[tb], acc[ta][tb], 0, 0, 0);
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ta], bl[tb], acc[ta][tb], 0, 0, 0);
+                    }
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ta], bh[tb], acc[ta][tb], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int n = n0 + wn * 64 + tb * 32 + (lane & 31);
+        if (n >= g.N) continue;
+        const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + wm * 64 + ta * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                if (m >= g.M) continue;
+                float v = acc[ta][tb][i] + bias;
+                if (g.add) {
+                    const int arow = g.add_mod ? (m % g.add_mod) : m;
+                    v += g.add[(size_t)arow * g.ldadd + n];
+                }
+                g.C[(size_t)m * g.ldc + n] = act_apply(v, g.act);
+            }
+        }
+    }
+}
+
 hipError_t launch_gemm(const GemmArgs& g, int precision, hipStream_t s) {
-    (void)precision;
-    dim3 grid((g.N + G_BN - 1) / G_BN, (g.M + G_BM - 1) / G_BM);
     const bool vec = (g.lda % 4 == 0) && (g.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
-    if (vec)
-        hipLaunchKernelGGL(k_gemm_f32<true>, grid, dim3(256), 0, s, g);
-    else
-        hipLaunchKernelGGL(k_gemm_f32<false>, grid, dim3(256), 0, s, g);
+    if (precision == 0) {
+        dim3 grid((g.N + G_BN - 1) / G_BN, (g.M + G_BM - 1) / G_BM);
+        if (vec)
+            hipLaunchKernelGGL(k_gemm_f32<true>, grid, dim3(256), 0, s, g);
+        else
+            hipLaunchKernelGGL(k_gemm_f32<false>, grid, dim3(256), 0, s, g);
+        return hipGetLastError();
+    }
+    const int nbx = (g.N + H_BN - 1) / H_BN, nby = (g.M + H_BM - 1) / H_BM;
+    dim3 grid(nbx * nby);
+    if (precision == 1) {
+        if (vec)
+            hipLaunchKernelGGL((k_gemm_bf16<true, true>), grid, dim3(256), 0, s, g, nbx, nby);
+        else
+            hipLaunchKernelGGL((k_gemm_bf16<true, false>), grid, dim3(256), 0, s, g, nbx, nby);
+    } else {
+        if (vec)
+            hipLaunchKernelGGL((k_gemm_bf16<false, true>), grid, dim3(256), 0, s, g, nbx, nby);
+        else
+            hipLaunchKernelGGL((k_gemm_bf16<false, false>), grid, dim3(256), 0, s, g, nbx, nby);
+    }
     return hipGetLastError();
 }
 

@@ -9,7 +9,7 @@ from tests.helpers import build_hip, fixture_inputs, y_to_device
 
 pytestmark = pytest.mark.gpu
 
-PRECISIONS = ["f32"]
+PRECISIONS = ["f32", "bf16x3"]
 TOL = {"f32": 2e-4, "bf16x3": 1e-3}       # abs; both inside the 1e-3 contract
 
 FWD = ["tiny_fwd", "tiny_fwd_cfg", "tiny_add_fwd", "tiny_etd_fwd", "tiny_text_fwd_cfg", "ntu_fwd",
