@@ -375,14 +375,187 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// MFMA attention (fp32-input v_mfma_f32_32x32x2_f32, exact fp32 products), one workgroup per (sample, head),
+// one wave per 32-query tile. Everything is computed TRANSPOSED so that no register shuffle is needed
+// between the two GEMMs:
+//   S^T[key, query] = K . Q^T     A = K tile from LDS, B = Q held in registers (pre-scaled by 1/sqrt(dh))
+//   softmax over keys             a query's scores live in ONE lane pair (lane, lane^32): in-register max/sum
+//                                 + one cross-half exchange
+//   O^T[dh, query]  = V^T . P^T   B = the S^T accumulator registers as they are (C/D layout == B layout up
+//                                 to a permutation of the contraction index, which A follows), A = V from LDS
+// K and V time-share one LDS slab [32*NT][DH+4] (pad 4 floats: the 16 lanes of a ds_read_b128 group land on
+// 16 different bank quads). Causality: wave w only visits key tiles 0..w; the diagonal tile is masked.
+// The result is transposed through the (by then dead) slab so global stores are row-contiguous.
+// -------------------------------------------------------------------------------------------------
+template <int NT, int DH>
+__global__ __launch_bounds__(64 * NT) void k_attn_mfma(const float* __restrict__ qkv, float* __restrict__ out, Dims dm) {
+    constexpr int DP = (DH < 32 ? 32 : DH);       // padded head dim (PV works on 32-wide dh tiles)
+    constexpr int LD = DP + 4;
+    constexpr int NC = DH / 8;                    // 8-wide contraction chunks of QK^T
+    constexpr int ND = DP / 32;                   // dh tiles of PV
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* slab = smem;                           // [32*NT][LD]
+    const int b = blockIdx.x, hd = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int Tq = dm.Tq, d = dm.d;
+    const size_t row0 = (size_t)b * Tq;
+    const float* qbase = qkv + row0 * (size_t)(3 * d) + hd * DH;
+
+    auto load_slab = [&](int which) {             // which: 1 = K, 2 = V
+        constexpr int C4 = DP / 4;
+        for (int idx = tid; idx < 32 * NT * C4; idx += 64 * NT) {
+            const int r = idx / C4, c = (idx - r * C4) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < Tq && c < DH) v = *reinterpret_cast<const f32x4*>(qbase + (size_t)r * (3 * d) + which * d + c);
+            *reinterpret_cast<f32x4*>(&slab[r * LD + c]) = v;
+        }
+    };
+    load_slab(1);
+    // Q fragments: lane (query, half) holds Q[query][8c + 4*half + 0..3], scaled
+    const float scale = 1.0f / sqrtf((float)DH);
+    const int qrow = 32 * w + l31;
+    f32x4 qf[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (qrow < Tq) v = *reinterpret_cast<const f32x4*>(qbase + (size_t)qrow * (3 * d) + 8 * c + 4 * half);
+        qf[c] = v * scale;
+    }
+    __syncthreads();
+    f32x16 st[NT];
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[kj][i] = 0.f;
+        if (kj <= w) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(&slab[(32 * kj + l31) * LD + 8 * c + 4 * half]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) st[kj] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[c][j], st[kj], 0, 0, 0);
+            }
+        }
+    }
+    // softmax over keys (rows of S^T): key = 32*kj + (i&3) + 8*(i>>2) + 4*half, query = 32*w + l31
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj) {
+        if (kj <= w) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = 32 * kj + (i & 3) + 8 * (i >> 2) + 4 * half;
+                const bool ok = (key <= qrow) && (key < Tq);
+                st[kj][i] = ok ? st[kj][i] : -INFINITY;
+                mx = fmaxf(mx, st[kj][i]);
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj) {
+        if (kj <= w) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = __expf(st[kj][i] - mx);
+                st[kj][i] = e;
+                sum += e;
+            }
+        }
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    __syncthreads();          // every wave is done with K
+    load_slab(2);
+    __syncthreads();
+    f32x16 oa[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oa[dt][i] = 0.f;
+#pragma unroll
+    for (int kj = 0; kj < NT; ++kj) {
+        if (kj <= w) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = 32 * kj + (i & 3) + 8 * (i >> 2) + 4 * half;   // the key this lane's P register belongs to
+                const float* vr = &slab[key * LD + l31];
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt)
+                    oa[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32 * dt], st[kj][i], oa[dt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();          // every wave is done with V: reuse the slab rows of this wave's queries
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = 32 * dt + (i & 3) + 8 * (i >> 2) + 4 * half;       // dh index (row of O^T)
+            slab[(32 * w + l31) * LD + c] = oa[dt][i] * inv;
+        }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    constexpr int C4 = DH / 4;            // float4 per output row
+    for (int idx = lane; idx < 32 * C4; idx += 64) {
+        const int r = idx / C4, c = (idx - r * C4) * 4;
+        const int q = 32 * w + r;
+        if (q < Tq)
+            *reinterpret_cast<f32x4*>(out + (row0 + q) * (size_t)d + hd * DH + c) =
+                *reinterpret_cast<const f32x4*>(&slab[(32 * w + r) * LD + c]);
+    }
+}
+
+template <int NT, int DH>
+static hipError_t attn_mfma_go(const float* qkv, float* out, const Dims& dm, hipStream_t s, bool configure_only) {
+    constexpr int DP = (DH < 32 ? 32 : DH);
+    const size_t lds = (size_t)32 * NT * (DP + 4) * sizeof(float);
+    if (configure_only)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_mfma<NT, DH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_attn_mfma<NT, DH>), dim3(dm.Bm, dm.H), dim3(64 * NT), lds, s, qkv, out, dm);
+    return hipGetLastError();
+}
+template <int DH>
+static hipError_t attn_mfma_nt(int nt, const float* qkv, float* out, const Dims& dm, hipStream_t s, bool cfg) {
+    switch (nt) {
+        case 1: return attn_mfma_go<1, DH>(qkv, out, dm, s, cfg);
+        case 2: return attn_mfma_go<2, DH>(qkv, out, dm, s, cfg);
+        case 3: return attn_mfma_go<3, DH>(qkv, out, dm, s, cfg);
+        case 4: return attn_mfma_go<4, DH>(qkv, out, dm, s, cfg);
+        case 5: return attn_mfma_go<5, DH>(qkv, out, dm, s, cfg);
+    }
+    return hipErrorInvalidValue;
+}
+static bool attn_mfma_ok(int Tq, int dh) { return Tq <= 160 && (dh == 16 || dh == 32 || dh == 64 || dh == 128); }
+static hipError_t attn_mfma(const float* qkv, float* out, const Dims& dm, hipStream_t s, bool cfg) {
+    const int nt = (dm.Tq + 31) / 32;
+    switch (dm.dh) {
+        case 16: return attn_mfma_nt<16>(nt, qkv, out, dm, s, cfg);
+        case 32: return attn_mfma_nt<32>(nt, qkv, out, dm, s, cfg);
+        case 64: return attn_mfma_nt<64>(nt, qkv, out, dm, s, cfg);
+        case 128: return attn_mfma_nt<128>(nt, qkv, out, dm, s, cfg);
+    }
+    return hipErrorInvalidValue;
+}
+
 static size_t attn_lds_bytes(int Tq, int dh) { return ((size_t)2 * Tq * (dh + 1) + 4 * dh + 4 * Tq) * sizeof(float); }
 // Called once at finalize (never during graph capture): allow > 64 KiB of dynamic LDS.
 hipError_t configure_attention(int Tq, int dh) {
+    if (attn_mfma_ok(Tq, dh)) {
+        Dims dm{};
+        dm.Tq = Tq;
+        dm.dh = dh;
+        return attn_mfma(nullptr, nullptr, dm, nullptr, true);
+    }
     const size_t lds = attn_lds_bytes(Tq, dh);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 hipError_t launch_attention(const float* qkv, float* out, const Dims& dm, hipStream_t s) {
+    if (attn_mfma_ok(dm.Tq, dm.dh)) return attn_mfma(qkv, out, dm, s, false);
     hipLaunchKernelGGL(k_attention, dim3(dm.Bm, dm.H), dim3(256), attn_lds_bytes(dm.Tq, dm.dh), s, qkv, out, dm);
     return hipGetLastError();
 }
