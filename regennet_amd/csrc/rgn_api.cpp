@@ -26,9 +26,10 @@ struct HostTensor {
 };
 
 struct Lin {  // one packed nn.Linear: offsets (bytes) into the weight blob
-    size_t w = 0, hi = 0, lo = 0, b = 0;
+    size_t w = 0, hi = 0, lo = 0, b = 0;   // fp32 [N,Kp]; bf16 hi/lo planes (row-major [N,Kp] or K32-blocked)
     int N = 0, K = 0, Kp = 0;
     bool has_bias = false;
+    bool blocked = false;                  // hi/lo are K32-blocked [Kp/32][N][32] (operands of k_gemm_x3)
 };
 
 struct LayerW {
@@ -80,6 +81,8 @@ struct rgn_ctx {
     float *xin = nullptr, *cmo_in = nullptr, *c0 = nullptr, *h = nullptr, *tmp = nullptr, *qkv = nullptr, *att = nullptr,
           *ffn = nullptr, *x0tok = nullptr, *pe_rows = nullptr, *emb1 = nullptr, *emb = nullptr, *call = nullptr,
           *condemb = nullptr, *scale = nullptr;
+    __bf16 *xin_hi = nullptr, *xin_lo = nullptr, *h_hi = nullptr, *h_lo = nullptr, *att_hi = nullptr, *att_lo = nullptr,
+           *ffn_hi = nullptr, *ffn_lo = nullptr;   // K32-blocked split planes (bf16 precision modes)
     StepCoef* d_tab = nullptr;
     int* d_step = nullptr;
     SampleParams* d_sp = nullptr;
@@ -96,6 +99,7 @@ struct rgn_ctx {
 
     // bound condition
     int B = 0;
+    int xin_rows = -1;                 // row count the xin planes are currently laid out for
     bool cond_has_scale = false;
 
     // graphs: key = B | guided<<20 | sampler<<21
@@ -209,8 +213,9 @@ size_t blob_put(rgn_ctx* c, const void* src, size_t bytes) {
 }
 
 // Pack W[N,K] (row-major fp32) into fp32 [N,Kp] plus bf16 hi/lo planes; bias optional.
-Lin pack_linear(rgn_ctx* c, const float* W, const float* bias, int N, int K) {
+Lin pack_linear(rgn_ctx* c, const float* W, const float* bias, int N, int K, bool blocked = false) {
     Lin L;
+    L.blocked = blocked;
     L.N = N;
     L.K = K;
     L.Kp = (int)align_up((size_t)K, 32);
@@ -220,9 +225,10 @@ Lin pack_linear(rgn_ctx* c, const float* W, const float* bias, int N, int K) {
         for (int k = 0; k < K; ++k) {
             const float v = W[(size_t)n * K + k];
             const size_t o = (size_t)n * L.Kp + k;
+            const size_t ob = blocked ? ((size_t)(k / 32) * N + n) * 32 + (k % 32) : o;
             w[o] = v;
-            hi[o] = f2bf(v);
-            lo[o] = f2bf(v - bf2f(hi[o]));
+            hi[ob] = f2bf(v);
+            lo[ob] = f2bf(v - bf2f(hi[ob]));
         }
     L.w = blob_put(c, w.data(), w.size() * 4);
     L.hi = blob_put(c, hi.data(), hi.size() * 2);
@@ -293,6 +299,23 @@ GemmArgs gemm_args(const rgn_ctx* c, const Lin& L, const float* A, int lda, floa
     return g;
 }
 
+// x [B,F,T] -> token-major GEMM operand: fp32 xin (F32 mode) or split K32-blocked planes (both guidance halves)
+int pack_state(rgn_ctx* c, const float* x, const Dims& dm, bool guided, hipStream_t s) {
+    if (c->cfg.precision == RGN_PREC_F32) {
+        RGN_LAUNCH(c, KC_UPDATE, s, launch_pack_x(x, c->xin, Planes{nullptr, nullptr, 0}, 1, dm, s));
+    } else {
+        const Planes xp{c->xin_hi, c->cfg.precision == RGN_PREC_BF16X3 ? c->xin_lo : nullptr, dm.Bm * dm.Tq};
+        if (xp.rows != c->xin_rows) {   // the blocked layout depends on the row count: K-padding columns must read as zero
+            const size_t bytes = (size_t)2 * c->cfg.max_batch * c->Tq * align_up((size_t)c->F, 32) * 2;
+            RGN_HIP(c, hipMemsetAsync(c->xin_hi, 0, bytes, s));
+            RGN_HIP(c, hipMemsetAsync(c->xin_lo, 0, bytes, s));
+            c->xin_rows = xp.rows;
+        }
+        RGN_LAUNCH(c, KC_UPDATE, s, launch_pack_x(x, nullptr, xp, guided ? 2 : 1, dm, s));
+    }
+    return RGN_OK;
+}
+
 // One denoiser evaluation on the bound condition, ending in k_update (sampler step or plain output).
 // Everything t-dependent is read on the device (d_step / d_sp) so the sequence is graph-capturable.
 int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, hipStream_t s) {
@@ -316,45 +339,62 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, hipStream_t s) {
         g = gemm_args(c, c->lin_g, c->emb, d, c->call, Ld, dm.Bm);
         RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
     }
+    // ---- the big GEMMs: F32 mode keeps fp32 activations (k_gemm_f32); the bf16 modes chain pre-split
+    //      K32-blocked planes between kernels (k_gemm_x3, DMA-fed) ---------------------------------------
+    const bool fast = prec != RGN_PREC_F32, x3 = prec == RGN_PREC_BF16X3;
+    auto pl = [&](__bf16* hi, __bf16* lo) { return Planes{fast ? hi : nullptr, (fast && x3) ? lo : nullptr, M}; };
+    const Planes none{nullptr, nullptr, 0};
+    const Planes xin_p = pl(c->xin_hi, c->xin_lo), h_p = pl(c->h_hi, c->h_lo), att_p = pl(c->att_hi, c->att_lo),
+                 ffn_p = pl(c->ffn_hi, c->ffn_lo);
+    auto big = [&](const Lin& L, const float* A32, int lda, const Planes& Ap, float* C, int ldc, const Planes& Cp,
+                   const float* add, int act, int rows) -> int {
+        if (!fast) {
+            GemmArgs g = gemm_args(c, L, A32, lda, C, ldc, rows);
+            g.add = add;
+            g.ldadd = d;
+            g.act = act;
+            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+        } else {
+            GemmX3Args g{};
+            g.Ahi = Ap.hi; g.Alo = Ap.lo; g.a_rows = Ap.rows;
+            g.Whi = c->dp<__bf16>(L.hi); g.Wlo = c->dp<__bf16>(L.lo);
+            g.bias = L.has_bias ? c->dp<float>(L.b) : nullptr;
+            g.add = add; g.ldadd = d;
+            g.C = C; g.ldc = ldc;
+            g.Chi = Cp.hi; g.Clo = Cp.lo; g.c_rows = Cp.rows;
+            g.M = rows; g.N = L.N; g.Kp = L.Kp; g.act = act;
+            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm_x3(g, x3, rows > 128 ? 1 : 0, s));
+        }
+        return RGN_OK;
+    };
+    int rc;
     // input embedding + hoisted condition part (InputProcess/fuse/pos-enc, cmdm.py:201-218)
-    {
-        GemmArgs g = gemm_args(c, c->lin_x, c->xin, c->F, c->h, d, Mb);
-        g.add = c->c0;
-        g.ldadd = d;
-        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+    if (fast) {   // xin planes and c0 already hold both guidance halves
+        if ((rc = big(c->lin_x, nullptr, 0, xin_p, c->h, d, h_p, c->c0, 0, M))) return rc;
+    } else {
+        if ((rc = big(c->lin_x, c->xin, c->F, none, c->h, d, none, c->c0, 0, Mb))) return rc;
         if (guided)
             RGN_HIP(c, hipMemcpyAsync(c->h + (size_t)Mb * d, c->h, (size_t)Mb * d * sizeof(float), hipMemcpyDeviceToDevice, s));
-        if (c->etd)
-            RGN_LAUNCH(c, KC_EMBED, s, launch_emb_rows(c->emb, c->dp<float>(c->off_pe), c->h, dm, c->cfg.wo_pos_emb, s));
     }
+    if (c->etd)
+        RGN_LAUNCH(c, KC_EMBED, s, launch_emb_rows(c->emb, c->dp<float>(c->off_pe), c->h, h_p, dm, c->cfg.wo_pos_emb, s));
     for (int l = 0; l < c->L; ++l) {
         const LayerW& w = c->layers[l];
-        GemmArgs g = gemm_args(c, w.qkv, c->h, d, c->qkv, 3 * d, M);
-        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
-        RGN_LAUNCH(c, KC_ATTN, s, launch_attention(c->qkv, c->att, dm, s));
-        g = gemm_args(c, w.out, c->att, d, c->tmp, d, M);
-        g.add = c->h;
-        g.ldadd = d;
-        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+        if ((rc = big(w.qkv, c->h, d, h_p, c->qkv, 3 * d, none, nullptr, 0, M))) return rc;
+        RGN_LAUNCH(c, KC_ATTN, s, launch_attention(c->qkv, fast ? nullptr : c->att, att_p, dm, s));
+        if ((rc = big(w.out, c->att, d, att_p, c->tmp, d, none, c->h, 0, M))) return rc;
         RGN_LAUNCH(c, KC_LN, s,
-                   launch_layernorm(c->tmp, c->h, M, d, c->dp<float>(w.ln[0]), c->dp<float>(w.ln[1]), c->call + (size_t)l * d, Ld,
-                                    dm.Tq, c->dp<float>(w.ln[2]), c->dp<float>(w.ln[3]), s));
-        g = gemm_args(c, w.ff1, c->h, d, c->ffn, c->ff, M);
-        g.act = 1;
-        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
-        g = gemm_args(c, w.ff2, c->ffn, c->ff, c->tmp, d, M);
-        g.add = c->h;
-        g.ldadd = d;
-        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+                   launch_layernorm(c->tmp, c->h, h_p, M, d, c->dp<float>(w.ln[0]), c->dp<float>(w.ln[1]), c->call + (size_t)l * d,
+                                    Ld, dm.Tq, c->dp<float>(w.ln[2]), c->dp<float>(w.ln[3]), s));
+        if ((rc = big(w.ff1, c->h, d, h_p, fast ? nullptr : c->ffn, c->ff, ffn_p, nullptr, 1, M))) return rc;
+        if ((rc = big(w.ff2, c->ffn, c->ff, ffn_p, c->tmp, d, none, c->h, 0, M))) return rc;
         RGN_LAUNCH(c, KC_LN, s,
-                   launch_layernorm(c->tmp, c->h, M, d, c->dp<float>(w.ln[4]), c->dp<float>(w.ln[5]), nullptr, 0, dm.Tq, nullptr,
-                                    nullptr, s));
+                   launch_layernorm(c->tmp, c->h, h_p, M, d, c->dp<float>(w.ln[4]), c->dp<float>(w.ln[5]), nullptr, 0, dm.Tq,
+                                    nullptr, nullptr, s));
     }
-    {
-        GemmArgs g = gemm_args(c, c->lin_out, c->h, d, c->x0tok, c->F, M);
-        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
-    }
-    RGN_LAUNCH(c, KC_UPDATE, s, launch_update(c->x0tok, c->scale, c->d_tab, c->d_step, c->d_sp, c->xin, dm, s));
+    if ((rc = big(c->lin_out, c->h, d, h_p, c->x0tok, c->F, none, nullptr, 0, M))) return rc;
+    RGN_LAUNCH(c, KC_UPDATE, s,
+               launch_update(c->x0tok, c->scale, c->d_tab, c->d_step, c->d_sp, fast ? nullptr : c->xin, xin_p, dm, s));
     return RGN_OK;
 }
 
@@ -537,7 +577,7 @@ int rgn_finalize_weights(rgn_handle h) {
             memcpy(wcf.data(), wcm, wcf.size() * 4);
             for (int n = 0; n < d; ++n) bconst[n] = (float)((double)bin[n] + (double)bcm[n]);
         }
-        c->lin_x = pack_linear(c, wxf.data(), nullptr, d, F);
+        c->lin_x = pack_linear(c, wxf.data(), nullptr, d, F, true);
         c->lin_c = pack_linear(c, wcf.data(), bconst.data(), d, F);
     }
     c->lin_t0 = pack_linear(c, W("embed_timestep.time_embed.0.weight"), W("embed_timestep.time_embed.0.bias"), d, d);
@@ -549,10 +589,10 @@ int rgn_finalize_weights(rgn_handle h) {
     for (int l = 0; l < c->L; ++l) {
         const std::string p = "seqTransDecoder.layers." + std::to_string(l) + ".";
         LayerW& lw = c->layers[l];
-        lw.qkv = pack_linear(c, W(p + "self_attn.in_proj_weight"), W(p + "self_attn.in_proj_bias"), 3 * d, d);
-        lw.out = pack_linear(c, W(p + "self_attn.out_proj.weight"), W(p + "self_attn.out_proj.bias"), d, d);
-        lw.ff1 = pack_linear(c, W(p + "linear1.weight"), W(p + "linear1.bias"), ff, d);
-        lw.ff2 = pack_linear(c, W(p + "linear2.weight"), W(p + "linear2.bias"), d, ff);
+        lw.qkv = pack_linear(c, W(p + "self_attn.in_proj_weight"), W(p + "self_attn.in_proj_bias"), 3 * d, d, true);
+        lw.out = pack_linear(c, W(p + "self_attn.out_proj.weight"), W(p + "self_attn.out_proj.bias"), d, d, true);
+        lw.ff1 = pack_linear(c, W(p + "linear1.weight"), W(p + "linear1.bias"), ff, d, true);
+        lw.ff2 = pack_linear(c, W(p + "linear2.weight"), W(p + "linear2.bias"), d, ff, true);
         const char* names[6] = {"norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "norm3.weight", "norm3.bias"};
         for (int i = 0; i < 6; ++i) lw.ln[i] = blob_put(c, W(p + names[i]), (size_t)d * 4);
         const float* wv = W(p + "multihead_attn.in_proj_weight") + (size_t)2 * d * d;
@@ -569,7 +609,7 @@ int rgn_finalize_weights(rgn_handle h) {
         }
     }
     c->lin_g = pack_linear(c, gall.data(), gb.data(), c->L * d, d);
-    c->lin_out = pack_linear(c, W("output_process.poseFinal.weight"), W("output_process.poseFinal.bias"), F, d);
+    c->lin_out = pack_linear(c, W("output_process.poseFinal.weight"), W("output_process.poseFinal.bias"), F, d, true);
     if (c->cfg.cond_mode == RGN_COND_TEXT) {
         c->lin_text = pack_linear(c, W("embed_text.weight"), W("embed_text.bias"), d, c->cfg.clip_dim);
         c->off_bt = c->lin_text.b;
@@ -591,7 +631,7 @@ int rgn_finalize_weights(rgn_handle h) {
     int rc;
     if ((rc = ws_alloc(c, &c->xin, Mb * F))) return rc;
     if ((rc = ws_alloc(c, &c->cmo_in, Mb * F))) return rc;
-    if ((rc = ws_alloc(c, &c->c0, Mb * d))) return rc;
+    if ((rc = ws_alloc(c, &c->c0, M * d))) return rc;
     if ((rc = ws_alloc(c, &c->h, M * d))) return rc;
     if ((rc = ws_alloc(c, &c->tmp, M * d))) return rc;
     if ((rc = ws_alloc(c, &c->qkv, M * 3 * d))) return rc;
@@ -604,6 +644,22 @@ int rgn_finalize_weights(rgn_handle h) {
     if ((rc = ws_alloc(c, &c->call, Bm * c->L * d))) return rc;
     if ((rc = ws_alloc(c, &c->condemb, Bm * d))) return rc;
     if ((rc = ws_alloc(c, &c->scale, B))) return rc;
+    if (c->cfg.precision != RGN_PREC_F32) {
+        const size_t Fp = align_up((size_t)F, 32), ffp = align_up((size_t)ff, 32);
+        if ((rc = ws_alloc(c, &c->xin_hi, M * Fp))) return rc;
+        if ((rc = ws_alloc(c, &c->xin_lo, M * Fp))) return rc;
+        if ((rc = ws_alloc(c, &c->h_hi, M * d))) return rc;
+        if ((rc = ws_alloc(c, &c->h_lo, M * d))) return rc;
+        if ((rc = ws_alloc(c, &c->att_hi, M * d))) return rc;
+        if ((rc = ws_alloc(c, &c->att_lo, M * d))) return rc;
+        if ((rc = ws_alloc(c, &c->ffn_hi, M * ffp))) return rc;
+        if ((rc = ws_alloc(c, &c->ffn_lo, M * ffp))) return rc;
+        RGN_HIP(c, hipMemset(c->xin_hi, 0, M * Fp * 2));   // K padding columns (and emb_trans_dec rows) must read as 0
+        RGN_HIP(c, hipMemset(c->xin_lo, 0, M * Fp * 2));
+        RGN_HIP(c, hipMemset(c->ffn_hi, 0, M * ffp * 2));
+        RGN_HIP(c, hipMemset(c->ffn_lo, 0, M * ffp * 2));
+        RGN_HIP(c, configure_gemm_x3());
+    }
     if ((rc = ws_alloc(c, &c->d_tab, (size_t)1024))) return rc;
     if ((rc = ws_alloc(c, &c->d_step, (size_t)4))) return rc;
     if ((rc = ws_alloc(c, &c->d_sp, (size_t)1))) return rc;
@@ -670,10 +726,11 @@ int rgn_set_condition(rgn_handle h, int32_t B, const float* cmotion, const int64
     const Dims dm = make_dims(c, B, false);
     const int d = c->d;
     // hoisted: c0 = cmo_process(cmotion) -> fuse half + all constant biases + positional encoding
-    RGN_LAUNCH(c, KC_UPDATE, s, launch_pack_x(cmotion, c->cmo_in, dm, s));
+    RGN_LAUNCH(c, KC_UPDATE, s, launch_pack_x(cmotion, c->cmo_in, Planes{nullptr, nullptr, 0}, 1, dm, s));
     GemmArgs g = gemm_args(c, c->lin_c, c->cmo_in, c->F, c->c0, d, B * dm.Tq);
     RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, c->cfg.precision, s));
     if (!c->cfg.wo_pos_emb) RGN_LAUNCH(c, KC_EMBED, s, launch_add_pe(c->c0, c->dp<float>(c->off_pe), dm, s));
+    RGN_HIP(c, hipMemcpyAsync(c->c0 + (size_t)B * dm.Tq * d, c->c0, (size_t)B * dm.Tq * d * sizeof(float), hipMemcpyDeviceToDevice, s));   // uncond half
     // condition embedding rows: [0,B) conditional, [B,2B) what mask_cond(force_mask=True) leaves
     if (c->cfg.cond_mode == RGN_COND_ACTION) {
         RGN_LAUNCH(c, KC_EMBED, s, launch_cond_rows(c->dp<float>(c->off_action), action, c->condemb, B, d, s));
@@ -710,7 +767,8 @@ int rgn_denoise(rgn_handle h, const float* x, const int64_t* t, int32_t flags, f
     sp.mode = 1;
     sp.guided = guided;
     RGN_HIP(c, hipMemcpyAsync(c->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
-    RGN_LAUNCH(c, KC_UPDATE, s, launch_pack_x(x, c->xin, dm, s));
+    rc = pack_state(c, x, dm, guided, s);
+    if (rc) return rc;
     rc = run_eval(c, c->B, guided, uncond, s);
     if (rc) return rc;
     return stream_exit(c, us);
@@ -750,7 +808,7 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
     sp.clip = clip_denoised != 0;
     RGN_HIP(c, hipMemcpyAsync(c->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
     RGN_HIP(c, hipMemcpyAsync(c->d_step, &first_index, sizeof(int), hipMemcpyHostToDevice, s));
-    RGN_LAUNCH(c, KC_UPDATE, s, launch_pack_x(x, c->xin, dm, s));
+    if ((rc = pack_state(c, x, dm, guided != 0, s))) return rc;
 
     hipGraphExec_t gexec = nullptr;
     if (use_graph && !c->prof) {

@@ -1,0 +1,283 @@
+// Split-bf16 ("bf16x3") MFMA GEMM on PRE-SPLIT operands — the dominant kernel of the hot path.
+//
+//   C[M,N] = act( (Ahi+Alo)[M,K] . (Whi+Wlo)[N,K]^T + bias + add )     with  a.b ~ ah.bh + ah.bl + al.bh
+//
+// Every activation that feeds a GEMM is stored by its producer as two bf16 planes (hi = rne(x),
+// lo = rne(x - hi)), so this kernel is a pure bf16 GEMM with four operand planes: no VALU conversion in
+// the main loop and all four planes go HBM/L2 -> LDS by direct-to-LDS DMA (global_load_lds_dwordx4,
+// 1 KiB per wave-instruction, no VGPR round trip).
+//
+// Operand memory layout ("K32-blocked planes"): element (row, k) of a plane lives at
+//   ((k/32) * rows + row) * 32 + k%32          i.e. [Kp/32][rows][32] bf16
+// so the [rows x 32] slice a block needs for one k-step is ONE contiguous run of 64-byte rows: every DMA
+// wave-instruction (16 rows x 64 B) reads a contiguous, 1 KiB-aligned span = 8 full 128-byte lines.
+// (With a plain row-major [rows][K] plane each instruction would touch 16 half-used lines.)
+// The producers (LayerNorm, GEMM epilogues, attention, sampler update) write this layout directly.
+//
+// LDS image of one plane tile: [rows][32] bf16, 64-byte rows, written lane-linear by the DMA. To make the
+// ds_read_b128 fragment reads conflict-free the 16-byte chunk c of row r is stored at chunk position
+// c ^ ((r>>2)&3): the permutation is applied to the per-lane global SOURCE address and again on the read
+// (both-sides-or-neither rule for global_load_lds).
+//
+// Pipeline: 3 LDS stages, ONE raw s_barrier per k-step. At step kt: counted wait (s_waitcnt vmcnt(LPT):
+// tile kt landed, tile kt+1 still in flight) -> barrier (tile kt visible to every wave AND every wave is
+// done reading tile kt-1) -> issue tile kt+2's DMA into the stage tile kt-1 occupied -> MFMAs on tile kt.
+// Each DMA therefore has two full k-steps of MFMA work to hide its latency; register fragments for the
+// second half of a k-step are fetched while the first half's MFMAs run.
+#include "rgn_internal.h"
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#ifndef RGN_ABLATE
+#define RGN_ABLATE 0   // tools/gemm_bench only: 1 = no DMA after the prologue, 2 = no MFMA, 3 = no LDS fragment reads
+#endif
+
+namespace rgn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define RGN_AS1 __attribute__((address_space(1)))
+#define RGN_AS3 __attribute__((address_space(3)))
+
+__device__ __forceinline__ float x3_act(float v, int act) {
+    if (act == 1) return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == 2) return v / (1.0f + __expf(-v));
+    return v;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else static_assert(N == 0, "add the vmcnt literal");
+}
+
+// BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN) = TM x TN tiles of 32x32.
+template <int BM, int BN, int WM, int WN, bool X3>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm_x3(GemmX3Args g, int nbx, int nby) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int NPL = X3 ? 2 : 1;                         // planes per operand
+    constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64;     // one plane tile (32 bf16 per row)
+    constexpr int STAGE = NPL * (A_BYTES + W_BYTES);
+    constexpr int NSTAGE = 3;
+    constexpr int A_IT = BM * 4 / NT, W_IT = BN * 4 / NT;   // DMA instructions per thread per plane
+    constexpr int LPT = NPL * (A_IT + W_IT);                // ... per thread per tile
+    static_assert(BM * 4 % NT == 0 && BN * 4 % NT == 0, "tile/threads mismatch");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][Ahi|Alo|Whi|Wlo]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nwg = nbx * nby, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int m0 = (vid / nbx) * BM, n0 = (vid % nbx) * BN;
+
+    // per-thread DMA source offsets (elements), k-invariant part
+    size_t a_src[A_IT], w_src[W_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int q = it * NT + tid, r = q >> 2, c = (q & 3) ^ ((r >> 2) & 3);
+        int m = m0 + r;
+        m = m < g.M ? m : g.M - 1;
+        a_src[it] = (size_t)m * 32 + c * 8;
+    }
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int q = it * NT + tid, r = q >> 2, c = (q & 3) ^ ((r >> 2) & 3);
+        int n = n0 + r;
+        n = n < g.N ? n : g.N - 1;
+        w_src[it] = (size_t)n * 32 + c * 8;
+    }
+    auto issue = [&](int kt, int stage) {
+        char* sb = smem + stage * STAGE;
+        const size_t ka = (size_t)kt * g.a_rows * 32, kw = (size_t)kt * g.N * 32;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int lo = (it * NT + (tid & ~63)) * 16;   // wave-uniform LDS byte offset of this 1 KiB piece
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.Ahi + a_src[it] + ka), (RGN_AS3 void*)(sb + lo), 16, 0, 0);
+            if (X3)
+                __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.Alo + a_src[it] + ka), (RGN_AS3 void*)(sb + A_BYTES + lo), 16, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int lo = (it * NT + (tid & ~63)) * 16;
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.Whi + w_src[it] + kw), (RGN_AS3 void*)(sb + NPL * A_BYTES + lo), 16, 0, 0);
+            if (X3)
+                __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.Wlo + w_src[it] + kw), (RGN_AS3 void*)(sb + NPL * A_BYTES + W_BYTES + lo), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    // fragment read offsets: row rr (within the block tile), chunk c = 2*ks + khalf at position c ^ ((rr>>2)&3)
+    const int l31 = lane & 31, kh = lane >> 5;
+    int a_off[TM][2], w_off[TN][2];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int rr = wm * (BM / WM) + t * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a_off[t][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int rr = wn * (BN / WN) + t * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w_off[t][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
+    }
+
+    const int nk = g.Kp / 32;
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int st_cur = 0, st_free = 2;          // stage of tile kt, stage that tile kt+2 goes to
+    for (int kt = 0; kt < nk; ++kt) {
+        if (RGN_ABLATE == 1) wait_vmcnt<0>();
+        else if (kt + 1 < nk) wait_vmcnt<LPT>();   // tile kt landed (tile kt+1 may still be in flight)
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk && RGN_ABLATE != 1) issue(kt + 2, st_free);
+        const char* sb = smem + st_cur * STAGE;
+        bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+        auto frags = [&](int ks, int buf) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                ah[buf][t] = *reinterpret_cast<const bf16x8*>(sb + a_off[t][ks]);
+                if (X3) al[buf][t] = *reinterpret_cast<const bf16x8*>(sb + A_BYTES + a_off[t][ks]);
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                bh[buf][t] = *reinterpret_cast<const bf16x8*>(sb + NPL * A_BYTES + w_off[t][ks]);
+                if (X3) bl[buf][t] = *reinterpret_cast<const bf16x8*>(sb + NPL * A_BYTES + W_BYTES + w_off[t][ks]);
+            }
+        };
+        if (RGN_ABLATE != 3 || kt == 0) frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 0 && (RGN_ABLATE != 3 || kt == 0)) frags(1, 1);
+            if (RGN_ABLATE == 2) { asm volatile("" :: "v"(ah[ks][0]), "v"(bh[ks][0]), "v"(al[ks][TM-1]), "v"(bl[ks][TN-1])); continue; }
+#pragma unroll
+            for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < TN; ++tb) {
+                    if (X3) {
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][ta], bh[ks][tb], acc[ta][tb], 0, 0, 0);
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][ta], bl[ks][tb], acc[ta][tb], 0, 0, 0);
+                    }
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][ta], bh[ks][tb], acc[ta][tb], 0, 0, 0);
+                }
+        }
+        st_free = st_cur;
+        st_cur = (st_cur == 2) ? 0 : st_cur + 1;
+        // stage of tile kt+2 in the next iteration is the one tile kt used: (kt)%3 == st_free  ✓
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------
+    // Straight from the MFMA C/D layout (col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)): for a fixed
+    // register the two half-waves write two full 128-byte row segments (fp32) or two 64-byte segments of the
+    // K32-blocked bf16 planes. Interior blocks take a branch-free path: one pointer per tile, constant row
+    // strides, residual loads batched per tile; only edge blocks pay per-element bounds checks.
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+    auto emit = [&](auto check_tag) {
+        constexpr bool CHECK = decltype(check_tag)::value;
+#pragma unroll
+        for (int tb = 0; tb < TN; ++tb) {
+            const int n = n0 + wn * (BN / WN) + tb * 32 + l31;
+            const bool n_ok = !CHECK || n < g.N;
+            const float bias = (g.bias && n_ok) ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int ta = 0; ta < TM; ++ta) {
+                const int mb = m0 + wm * (BM / WM) + ta * 32 + 4 * kh;      // row of register 0
+                float r[16];
+                if (g.add) {
+                    const float* ap = g.add + (size_t)mb * g.ldadd + n;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int ro = (i & 3) + 8 * (i >> 2);
+                        r[i] = (!CHECK || (n_ok && mb + ro < g.M)) ? ap[(size_t)ro * g.ldadd] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = acc[ta][tb][i] + bias;
+                    if (g.add) v += r[i];
+                    r[i] = x3_act(v, g.act);
+                }
+                if (g.C) {
+                    float* cp = g.C + (size_t)mb * g.ldc + n;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int ro = (i & 3) + 8 * (i >> 2);
+                        if (!CHECK || (n_ok && mb + ro < g.M)) cp[(size_t)ro * g.ldc] = r[i];
+                    }
+                }
+                if (g.Chi) {   // K32-blocked planes [N/32][c_rows][32]: a 32-column tile is one contiguous run of rows
+                    const size_t o = ((size_t)(n >> 5) * g.c_rows + mb) * 32 + (n & 31);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int ro = (i & 3) + 8 * (i >> 2);
+                        if (!CHECK || (n_ok && mb + ro < g.M)) {
+                            const __bf16 h = (__bf16)r[i];
+                            g.Chi[o + ro * 32] = h;
+                            if (g.Clo) g.Clo[o + ro * 32] = (__bf16)(r[i] - (float)h);
+                        }
+                    }
+                }
+            }
+        }
+    };
+    if (interior) emit(std::false_type{});
+    else emit(std::true_type{});
+}
+
+template <int BM, int BN, int WM, int WN>
+static hipError_t x3_launch(const GemmX3Args& g, bool x3, hipStream_t s, bool configure_only) {
+    const int lds = 3 * (x3 ? 2 : 1) * (BM * 64 + BN * 64);
+    if (configure_only) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_x3<BM, BN, WM, WN, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 6 * (BM * 64 + BN * 64));
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_x3<BM, BN, WM, WN, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (BM * 64 + BN * 64));
+    }
+    const int nbx = (g.N + BN - 1) / BN, nby = (g.M + BM - 1) / BM;
+    if (x3)
+        hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, true>), dim3(nbx * nby), dim3(64 * WM * WN), lds, s, g, nbx, nby);
+    else
+        hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, false>), dim3(nbx * nby), dim3(64 * WM * WN), lds, s, g, nbx, nby);
+    return hipGetLastError();
+}
+
+// variant: 0 = 128x128 (4 waves), 1 = 256x128 (8 waves), 2 = 128x256 (8 waves), 3 = 256x256 (16 waves.. unused)
+hipError_t launch_gemm_x3(const GemmX3Args& g, bool x3, int variant, hipStream_t s) {
+    switch (variant) {
+        case 1: return x3_launch<256, 128, 4, 2>(g, x3, s, false);
+        case 2: return x3_launch<128, 256, 2, 4>(g, x3, s, false);
+        default: return x3_launch<128, 128, 2, 2>(g, x3, s, false);
+    }
+}
+hipError_t configure_gemm_x3() {
+    GemmX3Args g{};
+    hipError_t e = x3_launch<128, 128, 2, 2>(g, true, nullptr, true);
+    if (e != hipSuccess) return e;
+    e = x3_launch<256, 128, 4, 2>(g, true, nullptr, true);
+    if (e != hipSuccess) return e;
+    return x3_launch<128, 256, 2, 4>(g, true, nullptr, true);
+}
+
+}  // namespace rgn

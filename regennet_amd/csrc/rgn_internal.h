@@ -61,6 +61,25 @@ struct GemmArgs {
     int act;                          // 0 none, 1 gelu(erf), 2 silu
 };
 
+// bf16 operand planes use the "K32-blocked" layout [Kp/32][rows][32] (see rgn_gemm_x3.hip).
+struct GemmX3Args {
+    const __bf16* Ahi; const __bf16* Alo; int a_rows;   // activation planes [Kp/32][a_rows][32], a_rows >= M
+    const __bf16* Whi; const __bf16* Wlo;               // weight planes [Kp/32][N][32]
+    const float* bias;
+    const float* add; int ldadd;                        // optional fp32 addend [M, ldadd]
+    float* C; int ldc;                                  // optional fp32 output [M, ldc]
+    __bf16* Chi; __bf16* Clo; int c_rows;               // optional split output planes [ceil(N/32)][c_rows][32]
+    int M, N, Kp;
+    int act;
+};
+
+// Split-bf16 activation planes in the K32-blocked layout; hi == nullptr means "not requested".
+struct Planes {
+    __bf16* hi;
+    __bf16* lo;
+    int rows;     // row count of the plane (the M of the consuming GEMM)
+};
+
 struct Dims {
     int B;        // motions in the bound condition
     int Bm;       // rows of the batched evaluation (B, or 2B under guidance)
@@ -72,18 +91,20 @@ struct Dims {
 
 // ---- launchers (rgn_kernels.hip) ----------------------------------------------------------------
 hipError_t launch_gemm(const GemmArgs& g, int precision, hipStream_t s);
+hipError_t launch_gemm_x3(const GemmX3Args& g, bool x3, int variant, hipStream_t s);
+hipError_t configure_gemm_x3();
 hipError_t configure_attention(int Tq, int dh);
-hipError_t launch_attention(const float* qkv, float* out, const Dims& dm, hipStream_t s);
+hipError_t launch_attention(const float* qkv, float* out, Planes op, const Dims& dm, hipStream_t s);
 // h_out = LN_b( LN_a(in) + addvec[row/Tq] ) when ln_b != nullptr, else LN_a(in)
-hipError_t launch_layernorm(const float* in, float* out, int M, int d, const float* ga, const float* ba,
+hipError_t launch_layernorm(const float* in, float* out, Planes op, int M, int d, const float* ga, const float* ba,
                             const float* addvec, int ldadd, int Tq, const float* gb, const float* bb, hipStream_t s);
 hipError_t launch_gather_pe(const float* pe, const StepCoef* tab, const int* d_step, const SampleParams* sp,
                             float* out, int Bm, int B, int d, hipStream_t s);
-hipError_t launch_emb_rows(const float* emb, const float* pe, float* h, const Dims& dm, int wo_pos, hipStream_t s);
+hipError_t launch_emb_rows(const float* emb, const float* pe, float* h, Planes hp, const Dims& dm, int wo_pos, hipStream_t s);
 hipError_t launch_add_pe(float* c0, const float* pe, const Dims& dm, hipStream_t s);
-hipError_t launch_pack_x(const float* x, float* xin, const Dims& dm, hipStream_t s);
+hipError_t launch_pack_x(const float* x, float* xin, Planes xp, int copies, const Dims& dm, hipStream_t s);
 hipError_t launch_update(const float* x0tok, const float* scale, const StepCoef* tab, const int* d_step,
-                         const SampleParams* sp, float* xin, const Dims& dm, hipStream_t s);
+                         const SampleParams* sp, float* xin, Planes xp, const Dims& dm, hipStream_t s);
 hipError_t launch_advance(int* d_step, hipStream_t s);
 hipError_t launch_cond_rows(const float* table, const int64_t* action, float* out, int B, int d, hipStream_t s);
 hipError_t launch_fill_rows(float* out, const float* row, int rows, int d, hipStream_t s);

@@ -16,6 +16,9 @@ namespace rgn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -26,6 +29,17 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// element (row, col) of a K32-blocked plane [cols/32][rows][32]
+__device__ __forceinline__ size_t plane_off(int rows, int row, int col) {
+    return ((size_t)(col >> 5) * rows + row) * 32 + (col & 31);
+}
+__device__ __forceinline__ void plane_put(const Planes& p, int row, int col, float v) {
+    const size_t o = plane_off(p.rows, row, col);
+    const __bf16 h = (__bf16)v;
+    p.hi[o] = h;
+    if (p.lo) p.lo[o] = (__bf16)(v - (float)h);
 }
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -151,9 +165,6 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
 // -> the 16 lanes of each ds_read_b128 group hit 16 disjoint bank quads.
 // Blocks are remapped so that the column tiles of one A row-block run on the same XCD (shared L2).
 // -------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int H_BM = 128, H_BN = 128, H_BK = 32, H_LD = H_BK + 8;   // bf16 elements per LDS row
 
 __device__ __forceinline__ void split_bf16(const f32x4 v, bf16x4& hi, bf16x4& lo) {
@@ -319,7 +330,7 @@ hipError_t launch_gemm(const GemmArgs& g, int precision, hipStream_t s) {
 // Replaces nn.MultiheadAttention inside TransformerDecoderLayer._sa_block with the mask of
 // generate_square_subsequent_mask (cmdm.py:168-171,220-227): softmax(q k^T / sqrt(dh) + causal) v.
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, float* __restrict__ out, Dims dm) {
+__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, float* __restrict__ out, Planes op, Dims dm) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, hd = blockIdx.y;
     const int Tq = dm.Tq, dh = dm.dh, d = dm.d, ldk = dh + 1;
@@ -369,7 +380,8 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
             for (int c = lane; c < dh; c += 64) {
                 float o = 0.f;
                 for (int j = 0; j <= i; ++j) o = fmaf(p[j], Vs[j * ldk + c], o);
-                out[(row0 + i) * (size_t)d + hd * dh + c] = o * inv;
+                if (out) out[(row0 + i) * (size_t)d + hd * dh + c] = o * inv;
+                if (op.hi) plane_put(op, (int)(row0 + i), hd * dh + c, o * inv);
             }
         __syncthreads();
     }
@@ -389,7 +401,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
 // The result is transposed through the (by then dead) slab so global stores are row-contiguous.
 // -------------------------------------------------------------------------------------------------
 template <int NT, int DH>
-__global__ __launch_bounds__(64 * NT) void k_attn_mfma(const float* __restrict__ qkv, float* __restrict__ out, Dims dm) {
+__global__ __launch_bounds__(64 * NT) void k_attn_mfma(const float* __restrict__ qkv, float* __restrict__ out, Planes op, Dims dm) {
     constexpr int DP = (DH < 32 ? 32 : DH);       // padded head dim (PV works on 32-wide dh tiles)
     constexpr int LD = DP + 4;
     constexpr int NC = DH / 8;                    // 8-wide contraction chunks of QK^T
@@ -503,40 +515,48 @@ __global__ __launch_bounds__(64 * NT) void k_attn_mfma(const float* __restrict__
     for (int idx = lane; idx < 32 * C4; idx += 64) {
         const int r = idx / C4, c = (idx - r * C4) * 4;
         const int q = 32 * w + r;
-        if (q < Tq)
-            *reinterpret_cast<f32x4*>(out + (row0 + q) * (size_t)d + hd * DH + c) =
-                *reinterpret_cast<const f32x4*>(&slab[(32 * w + r) * LD + c]);
+        if (q < Tq) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&slab[(32 * w + r) * LD + c]);
+            if (out) *reinterpret_cast<f32x4*>(out + (row0 + q) * (size_t)d + hd * DH + c) = v;
+            if (op.hi) {   // 4 consecutive columns stay inside one 32-column block
+                const size_t o = plane_off(op.rows, (int)(row0 + q), hd * DH + c);
+                bf16x4 h, l;
+                split_bf16(v, h, l);
+                *reinterpret_cast<bf16x4*>(op.hi + o) = h;
+                if (op.lo) *reinterpret_cast<bf16x4*>(op.lo + o) = l;
+            }
+        }
     }
 }
 
 template <int NT, int DH>
-static hipError_t attn_mfma_go(const float* qkv, float* out, const Dims& dm, hipStream_t s, bool configure_only) {
+static hipError_t attn_mfma_go(const float* qkv, float* out, Planes op, const Dims& dm, hipStream_t s, bool configure_only) {
     constexpr int DP = (DH < 32 ? 32 : DH);
     const size_t lds = (size_t)32 * NT * (DP + 4) * sizeof(float);
     if (configure_only)
         return hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_mfma<NT, DH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_attn_mfma<NT, DH>), dim3(dm.Bm, dm.H), dim3(64 * NT), lds, s, qkv, out, dm);
+    hipLaunchKernelGGL((k_attn_mfma<NT, DH>), dim3(dm.Bm, dm.H), dim3(64 * NT), lds, s, qkv, out, op, dm);
     return hipGetLastError();
 }
 template <int DH>
-static hipError_t attn_mfma_nt(int nt, const float* qkv, float* out, const Dims& dm, hipStream_t s, bool cfg) {
+static hipError_t attn_mfma_nt(int nt, const float* qkv, float* out, Planes op, const Dims& dm, hipStream_t s, bool cfg) {
     switch (nt) {
-        case 1: return attn_mfma_go<1, DH>(qkv, out, dm, s, cfg);
-        case 2: return attn_mfma_go<2, DH>(qkv, out, dm, s, cfg);
-        case 3: return attn_mfma_go<3, DH>(qkv, out, dm, s, cfg);
-        case 4: return attn_mfma_go<4, DH>(qkv, out, dm, s, cfg);
-        case 5: return attn_mfma_go<5, DH>(qkv, out, dm, s, cfg);
+        case 1: return attn_mfma_go<1, DH>(qkv, out, op, dm, s, cfg);
+        case 2: return attn_mfma_go<2, DH>(qkv, out, op, dm, s, cfg);
+        case 3: return attn_mfma_go<3, DH>(qkv, out, op, dm, s, cfg);
+        case 4: return attn_mfma_go<4, DH>(qkv, out, op, dm, s, cfg);
+        case 5: return attn_mfma_go<5, DH>(qkv, out, op, dm, s, cfg);
     }
     return hipErrorInvalidValue;
 }
 static bool attn_mfma_ok(int Tq, int dh) { return Tq <= 160 && (dh == 16 || dh == 32 || dh == 64 || dh == 128); }
-static hipError_t attn_mfma(const float* qkv, float* out, const Dims& dm, hipStream_t s, bool cfg) {
+static hipError_t attn_mfma(const float* qkv, float* out, Planes op, const Dims& dm, hipStream_t s, bool cfg) {
     const int nt = (dm.Tq + 31) / 32;
     switch (dm.dh) {
-        case 16: return attn_mfma_nt<16>(nt, qkv, out, dm, s, cfg);
-        case 32: return attn_mfma_nt<32>(nt, qkv, out, dm, s, cfg);
-        case 64: return attn_mfma_nt<64>(nt, qkv, out, dm, s, cfg);
-        case 128: return attn_mfma_nt<128>(nt, qkv, out, dm, s, cfg);
+        case 16: return attn_mfma_nt<16>(nt, qkv, out, op, dm, s, cfg);
+        case 32: return attn_mfma_nt<32>(nt, qkv, out, op, dm, s, cfg);
+        case 64: return attn_mfma_nt<64>(nt, qkv, out, op, dm, s, cfg);
+        case 128: return attn_mfma_nt<128>(nt, qkv, out, op, dm, s, cfg);
     }
     return hipErrorInvalidValue;
 }
@@ -548,15 +568,15 @@ hipError_t configure_attention(int Tq, int dh) {
         Dims dm{};
         dm.Tq = Tq;
         dm.dh = dh;
-        return attn_mfma(nullptr, nullptr, dm, nullptr, true);
+        return attn_mfma(nullptr, nullptr, Planes{nullptr, nullptr, 0}, dm, nullptr, true);
     }
     const size_t lds = attn_lds_bytes(Tq, dh);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
-hipError_t launch_attention(const float* qkv, float* out, const Dims& dm, hipStream_t s) {
-    if (attn_mfma_ok(dm.Tq, dm.dh)) return attn_mfma(qkv, out, dm, s, false);
-    hipLaunchKernelGGL(k_attention, dim3(dm.Bm, dm.H), dim3(256), attn_lds_bytes(dm.Tq, dm.dh), s, qkv, out, dm);
+hipError_t launch_attention(const float* qkv, float* out, Planes op, const Dims& dm, hipStream_t s) {
+    if (attn_mfma_ok(dm.Tq, dm.dh)) return attn_mfma(qkv, out, op, dm, s, false);
+    hipLaunchKernelGGL(k_attention, dim3(dm.Bm, dm.H), dim3(256), attn_lds_bytes(dm.Tq, dm.dh), s, qkv, out, op, dm);
     return hipGetLastError();
 }
 
@@ -568,7 +588,7 @@ hipError_t launch_attention(const float* qkv, float* out, const Dims& dm, hipStr
 // 1-token cross-attention result, which is constant over the sequence.
 // =================================================================================================
 template <int VPL>
-__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in, float* __restrict__ out, int M, int d,
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in, float* __restrict__ out, Planes op, int M, int d,
                                                     const float* __restrict__ ga, const float* __restrict__ ba,
                                                     const float* __restrict__ addvec, int ldadd, int Tq,
                                                     const float* __restrict__ gb, const float* __restrict__ bb) {
@@ -616,12 +636,16 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
     float* y = out + (size_t)row * d;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) y[lane + 64 * i] = v[i];
+    if (op.hi) {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) plane_put(op, row, lane + 64 * i, v[i]);
+    }
 }
 
-hipError_t launch_layernorm(const float* in, float* out, int M, int d, const float* ga, const float* ba,
+hipError_t launch_layernorm(const float* in, float* out, Planes op, int M, int d, const float* ga, const float* ba,
                             const float* addvec, int ldadd, int Tq, const float* gb, const float* bb, hipStream_t s) {
     dim3 grid((M + 3) / 4), block(256);
-#define RGN_LN(V) hipLaunchKernelGGL(k_layernorm<V>, grid, block, 0, s, in, out, M, d, ga, ba, addvec, ldadd, Tq, gb, bb)
+#define RGN_LN(V) hipLaunchKernelGGL(k_layernorm<V>, grid, block, 0, s, in, out, op, M, d, ga, ba, addvec, ldadd, Tq, gb, bb)
     switch (d / 64) {
         case 1: RGN_LN(1); break;
         case 2: RGN_LN(2); break;
@@ -656,14 +680,17 @@ hipError_t launch_gather_pe(const float* pe, const StepCoef* tab, const int* d_s
 }
 
 // emb_trans_dec: token 0 of every sample is emb[b] (+ pe[0])            (cmdm.py:212-218)
-__global__ void k_emb_rows(const float* __restrict__ emb, const float* __restrict__ pe, float* __restrict__ h, Dims dm,
-                           int wo_pos) {
+__global__ void k_emb_rows(const float* __restrict__ emb, const float* __restrict__ pe, float* __restrict__ h, Planes hp,
+                           Dims dm, int wo_pos) {
     const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < dm.d; c += blockDim.x)
-        h[(size_t)b * dm.Tq * dm.d + c] = emb[(size_t)b * dm.d + c] + (wo_pos ? 0.f : pe[c]);
+    for (int c = threadIdx.x; c < dm.d; c += blockDim.x) {
+        const float v = emb[(size_t)b * dm.d + c] + (wo_pos ? 0.f : pe[c]);
+        h[(size_t)b * dm.Tq * dm.d + c] = v;
+        if (hp.hi) plane_put(hp, b * dm.Tq, c, v);
+    }
 }
-hipError_t launch_emb_rows(const float* emb, const float* pe, float* h, const Dims& dm, int wo_pos, hipStream_t s) {
-    hipLaunchKernelGGL(k_emb_rows, dim3(dm.Bm), dim3(256), 0, s, emb, pe, h, dm, wo_pos);
+hipError_t launch_emb_rows(const float* emb, const float* pe, float* h, Planes hp, const Dims& dm, int wo_pos, hipStream_t s) {
+    hipLaunchKernelGGL(k_emb_rows, dim3(dm.Bm), dim3(256), 0, s, emb, pe, h, hp, dm, wo_pos);
     return hipGetLastError();
 }
 
@@ -681,7 +708,8 @@ hipError_t launch_add_pe(float* c0, const float* pe, const Dims& dm, hipStream_t
 // Boundary layout <-> token-major transposes, fused with the sampler arithmetic.
 // =================================================================================================
 // InputProcess permute (cmdm.py:312): x [B,F,T] -> xin[(b*Tq+etd+t), f]; 32x32 LDS tiles, both sides coalesced.
-__global__ __launch_bounds__(256) void k_pack_x(const float* __restrict__ x, float* __restrict__ xin, Dims dm) {
+__global__ __launch_bounds__(256) void k_pack_x(const float* __restrict__ x, float* __restrict__ xin, Planes xp, int copies,
+                                                 Dims dm) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z, f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -692,12 +720,17 @@ __global__ __launch_bounds__(256) void k_pack_x(const float* __restrict__ x, flo
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int t = t0 + i, f = f0 + tx;
-        if (t < dm.T && f < dm.F) xin[((size_t)b * dm.Tq + dm.etd + t) * dm.F + f] = tile[tx][i];
+        if (t < dm.T && f < dm.F) {
+            const int row = b * dm.Tq + dm.etd + t;
+            if (xin) xin[(size_t)row * dm.F + f] = tile[tx][i];
+            if (xp.hi)
+                for (int cpy = 0; cpy < copies; ++cpy) plane_put(xp, row + cpy * dm.B * dm.Tq, f, tile[tx][i]);
+        }
     }
 }
-hipError_t launch_pack_x(const float* x, float* xin, const Dims& dm, hipStream_t s) {
+hipError_t launch_pack_x(const float* x, float* xin, Planes xp, int copies, const Dims& dm, hipStream_t s) {
     dim3 grid((dm.T + 31) / 32, (dm.F + 31) / 32, dm.B);
-    hipLaunchKernelGGL(k_pack_x, grid, dim3(256), 0, s, x, xin, dm);
+    hipLaunchKernelGGL(k_pack_x, grid, dim3(256), 0, s, x, xin, xp, copies, dm);
     return hipGetLastError();
 }
 
@@ -748,7 +781,8 @@ hipError_t launch_randn(float* x, int B, int FT, unsigned long long seed, unsign
 // Writes the new state in boundary layout [B,F,T] and token-major xin for the next step's GEMM.
 __global__ __launch_bounds__(256) void k_update(const float* __restrict__ x0tok, const float* __restrict__ scale,
                                                  const StepCoef* __restrict__ tab, const int* __restrict__ d_step,
-                                                 const SampleParams* __restrict__ spp, float* __restrict__ xin, Dims dm) {
+                                                 const SampleParams* __restrict__ spp, float* __restrict__ xin, Planes xp,
+                                                 Dims dm) {
     __shared__ float tc[32][33];
     __shared__ float tu[32][33];
     const SampleParams sp = *spp;
@@ -808,13 +842,20 @@ __global__ __launch_bounds__(256) void k_update(const float* __restrict__ x0tok,
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int t = t0 + i, f = f0 + tx;
-        if (t < dm.T && f < dm.F) xin[((size_t)b * dm.Tq + dm.etd + t) * dm.F + f] = tc[i][tx];
+        if (t < dm.T && f < dm.F) {
+            const int row = b * dm.Tq + dm.etd + t;
+            if (xin) xin[(size_t)row * dm.F + f] = tc[i][tx];
+            if (xp.hi) {
+                plane_put(xp, row, f, tc[i][tx]);
+                if (sp.guided) plane_put(xp, row + dm.B * dm.Tq, f, tc[i][tx]);   // uncond half sees the same x_t
+            }
+        }
     }
 }
 hipError_t launch_update(const float* x0tok, const float* scale, const StepCoef* tab, const int* d_step,
-                         const SampleParams* sp, float* xin, const Dims& dm, hipStream_t s) {
+                         const SampleParams* sp, float* xin, Planes xp, const Dims& dm, hipStream_t s) {
     dim3 grid((dm.T + 31) / 32, (dm.F + 31) / 32, dm.B);
-    hipLaunchKernelGGL(k_update, grid, dim3(256), 0, s, x0tok, scale, tab, d_step, sp, xin, dm);
+    hipLaunchKernelGGL(k_update, grid, dim3(256), 0, s, x0tok, scale, tab, d_step, sp, xin, xp, dm);
     return hipGetLastError();
 }
 
