@@ -197,3 +197,13 @@ def test_boundary_protocol_and_errors():
         eng.finalize()
     assert e.value.code == -4 and "missing keys" in str(e.value)
     eng.close()
+
+
+def test_cgenerate_cli_synthetic(tmp_path):
+    """The cgenerate-style entry point end to end (synthetic checkpoint + clips, ddim5, CFG)."""
+    from regennet_amd.sample import cgenerate
+    out = cgenerate.main(["--synthetic", "--num_samples", "3", "--num_repetitions", "2", "--timestep_respacing", "ddim5",
+                          "--use_ddim", "--guidance_param", "2.5", "--output_dir", str(tmp_path)])
+    res = np.load(out, allow_pickle=True).item()
+    assert res["output"].shape == (6, 56, 6, 60) and res["cmotion"].shape == (6, 56, 6, 60)
+    assert np.isfinite(res["output"]).all()
