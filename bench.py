@@ -34,13 +34,13 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}   # MI355X_MICROA
 
 
 def gemm_flops_per_eval(cfg, B, guided):
-    """Algorithmic FLOPs of the GEMM-class launches of one evaluation (everything except attention scores/AV)."""
+    """Algorithmic FLOPs of the GEMM-class launches of one evaluation (everything except attention scores/AV; the
+    timestep MLP and the folded 1-token cross-attention are per-schedule work, not per-step)."""
     T, d, ff, L, F = cfg["num_frames"], cfg["latent_dim"], cfg["ff_size"], cfg["layers"], cfg["njoints"] * cfg["nfeats"]
     Bm = 2 * B if guided else B
     M = Bm * T
     mac = M * (3 * d * d + d * d + 2 * d * ff) * L          # qkv, out_proj, ffn1, ffn2
     mac += B * T * F * d + M * d * F                        # input embedding (folded fuse half), output projection
-    mac += Bm * (2 * d * d + L * d * d)                     # timestep MLP + folded 1-token cross-attention
     return 2.0 * mac
 
 

@@ -80,9 +80,12 @@ struct rgn_ctx {
     // workspace
     float *xin = nullptr, *cmo_in = nullptr, *c0 = nullptr, *h = nullptr, *tmp = nullptr, *qkv = nullptr, *att = nullptr,
           *ffn = nullptr, *x0tok = nullptr, *pe_rows = nullptr, *emb1 = nullptr, *emb = nullptr, *call = nullptr,
-          *condemb = nullptr, *scale = nullptr;
+          *condemb = nullptr, *scale = nullptr, *te_all = nullptr, *call_time = nullptr, *call_cond = nullptr, *sched_tmp = nullptr;
     __bf16 *xin_hi = nullptr, *xin_lo = nullptr, *h_hi = nullptr, *h_lo = nullptr, *att_hi = nullptr, *att_lo = nullptr,
            *ffn_hi = nullptr, *ffn_lo = nullptr;   // K32-blocked split planes (bf16 precision modes)
+    __bf16 *q_hi = nullptr, *q_lo = nullptr, *k_hi = nullptr, *k_lo = nullptr, *vt_hi = nullptr, *vt_lo = nullptr;   // attention-ready planes
+    bool attn_x3 = false;
+    int Tqp = 0;
     StepCoef* d_tab = nullptr;
     int* d_step = nullptr;
     SampleParams* d_sp = nullptr;
@@ -318,22 +321,26 @@ int pack_state(rgn_ctx* c, const float* x, const Dims& dm, bool guided, hipStrea
 
 // One denoiser evaluation on the bound condition, ending in k_update (sampler step or plain output).
 // Everything t-dependent is read on the device (d_step / d_sp) so the sequence is graph-capturable.
-int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, hipStream_t s) {
+int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStream_t s) {
     const Dims dm = make_dims(c, B, guided);
     const int prec = c->cfg.precision;
     const int d = c->d, Ld = c->L * c->d, M = dm.Bm * dm.Tq, Mb = B * dm.Tq;
 
-    // timestep embedding (TimestepEmbedder cmdm.py:284-298) + condition embedding (cmdm.py:181-187)
-    RGN_LAUNCH(c, KC_EMBED, s, launch_gather_pe(c->dp<float>(c->off_pe), c->d_tab, c->d_step, c->d_sp, c->pe_rows, dm.Bm, B, d, s));
-    {
+    // timestep embedding (TimestepEmbedder cmdm.py:284-298) + condition embedding (cmdm.py:181-187).
+    // Inside a sampling loop every sample shares t, so TE[s] and the folded cross-attention vectors were computed
+    // once per schedule / condition (rgn_set_schedule, rgn_set_condition); rgn_denoise takes arbitrary per-sample
+    // timesteps and evaluates them here.
+    const bool has_cond = c->cfg.cond_mode != RGN_COND_NONE;
+    const float* cond_rows = !has_cond ? nullptr : ((uncond && !guided) ? c->condemb + (size_t)B * d : c->condemb);
+    const float* ccond_rows = !has_cond ? nullptr : ((uncond && !guided) ? c->call_cond + (size_t)B * Ld : c->call_cond);
+    if (!sampling) {
+        RGN_LAUNCH(c, KC_EMBED, s, launch_gather_pe(c->dp<float>(c->off_pe), c->d_tab, c->d_step, c->d_sp, c->pe_rows, dm.Bm, B, d, s));
         GemmArgs g = gemm_args(c, c->lin_t0, c->pe_rows, d, c->emb1, d, dm.Bm);
         g.act = 2;
         RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
         g = gemm_args(c, c->lin_t2, c->emb1, d, c->emb, d, dm.Bm);
-        if (c->cfg.cond_mode != RGN_COND_NONE) {
-            g.add = (uncond && !guided) ? c->condemb + (size_t)B * d : c->condemb;
-            g.ldadd = d;
-        }
+        g.add = cond_rows;
+        g.ldadd = d;
         RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
         // cross-attention onto the 1-token memory, all layers at once: call[b, l*d:(l+1)*d]
         g = gemm_args(c, c->lin_g, c->emb, d, c->call, Ld, dm.Bm);
@@ -363,7 +370,7 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, hipStream_t s) {
             g.C = C; g.ldc = ldc;
             g.Chi = Cp.hi; g.Clo = Cp.lo; g.c_rows = Cp.rows;
             g.M = rows; g.N = L.N; g.Kp = L.Kp; g.act = act;
-            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm_x3(g, x3, rows > 128 ? 1 : 0, s));
+            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm_x3(g, x3, 0, s));
         }
         return RGN_OK;
     };
@@ -376,21 +383,46 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, hipStream_t s) {
         if (guided)
             RGN_HIP(c, hipMemcpyAsync(c->h + (size_t)Mb * d, c->h, (size_t)Mb * d * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    if (c->etd)
-        RGN_LAUNCH(c, KC_EMBED, s, launch_emb_rows(c->emb, c->dp<float>(c->off_pe), c->h, h_p, dm, c->cfg.wo_pos_emb, s));
+    if (c->etd) {
+        if (sampling)
+            RGN_LAUNCH(c, KC_EMBED, s, launch_emb_rows(cond_rows, c->te_all, c->d_step, c->dp<float>(c->off_pe), c->h, h_p, dm, c->cfg.wo_pos_emb, s));
+        else
+            RGN_LAUNCH(c, KC_EMBED, s, launch_emb_rows(c->emb, nullptr, nullptr, c->dp<float>(c->off_pe), c->h, h_p, dm, c->cfg.wo_pos_emb, s));
+    }
     for (int l = 0; l < c->L; ++l) {
         const LayerW& w = c->layers[l];
-        if ((rc = big(w.qkv, c->h, d, h_p, c->qkv, 3 * d, none, nullptr, 0, M))) return rc;
-        RGN_LAUNCH(c, KC_ATTN, s, launch_attention(c->qkv, fast ? nullptr : c->att, att_p, dm, s));
+        if (fast && c->attn_x3) {
+            // in_proj GEMM scatters q (pre-scaled), k and v^T as attention-ready split planes; no fp32 qkv round trip
+            GemmX3Args g{};
+            g.Ahi = h_p.hi; g.Alo = h_p.lo; g.a_rows = h_p.rows;
+            g.Whi = c->dp<__bf16>(w.qkv.hi); g.Wlo = c->dp<__bf16>(w.qkv.lo);
+            g.bias = c->dp<float>(w.qkv.b);
+            g.M = M; g.N = 3 * d; g.Kp = w.qkv.Kp;
+            g.Qhi = c->q_hi; g.Qlo = x3 ? c->q_lo : nullptr; g.Khi = c->k_hi; g.Klo = x3 ? c->k_lo : nullptr;
+            g.Vthi = c->vt_hi; g.Vtlo = x3 ? c->vt_lo : nullptr;
+            g.d = d; g.H = c->H; g.dh = dm.dh; g.Tq = dm.Tq; g.Tqp = c->Tqp;
+            g.qscale = 1.0f / sqrtf((float)dm.dh);
+            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm_x3(g, x3, 0, s));
+            AttnX3Args a{};
+            a.Qhi = c->q_hi; a.Qlo = c->q_lo; a.Khi = c->k_hi; a.Klo = c->k_lo; a.Vthi = c->vt_hi; a.Vtlo = c->vt_lo;
+            a.out = att_p;
+            a.Bm = dm.Bm; a.H = c->H; a.dh = dm.dh; a.d = d; a.Tq = dm.Tq; a.Tqp = c->Tqp; a.x3 = x3;
+            RGN_LAUNCH(c, KC_ATTN, s, launch_attn_x3(a, s));
+        } else {
+            if ((rc = big(w.qkv, c->h, d, h_p, c->qkv, 3 * d, none, nullptr, 0, M))) return rc;
+            RGN_LAUNCH(c, KC_ATTN, s, launch_attention(c->qkv, fast ? nullptr : c->att, att_p, dm, s));
+        }
         if ((rc = big(w.out, c->att, d, att_p, c->tmp, d, none, c->h, 0, M))) return rc;
         RGN_LAUNCH(c, KC_LN, s,
-                   launch_layernorm(c->tmp, c->h, h_p, M, d, c->dp<float>(w.ln[0]), c->dp<float>(w.ln[1]), c->call + (size_t)l * d,
-                                    Ld, dm.Tq, c->dp<float>(w.ln[2]), c->dp<float>(w.ln[3]), s));
+                   launch_layernorm(c->tmp, c->h, h_p, M, d, c->dp<float>(w.ln[0]), c->dp<float>(w.ln[1]),
+                                    sampling ? (ccond_rows ? ccond_rows + (size_t)l * d : nullptr) : c->call + (size_t)l * d, Ld,
+                                    sampling ? c->call_time + (size_t)l * d : nullptr, Ld, c->d_step, dm.Tq,
+                                    c->dp<float>(w.ln[2]), c->dp<float>(w.ln[3]), s));
         if ((rc = big(w.ff1, c->h, d, h_p, fast ? nullptr : c->ffn, c->ff, ffn_p, nullptr, 1, M))) return rc;
         if ((rc = big(w.ff2, c->ffn, c->ff, ffn_p, c->tmp, d, none, c->h, 0, M))) return rc;
         RGN_LAUNCH(c, KC_LN, s,
-                   launch_layernorm(c->tmp, c->h, h_p, M, d, c->dp<float>(w.ln[4]), c->dp<float>(w.ln[5]), nullptr, 0, dm.Tq,
-                                    nullptr, nullptr, s));
+                   launch_layernorm(c->tmp, c->h, h_p, M, d, c->dp<float>(w.ln[4]), c->dp<float>(w.ln[5]), nullptr, 0, nullptr, 0,
+                                    nullptr, dm.Tq, nullptr, nullptr, s));
     }
     if ((rc = big(c->lin_out, c->h, d, h_p, c->x0tok, c->F, none, nullptr, 0, M))) return rc;
     RGN_LAUNCH(c, KC_UPDATE, s,
@@ -644,6 +676,10 @@ int rgn_finalize_weights(rgn_handle h) {
     if ((rc = ws_alloc(c, &c->call, Bm * c->L * d))) return rc;
     if ((rc = ws_alloc(c, &c->condemb, Bm * d))) return rc;
     if ((rc = ws_alloc(c, &c->scale, B))) return rc;
+    if ((rc = ws_alloc(c, &c->te_all, (size_t)1024 * d))) return rc;
+    if ((rc = ws_alloc(c, &c->sched_tmp, (size_t)2 * 1024 * d))) return rc;
+    if ((rc = ws_alloc(c, &c->call_time, (size_t)1024 * c->L * d))) return rc;
+    if ((rc = ws_alloc(c, &c->call_cond, Bm * c->L * d))) return rc;
     if (c->cfg.precision != RGN_PREC_F32) {
         const size_t Fp = align_up((size_t)F, 32), ffp = align_up((size_t)ff, 32);
         if ((rc = ws_alloc(c, &c->xin_hi, M * Fp))) return rc;
@@ -659,6 +695,17 @@ int rgn_finalize_weights(rgn_handle h) {
         RGN_HIP(c, hipMemset(c->ffn_hi, 0, M * ffp * 2));
         RGN_HIP(c, hipMemset(c->ffn_lo, 0, M * ffp * 2));
         RGN_HIP(c, configure_gemm_x3());
+        c->attn_x3 = attn_x3_supported(c->Tq, d / c->H);
+        if (c->attn_x3) {
+            c->Tqp = (c->Tq + 31) / 32 * 32;
+            const size_t n = Bm * c->H * (size_t)c->Tqp * (d / c->H);
+            __bf16** bufs[6] = {&c->q_hi, &c->q_lo, &c->k_hi, &c->k_lo, &c->vt_hi, &c->vt_lo};
+            for (auto bp : bufs) {
+                if ((rc = ws_alloc(c, bp, n))) return rc;
+                RGN_HIP(c, hipMemset(*bp, 0, n * 2));   // padding tokens (t >= Tq) are never written and must read as 0
+            }
+            RGN_HIP(c, configure_attn_x3(c->Tq, d / c->H));
+        }
     }
     if ((rc = ws_alloc(c, &c->d_tab, (size_t)1024))) return rc;
     if ((rc = ws_alloc(c, &c->d_step, (size_t)4))) return rc;
@@ -707,7 +754,23 @@ int rgn_set_schedule(rgn_handle h, const rgn_schedule* s) {
     h->tab_valid = false;
     h->have_sched = true;
     RGN_HIP(h, hipSetDevice(h->cfg.device));
-    return build_step_table(h, 0.0f);
+    int rc = build_step_table(h, 0.0f);
+    if (rc) return rc;
+    // per-step timestep embedding TE[i] = time_embed(pe[timestep_map[i]]) and its folded cross-attention image
+    // call_time[i] = TE[i] . G^T + g  (cmdm.py:297-298 + the 1-token multihead_attn of every layer), once per schedule
+    rgn_ctx* c = h;
+    hipStream_t es = c->stream;
+    const int d = c->d, S = c->S;
+    RGN_LAUNCH(c, KC_EMBED, es, launch_gather_pe_all(c->dp<float>(c->off_pe), c->d_tab, c->sched_tmp, S, d, es));
+    GemmArgs g = gemm_args(c, c->lin_t0, c->sched_tmp, d, c->sched_tmp + (size_t)1024 * d, d, S);
+    g.act = 2;
+    RGN_LAUNCH(c, KC_GEMM, es, launch_gemm(g, c->cfg.precision, es));
+    g = gemm_args(c, c->lin_t2, c->sched_tmp + (size_t)1024 * d, d, c->te_all, d, S);
+    RGN_LAUNCH(c, KC_GEMM, es, launch_gemm(g, c->cfg.precision, es));
+    g = gemm_args(c, c->lin_g, c->te_all, d, c->call_time, c->L * d, S);
+    RGN_LAUNCH(c, KC_GEMM, es, launch_gemm(g, c->cfg.precision, es));
+    RGN_HIP(c, hipStreamSynchronize(es));
+    return RGN_OK;
 }
 
 int rgn_set_condition(rgn_handle h, int32_t B, const float* cmotion, const int64_t* action, const float* text_feat,
@@ -740,6 +803,11 @@ int rgn_set_condition(rgn_handle h, int32_t B, const float* cmotion, const int64
         RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(t, c->cfg.precision, s));
         RGN_LAUNCH(c, KC_EMBED, s, launch_fill_rows(c->condemb + (size_t)B * d, c->dp<float>(c->off_bt), B, d, s));  // embed_text(0) = bias
     }
+    if (c->cfg.cond_mode != RGN_COND_NONE) {   // folded cross-attention image of the condition rows (cond | uncond)
+        GemmArgs cg = gemm_args(c, c->lin_g, c->condemb, d, c->call_cond, c->L * d, 2 * B);
+        cg.bias = nullptr;
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(cg, c->cfg.precision, s));
+    }
     c->cond_has_scale = scale != nullptr;
     if (scale) RGN_HIP(c, hipMemcpyAsync(c->scale, scale, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
     c->B = B;
@@ -769,7 +837,7 @@ int rgn_denoise(rgn_handle h, const float* x, const int64_t* t, int32_t flags, f
     RGN_HIP(c, hipMemcpyAsync(c->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
     rc = pack_state(c, x, dm, guided, s);
     if (rc) return rc;
-    rc = run_eval(c, c->B, guided, uncond, s);
+    rc = run_eval(c, c->B, guided, uncond, false, s);
     if (rc) return rc;
     return stream_exit(c, us);
 }
@@ -817,7 +885,7 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
         if (it == c->graphs.end()) {
             hipGraph_t graph = nullptr;
             RGN_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            rc = run_eval(c, c->B, guided != 0, false, s);
+            rc = run_eval(c, c->B, guided != 0, false, true, s);
             if (rc == RGN_OK && launch_advance(c->d_step, s) != hipSuccess) rc = c->fail(RGN_ERR_HIP, "launch_advance");
             hipError_t e = hipStreamEndCapture(s, &graph);
             if (rc) {
@@ -836,7 +904,7 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
         if (gexec) {
             RGN_HIP(c, hipGraphLaunch(gexec, s));
         } else {
-            rc = run_eval(c, c->B, guided != 0, false, s);
+            rc = run_eval(c, c->B, guided != 0, false, true, s);
             if (rc) return rc;
             RGN_LAUNCH(c, KC_MISC, s, launch_advance(c->d_step, s));
         }

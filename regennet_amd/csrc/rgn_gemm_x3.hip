@@ -30,10 +30,6 @@
 
 #include <type_traits>
 
-#ifndef RGN_ABLATE
-#define RGN_ABLATE 0   // tools/gemm_bench only: 1 = no DMA after the prologue, 2 = no MFMA, 3 = no LDS fragment reads
-#endif
-
 namespace rgn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -43,8 +39,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define RGN_AS1 __attribute__((address_space(1)))
 #define RGN_AS3 __attribute__((address_space(3)))
 
+// erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7) on fast exp/rcp: ~12 VALU instead of ~30 for erff();
+// far inside the fp32 noise of the surrounding GEMM and of the 1e-3 tolerance.
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(e, x);
+}
 __device__ __forceinline__ float x3_act(float v, int act) {
-    if (act == 1) return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == 1) return v * 0.5f * (1.0f + fast_erf(v * 0.70710678118654752440f));
     if (act == 2) return v / (1.0f + __expf(-v));
     return v;
 }
@@ -62,14 +70,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN) = TM x TN tiles of 32x32.
-template <int BM, int BN, int WM, int WN, bool X3>
-__global__ __launch_bounds__(64 * WM * WN) void k_gemm_x3(GemmX3Args g, int nbx, int nby) {
+template <int BM, int BN, int WM, int WN, bool X3, int NSTAGE, bool QKV>
+__global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_x3(GemmX3Args g, int nbx, int nby) {
     constexpr int NT = 64 * WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NPL = X3 ? 2 : 1;                         // planes per operand
     constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64;     // one plane tile (32 bf16 per row)
     constexpr int STAGE = NPL * (A_BYTES + W_BYTES);
-    constexpr int NSTAGE = 3;
     constexpr int A_IT = BM * 4 / NT, W_IT = BN * 4 / NT;   // DMA instructions per thread per plane
     constexpr int LPT = NPL * (A_IT + W_IT);                // ... per thread per tile
     static_assert(BM * 4 % NT == 0 && BN * 4 % NT == 0, "tile/threads mismatch");
@@ -143,16 +150,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_x3(GemmX3Args g, int nbx,
     }
 
     const int nk = g.Kp / 32;
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    int st_cur = 0, st_free = 2;          // stage of tile kt, stage that tile kt+2 goes to
-    for (int kt = 0; kt < nk; ++kt) {
-        if (RGN_ABLATE == 1) wait_vmcnt<0>();
-        else if (kt + 1 < nk) wait_vmcnt<LPT>();   // tile kt landed (tile kt+1 may still be in flight)
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk && RGN_ABLATE != 1) issue(kt + 2, st_free);
-        const char* sb = smem + st_cur * STAGE;
+    auto compute = [&](const char* sb) {
         bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
         auto frags = [&](int ks, int buf) {
 #pragma unroll
@@ -166,11 +164,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_x3(GemmX3Args g, int nbx,
                 if (X3) bl[buf][t] = *reinterpret_cast<const bf16x8*>(sb + NPL * A_BYTES + W_BYTES + w_off[t][ks]);
             }
         };
-        if (RGN_ABLATE != 3 || kt == 0) frags(0, 0);
+        frags(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            if (ks == 0 && (RGN_ABLATE != 3 || kt == 0)) frags(1, 1);
-            if (RGN_ABLATE == 2) { asm volatile("" :: "v"(ah[ks][0]), "v"(bh[ks][0]), "v"(al[ks][TM-1]), "v"(bl[ks][TN-1])); continue; }
+            if (ks == 0) frags(1, 1);
 #pragma unroll
             for (int ta = 0; ta < TM; ++ta)
 #pragma unroll
@@ -182,9 +179,34 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_x3(GemmX3Args g, int nbx,
                     acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][ta], bh[ks][tb], acc[ta][tb], 0, 0, 0);
                 }
         }
-        st_free = st_cur;
-        st_cur = (st_cur == 2) ? 0 : st_cur + 1;
-        // stage of tile kt+2 in the next iteration is the one tile kt used: (kt)%3 == st_free  ✓
+    };
+    if constexpr (NSTAGE == 3) {
+        issue(0, 0);
+        if (nk > 1) issue(1, 1);
+        int st_cur = 0, st_free = 2;          // stage of tile kt, stage that tile kt+2 goes to
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) wait_vmcnt<LPT>();   // tile kt landed (tile kt+1 may still be in flight)
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) issue(kt + 2, st_free);
+            compute(smem + st_cur * STAGE);
+            st_free = st_cur;
+            st_cur = (st_cur == 2) ? 0 : st_cur + 1;
+        }
+    } else {   // 2 stages, two barriers per k-step; small enough for two workgroups per CU
+        issue(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) {
+                issue(kt + 1, (kt + 1) & 1);
+                wait_vmcnt<LPT>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            compute(smem + (kt & 1) * STAGE);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();     // stage (kt&1) may now be overwritten by tile kt+2
+        }
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------
@@ -195,6 +217,23 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_x3(GemmX3Args g, int nbx,
     const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
     auto emit = [&](auto check_tag) {
         constexpr bool CHECK = decltype(check_tag)::value;
+        // (sample, token) of the first row of every 4-row register group, for the attention-ready scatter
+        int row_b[TM][4], row_t[TM][4];
+        bool rows_same[TM];
+        if constexpr (QKV) {
+#pragma unroll
+            for (int ta = 0; ta < TM; ++ta) {
+                rows_same[ta] = true;
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    const int m4 = m0 + wm * (BM / WM) + ta * 32 + 4 * kh + 8 * i4;
+                    row_b[ta][i4] = m4 / g.Tq;
+                    row_t[ta][i4] = m4 - row_b[ta][i4] * g.Tq;
+                    rows_same[ta] = rows_same[ta] && (row_t[ta][i4] + 3 < g.Tq);
+                }
+                rows_same[ta] = __all(rows_same[ta]);
+            }
+        }
 #pragma unroll
         for (int tb = 0; tb < TN; ++tb) {
             const int n = n0 + wn * (BN / WN) + tb * 32 + l31;
@@ -218,7 +257,63 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_x3(GemmX3Args g, int nbx,
                     if (g.add) v += r[i];
                     r[i] = x3_act(v, g.act);
                 }
-                if (g.C) {
+                if constexpr (QKV) {   // attention-ready scatter of the packed in_proj output (see GemmX3Args)
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                    const int which = n / g.d, cin = n - which * g.d, hd = cin / g.dh, c = cin - hd * g.dh;
+                    __bf16* ph = which == 0 ? g.Qhi : (which == 1 ? g.Khi : g.Vthi);
+                    __bf16* pl = which == 0 ? g.Qlo : (which == 1 ? g.Klo : g.Vtlo);
+                    const bool fastp = !CHECK && rows_same[ta];          // every 4-row group of this tile stays inside one sample
+                    if (which == 2 && fastp) {                            // V^T: 4 consecutive tokens -> one 8-byte store
+#pragma unroll
+                        for (int i4 = 0; i4 < 4; ++i4) {
+                            bf16x4 hv, lv;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float x = r[4 * i4 + e];
+                                hv[e] = (__bf16)x;
+                                lv[e] = (__bf16)(x - (float)hv[e]);
+                            }
+                            const size_t o = (((size_t)row_b[ta][i4] * g.H + hd) * g.dh + c) * g.Tqp + row_t[ta][i4];
+                            *reinterpret_cast<bf16x4*>(ph + o) = hv;
+                            if (pl) *reinterpret_cast<bf16x4*>(pl + o) = lv;
+                        }
+                    } else if (which != 2 && fastp) {                     // q / k: pair adjacent columns across lane^1 -> 4-byte stores
+                        const float sc = which == 0 ? g.qscale : 1.0f;
+                        const bool odd = lane & 1;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float mine = (odd ? r[i + 8] : r[i]) * sc;
+                            const float give = (odd ? r[i] : r[i + 8]) * sc;
+                            const float got = __shfl_xor(give, 1, 64);
+                            const float c0 = odd ? got : mine, c1 = odd ? mine : got;
+                            const int ii = odd ? i + 8 : i, i4 = ii >> 2, e = ii & 3;
+                            const size_t o = (((size_t)row_b[ta][i4] * g.H + hd) * g.Tqp + row_t[ta][i4] + e) * g.dh + (c & ~1);
+                            const __bf16 h0 = (__bf16)c0, h1 = (__bf16)c1;
+                            bf16x2 hv = {h0, h1};
+                            *reinterpret_cast<bf16x2*>(ph + o) = hv;
+                            if (pl) {
+                                bf16x2 lv = {(__bf16)(c0 - (float)h0), (__bf16)(c1 - (float)h1)};
+                                *reinterpret_cast<bf16x2*>(pl + o) = lv;
+                            }
+                        }
+                    } else {                                              // edge blocks / samples whose length is not a multiple of 4
+                        const float sc = which == 0 ? g.qscale : 1.0f;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int m = mb + (i & 3) + 8 * (i >> 2);
+                            if (!n_ok || m >= g.M) continue;
+                            const int bb = m / g.Tq, tt = m - bb * g.Tq;
+                            const size_t sl = (size_t)bb * g.H + hd;
+                            const float x = r[i] * sc;
+                            const __bf16 h = (__bf16)x;
+                            const size_t o = which == 2 ? (sl * g.dh + c) * g.Tqp + tt : (sl * g.Tqp + tt) * g.dh + c;
+                            ph[o] = h;
+                            if (pl) pl[o] = (__bf16)(x - (float)h);
+                        }
+                    }
+                }
+                if (!QKV && g.C) {
                     float* cp = g.C + (size_t)mb * g.ldc + n;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -226,15 +321,39 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_x3(GemmX3Args g, int nbx,
                         if (!CHECK || (n_ok && mb + ro < g.M)) cp[(size_t)ro * g.ldc] = r[i];
                     }
                 }
-                if (g.Chi) {   // K32-blocked planes [N/32][c_rows][32]: a 32-column tile is one contiguous run of rows
-                    const size_t o = ((size_t)(n >> 5) * g.c_rows + mb) * 32 + (n & 31);
+                if (!QKV && g.Chi) {   // K32-blocked planes [N/32][c_rows][32]: a 32-column tile is one contiguous run of rows
+                    if (!CHECK) {
+                        // pair adjacent columns across lanes (lane^1) so every store is a packed bf16x2 (4 B):
+                        // even lanes store rows of registers 0..7, odd lanes those of registers 8..15
+                        const size_t o = ((size_t)(n >> 5) * g.c_rows + mb) * 32 + (n & 30);
+                        const bool odd = lane & 1;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int ro = (i & 3) + 8 * (i >> 2);
-                        if (!CHECK || (n_ok && mb + ro < g.M)) {
-                            const __bf16 h = (__bf16)r[i];
-                            g.Chi[o + ro * 32] = h;
-                            if (g.Clo) g.Clo[o + ro * 32] = (__bf16)(r[i] - (float)h);
+                        for (int i = 0; i < 8; ++i) {
+                            const float mine = odd ? r[i + 8] : r[i];          // value this lane contributes to its own store
+                            const float give = odd ? r[i] : r[i + 8];          // value the partner needs
+                            const float got = __shfl_xor(give, 1, 64);
+                            const float lo_col = odd ? got : mine, hi_col = odd ? mine : got;   // columns n&~1, (n&~1)+1
+                            const int ii = odd ? i + 8 : i;
+                            const int ro = (ii & 3) + 8 * (ii >> 2);
+                            const __bf16 h0 = (__bf16)lo_col, h1 = (__bf16)hi_col;
+                            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                            bf16x2 hv = {h0, h1};
+                            *reinterpret_cast<bf16x2*>(g.Chi + o + ro * 32) = hv;
+                            if (g.Clo) {
+                                bf16x2 lv = {(__bf16)(lo_col - (float)h0), (__bf16)(hi_col - (float)h1)};
+                                *reinterpret_cast<bf16x2*>(g.Clo + o + ro * 32) = lv;
+                            }
+                        }
+                    } else {
+                        const size_t o = ((size_t)(n >> 5) * g.c_rows + mb) * 32 + (n & 31);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int ro = (i & 3) + 8 * (i >> 2);
+                            if (n_ok && mb + ro < g.M) {
+                                const __bf16 h = (__bf16)r[i];
+                                g.Chi[o + ro * 32] = h;
+                                if (g.Clo) g.Clo[o + ro * 32] = (__bf16)(r[i] - (float)h);
+                            }
                         }
                     }
                 }
@@ -245,39 +364,40 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_x3(GemmX3Args g, int nbx,
     else emit(std::true_type{});
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSTAGE>
 static hipError_t x3_launch(const GemmX3Args& g, bool x3, hipStream_t s, bool configure_only) {
-    const int lds = 3 * (x3 ? 2 : 1) * (BM * 64 + BN * 64);
+    const int lds = NSTAGE * (x3 ? 2 : 1) * (BM * 64 + BN * 64);
     if (configure_only) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_x3<BM, BN, WM, WN, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 6 * (BM * 64 + BN * 64));
+        const int big = NSTAGE * 2 * (BM * 64 + BN * 64), small = NSTAGE * (BM * 64 + BN * 64);
+        hipError_t e;
+#define RGN_CFG(X3V, QV, BYTES)                                                                                        \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_x3<BM, BN, WM, WN, X3V, NSTAGE, QV>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);                                        \
         if (e != hipSuccess) return e;
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_x3<BM, BN, WM, WN, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (BM * 64 + BN * 64));
+        RGN_CFG(true, false, big) RGN_CFG(false, false, small) RGN_CFG(true, true, big) RGN_CFG(false, true, small)
+#undef RGN_CFG
+        return hipSuccess;
     }
     const int nbx = (g.N + BN - 1) / BN, nby = (g.M + BM - 1) / BM;
-    if (x3)
-        hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, true>), dim3(nbx * nby), dim3(64 * WM * WN), lds, s, g, nbx, nby);
-    else
-        hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, false>), dim3(nbx * nby), dim3(64 * WM * WN), lds, s, g, nbx, nby);
+    const dim3 grid(nbx * nby), block(64 * WM * WN);
+    const bool qkv = g.Qhi != nullptr;
+    if (x3 && !qkv) hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, true, NSTAGE, false>), grid, block, lds, s, g, nbx, nby);
+    else if (x3 && qkv) hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, true, NSTAGE, true>), grid, block, lds, s, g, nbx, nby);
+    else if (!qkv) hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, false, NSTAGE, false>), grid, block, lds, s, g, nbx, nby);
+    else hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, false, NSTAGE, true>), grid, block, lds, s, g, nbx, nby);
     return hipGetLastError();
 }
 
-// variant: 0 = 128x128 (4 waves), 1 = 256x128 (8 waves), 2 = 128x256 (8 waves), 3 = 256x256 (16 waves.. unused)
+// variant: 0 = 128x128 / 4 waves / 2 stages (64 KiB: two workgroups per CU), 1 = 256x128 / 8 waves / 3 stages
 hipError_t launch_gemm_x3(const GemmX3Args& g, bool x3, int variant, hipStream_t s) {
-    switch (variant) {
-        case 1: return x3_launch<256, 128, 4, 2>(g, x3, s, false);
-        case 2: return x3_launch<128, 256, 2, 4>(g, x3, s, false);
-        default: return x3_launch<128, 128, 2, 2>(g, x3, s, false);
-    }
+    if (variant == 1) return x3_launch<256, 128, 4, 2, 3>(g, x3, s, false);
+    return x3_launch<128, 128, 2, 2, 2>(g, x3, s, false);
 }
 hipError_t configure_gemm_x3() {
     GemmX3Args g{};
-    hipError_t e = x3_launch<128, 128, 2, 2>(g, true, nullptr, true);
+    hipError_t e = x3_launch<128, 128, 2, 2, 2>(g, true, nullptr, true);
     if (e != hipSuccess) return e;
-    e = x3_launch<256, 128, 4, 2>(g, true, nullptr, true);
-    if (e != hipSuccess) return e;
-    return x3_launch<128, 256, 2, 4>(g, true, nullptr, true);
+    return x3_launch<256, 128, 4, 2, 3>(g, true, nullptr, true);
 }
 
 }  // namespace rgn

@@ -71,6 +71,11 @@ struct GemmX3Args {
     __bf16* Chi; __bf16* Clo; int c_rows;               // optional split output planes [ceil(N/32)][c_rows][32]
     int M, N, Kp;
     int act;
+    // Optional "attention-ready" output of the packed in_proj GEMM (N = 3*d): instead of C / Chi the epilogue
+    // scatters q (pre-scaled by 1/sqrt(dh)), k as [Bm*H][Tqp][dh] and v TRANSPOSED as [Bm*H][dh][Tqp] split planes.
+    __bf16 *Qhi, *Qlo, *Khi, *Klo, *Vthi, *Vtlo;
+    int d, H, dh, Tq, Tqp;
+    float qscale;
 };
 
 // Split-bf16 activation planes in the K32-blocked layout; hi == nullptr means "not requested".
@@ -94,13 +99,26 @@ hipError_t launch_gemm(const GemmArgs& g, int precision, hipStream_t s);
 hipError_t launch_gemm_x3(const GemmX3Args& g, bool x3, int variant, hipStream_t s);
 hipError_t configure_gemm_x3();
 hipError_t configure_attention(int Tq, int dh);
+struct AttnX3Args {
+    const __bf16 *Qhi, *Qlo, *Khi, *Klo, *Vthi, *Vtlo;   // layouts above
+    Planes out;                                            // K32-blocked planes of the out_proj GEMM
+    int Bm, H, dh, d, Tq, Tqp;
+    bool x3;
+};
+bool attn_x3_supported(int Tq, int dh);
+hipError_t configure_attn_x3(int Tq, int dh);
+hipError_t launch_attn_x3(const AttnX3Args& a, hipStream_t s);
 hipError_t launch_attention(const float* qkv, float* out, Planes op, const Dims& dm, hipStream_t s);
 // h_out = LN_b( LN_a(in) + addvec[row/Tq] ) when ln_b != nullptr, else LN_a(in)
+// addvec: per-sample vector (row/Tq)*ldadd, may be nullptr; stepvec: per-step vector at (*d_step)*ldstep, may be nullptr
 hipError_t launch_layernorm(const float* in, float* out, Planes op, int M, int d, const float* ga, const float* ba,
-                            const float* addvec, int ldadd, int Tq, const float* gb, const float* bb, hipStream_t s);
+                            const float* addvec, int ldadd, const float* stepvec, int ldstep, const int* d_step, int Tq,
+                            const float* gb, const float* bb, hipStream_t s);
 hipError_t launch_gather_pe(const float* pe, const StepCoef* tab, const int* d_step, const SampleParams* sp,
                             float* out, int Bm, int B, int d, hipStream_t s);
-hipError_t launch_emb_rows(const float* emb, const float* pe, float* h, Planes hp, const Dims& dm, int wo_pos, hipStream_t s);
+hipError_t launch_gather_pe_all(const float* pe, const StepCoef* tab, float* out, int S, int d, hipStream_t s);
+hipError_t launch_emb_rows(const float* emb, const float* stepemb, const int* d_step, const float* pe, float* h, Planes hp,
+                           const Dims& dm, int wo_pos, hipStream_t s);
 hipError_t launch_add_pe(float* c0, const float* pe, const Dims& dm, hipStream_t s);
 hipError_t launch_pack_x(const float* x, float* xin, Planes xp, int copies, const Dims& dm, hipStream_t s);
 hipError_t launch_update(const float* x0tok, const float* scale, const StepCoef* tab, const int* d_step,

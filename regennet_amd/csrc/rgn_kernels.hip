@@ -590,8 +590,9 @@ hipError_t launch_attention(const float* qkv, float* out, Planes op, const Dims&
 template <int VPL>
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in, float* __restrict__ out, Planes op, int M, int d,
                                                     const float* __restrict__ ga, const float* __restrict__ ba,
-                                                    const float* __restrict__ addvec, int ldadd, int Tq,
-                                                    const float* __restrict__ gb, const float* __restrict__ bb) {
+                                                    const float* __restrict__ addvec, int ldadd,
+                                                    const float* __restrict__ stepvec, int ldstep, const int* __restrict__ d_step,
+                                                    int Tq, const float* __restrict__ gb, const float* __restrict__ bb) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -615,11 +616,14 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
 #pragma unroll
     for (int i = 0; i < VPL; ++i) v[i] = (v[i] - mean) * rstd * ga[lane + 64 * i] + ba[lane + 64 * i];
     if (gb) {
-        const float* av = addvec + (size_t)(row / Tq) * ldadd;
+        const float* av = addvec ? addvec + (size_t)(row / Tq) * ldadd : nullptr;
+        const float* sv = stepvec ? stepvec + (size_t)(*d_step) * ldstep : nullptr;
         s = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
-            v[i] += av[lane + 64 * i];
+            float a = sv ? sv[lane + 64 * i] : 0.f;
+            if (av) a += av[lane + 64 * i];
+            v[i] += a;
             s += v[i];
         }
         mean = wave_sum(s) * invd;
@@ -643,9 +647,10 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
 }
 
 hipError_t launch_layernorm(const float* in, float* out, Planes op, int M, int d, const float* ga, const float* ba,
-                            const float* addvec, int ldadd, int Tq, const float* gb, const float* bb, hipStream_t s) {
+                            const float* addvec, int ldadd, const float* stepvec, int ldstep, const int* d_step, int Tq,
+                            const float* gb, const float* bb, hipStream_t s) {
     dim3 grid((M + 3) / 4), block(256);
-#define RGN_LN(V) hipLaunchKernelGGL(k_layernorm<V>, grid, block, 0, s, in, out, op, M, d, ga, ba, addvec, ldadd, Tq, gb, bb)
+#define RGN_LN(V) hipLaunchKernelGGL(k_layernorm<V>, grid, block, 0, s, in, out, op, M, d, ga, ba, addvec, ldadd, stepvec, ldstep, d_step, Tq, gb, bb)
     switch (d / 64) {
         case 1: RGN_LN(1); break;
         case 2: RGN_LN(2); break;
@@ -679,18 +684,32 @@ hipError_t launch_gather_pe(const float* pe, const StepCoef* tab, const int* d_s
     return hipGetLastError();
 }
 
+// schedule-time variant: out[i,:] = pe[timestep_map[i],:] for every loop index i (the timestep embedding of the
+// sampling loop depends on the step only, so its MLP and the folded cross-attention GEMM run once per schedule)
+__global__ void k_gather_pe_all(const float* __restrict__ pe, const StepCoef* __restrict__ tab, float* __restrict__ out, int d) {
+    const int i = blockIdx.x;
+    const long long t = tab[i].t_model;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) out[(size_t)i * d + c] = pe[(size_t)t * d + c];
+}
+hipError_t launch_gather_pe_all(const float* pe, const StepCoef* tab, float* out, int S, int d, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_pe_all, dim3(S), dim3(d >= 256 ? 256 : 64), 0, s, pe, tab, out, d);
+    return hipGetLastError();
+}
+
 // emb_trans_dec: token 0 of every sample is emb[b] (+ pe[0])            (cmdm.py:212-218)
-__global__ void k_emb_rows(const float* __restrict__ emb, const float* __restrict__ pe, float* __restrict__ h, Planes hp,
-                           Dims dm, int wo_pos) {
+__global__ void k_emb_rows(const float* __restrict__ emb, const float* __restrict__ stepemb, const int* __restrict__ d_step,
+                           const float* __restrict__ pe, float* __restrict__ h, Planes hp, Dims dm, int wo_pos) {
     const int b = blockIdx.x;
+    const float* se = stepemb ? stepemb + (size_t)(*d_step) * dm.d : nullptr;   // sampling loop: time part per step
     for (int c = threadIdx.x; c < dm.d; c += blockDim.x) {
-        const float v = emb[(size_t)b * dm.d + c] + (wo_pos ? 0.f : pe[c]);
+        const float v = (emb ? emb[(size_t)b * dm.d + c] : 0.f) + (se ? se[c] : 0.f) + (wo_pos ? 0.f : pe[c]);
         h[(size_t)b * dm.Tq * dm.d + c] = v;
         if (hp.hi) plane_put(hp, b * dm.Tq, c, v);
     }
 }
-hipError_t launch_emb_rows(const float* emb, const float* pe, float* h, Planes hp, const Dims& dm, int wo_pos, hipStream_t s) {
-    hipLaunchKernelGGL(k_emb_rows, dim3(dm.Bm), dim3(256), 0, s, emb, pe, h, hp, dm, wo_pos);
+hipError_t launch_emb_rows(const float* emb, const float* stepemb, const int* d_step, const float* pe, float* h, Planes hp,
+                           const Dims& dm, int wo_pos, hipStream_t s) {
+    hipLaunchKernelGGL(k_emb_rows, dim3(dm.Bm), dim3(256), 0, s, emb, stepemb, d_step, pe, h, hp, dm, wo_pos);
     return hipGetLastError();
 }
 

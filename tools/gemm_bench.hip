@@ -46,10 +46,15 @@ int main(int argc, char** argv) {
         CK(configure_gemm_x3());
         GemmX3Args g{};
         g.Ahi = dAh; g.Alo = dAl; g.a_rows = M; g.Whi = dWh; g.Wlo = dWl; g.bias = dB; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.Kp = Kp;
+        __bf16 *dCh = nullptr, *dCl = nullptr;
+        const bool planes_out = getenv("PLANES") != nullptr;
+        if (planes_out) { CK(hipMalloc(&dCh, (size_t)M * ((N + 31) / 32 * 32) * 2)); CK(hipMalloc(&dCl, (size_t)M * ((N + 31) / 32 * 32) * 2)); g.Chi = dCh; g.Clo = dCl; g.c_rows = M; g.act = 1; }
         CK(launch_gemm_x3(g, true, variant, nullptr));
         CK(hipDeviceSynchronize());
         std::vector<float> C((size_t)M * N);
         CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<uint16_t> Ph, Pl;
+        if (planes_out) { Ph.resize((size_t)M * ((N + 31) / 32 * 32)); Pl.resize(Ph.size()); CK(hipMemcpy(Ph.data(), dCh, Ph.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(Pl.data(), dCl, Pl.size() * 2, hipMemcpyDeviceToHost)); }
         double maxerr = 0, maxref = 0;
         std::mt19937 pick(7);
         const int nchk = (M * (long)N < 100000) ? M * N : 4000;
@@ -58,7 +63,9 @@ int main(int argc, char** argv) {
             if (nchk == M * N) { m = c / N; n = c % N; } else { m = pick() % M; n = pick() % N; if (c < 64) { m = M - 1 - (c % 8); n = N - 1 - (c / 8); } }
             double ref = bias[n];
             for (int k = 0; k < K; ++k) ref += (double)A[(size_t)m * K + k] * W[(size_t)n * K + k];
-            maxerr = fmax(maxerr, fabs(ref - C[(size_t)m * N + n])); maxref = fmax(maxref, fabs(ref));
+            if (planes_out) { ref = 0.5 * ref * (1.0 + erf(ref * 0.7071067811865476)); size_t o = ((size_t)(n / 32) * M + m) * 32 + n % 32; double got = (double)bf2f(Ph[o]) + (double)bf2f(Pl[o]); maxerr = fmax(maxerr, fabs(ref - got)); maxerr = fmax(maxerr, fabs(ref - C[(size_t)m * N + n])); }
+            else maxerr = fmax(maxerr, fabs(ref - C[(size_t)m * N + n]));
+            maxref = fmax(maxref, fabs(ref));
         }
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         for (int i = 0; i < 3; ++i) CK(launch_gemm_x3(g, true, variant, nullptr));
