@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--respacing", default="", help="timestep_respacing ('' = 1000-step DDPM)")
     ap.add_argument("--sampler", default="ddpm", choices=["ddpm", "ddim"])
     ap.add_argument("--guided", action="store_true")
-    ap.add_argument("--precision", default=os.environ.get("REGENNET_PRECISION", "f32"))
+    ap.add_argument("--precision", default=os.environ.get("REGENNET_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-evals", type=int, default=3)
@@ -118,10 +118,7 @@ def main():
     if world > 1:
         ptr, nbytes = eng.weight_blob()
 
-        class _Blob:
-            __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
-
-        blob = torch.as_tensor(_Blob(), device=dev)
+        blob = dist_util.device_view(ptr, nbytes, dev)      # zero-copy uint8 view of the packed weight blob
         dist_util.broadcast_flat(blob, 0)                   # ONE collective over xGMI
         torch.cuda.synchronize()
     fm = ClassifierFreeSampleModel(model) if a.guided else model

@@ -30,6 +30,10 @@
 
 #include <type_traits>
 
+#ifndef RGN_PP_ABLATE
+#define RGN_PP_ABLATE 0   // tools only: 1 = MFMA + barriers only, 2 = MFMA only (no barriers / LDS / DMA after prologue)
+#endif
+
 namespace rgn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -67,6 +71,159 @@ __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else static_assert(N == 0, "add the vmcnt literal");
+}
+
+// ---- epilogue ------------------------------------------------------------------------------------------
+// Straight from the MFMA C/D layout (col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)): for a fixed register
+// the two half-waves write two full 128-byte row segments (fp32) or two 64-byte segments of the K32-blocked bf16
+// planes. Interior blocks take a branch-free path (CHECK = false): one pointer per tile, constant row strides,
+// residual loads batched per tile; only edge blocks pay per-element bounds checks.
+// mw / nw: first row / column of this wave's TM x TN tiles of 32x32.
+template <int TM, int TN, bool QKV, bool CHECK>
+__device__ __forceinline__ void x3_epilogue(const GemmX3Args& g, f32x16 (&acc)[TM][TN], int mw, int nw, int lane) {
+    const int l31 = lane & 31, kh = lane >> 5;
+            // (sample, token) of the first row of every 4-row register group, for the attention-ready scatter
+    int row_b[TM][4], row_t[TM][4];
+    bool rows_same[TM];
+    if constexpr (QKV) {
+#pragma unroll
+        for (int ta = 0; ta < TM; ++ta) {
+            rows_same[ta] = true;
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const int m4 = mw + ta * 32 + 4 * kh + 8 * i4;
+                row_b[ta][i4] = m4 / g.Tq;
+                row_t[ta][i4] = m4 - row_b[ta][i4] * g.Tq;
+                rows_same[ta] = rows_same[ta] && (row_t[ta][i4] + 3 < g.Tq);
+            }
+            rows_same[ta] = __all(rows_same[ta]);
+        }
+    }
+#pragma unroll
+    for (int tb = 0; tb < TN; ++tb) {
+        const int n = nw + tb * 32 + l31;
+        const bool n_ok = !CHECK || n < g.N;
+        const float bias = (g.bias && n_ok) ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int ta = 0; ta < TM; ++ta) {
+            const int mb = mw + ta * 32 + 4 * kh;      // row of register 0
+            float r[16];
+            if (g.add) {
+                const float* ap = g.add + (size_t)mb * g.ldadd + n;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ro = (i & 3) + 8 * (i >> 2);
+                    r[i] = (!CHECK || (n_ok && mb + ro < g.M)) ? ap[(size_t)ro * g.ldadd] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = acc[ta][tb][i] + bias;
+                if (g.add) v += r[i];
+                r[i] = x3_act(v, g.act);
+            }
+            if constexpr (QKV) {   // attention-ready scatter of the packed in_proj output (see GemmX3Args)
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                const int which = n / g.d, cin = n - which * g.d, hd = cin / g.dh, c = cin - hd * g.dh;
+                __bf16* ph = which == 0 ? g.Qhi : (which == 1 ? g.Khi : g.Vthi);
+                __bf16* pl = which == 0 ? g.Qlo : (which == 1 ? g.Klo : g.Vtlo);
+                const bool fastp = !CHECK && rows_same[ta];          // every 4-row group of this tile stays inside one sample
+                if (which == 2 && fastp) {                            // V^T: 4 consecutive tokens -> one 8-byte store
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        bf16x4 hv, lv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x = r[4 * i4 + e];
+                            hv[e] = (__bf16)x;
+                            lv[e] = (__bf16)(x - (float)hv[e]);
+                        }
+                        const size_t o = (((size_t)row_b[ta][i4] * g.H + hd) * g.dh + c) * g.Tqp + row_t[ta][i4];
+                        *reinterpret_cast<bf16x4*>(ph + o) = hv;
+                        if (pl) *reinterpret_cast<bf16x4*>(pl + o) = lv;
+                    }
+                } else if (which != 2 && fastp) {                     // q / k: pair adjacent columns across lane^1 -> 4-byte stores
+                    const float sc = which == 0 ? g.qscale : 1.0f;
+                    const bool odd = lane & 1;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float mine = (odd ? r[i + 8] : r[i]) * sc;
+                        const float give = (odd ? r[i] : r[i + 8]) * sc;
+                        const float got = __shfl_xor(give, 1, 64);
+                        const float c0 = odd ? got : mine, c1 = odd ? mine : got;
+                        const int ii = odd ? i + 8 : i, i4 = ii >> 2, e = ii & 3;
+                        const size_t o = (((size_t)row_b[ta][i4] * g.H + hd) * g.Tqp + row_t[ta][i4] + e) * g.dh + (c & ~1);
+                        const __bf16 h0 = (__bf16)c0, h1 = (__bf16)c1;
+                        bf16x2 hv = {h0, h1};
+                        *reinterpret_cast<bf16x2*>(ph + o) = hv;
+                        if (pl) {
+                            bf16x2 lv = {(__bf16)(c0 - (float)h0), (__bf16)(c1 - (float)h1)};
+                            *reinterpret_cast<bf16x2*>(pl + o) = lv;
+                        }
+                    }
+                } else {                                              // edge blocks / samples whose length is not a multiple of 4
+                    const float sc = which == 0 ? g.qscale : 1.0f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int m = mb + (i & 3) + 8 * (i >> 2);
+                        if (!n_ok || m >= g.M) continue;
+                        const int bb = m / g.Tq, tt = m - bb * g.Tq;
+                        const size_t sl = (size_t)bb * g.H + hd;
+                        const float x = r[i] * sc;
+                        const __bf16 h = (__bf16)x;
+                        const size_t o = which == 2 ? (sl * g.dh + c) * g.Tqp + tt : (sl * g.Tqp + tt) * g.dh + c;
+                        ph[o] = h;
+                        if (pl) pl[o] = (__bf16)(x - (float)h);
+                    }
+                }
+            }
+            if (!QKV && g.C) {
+                float* cp = g.C + (size_t)mb * g.ldc + n;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ro = (i & 3) + 8 * (i >> 2);
+                    if (!CHECK || (n_ok && mb + ro < g.M)) cp[(size_t)ro * g.ldc] = r[i];
+                }
+            }
+            if (!QKV && g.Chi) {   // K32-blocked planes [N/32][c_rows][32]: a 32-column tile is one contiguous run of rows
+                if (!CHECK) {
+                    // pair adjacent columns across lanes (lane^1) so every store is a packed bf16x2 (4 B):
+                    // even lanes store rows of registers 0..7, odd lanes those of registers 8..15
+                    const size_t o = ((size_t)(n >> 5) * g.c_rows + mb) * 32 + (n & 30);
+                    const bool odd = lane & 1;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float mine = odd ? r[i + 8] : r[i];          // value this lane contributes to its own store
+                        const float give = odd ? r[i] : r[i + 8];          // value the partner needs
+                        const float got = __shfl_xor(give, 1, 64);
+                        const float lo_col = odd ? got : mine, hi_col = odd ? mine : got;   // columns n&~1, (n&~1)+1
+                        const int ii = odd ? i + 8 : i;
+                        const int ro = (ii & 3) + 8 * (ii >> 2);
+                        const __bf16 h0 = (__bf16)lo_col, h1 = (__bf16)hi_col;
+                        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                        bf16x2 hv = {h0, h1};
+                        *reinterpret_cast<bf16x2*>(g.Chi + o + ro * 32) = hv;
+                        if (g.Clo) {
+                            bf16x2 lv = {(__bf16)(lo_col - (float)h0), (__bf16)(hi_col - (float)h1)};
+                            *reinterpret_cast<bf16x2*>(g.Clo + o + ro * 32) = lv;
+                        }
+                    }
+                } else {
+                    const size_t o = ((size_t)(n >> 5) * g.c_rows + mb) * 32 + (n & 31);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int ro = (i & 3) + 8 * (i >> 2);
+                        if (n_ok && mb + ro < g.M) {
+                            const __bf16 h = (__bf16)r[i];
+                            g.Chi[o + ro * 32] = h;
+                            if (g.Clo) g.Clo[o + ro * 32] = (__bf16)(r[i] - (float)h);
+                        }
+                    }
+                }
+            }
+        }
+    }
 }
 
 // BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN) = TM x TN tiles of 32x32.
@@ -209,159 +366,197 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_x3(GemmX3Args g, int n
         }
     }
 
-    // ---- epilogue ------------------------------------------------------------------------------------
-    // Straight from the MFMA C/D layout (col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)): for a fixed
-    // register the two half-waves write two full 128-byte row segments (fp32) or two 64-byte segments of the
-    // K32-blocked bf16 planes. Interior blocks take a branch-free path: one pointer per tile, constant row
-    // strides, residual loads batched per tile; only edge blocks pay per-element bounds checks.
     const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
-    auto emit = [&](auto check_tag) {
-        constexpr bool CHECK = decltype(check_tag)::value;
-        // (sample, token) of the first row of every 4-row register group, for the attention-ready scatter
-        int row_b[TM][4], row_t[TM][4];
-        bool rows_same[TM];
-        if constexpr (QKV) {
+    if (interior) x3_epilogue<TM, TN, QKV, false>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+    else x3_epilogue<TM, TN, QKV, true>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+}
+
+// =================================================================================================
+// Ping-pong variant: 256x128 tile, 8 waves = two groups of four (one wave of each group per SIMD), 3 stages.
+// A k-step is two phases separated by raw s_barriers. In the even phase group A issues its 24 MFMAs back to back
+// on tile kt while group B (idle matrix pipe) reads its fragments of tile kt from LDS and issues its share of
+// the DMA for tile kt+2; in the odd phase the roles swap (B computes tile kt, A prepares tile kt+1 / DMA kt+3).
+// The two waves that share a SIMD therefore never compete for the matrix pipe and never idle it together, and
+// every DMA has >= 3 phases (>= 2300 matrix cycles) to land. One counted s_waitcnt vmcnt per k-step per wave.
+//   stage of tile j : j % 3.   DMA(j+2) is issued in the off-phase that precedes MFMA(j); it overwrites the stage
+//   of tile j-1, whose last LDS reader finished one barrier earlier.
+// =================================================================================================
+template <bool X3, bool QKV>
+__global__ __launch_bounds__(512, 2) void k_gemm_x3_pp(GemmX3Args g, int nbx, int nby) {
+    constexpr int BM = 256, BN = 128, NT = 512, TM = 2, TN = 2;
+    constexpr int NPL = X3 ? 2 : 1;
+    constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64;
+    constexpr int STAGE = NPL * (A_BYTES + W_BYTES);
+    constexpr int A_IT = BM * 4 / NT, W_IT = BN * 4 / NT;   // 2, 1
+    constexpr int LPT = NPL * (A_IT + W_IT);                // DMA instructions per wave per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool gA = wave < 4;                               // group A: rows 0..127, group B: rows 128..255
+    const int wq = wave & 3, wm = wq >> 1, wn = wq & 1;
+    const int nwg = nbx * nby, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int m0 = (vid / nbx) * BM, n0 = (vid % nbx) * BN;
+    const int mrow = (gA ? 0 : 128) + wm * 64;              // first tile row of this wave inside the block tile
+
+    size_t a_src[A_IT], w_src[W_IT];
 #pragma unroll
-            for (int ta = 0; ta < TM; ++ta) {
-                rows_same[ta] = true;
+    for (int it = 0; it < A_IT; ++it) {
+        const int q = it * NT + tid, r = q >> 2, c = (q & 3) ^ ((r >> 2) & 3);
+        int m = m0 + r;
+        m = m < g.M ? m : g.M - 1;
+        a_src[it] = (size_t)m * 32 + c * 8;
+    }
 #pragma unroll
-                for (int i4 = 0; i4 < 4; ++i4) {
-                    const int m4 = m0 + wm * (BM / WM) + ta * 32 + 4 * kh + 8 * i4;
-                    row_b[ta][i4] = m4 / g.Tq;
-                    row_t[ta][i4] = m4 - row_b[ta][i4] * g.Tq;
-                    rows_same[ta] = rows_same[ta] && (row_t[ta][i4] + 3 < g.Tq);
-                }
-                rows_same[ta] = __all(rows_same[ta]);
-            }
+    for (int it = 0; it < W_IT; ++it) {
+        const int q = it * NT + tid, r = q >> 2, c = (q & 3) ^ ((r >> 2) & 3);
+        int n = n0 + r;
+        n = n < g.N ? n : g.N - 1;
+        w_src[it] = (size_t)n * 32 + c * 8;
+    }
+    auto issue = [&](int kt, int stage) {                    // this wave's share of tile kt
+        char* sb = smem + stage * STAGE;
+        const size_t ka = (size_t)kt * g.a_rows * 32, kw = (size_t)kt * g.N * 32;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int lo = (it * NT + (tid & ~63)) * 16;
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.Ahi + a_src[it] + ka), (RGN_AS3 void*)(sb + lo), 16, 0, 0);
+            if (X3)
+                __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.Alo + a_src[it] + ka), (RGN_AS3 void*)(sb + A_BYTES + lo), 16, 0, 0);
         }
 #pragma unroll
-        for (int tb = 0; tb < TN; ++tb) {
-            const int n = n0 + wn * (BN / WN) + tb * 32 + l31;
-            const bool n_ok = !CHECK || n < g.N;
-            const float bias = (g.bias && n_ok) ? g.bias[n] : 0.f;
+        for (int it = 0; it < W_IT; ++it) {
+            const int lo = (it * NT + (tid & ~63)) * 16;
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.Whi + w_src[it] + kw), (RGN_AS3 void*)(sb + NPL * A_BYTES + lo), 16, 0, 0);
+            if (X3)
+                __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.Wlo + w_src[it] + kw), (RGN_AS3 void*)(sb + NPL * A_BYTES + W_BYTES + lo), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
 #pragma unroll
-            for (int ta = 0; ta < TM; ++ta) {
-                const int mb = m0 + wm * (BM / WM) + ta * 32 + 4 * kh;      // row of register 0
-                float r[16];
-                if (g.add) {
-                    const float* ap = g.add + (size_t)mb * g.ldadd + n;
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int ro = (i & 3) + 8 * (i >> 2);
-                        r[i] = (!CHECK || (n_ok && mb + ro < g.M)) ? ap[(size_t)ro * g.ldadd] : 0.f;
-                    }
-                }
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float v = acc[ta][tb][i] + bias;
-                    if (g.add) v += r[i];
-                    r[i] = x3_act(v, g.act);
-                }
-                if constexpr (QKV) {   // attention-ready scatter of the packed in_proj output (see GemmX3Args)
-                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                    const int which = n / g.d, cin = n - which * g.d, hd = cin / g.dh, c = cin - hd * g.dh;
-                    __bf16* ph = which == 0 ? g.Qhi : (which == 1 ? g.Khi : g.Vthi);
-                    __bf16* pl = which == 0 ? g.Qlo : (which == 1 ? g.Klo : g.Vtlo);
-                    const bool fastp = !CHECK && rows_same[ta];          // every 4-row group of this tile stays inside one sample
-                    if (which == 2 && fastp) {                            // V^T: 4 consecutive tokens -> one 8-byte store
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    const int l31 = lane & 31, kh = lane >> 5;
+    int a_off[TM][2], w_off[TN][2];
 #pragma unroll
-                        for (int i4 = 0; i4 < 4; ++i4) {
-                            bf16x4 hv, lv;
+    for (int t = 0; t < TM; ++t) {
+        const int rr = mrow + t * 32 + l31;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float x = r[4 * i4 + e];
-                                hv[e] = (__bf16)x;
-                                lv[e] = (__bf16)(x - (float)hv[e]);
-                            }
-                            const size_t o = (((size_t)row_b[ta][i4] * g.H + hd) * g.dh + c) * g.Tqp + row_t[ta][i4];
-                            *reinterpret_cast<bf16x4*>(ph + o) = hv;
-                            if (pl) *reinterpret_cast<bf16x4*>(pl + o) = lv;
-                        }
-                    } else if (which != 2 && fastp) {                     // q / k: pair adjacent columns across lane^1 -> 4-byte stores
-                        const float sc = which == 0 ? g.qscale : 1.0f;
-                        const bool odd = lane & 1;
+        for (int ks = 0; ks < 2; ++ks) a_off[t][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
+    }
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const float mine = (odd ? r[i + 8] : r[i]) * sc;
-                            const float give = (odd ? r[i] : r[i + 8]) * sc;
-                            const float got = __shfl_xor(give, 1, 64);
-                            const float c0 = odd ? got : mine, c1 = odd ? mine : got;
-                            const int ii = odd ? i + 8 : i, i4 = ii >> 2, e = ii & 3;
-                            const size_t o = (((size_t)row_b[ta][i4] * g.H + hd) * g.Tqp + row_t[ta][i4] + e) * g.dh + (c & ~1);
-                            const __bf16 h0 = (__bf16)c0, h1 = (__bf16)c1;
-                            bf16x2 hv = {h0, h1};
-                            *reinterpret_cast<bf16x2*>(ph + o) = hv;
-                            if (pl) {
-                                bf16x2 lv = {(__bf16)(c0 - (float)h0), (__bf16)(c1 - (float)h1)};
-                                *reinterpret_cast<bf16x2*>(pl + o) = lv;
-                            }
-                        }
-                    } else {                                              // edge blocks / samples whose length is not a multiple of 4
-                        const float sc = which == 0 ? g.qscale : 1.0f;
+    for (int t = 0; t < TN; ++t) {
+        const int rr = wn * 64 + t * 32 + l31;
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const int m = mb + (i & 3) + 8 * (i >> 2);
-                            if (!n_ok || m >= g.M) continue;
-                            const int bb = m / g.Tq, tt = m - bb * g.Tq;
-                            const size_t sl = (size_t)bb * g.H + hd;
-                            const float x = r[i] * sc;
-                            const __bf16 h = (__bf16)x;
-                            const size_t o = which == 2 ? (sl * g.dh + c) * g.Tqp + tt : (sl * g.Tqp + tt) * g.dh + c;
-                            ph[o] = h;
-                            if (pl) pl[o] = (__bf16)(x - (float)h);
-                        }
-                    }
-                }
-                if (!QKV && g.C) {
-                    float* cp = g.C + (size_t)mb * g.ldc + n;
+        for (int ks = 0; ks < 2; ++ks) w_off[t][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
+    }
+    bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+    auto read_frags = [&](int stage) {
+        const char* sb = smem + stage * STAGE;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int ro = (i & 3) + 8 * (i >> 2);
-                        if (!CHECK || (n_ok && mb + ro < g.M)) cp[(size_t)ro * g.ldc] = r[i];
-                    }
-                }
-                if (!QKV && g.Chi) {   // K32-blocked planes [N/32][c_rows][32]: a 32-column tile is one contiguous run of rows
-                    if (!CHECK) {
-                        // pair adjacent columns across lanes (lane^1) so every store is a packed bf16x2 (4 B):
-                        // even lanes store rows of registers 0..7, odd lanes those of registers 8..15
-                        const size_t o = ((size_t)(n >> 5) * g.c_rows + mb) * 32 + (n & 30);
-                        const bool odd = lane & 1;
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const float mine = odd ? r[i + 8] : r[i];          // value this lane contributes to its own store
-                            const float give = odd ? r[i] : r[i + 8];          // value the partner needs
-                            const float got = __shfl_xor(give, 1, 64);
-                            const float lo_col = odd ? got : mine, hi_col = odd ? mine : got;   // columns n&~1, (n&~1)+1
-                            const int ii = odd ? i + 8 : i;
-                            const int ro = (ii & 3) + 8 * (ii >> 2);
-                            const __bf16 h0 = (__bf16)lo_col, h1 = (__bf16)hi_col;
-                            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                            bf16x2 hv = {h0, h1};
-                            *reinterpret_cast<bf16x2*>(g.Chi + o + ro * 32) = hv;
-                            if (g.Clo) {
-                                bf16x2 lv = {(__bf16)(lo_col - (float)h0), (__bf16)(hi_col - (float)h1)};
-                                *reinterpret_cast<bf16x2*>(g.Clo + o + ro * 32) = lv;
-                            }
-                        }
-                    } else {
-                        const size_t o = ((size_t)(n >> 5) * g.c_rows + mb) * 32 + (n & 31);
+            for (int t = 0; t < TM; ++t) {
+                ah[ks][t] = *reinterpret_cast<const bf16x8*>(sb + a_off[t][ks]);
+                if (X3) al[ks][t] = *reinterpret_cast<const bf16x8*>(sb + A_BYTES + a_off[t][ks]);
+            }
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const int ro = (i & 3) + 8 * (i >> 2);
-                            if (n_ok && mb + ro < g.M) {
-                                const __bf16 h = (__bf16)r[i];
-                                g.Chi[o + ro * 32] = h;
-                                if (g.Clo) g.Clo[o + ro * 32] = (__bf16)(r[i] - (float)h);
-                            }
-                        }
-                    }
-                }
+            for (int t = 0; t < TN; ++t) {
+                bh[ks][t] = *reinterpret_cast<const bf16x8*>(sb + NPL * A_BYTES + w_off[t][ks]);
+                if (X3) bl[ks][t] = *reinterpret_cast<const bf16x8*>(sb + NPL * A_BYTES + W_BYTES + w_off[t][ks]);
             }
         }
     };
-    if (interior) emit(std::false_type{});
-    else emit(std::true_type{});
+    auto mfmas = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < TN; ++tb) {
+                    if (X3) {
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][ta], bh[ks][tb], acc[ta][tb], 0, 0, 0);
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][ta], bl[ks][tb], acc[ta][tb], 0, 0, 0);
+                    }
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][ta], bh[ks][tb], acc[ta][tb], 0, 0, 0);
+                }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    const int nk = g.Kp / 32;
+    // prologue: tiles 0 and 1 by everyone, tile 2 by group A (its off-phase "-1"); group A then reads tile 0
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (gA && nk > 2) issue(2, 2);
+    {
+        const int later = (nk > 1 ? 1 : 0) + ((gA && nk > 2) ? 1 : 0);   // tile groups younger than tile 0
+        if (later == 2) wait_vmcnt<2 * LPT>();
+        else if (later == 1) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (gA || RGN_PP_ABLATE) read_frags(0);
+    int st_j = 0;                                            // stage of tile j
+    for (int j = 0; j < nk; ++j) {
+        const int st_j1 = st_j == 2 ? 0 : st_j + 1;         // stage of tile j+1 (and of tile j-2)
+        const int st_j2 = st_j1 == 2 ? 0 : st_j1 + 1;       // stage of tile j+2 (== stage of tile j-1)
+        // ---- even phase: A computes tile j; B reads its fragments of tile j and issues DMA(j+2)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of the previous phase are done
+        if (RGN_PP_ABLATE != 2) __builtin_amdgcn_s_barrier();
+        if (gA) {
+            mfmas();
+        } else if (RGN_PP_ABLATE == 0) {
+            read_frags(st_j);
+            if (j + 2 < nk) issue(j + 2, st_j2);
+        }
+        // tile j+1 must have landed before anyone reads it (A: next phase, B: next even phase)
+        if (j + 2 < nk && RGN_PP_ABLATE == 0) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
+        // ---- odd phase: B computes tile j; A reads its fragments of tile j+1 and issues DMA(j+3)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (RGN_PP_ABLATE != 2) __builtin_amdgcn_s_barrier();
+        if (gA) {
+            if (RGN_PP_ABLATE == 0) {
+                if (j + 1 < nk) read_frags(st_j1);
+                if (j + 3 < nk) issue(j + 3, st_j);         // stage of tile j: both groups are done reading it
+            }
+        } else {
+            mfmas();
+        }
+        st_j = st_j1;
+    }
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+    if (interior) x3_epilogue<TM, TN, QKV, false>(g, acc, m0 + mrow, n0 + wn * 64, lane);
+    else x3_epilogue<TM, TN, QKV, true>(g, acc, m0 + mrow, n0 + wn * 64, lane);
+}
+
+static hipError_t x3_pp_launch(const GemmX3Args& g, bool x3, hipStream_t s, bool configure_only) {
+    const int lds = 3 * (x3 ? 2 : 1) * (256 * 64 + 128 * 64);
+    if (configure_only) {
+        hipError_t e;
+#define RGN_CFG(X3V, QV, BYTES)                                                                                          \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_x3_pp<X3V, QV>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES); \
+        if (e != hipSuccess) return e;
+        RGN_CFG(true, false, 147456) RGN_CFG(false, false, 73728) RGN_CFG(true, true, 147456) RGN_CFG(false, true, 73728)
+#undef RGN_CFG
+        return hipSuccess;
+    }
+    const int nbx = (g.N + 127) / 128, nby = (g.M + 255) / 256;
+    const dim3 grid(nbx * nby), block(512);
+    const bool qkv = g.Qhi != nullptr;
+    if (x3 && !qkv) hipLaunchKernelGGL((k_gemm_x3_pp<true, false>), grid, block, lds, s, g, nbx, nby);
+    else if (x3 && qkv) hipLaunchKernelGGL((k_gemm_x3_pp<true, true>), grid, block, lds, s, g, nbx, nby);
+    else if (!qkv) hipLaunchKernelGGL((k_gemm_x3_pp<false, false>), grid, block, lds, s, g, nbx, nby);
+    else hipLaunchKernelGGL((k_gemm_x3_pp<false, true>), grid, block, lds, s, g, nbx, nby);
+    return hipGetLastError();
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE>
@@ -388,14 +583,18 @@ static hipError_t x3_launch(const GemmX3Args& g, bool x3, hipStream_t s, bool co
     return hipGetLastError();
 }
 
-// variant: 0 = 128x128 / 4 waves / 2 stages (64 KiB: two workgroups per CU), 1 = 256x128 / 8 waves / 3 stages
+// variant: 0 = 128x128 / 4 waves / 2 stages (64 KiB: two workgroups per CU), 1 = 256x128 / 8 waves / 3 stages,
+//          2 = 256x128 / 8 waves / 3 stages, ping-pong wave groups (k_gemm_x3_pp)
 hipError_t launch_gemm_x3(const GemmX3Args& g, bool x3, int variant, hipStream_t s) {
+    if (variant == 2) return x3_pp_launch(g, x3, s, false);
     if (variant == 1) return x3_launch<256, 128, 4, 2, 3>(g, x3, s, false);
     return x3_launch<128, 128, 2, 2, 2>(g, x3, s, false);
 }
 hipError_t configure_gemm_x3() {
     GemmX3Args g{};
     hipError_t e = x3_launch<128, 128, 2, 2, 2>(g, true, nullptr, true);
+    if (e != hipSuccess) return e;
+    e = x3_pp_launch(g, true, nullptr, true);
     if (e != hipSuccess) return e;
     return x3_launch<256, 128, 4, 2, 3>(g, true, nullptr, true);
 }

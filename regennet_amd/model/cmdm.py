@@ -132,7 +132,7 @@ class CMDM(nn.Module):
         self.output_process = _Pose("poseFinal", d, self.input_feats)
         self.rot2xyz = _Rot2xyzUnavailable()
 
-        self.precision = os.environ.get("REGENNET_PRECISION", kargs.get("precision", "f32"))
+        self.precision = os.environ.get("REGENNET_PRECISION", kargs.get("precision", "bf16x3"))
         self._engine = None
         self._engine_stale = True
         self._cond_key = None

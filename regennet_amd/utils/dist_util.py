@@ -55,6 +55,15 @@ def shard_bounds(total, rank=None, world_size=None):
     return lo, lo + base + (1 if r < extra else 0)
 
 
+def device_view(ptr, nbytes, device):
+    """Zero-copy uint8 tensor over raw device memory (e.g. the engine's packed weight blob, rgn_weight_blob)."""
+
+    class _Raw:
+        __cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+    return torch.as_tensor(_Raw(), device=device)
+
+
 def broadcast_flat(buf, src=0):
     """Broadcast one flat tensor from `src` (the packed weight blob): one collective over xGMI."""
     if dist.is_initialized() and dist.get_world_size() > 1:

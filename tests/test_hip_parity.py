@@ -207,3 +207,31 @@ def test_cgenerate_cli_synthetic(tmp_path):
     res = np.load(out, allow_pickle=True).item()
     assert res["output"].shape == (6, 56, 6, 60) and res["cmotion"].shape == (6, 56, 6, 60)
     assert np.isfinite(res["output"]).all()
+
+
+def test_weight_blob_view_transfers_a_checkpoint():
+    """The multi-GPU start-up path: copying rank 0's packed blob into another engine (what the RCCL broadcast does)
+    makes that engine reproduce rank 0's outputs bit for bit."""
+    from regennet_amd import synth
+    from regennet_amd.utils import dist_util
+    cfg = synth.get_config("tiny")
+    ma, da = build_hip(cfg, synth.make_state_dict(cfg, seed=0), resp="ddim5", precision="bf16x3")
+    mb, db = build_hip(cfg, synth.make_state_dict(cfg, seed=123), resp="ddim5", precision="bf16x3")
+    B = 2
+    y = y_to_device({"cmotion": synth.make_cmotion(cfg, B), "action": synth.make_actions(cfg, B)})
+    kw = dict(clip_denoised=False, model_kwargs={"y": y}, seed=5)
+    ea, _ = ma._get_engine(B)
+    eb, _ = mb._get_engine(B)
+    out_a = da.ddim_sample_loop(ma, (B, 5, 6, 8), **kw)
+    out_b0 = db.ddim_sample_loop(mb, (B, 5, 6, 8), **kw)
+    assert not torch.allclose(out_a, out_b0)
+    (pa, na), (pb, nb) = ea.weight_blob(), eb.weight_blob()
+    assert na == nb and na > 0
+    va, vb = dist_util.device_view(pa, na, "cuda:0"), dist_util.device_view(pb, nb, "cuda:0")
+    assert va.dtype == torch.uint8 and va.numel() == na and va.data_ptr() == pa
+    vb.copy_(va)
+    torch.cuda.synchronize()
+    eb.set_schedule(db.timestep_map, db._engine_tables(), db._sched_token)   # per-schedule tables depend on the weights
+    mb._cond_key = None                                                      # ... and so does the hoisted condition
+    out_b1 = db.ddim_sample_loop(mb, (B, 5, 6, 8), **kw)
+    assert torch.equal(out_a, out_b1)

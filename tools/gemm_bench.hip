@@ -30,8 +30,9 @@ int main(int argc, char** argv) {
     for (auto sh : shapes) {
         const int M = sh.M, N = sh.N, K = sh.K, Kp = (K + 31) / 32 * 32;
         std::vector<float> A((size_t)M * K), W((size_t)N * K), bias(N);
-        for (auto& v : A) v = U(rng);
-        for (auto& v : W) v = U(rng) * 0.1f;
+        const bool zero = getenv("ZERO") != nullptr;
+        for (auto& v : A) v = zero ? 0.f : U(rng);
+        for (auto& v : W) v = zero ? 0.f : U(rng) * 0.1f;
         for (auto& v : bias) v = U(rng);
         std::vector<uint16_t> Ah((size_t)M * Kp, 0), Al((size_t)M * Kp, 0), Wh((size_t)N * Kp, 0), Wl((size_t)N * Kp, 0);
         for (int m = 0; m < M; ++m) for (int k = 0; k < K; ++k) { float v = A[(size_t)m * K + k]; uint16_t h = f2bf(v); size_t o = ((size_t)(k / 32) * M + m) * 32 + k % 32; Ah[o] = h; Al[o] = f2bf(v - bf2f(h)); }
