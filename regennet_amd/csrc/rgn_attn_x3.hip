@@ -8,8 +8,9 @@
 //   softmax over keys               in-register max/sum + one lane^32 exchange
 //   O^T[dh, query]  = V^T . P^T     B = P from the S^T accumulator registers (split into hi/lo bf16 in place: the
 //                                   C/D layout is the B layout up to a permutation of the key index), A = V^T tile:
-//                                   the GEMM epilogue stores v transposed [dh][Tqp], so a lane's 8 keys are two
-//                                   8-byte LDS reads (rows padded to Tqp+4 bf16: conflict-free ds_read_b64)
+//                                   v is transposed on its way into LDS (two keys packed per 4-byte ds_write, lanes
+//                                   along keys: conflict-free), so a lane's 8 keys are two 8-byte LDS reads
+//                                   (rows padded to Tqp+4 bf16: conflict-free ds_read_b64)
 // K and V^T time-share the LDS slab. The result is transposed through the dead slab and written as split planes in
 // the K32-blocked layout the out_proj GEMM consumes.
 #include "rgn_internal.h"
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(64 * NT) void k_attn_x3(AttnX3Args a) {
     const int Tq = a.Tq;
     const size_t slab = (size_t)b * a.H + hd;
     const __bf16* gK[2] = {a.Khi + slab * a.Tqp * DH, a.Klo + (X3 ? slab * a.Tqp * DH : 0)};
-    const __bf16* gV[2] = {a.Vthi + slab * DH * a.Tqp, a.Vtlo + (X3 ? slab * DH * a.Tqp : 0)};
+    const __bf16* gV[2] = {a.Vthi + slab * a.Tqp * DH, a.Vtlo + (X3 ? slab * a.Tqp * DH : 0)};
     constexpr int NPL = X3 ? 2 : 1;
 
     // ---- K -> LDS (rows >= Tq read as zero)
@@ -121,13 +122,27 @@ __global__ __launch_bounds__(64 * NT) void k_attn_x3(AttnX3Args a) {
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     __syncthreads();          // every wave is done with K
-    // ---- V^T -> LDS: [DP][VLD], rows >= DH and keys >= Tq read as zero
+    // ---- V -> LDS transposed: Vt[dh][key] (row stride VLD); lanes run along key PAIRS so each ds_write_b32 packs
+    //      (key, key+1) of one dh column and a wave's writes fall on consecutive banks. Keys >= Tq read as zero.
+    if (DP > DH) {   // zero the dh padding rows (DH = 16 only)
+        for (int idx = tid; idx < NPL * (DP - DH) * VLD / 2; idx += 64 * NT) {
+            const int p = idx / ((DP - DH) * VLD / 2), o = idx - p * ((DP - DH) * VLD / 2);
+            reinterpret_cast<unsigned int*>(&sh[p * PLANE + DH * VLD])[o] = 0u;
+        }
+    }
     for (int p = 0; p < NPL; ++p)
-        for (int idx = tid; idx < DP * (TQP / 4); idx += 64 * NT) {
-            const int r = idx / (TQP / 4), c = (idx - r * (TQP / 4)) * 4;
-            u32x2 v = {0u, 0u};
-            if (r < DH && c < a.Tqp) v = *reinterpret_cast<const u32x2*>(gV[p] + (size_t)r * a.Tqp + c);
-            *reinterpret_cast<u32x2*>(&sh[p * PLANE + r * VLD + c]) = v;
+        for (int idx = tid; idx < (TQP / 2) * (DH / 8); idx += 64 * NT) {
+            const int kp = idx % (TQP / 2), c = (idx / (TQP / 2)) * 8;
+            const int k0 = 2 * kp;
+            u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+            if (k0 < Tq) v0 = *reinterpret_cast<const u32x4*>(gV[p] + (size_t)k0 * DH + c);
+            if (k0 + 1 < Tq) v1 = *reinterpret_cast<const u32x4*>(gV[p] + (size_t)(k0 + 1) * DH + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned int e0 = (v0[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                const unsigned int e1 = (v1[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                *reinterpret_cast<unsigned int*>(&sh[p * PLANE + (c + j) * VLD + k0]) = e0 | (e1 << 16);
+            }
         }
     __syncthreads();
     f32x16 oa[ND];

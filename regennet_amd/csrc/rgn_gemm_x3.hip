@@ -123,27 +123,12 @@ __device__ __forceinline__ void x3_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
                 r[i] = x3_act(v, g.act);
             }
             if constexpr (QKV) {   // attention-ready scatter of the packed in_proj output (see GemmX3Args)
-                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
                 const int which = n / g.d, cin = n - which * g.d, hd = cin / g.dh, c = cin - hd * g.dh;
                 __bf16* ph = which == 0 ? g.Qhi : (which == 1 ? g.Khi : g.Vthi);
                 __bf16* pl = which == 0 ? g.Qlo : (which == 1 ? g.Klo : g.Vtlo);
                 const bool fastp = !CHECK && rows_same[ta];          // every 4-row group of this tile stays inside one sample
-                if (which == 2 && fastp) {                            // V^T: 4 consecutive tokens -> one 8-byte store
-#pragma unroll
-                    for (int i4 = 0; i4 < 4; ++i4) {
-                        bf16x4 hv, lv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float x = r[4 * i4 + e];
-                            hv[e] = (__bf16)x;
-                            lv[e] = (__bf16)(x - (float)hv[e]);
-                        }
-                        const size_t o = (((size_t)row_b[ta][i4] * g.H + hd) * g.dh + c) * g.Tqp + row_t[ta][i4];
-                        *reinterpret_cast<bf16x4*>(ph + o) = hv;
-                        if (pl) *reinterpret_cast<bf16x4*>(pl + o) = lv;
-                    }
-                } else if (which != 2 && fastp) {                     // q / k: pair adjacent columns across lane^1 -> 4-byte stores
+                if (fastp) {                                          // pair adjacent columns across lane^1 -> 4-byte stores
                     const float sc = which == 0 ? g.qscale : 1.0f;
                     const bool odd = lane & 1;
 #pragma unroll
@@ -172,7 +157,7 @@ __device__ __forceinline__ void x3_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
                         const size_t sl = (size_t)bb * g.H + hd;
                         const float x = r[i] * sc;
                         const __bf16 h = (__bf16)x;
-                        const size_t o = which == 2 ? (sl * g.dh + c) * g.Tqp + tt : (sl * g.Tqp + tt) * g.dh + c;
+                        const size_t o = (sl * g.Tqp + tt) * g.dh + c;
                         ph[o] = h;
                         if (pl) pl[o] = (__bf16)(x - (float)h);
                     }

@@ -72,7 +72,8 @@ struct GemmX3Args {
     int M, N, Kp;
     int act;
     // Optional "attention-ready" output of the packed in_proj GEMM (N = 3*d): instead of C / Chi the epilogue
-    // scatters q (pre-scaled by 1/sqrt(dh)), k as [Bm*H][Tqp][dh] and v TRANSPOSED as [Bm*H][dh][Tqp] split planes.
+    // scatters q (pre-scaled by 1/sqrt(dh)), k and v as [Bm*H][Tqp][dh] split planes (one contiguous slab per head;
+    // the Vt* pointers hold v, which k_attn_x3 transposes on its way into LDS).
     __bf16 *Qhi, *Qlo, *Khi, *Klo, *Vthi, *Vtlo;
     int d, H, dh, Tq, Tqp;
     float qscale;
