@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -92,6 +93,9 @@ struct rgn_ctx {
     std::vector<void*> allocs;
     hipStream_t stream = nullptr;      // all work runs here; callers' streams are joined by events
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // extra chains of the multi-stream evaluation
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    int nchains = 4;                   // REGENNET_STREAMS = 1, 2 or 4 (default)
 
     // schedule (host copies)
     int S = 0;
@@ -319,6 +323,109 @@ int pack_state(rgn_ctx* c, const float* x, const Dims& dm, bool guided, hipStrea
     return RGN_OK;
 }
 
+// Embedding GEMM + the L decoder layers + output projection for samples [s0, s0+ns) of the evaluation's sample list
+// (row range [s0*Tq, (s0+ns)*Tq)), enqueued on stream s. F32 mode is always called with the full range.
+int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const float* cond_rows, const float* ccond_rows,
+               int s0, int ns, hipStream_t s) {
+    const int prec = c->cfg.precision;
+    const int d = c->d, Ld = c->L * c->d, Mtot = dmf.Bm * dmf.Tq, Mb = dmf.B * dmf.Tq;
+    const int row0 = s0 * dmf.Tq, M = ns * dmf.Tq;
+    Dims dm = dmf;
+    dm.Bm = ns;
+    // ---- the big GEMMs: F32 mode keeps fp32 activations (k_gemm_f32); the bf16 modes chain pre-split
+    //      K32-blocked planes between kernels (k_gemm_x3, DMA-fed). Plane pointers are advanced by row0 rows
+    //      (32 elements each) while Planes::rows stays the row count of the whole evaluation.
+    const bool fast = prec != RGN_PREC_F32, x3 = prec == RGN_PREC_BF16X3;
+    auto pl = [&](__bf16* hi, __bf16* lo) {
+        return Planes{fast ? hi + (size_t)row0 * 32 : nullptr, (fast && x3) ? lo + (size_t)row0 * 32 : nullptr, Mtot};
+    };
+    const Planes none{nullptr, nullptr, 0};
+    const Planes xin_p = pl(c->xin_hi, c->xin_lo), h_p = pl(c->h_hi, c->h_lo), att_p = pl(c->att_hi, c->att_lo),
+                 ffn_p = pl(c->ffn_hi, c->ffn_lo);
+    float* h = c->h + (size_t)row0 * d;
+    float* tmp = c->tmp + (size_t)row0 * d;
+    float* qkv = c->qkv + (size_t)row0 * 3 * d;
+    float* att = c->att + (size_t)row0 * d;
+    float* ffn = c->ffn + (size_t)row0 * c->ff;
+    auto big = [&](const Lin& L, const float* A32, int lda, const Planes& Ap, float* C, int ldc, const Planes& Cp,
+                   const float* add, int act, int rows) -> int {
+        if (!fast) {
+            GemmArgs g = gemm_args(c, L, A32, lda, C, ldc, rows);
+            g.add = add;
+            g.ldadd = d;
+            g.act = act;
+            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+        } else {
+            GemmX3Args g{};
+            g.Ahi = Ap.hi; g.Alo = Ap.lo; g.a_rows = Ap.rows;
+            g.Whi = c->dp<__bf16>(L.hi); g.Wlo = c->dp<__bf16>(L.lo);
+            g.bias = L.has_bias ? c->dp<float>(L.b) : nullptr;
+            g.add = add; g.ldadd = d;
+            g.C = C; g.ldc = ldc;
+            g.Chi = Cp.hi; g.Clo = Cp.lo; g.c_rows = Cp.rows;
+            g.M = rows; g.N = L.N; g.Kp = L.Kp; g.act = act;
+            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm_x3(g, x3, 0, s));
+        }
+        return RGN_OK;
+    };
+    int rc;
+    // input embedding + hoisted condition part (InputProcess/fuse/pos-enc, cmdm.py:201-218)
+    if (fast) {   // xin planes and c0 already hold both guidance halves
+        if ((rc = big(c->lin_x, nullptr, 0, xin_p, h, d, h_p, c->c0 + (size_t)row0 * d, 0, M))) return rc;
+    } else {
+        if ((rc = big(c->lin_x, c->xin, c->F, none, c->h, d, none, c->c0, 0, Mb))) return rc;
+        if (guided)
+            RGN_HIP(c, hipMemcpyAsync(c->h + (size_t)Mb * d, c->h, (size_t)Mb * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    if (c->etd) {
+        if (sampling)
+            RGN_LAUNCH(c, KC_EMBED, s, launch_emb_rows(cond_rows ? cond_rows + (size_t)s0 * d : nullptr, c->te_all, c->d_step,
+                                                      c->dp<float>(c->off_pe), h, h_p, dm, c->cfg.wo_pos_emb, s));
+        else
+            RGN_LAUNCH(c, KC_EMBED, s, launch_emb_rows(c->emb + (size_t)s0 * d, nullptr, nullptr, c->dp<float>(c->off_pe), h, h_p, dm,
+                                                      c->cfg.wo_pos_emb, s));
+    }
+    const size_t slab0 = (size_t)s0 * c->H * c->Tqp * dm.dh;      // attention-ready planes: first slab of this range
+    for (int l = 0; l < c->L; ++l) {
+        const LayerW& w = c->layers[l];
+        if (fast && c->attn_x3) {
+            // in_proj GEMM scatters q (pre-scaled), k and v as attention-ready split planes; no fp32 qkv round trip
+            GemmX3Args g{};
+            g.Ahi = h_p.hi; g.Alo = h_p.lo; g.a_rows = h_p.rows;
+            g.Whi = c->dp<__bf16>(w.qkv.hi); g.Wlo = c->dp<__bf16>(w.qkv.lo);
+            g.bias = c->dp<float>(w.qkv.b);
+            g.M = M; g.N = 3 * d; g.Kp = w.qkv.Kp;
+            g.Qhi = c->q_hi + slab0; g.Qlo = x3 ? c->q_lo + slab0 : nullptr;
+            g.Khi = c->k_hi + slab0; g.Klo = x3 ? c->k_lo + slab0 : nullptr;
+            g.Vthi = c->vt_hi + slab0; g.Vtlo = x3 ? c->vt_lo + slab0 : nullptr;
+            g.d = d; g.H = c->H; g.dh = dm.dh; g.Tq = dm.Tq; g.Tqp = c->Tqp;
+            g.qscale = 1.0f / sqrtf((float)dm.dh);
+            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm_x3(g, x3, 0, s));
+            AttnX3Args a{};
+            a.Qhi = g.Qhi; a.Qlo = c->q_lo + slab0; a.Khi = g.Khi; a.Klo = c->k_lo + slab0; a.Vthi = g.Vthi; a.Vtlo = c->vt_lo + slab0;
+            a.out = att_p;
+            a.Bm = ns; a.H = c->H; a.dh = dm.dh; a.d = d; a.Tq = dm.Tq; a.Tqp = c->Tqp; a.x3 = x3;
+            RGN_LAUNCH(c, KC_ATTN, s, launch_attn_x3(a, s));
+        } else {
+            if ((rc = big(w.qkv, h, d, h_p, qkv, 3 * d, none, nullptr, 0, M))) return rc;
+            RGN_LAUNCH(c, KC_ATTN, s, launch_attention(qkv, fast ? nullptr : att, att_p, dm, s));
+        }
+        if ((rc = big(w.out, att, d, att_p, tmp, d, none, h, 0, M))) return rc;
+        const float* per_sample = sampling ? (ccond_rows ? ccond_rows + (size_t)s0 * Ld + (size_t)l * d : nullptr)
+                                           : c->call + (size_t)s0 * Ld + (size_t)l * d;
+        RGN_LAUNCH(c, KC_LN, s,
+                   launch_layernorm(tmp, h, h_p, M, d, c->dp<float>(w.ln[0]), c->dp<float>(w.ln[1]), per_sample, Ld,
+                                    sampling ? c->call_time + (size_t)l * d : nullptr, Ld, c->d_step, dm.Tq,
+                                    c->dp<float>(w.ln[2]), c->dp<float>(w.ln[3]), s));
+        if ((rc = big(w.ff1, h, d, h_p, fast ? nullptr : ffn, c->ff, ffn_p, nullptr, 1, M))) return rc;
+        if ((rc = big(w.ff2, ffn, c->ff, ffn_p, tmp, d, none, h, 0, M))) return rc;
+        RGN_LAUNCH(c, KC_LN, s,
+                   launch_layernorm(tmp, h, h_p, M, d, c->dp<float>(w.ln[4]), c->dp<float>(w.ln[5]), nullptr, 0, nullptr, 0,
+                                    nullptr, dm.Tq, nullptr, nullptr, s));
+    }
+    return big(c->lin_out, h, d, h_p, c->x0tok + (size_t)row0 * c->F, c->F, none, nullptr, 0, M);
+}
+
 // One denoiser evaluation on the bound condition, ending in k_update (sampler step or plain output).
 // Everything t-dependent is read on the device (d_step / d_sp) so the sequence is graph-capturable.
 int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStream_t s) {
@@ -346,87 +453,30 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
         g = gemm_args(c, c->lin_g, c->emb, d, c->call, Ld, dm.Bm);
         RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
     }
-    // ---- the big GEMMs: F32 mode keeps fp32 activations (k_gemm_f32); the bf16 modes chain pre-split
-    //      K32-blocked planes between kernels (k_gemm_x3, DMA-fed) ---------------------------------------
-    const bool fast = prec != RGN_PREC_F32, x3 = prec == RGN_PREC_BF16X3;
-    auto pl = [&](__bf16* hi, __bf16* lo) { return Planes{fast ? hi : nullptr, (fast && x3) ? lo : nullptr, M}; };
-    const Planes none{nullptr, nullptr, 0};
-    const Planes xin_p = pl(c->xin_hi, c->xin_lo), h_p = pl(c->h_hi, c->h_lo), att_p = pl(c->att_hi, c->att_lo),
-                 ffn_p = pl(c->ffn_hi, c->ffn_lo);
-    auto big = [&](const Lin& L, const float* A32, int lda, const Planes& Ap, float* C, int ldc, const Planes& Cp,
-                   const float* add, int act, int rows) -> int {
-        if (!fast) {
-            GemmArgs g = gemm_args(c, L, A32, lda, C, ldc, rows);
-            g.add = add;
-            g.ldadd = d;
-            g.act = act;
-            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
-        } else {
-            GemmX3Args g{};
-            g.Ahi = Ap.hi; g.Alo = Ap.lo; g.a_rows = Ap.rows;
-            g.Whi = c->dp<__bf16>(L.hi); g.Wlo = c->dp<__bf16>(L.lo);
-            g.bias = L.has_bias ? c->dp<float>(L.b) : nullptr;
-            g.add = add; g.ldadd = d;
-            g.C = C; g.ldc = ldc;
-            g.Chi = Cp.hi; g.Clo = Cp.lo; g.c_rows = Cp.rows;
-            g.M = rows; g.N = L.N; g.Kp = L.Kp; g.act = act;
-            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm_x3(g, x3, 0, s));
-        }
-        return RGN_OK;
-    };
+    // ---- layers. In the bf16 modes the samples of the evaluation are split into contiguous groups that run as
+    //      independent kernel chains on separate streams (fork/join with events, also inside graph capture): the
+    //      MFMA-bound GEMM main loops of one chain overlap the HBM-bound phases (GEMM epilogues, LayerNorm, attention)
+    //      of the others. Samples are independent, so no kernel ever looks across a split.
+    const bool fast = prec != RGN_PREC_F32;
     int rc;
-    // input embedding + hoisted condition part (InputProcess/fuse/pos-enc, cmdm.py:201-218)
-    if (fast) {   // xin planes and c0 already hold both guidance halves
-        if ((rc = big(c->lin_x, nullptr, 0, xin_p, c->h, d, h_p, c->c0, 0, M))) return rc;
-    } else {
-        if ((rc = big(c->lin_x, c->xin, c->F, none, c->h, d, none, c->c0, 0, Mb))) return rc;
-        if (guided)
-            RGN_HIP(c, hipMemcpyAsync(c->h + (size_t)Mb * d, c->h, (size_t)Mb * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+    int nch = (fast && !c->prof) ? c->nchains : 1;       // per-kernel event timing wants un-overlapped kernels
+    if (nch > dm.Bm) nch = dm.Bm;
+    if (nch > 1) RGN_HIP(c, hipEventRecord(c->ev_fork, s));
+    const int per = dm.Bm / nch, extra = dm.Bm % nch;
+    int s0 = per + (extra > 0 ? 1 : 0);                   // chain 0 (main stream) takes [0, s0) and is enqueued last
+    const int first_n = s0;
+    for (int k = 1; k < nch; ++k) {
+        const int n = per + (k < extra ? 1 : 0);
+        RGN_HIP(c, hipStreamWaitEvent(c->side[k - 1], c->ev_fork, 0));
+        if ((rc = run_layers(c, dm, guided, sampling, cond_rows, ccond_rows, s0, n, c->side[k - 1]))) return rc;
+        RGN_HIP(c, hipEventRecord(c->ev_join[k - 1], c->side[k - 1]));
+        s0 += n;
     }
-    if (c->etd) {
-        if (sampling)
-            RGN_LAUNCH(c, KC_EMBED, s, launch_emb_rows(cond_rows, c->te_all, c->d_step, c->dp<float>(c->off_pe), c->h, h_p, dm, c->cfg.wo_pos_emb, s));
-        else
-            RGN_LAUNCH(c, KC_EMBED, s, launch_emb_rows(c->emb, nullptr, nullptr, c->dp<float>(c->off_pe), c->h, h_p, dm, c->cfg.wo_pos_emb, s));
-    }
-    for (int l = 0; l < c->L; ++l) {
-        const LayerW& w = c->layers[l];
-        if (fast && c->attn_x3) {
-            // in_proj GEMM scatters q (pre-scaled), k and v^T as attention-ready split planes; no fp32 qkv round trip
-            GemmX3Args g{};
-            g.Ahi = h_p.hi; g.Alo = h_p.lo; g.a_rows = h_p.rows;
-            g.Whi = c->dp<__bf16>(w.qkv.hi); g.Wlo = c->dp<__bf16>(w.qkv.lo);
-            g.bias = c->dp<float>(w.qkv.b);
-            g.M = M; g.N = 3 * d; g.Kp = w.qkv.Kp;
-            g.Qhi = c->q_hi; g.Qlo = x3 ? c->q_lo : nullptr; g.Khi = c->k_hi; g.Klo = x3 ? c->k_lo : nullptr;
-            g.Vthi = c->vt_hi; g.Vtlo = x3 ? c->vt_lo : nullptr;
-            g.d = d; g.H = c->H; g.dh = dm.dh; g.Tq = dm.Tq; g.Tqp = c->Tqp;
-            g.qscale = 1.0f / sqrtf((float)dm.dh);
-            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm_x3(g, x3, 0, s));
-            AttnX3Args a{};
-            a.Qhi = c->q_hi; a.Qlo = c->q_lo; a.Khi = c->k_hi; a.Klo = c->k_lo; a.Vthi = c->vt_hi; a.Vtlo = c->vt_lo;
-            a.out = att_p;
-            a.Bm = dm.Bm; a.H = c->H; a.dh = dm.dh; a.d = d; a.Tq = dm.Tq; a.Tqp = c->Tqp; a.x3 = x3;
-            RGN_LAUNCH(c, KC_ATTN, s, launch_attn_x3(a, s));
-        } else {
-            if ((rc = big(w.qkv, c->h, d, h_p, c->qkv, 3 * d, none, nullptr, 0, M))) return rc;
-            RGN_LAUNCH(c, KC_ATTN, s, launch_attention(c->qkv, fast ? nullptr : c->att, att_p, dm, s));
-        }
-        if ((rc = big(w.out, c->att, d, att_p, c->tmp, d, none, c->h, 0, M))) return rc;
-        RGN_LAUNCH(c, KC_LN, s,
-                   launch_layernorm(c->tmp, c->h, h_p, M, d, c->dp<float>(w.ln[0]), c->dp<float>(w.ln[1]),
-                                    sampling ? (ccond_rows ? ccond_rows + (size_t)l * d : nullptr) : c->call + (size_t)l * d, Ld,
-                                    sampling ? c->call_time + (size_t)l * d : nullptr, Ld, c->d_step, dm.Tq,
-                                    c->dp<float>(w.ln[2]), c->dp<float>(w.ln[3]), s));
-        if ((rc = big(w.ff1, c->h, d, h_p, fast ? nullptr : c->ffn, c->ff, ffn_p, nullptr, 1, M))) return rc;
-        if ((rc = big(w.ff2, c->ffn, c->ff, ffn_p, c->tmp, d, none, c->h, 0, M))) return rc;
-        RGN_LAUNCH(c, KC_LN, s,
-                   launch_layernorm(c->tmp, c->h, h_p, M, d, c->dp<float>(w.ln[4]), c->dp<float>(w.ln[5]), nullptr, 0, nullptr, 0,
-                                    nullptr, dm.Tq, nullptr, nullptr, s));
-    }
-    if ((rc = big(c->lin_out, c->h, d, h_p, c->x0tok, c->F, none, nullptr, 0, M))) return rc;
+    if ((rc = run_layers(c, dm, guided, sampling, cond_rows, ccond_rows, 0, first_n, s))) return rc;
+    for (int k = 1; k < nch; ++k) RGN_HIP(c, hipStreamWaitEvent(s, c->ev_join[k - 1], 0));
     RGN_LAUNCH(c, KC_UPDATE, s,
-               launch_update(c->x0tok, c->scale, c->d_tab, c->d_step, c->d_sp, fast ? nullptr : c->xin, xin_p, dm, s));
+               launch_update(c->x0tok, c->scale, c->d_tab, c->d_step, c->d_sp, fast ? nullptr : c->xin,
+                             Planes{fast ? c->xin_hi : nullptr, (fast && prec == RGN_PREC_BF16X3) ? c->xin_lo : nullptr, M}, dm, s));
     return RGN_OK;
 }
 
@@ -525,6 +575,11 @@ int rgn_destroy(rgn_handle h) {
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (int i = 0; i < 3; ++i) {
+        if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->dblob) (void)hipFree(h->dblob);
     delete h;
@@ -714,6 +769,12 @@ int rgn_finalize_weights(rgn_handle h) {
     RGN_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     RGN_HIP(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     RGN_HIP(c, hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) {
+        RGN_HIP(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+        RGN_HIP(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    }
+    RGN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    if (const char* e = getenv("REGENNET_STREAMS")) c->nchains = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
     RGN_HIP(c, hipMemset(c->xin, 0, Mb * F * sizeof(float)));
     RGN_HIP(c, hipMemset(c->cmo_in, 0, Mb * F * sizeof(float)));
     RGN_HIP(c, hipMemset(c->d_step, 0, 4 * sizeof(int)));
