@@ -178,7 +178,11 @@ def main():
         peak = PEAK_TFLOPS[a.precision]
         roof = {"bound": "mfma", "kernel": "k_gemm (all MFMA GEMM launches of one denoiser evaluation)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": None, "launches_per_eval": gemm_n // n_eval, "avg_launch_us": round(1e3 * gemm_ms / max(gemm_n, 1), 2),
+                "traffic": None,
+                "note": "HIP events on the engine stream around every GEMM launch, single-chain eager pass; each bracket carries "
+                        "~8-10 us of dispatch/event latency that rocprofv3's kernel timestamps do not (profiles/*_streams1.csv); "
+                        "the timed region replays a 4-chain hipGraph in which kernels of different chains overlap",
+                "launches_per_eval": gemm_n // n_eval, "avg_launch_us": round(1e3 * gemm_ms / max(gemm_n, 1), 2),
                 "class_ms_per_eval": {k: round(v[0] / n_eval, 4) for k, v in prof.items()}}
 
     if rank == 0:

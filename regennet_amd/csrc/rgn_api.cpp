@@ -114,7 +114,8 @@ struct rgn_ctx {
 
     // profiling
     bool prof = false;
-    std::vector<ProfEv> prof_ev;
+    std::vector<ProfEv> prof_pool;     // pre-created event pairs
+    size_t prof_used = 0;
     double prof_ms[KC_COUNT] = {0};
     int64_t prof_n[KC_COUNT] = {0};
 
@@ -138,20 +139,19 @@ const char* kclass_names[KC_COUNT] = {"gemm_mfma", "attention", "layernorm", "em
     } while (0)
 
 // Launch wrapper: optional HIP-event bracketing per kernel class (eager mode only).
+// Launch wrapper: optional HIP-event bracketing per kernel class. Events come from a pool created by
+// rgn_profile_enable (no creation cost between launches); launches beyond the pool are simply not timed.
 #define RGN_LAUNCH(h, KCLS, stream, call)                                        \
     do {                                                                         \
-        ProfEv _pe{};                                                            \
-        const bool _p = (h)->prof;                                               \
+        const bool _p = (h)->prof && (h)->prof_used < (h)->prof_pool.size();     \
         if (_p) {                                                                \
-            _pe.kc = (KCLS);                                                     \
-            (void)hipEventCreate(&_pe.a);                                        \
-            (void)hipEventCreate(&_pe.b);                                        \
-            (void)hipEventRecord(_pe.a, (stream));                               \
+            (h)->prof_pool[(h)->prof_used].kc = (KCLS);                          \
+            (void)hipEventRecord((h)->prof_pool[(h)->prof_used].a, (stream));    \
         }                                                                        \
         RGN_HIP(h, call);                                                        \
         if (_p) {                                                                \
-            (void)hipEventRecord(_pe.b, (stream));                               \
-            (h)->prof_ev.push_back(_pe);                                         \
+            (void)hipEventRecord((h)->prof_pool[(h)->prof_used].b, (stream));    \
+            (h)->prof_used++;                                                    \
         }                                                                        \
     } while (0)
 
@@ -568,7 +568,7 @@ int rgn_destroy(rgn_handle h) {
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
-    for (auto& e : h->prof_ev) {
+    for (auto& e : h->prof_pool) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
@@ -1014,11 +1014,14 @@ int rgn_profile_enable(rgn_handle h, int32_t on) {
     if (!h) return RGN_ERR_INVALID_ARG;
     (void)hipSetDevice(h->cfg.device);
     (void)hipDeviceSynchronize();
-    for (auto& e : h->prof_ev) {
-        (void)hipEventDestroy(e.a);
-        (void)hipEventDestroy(e.b);
+    if (on && h->prof_pool.empty()) {
+        h->prof_pool.resize(1024);
+        for (auto& e : h->prof_pool) {
+            RGN_HIP(h, hipEventCreate(&e.a));
+            RGN_HIP(h, hipEventCreate(&e.b));
+        }
     }
-    h->prof_ev.clear();
+    h->prof_used = 0;
     for (int i = 0; i < KC_COUNT; ++i) {
         h->prof_ms[i] = 0;
         h->prof_n[i] = 0;
@@ -1030,19 +1033,17 @@ int rgn_profile_enable(rgn_handle h, int32_t on) {
 int rgn_profile_query(rgn_handle h, int32_t idx, const char** name, double* total_ms, int64_t* launches) {
     if (!h) return RGN_ERR_INVALID_ARG;
     if (idx < 0 || idx >= KC_COUNT || !name || !total_ms || !launches) return h->fail(RGN_ERR_INVALID_ARG, "rgn_profile_query: bad argument");
-    if (!h->prof_ev.empty()) {
+    if (h->prof_used > 0) {
         (void)hipSetDevice(h->cfg.device);
         (void)hipDeviceSynchronize();
-        for (auto& e : h->prof_ev) {
+        for (size_t i = 0; i < h->prof_used; ++i) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
-                h->prof_ms[e.kc] += ms;
-                h->prof_n[e.kc] += 1;
+            if (hipEventElapsedTime(&ms, h->prof_pool[i].a, h->prof_pool[i].b) == hipSuccess) {
+                h->prof_ms[h->prof_pool[i].kc] += ms;
+                h->prof_n[h->prof_pool[i].kc] += 1;
             }
-            (void)hipEventDestroy(e.a);
-            (void)hipEventDestroy(e.b);
         }
-        h->prof_ev.clear();
+        h->prof_used = 0;
     }
     *name = kclass_names[idx];
     *total_ms = h->prof_ms[idx];
