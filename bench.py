@@ -176,9 +176,18 @@ def main():
         fl = gemm_flops_per_eval(cfg, B, a.guided) * n_eval
         achieved = fl / (gemm_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[a.precision]
+        traffic = None   # HBM bytes per GEMM launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_bench_streams1.json")   # FETCH x2 gfx950 correction), same workload only
+        if os.path.exists(pmc) and (a.config, B, a.precision, a.guided) == ("ntu", 256, "bf16x3", False):
+            with open(pmc) as fh:
+                pj = json.load(fh)
+            n1, n2 = pj["k_gemm_x3"]["FETCH_SIZE"]["launches"], pj["k_gemm_x3[qkv]"]["FETCH_SIZE"]["launches"]
+            t1 = pj["k_gemm_x3"]["hbm_fetch_MB_per_launch_corrected"] + pj["k_gemm_x3"]["hbm_write_MB_per_launch"]
+            t2 = pj["k_gemm_x3[qkv]"]["hbm_fetch_MB_per_launch_corrected"] + pj["k_gemm_x3[qkv]"]["hbm_write_MB_per_launch"]
+            traffic = round((n1 * t1 + n2 * t2) / (n1 + n2) * 1e6)
         roof = {"bound": "mfma", "kernel": "k_gemm (all MFMA GEMM launches of one denoiser evaluation)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": None,
+                "traffic": traffic,
                 "note": "HIP events on the engine stream around every GEMM launch, single-chain eager pass; each bracket carries "
                         "~8-10 us of dispatch/event latency that rocprofv3's kernel timestamps do not (profiles/*_streams1.csv); "
                         "the timed region replays a 4-chain hipGraph in which kernels of different chains overlap",
