@@ -87,6 +87,7 @@ struct rgn_ctx {
     __bf16 *q_hi = nullptr, *q_lo = nullptr, *k_hi = nullptr, *k_lo = nullptr, *vt_hi = nullptr, *vt_lo = nullptr;   // attention-ready planes
     bool attn_x3 = false;
     int Tqp = 0;
+    bool fuse_ln = false;              // out_proj / linear2 GEMMs carry their LayerNorms (k_gemm_x3_ln)
     StepCoef* d_tab = nullptr;
     int* d_step = nullptr;
     SampleParams* d_sp = nullptr;
@@ -410,13 +411,35 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             if ((rc = big(w.qkv, h, d, h_p, qkv, 3 * d, none, nullptr, 0, M))) return rc;
             RGN_LAUNCH(c, KC_ATTN, s, launch_attention(qkv, fast ? nullptr : att, att_p, dm, s));
         }
-        if ((rc = big(w.out, att, d, att_p, tmp, d, none, h, 0, M))) return rc;
         const float* per_sample = sampling ? (ccond_rows ? ccond_rows + (size_t)s0 * Ld + (size_t)l * d : nullptr)
                                            : c->call + (size_t)s0 * Ld + (size_t)l * d;
+        const float* step_vec = sampling ? c->call_time + (size_t)l * d : nullptr;
+        if (fast && c->fuse_ln) {
+            // out_proj + residual + norm1 + folded cross-attention + norm2 in one kernel; then linear1 (GELU);
+            // then linear2 + residual + norm3 in one kernel. The pre-norm tensors never reach HBM.
+            GemmLnArgs g{};
+            g.Ahi = att_p.hi; g.Alo = att_p.lo; g.a_rows = att_p.rows;
+            g.Whi = c->dp<__bf16>(w.out.hi); g.Wlo = c->dp<__bf16>(w.out.lo);
+            g.bias = c->dp<float>(w.out.b);
+            g.resid = h; g.out = h; g.ohi = h_p.hi; g.olo = h_p.lo; g.o_rows = h_p.rows;
+            g.M = M; g.Kp = w.out.Kp;
+            g.ga = c->dp<float>(w.ln[0]); g.ba = c->dp<float>(w.ln[1]); g.gb = c->dp<float>(w.ln[2]); g.bb = c->dp<float>(w.ln[3]);
+            g.pervec = per_sample; g.ldper = Ld; g.stepvec = step_vec; g.ldstep = Ld; g.d_step = c->d_step; g.Tq = dm.Tq;
+            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm_ln(g, x3, s));
+            if ((rc = big(w.ff1, h, d, h_p, nullptr, c->ff, ffn_p, nullptr, 1, M))) return rc;
+            g.Ahi = ffn_p.hi; g.Alo = ffn_p.lo; g.a_rows = ffn_p.rows;
+            g.Whi = c->dp<__bf16>(w.ff2.hi); g.Wlo = c->dp<__bf16>(w.ff2.lo);
+            g.bias = c->dp<float>(w.ff2.b);
+            g.Kp = w.ff2.Kp;
+            g.ga = c->dp<float>(w.ln[4]); g.ba = c->dp<float>(w.ln[5]); g.gb = nullptr; g.bb = nullptr;
+            g.pervec = nullptr; g.stepvec = nullptr;
+            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm_ln(g, x3, s));
+            continue;
+        }
+        if ((rc = big(w.out, att, d, att_p, tmp, d, none, h, 0, M))) return rc;
         RGN_LAUNCH(c, KC_LN, s,
-                   launch_layernorm(tmp, h, h_p, M, d, c->dp<float>(w.ln[0]), c->dp<float>(w.ln[1]), per_sample, Ld,
-                                    sampling ? c->call_time + (size_t)l * d : nullptr, Ld, c->d_step, dm.Tq,
-                                    c->dp<float>(w.ln[2]), c->dp<float>(w.ln[3]), s));
+                   launch_layernorm(tmp, h, h_p, M, d, c->dp<float>(w.ln[0]), c->dp<float>(w.ln[1]), per_sample, Ld, step_vec, Ld,
+                                    c->d_step, dm.Tq, c->dp<float>(w.ln[2]), c->dp<float>(w.ln[3]), s));
         if ((rc = big(w.ff1, h, d, h_p, fast ? nullptr : ffn, c->ff, ffn_p, nullptr, 1, M))) return rc;
         if ((rc = big(w.ff2, ffn, c->ff, ffn_p, tmp, d, none, h, 0, M))) return rc;
         RGN_LAUNCH(c, KC_LN, s,
@@ -750,6 +773,9 @@ int rgn_finalize_weights(rgn_handle h) {
         RGN_HIP(c, hipMemset(c->ffn_hi, 0, M * ffp * 2));
         RGN_HIP(c, hipMemset(c->ffn_lo, 0, M * ffp * 2));
         RGN_HIP(c, configure_gemm_x3());
+        // measured slower than GEMM + k_layernorm at B=256 (heavy epilogue, 64-row tiles): opt-in only
+        c->fuse_ln = gemm_ln_supported(d) && getenv("REGENNET_FUSED_LN") != nullptr;
+        if (c->fuse_ln) RGN_HIP(c, configure_gemm_ln());
         c->attn_x3 = attn_x3_supported(c->Tq, d / c->H);
         if (c->attn_x3) {
             c->Tqp = (c->Tq + 31) / 32 * 32;

@@ -38,7 +38,12 @@ __global__ __launch_bounds__(64 * NT) void k_attn_x3(AttnX3Args a) {
     constexpr int OLD = DP + 4;                    // fp32 output patch row stride
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* sh = reinterpret_cast<__bf16*>(smem);  // [2 planes][PLANE]
-    const int b = blockIdx.x, hd = blockIdx.y;
+    // XCD-affine mapping (block id -> XCD id%8): every XCD gets one contiguous range of samples, matching the row ranges
+    // the in_proj / out_proj GEMM tiles occupy on that XCD
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int b = vid / a.H, hd = vid - b * a.H;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = lane >> 5, l31 = lane & 31;
@@ -228,9 +233,9 @@ static hipError_t ax3_go(const AttnX3Args& a, hipStream_t s, bool cfg) {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_x3<NT, DH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     if (a.x3)
-        hipLaunchKernelGGL((k_attn_x3<NT, DH, true>), dim3(a.Bm, a.H), dim3(64 * NT), lds, s, a);
+        hipLaunchKernelGGL((k_attn_x3<NT, DH, true>), dim3(a.Bm * a.H), dim3(64 * NT), lds, s, a);
     else
-        hipLaunchKernelGGL((k_attn_x3<NT, DH, false>), dim3(a.Bm, a.H), dim3(64 * NT), lds, s, a);
+        hipLaunchKernelGGL((k_attn_x3<NT, DH, false>), dim3(a.Bm * a.H), dim3(64 * NT), lds, s, a);
     return hipGetLastError();
 }
 template <int DH>

@@ -79,6 +79,25 @@ struct GemmX3Args {
     float qscale;
 };
 
+// Row-complete GEMM + fused residual LayerNorm(s) (rgn_gemm_ln.hip); N is fixed to 512.
+struct GemmLnArgs {
+    const __bf16* Ahi; const __bf16* Alo; int a_rows;   // activation planes [Kp/32][a_rows][32]
+    const __bf16* Whi; const __bf16* Wlo;               // weight planes [Kp/32][512][32]
+    const float* bias;
+    const float* resid;                                 // fp32 residual [M,512] (may alias out)
+    float* out;                                         // fp32 result [M,512]
+    __bf16* ohi; __bf16* olo; int o_rows;               // split planes of the result (K32-blocked), optional
+    int M, Kp;
+    const float *ga, *ba;                               // LayerNorm a
+    const float *gb, *bb;                               // LayerNorm b (nullptr: single norm)
+    const float* pervec; int ldper;                     // + pervec[(row / Tq) * ldper + n]   (nullable)
+    const float* stepvec; int ldstep; const int* d_step;   // + stepvec[(*d_step) * ldstep + n] (nullable)
+    int Tq;
+};
+bool gemm_ln_supported(int N);
+hipError_t configure_gemm_ln();
+hipError_t launch_gemm_ln(const GemmLnArgs& g, bool x3, hipStream_t s);
+
 // Split-bf16 activation planes in the K32-blocked layout; hi == nullptr means "not requested".
 struct Planes {
     __bf16* hi;

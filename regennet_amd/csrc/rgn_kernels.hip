@@ -594,7 +594,12 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
                                                     const float* __restrict__ stepvec, int ldstep, const int* __restrict__ d_step,
                                                     int Tq, const float* __restrict__ gb, const float* __restrict__ bb) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD-affine mapping: hardware places block b on XCD b%8; give every XCD one contiguous range of rows, the same
+    // range whose tiles the neighbouring GEMMs compute on that XCD (their L2 still holds what this kernel reads/writes)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int row = vid * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const float* x = in + (size_t)row * d;
     float v[VPL];

@@ -235,3 +235,32 @@ def test_weight_blob_view_transfers_a_checkpoint():
     mb._cond_key = None                                                      # ... and so does the hoisted condition
     out_b1 = db.ddim_sample_loop(mb, (B, 5, 6, 8), **kw)
     assert torch.equal(out_a, out_b1)
+
+
+def test_chain_count_does_not_change_results(golden, monkeypatch):
+    """1, 2 or 4 concurrent kernel chains (REGENNET_STREAMS) are a scheduling choice only: bit-identical samples."""
+    g = golden("ntu_ddpm50")
+    cfg, sd, y, tape = fixture_inputs(g, loop=True)
+    outs = []
+    for n in ("1", "2", "4"):
+        monkeypatch.setenv("REGENNET_STREAMS", n)
+        model, diffusion = build_hip(cfg, sd, resp="50", precision="bf16x3")
+        outs.append(diffusion.p_sample_loop(model, (2, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y_to_device(y)},
+                                            noise_tape=torch.from_numpy(tape)))
+        model._engine.close()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert np.abs(outs[0].cpu().numpy() - g["final"]).max() < 1e-3
+
+
+def test_fused_layernorm_gemm_variant(golden, monkeypatch):
+    """The opt-in row-complete GEMM with both LayerNorms in its epilogue (REGENNET_FUSED_LN=1) meets the same bound."""
+    monkeypatch.setenv("REGENNET_FUSED_LN", "1")
+    for name in ("ntu_ddpm50", "ntu_action_ddim100_cfg"):
+        g = golden(name)
+        cfg, sd, y, tape = fixture_inputs(g, loop=True)
+        model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision="bf16x3")
+        fm = _wrap(model, bool(g["guided"]))
+        fn = diffusion.p_sample_loop if str(g["mode"]) == "ddpm" else diffusion.ddim_sample_loop
+        out = fn(fm, (2, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
+        assert np.abs(out.cpu().numpy() - g["final"]).max() < 1e-3
+        model._engine.close()
