@@ -94,9 +94,10 @@ struct rgn_ctx {
     std::vector<void*> allocs;
     hipStream_t stream = nullptr;      // all work runs here; callers' streams are joined by events
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // extra chains of the multi-stream evaluation
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-    int nchains = 4;                   // REGENNET_STREAMS = 1, 2 or 4 (default)
+    static constexpr int MAX_SIDE = 15;
+    hipStream_t side[MAX_SIDE] = {};   // extra chains of the multi-stream evaluation
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {};
+    int nchains = 4;                   // REGENNET_STREAMS = 1 .. 16 (default 4)
 
     // schedule (host copies)
     int S = 0;
@@ -401,6 +402,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             g.Vthi = c->vt_hi + slab0; g.Vtlo = x3 ? c->vt_lo + slab0 : nullptr;
             g.d = d; g.H = c->H; g.dh = dm.dh; g.Tq = dm.Tq; g.Tqp = c->Tqp;
             g.qscale = 1.0f / sqrtf((float)dm.dh);
+            g.tq_magic = (unsigned)((1ull << 32) / (unsigned)dm.Tq) + 1u;
             RGN_LAUNCH(c, KC_GEMM, s, launch_gemm_x3(g, x3, 0, s));
             AttnX3Args a{};
             a.Qhi = g.Qhi; a.Qlo = c->q_lo + slab0; a.Khi = g.Khi; a.Klo = c->k_lo + slab0; a.Vthi = g.Vthi; a.Vtlo = c->vt_lo + slab0;
@@ -598,7 +600,7 @@ int rgn_destroy(rgn_handle h) {
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_out) (void)hipEventDestroy(h->ev_out);
     if (h->stream) (void)hipStreamDestroy(h->stream);
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < rgn_ctx::MAX_SIDE; ++i) {
         if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
@@ -795,12 +797,12 @@ int rgn_finalize_weights(rgn_handle h) {
     RGN_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     RGN_HIP(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     RGN_HIP(c, hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < rgn_ctx::MAX_SIDE; ++i) {
         RGN_HIP(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
         RGN_HIP(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
     RGN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    if (const char* e = getenv("REGENNET_STREAMS")) c->nchains = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
+    if (const char* e = getenv("REGENNET_STREAMS")) c->nchains = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
     RGN_HIP(c, hipMemset(c->xin, 0, Mb * F * sizeof(float)));
     RGN_HIP(c, hipMemset(c->cmo_in, 0, Mb * F * sizeof(float)));
     RGN_HIP(c, hipMemset(c->d_step, 0, 4 * sizeof(int)));

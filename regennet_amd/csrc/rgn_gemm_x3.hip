@@ -82,24 +82,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int TM, int TN, bool QKV, bool CHECK>
 __device__ __forceinline__ void x3_epilogue(const GemmX3Args& g, f32x16 (&acc)[TM][TN], int mw, int nw, int lane) {
     const int l31 = lane & 31, kh = lane >> 5;
-            // (sample, token) of the first row of every 4-row register group, for the attention-ready scatter
-    int row_b[TM][4], row_t[TM][4];
-    bool rows_same[TM];
-    if constexpr (QKV) {
-#pragma unroll
-        for (int ta = 0; ta < TM; ++ta) {
-            rows_same[ta] = true;
-#pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                const int m4 = mw + ta * 32 + 4 * kh + 8 * i4;
-                row_b[ta][i4] = m4 / g.Tq;
-                row_t[ta][i4] = m4 - row_b[ta][i4] * g.Tq;
-                rows_same[ta] = rows_same[ta] && (row_t[ta][i4] + 3 < g.Tq);
-            }
-            rows_same[ta] = __all(rows_same[ta]);
-        }
-    }
-#pragma unroll
+        #pragma unroll
     for (int tb = 0; tb < TN; ++tb) {
         const int n = nw + tb * 32 + l31;
         const bool n_ok = !CHECK || n < g.N;
@@ -127,8 +110,7 @@ __device__ __forceinline__ void x3_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
                 const int which = n / g.d, cin = n - which * g.d, hd = cin / g.dh, c = cin - hd * g.dh;
                 __bf16* ph = which == 0 ? g.Qhi : (which == 1 ? g.Khi : g.Vthi);
                 __bf16* pl = which == 0 ? g.Qlo : (which == 1 ? g.Klo : g.Vtlo);
-                const bool fastp = !CHECK && rows_same[ta];          // every 4-row group of this tile stays inside one sample
-                if (fastp) {                                          // pair adjacent columns across lane^1 -> 4-byte stores
+                if (!CHECK) {                                          // pair adjacent columns across lane^1 -> 4-byte stores
                     const float sc = which == 0 ? g.qscale : 1.0f;
                     const bool odd = lane & 1;
 #pragma unroll
@@ -137,8 +119,10 @@ __device__ __forceinline__ void x3_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
                         const float give = (odd ? r[i] : r[i + 8]) * sc;
                         const float got = __shfl_xor(give, 1, 64);
                         const float c0 = odd ? got : mine, c1 = odd ? mine : got;
-                        const int ii = odd ? i + 8 : i, i4 = ii >> 2, e = ii & 3;
-                        const size_t o = (((size_t)row_b[ta][i4] * g.H + hd) * g.Tqp + row_t[ta][i4] + e) * g.dh + (c & ~1);
+                        const int ii = odd ? i + 8 : i;
+                        const unsigned m = (unsigned)(mb + (ii & 3) + 8 * (ii >> 2));
+                        const unsigned bb = __umulhi(m, g.tq_magic), tt = m - bb * (unsigned)g.Tq;   // m / Tq, m % Tq (exact: m*Tq < 2^32)
+                        const size_t o = (((size_t)bb * g.H + hd) * g.Tqp + tt) * g.dh + (c & ~1);
                         const __bf16 h0 = (__bf16)c0, h1 = (__bf16)c1;
                         bf16x2 hv = {h0, h1};
                         *reinterpret_cast<bf16x2*>(ph + o) = hv;
@@ -147,7 +131,7 @@ __device__ __forceinline__ void x3_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
                             *reinterpret_cast<bf16x2*>(pl + o) = lv;
                         }
                     }
-                } else {                                              // edge blocks / samples whose length is not a multiple of 4
+                } else {                                              // edge blocks
                     const float sc = which == 0 ? g.qscale : 1.0f;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {

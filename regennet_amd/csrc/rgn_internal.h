@@ -76,6 +76,7 @@ struct GemmX3Args {
     // the Vt* pointers hold v, which k_attn_x3 transposes on its way into LDS).
     __bf16 *Qhi, *Qlo, *Khi, *Klo, *Vthi, *Vtlo;
     int d, H, dh, Tq, Tqp;
+    unsigned tq_magic;                               // floor(2^32 / Tq) + 1: m / Tq == umulhi(m, tq_magic) for m * Tq < 2^32
     float qscale;
 };
 
