@@ -340,194 +340,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_x3(GemmX3Args g, int n
     else x3_epilogue<TM, TN, QKV, true>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
 }
 
-// =================================================================================================
-// Ping-pong variant: 256x128 tile, 8 waves = two groups of four (one wave of each group per SIMD), 3 stages.
-// A k-step is two phases separated by raw s_barriers. In the even phase group A issues its 24 MFMAs back to back
-// on tile kt while group B (idle matrix pipe) reads its fragments of tile kt from LDS and issues its share of
-// the DMA for tile kt+2; in the odd phase the roles swap (B computes tile kt, A prepares tile kt+1 / DMA kt+3).
-// The two waves that share a SIMD therefore never compete for the matrix pipe and never idle it together, and
-// every DMA has >= 3 phases (>= 2300 matrix cycles) to land. One counted s_waitcnt vmcnt per k-step per wave.
-//   stage of tile j : j % 3.   DMA(j+2) is issued in the off-phase that precedes MFMA(j); it overwrites the stage
-//   of tile j-1, whose last LDS reader finished one barrier earlier.
-// =================================================================================================
-template <bool X3, bool QKV>
-__global__ __launch_bounds__(512, 2) void k_gemm_x3_pp(GemmX3Args g, int nbx, int nby) {
-    constexpr int BM = 256, BN = 128, NT = 512, TM = 2, TN = 2;
-    constexpr int NPL = X3 ? 2 : 1;
-    constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64;
-    constexpr int STAGE = NPL * (A_BYTES + W_BYTES);
-    constexpr int A_IT = BM * 4 / NT, W_IT = BN * 4 / NT;   // 2, 1
-    constexpr int LPT = NPL * (A_IT + W_IT);                // DMA instructions per wave per tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool gA = wave < 4;                               // group A: rows 0..127, group B: rows 128..255
-    const int wq = wave & 3, wm = wq >> 1, wn = wq & 1;
-    const int nwg = nbx * nby, bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int m0 = (vid / nbx) * BM, n0 = (vid % nbx) * BN;
-    const int mrow = (gA ? 0 : 128) + wm * 64;              // first tile row of this wave inside the block tile
-
-    size_t a_src[A_IT], w_src[W_IT];
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-        const int q = it * NT + tid, r = q >> 2, c = (q & 3) ^ ((r >> 2) & 3);
-        int m = m0 + r;
-        m = m < g.M ? m : g.M - 1;
-        a_src[it] = (size_t)m * 32 + c * 8;
-    }
-#pragma unroll
-    for (int it = 0; it < W_IT; ++it) {
-        const int q = it * NT + tid, r = q >> 2, c = (q & 3) ^ ((r >> 2) & 3);
-        int n = n0 + r;
-        n = n < g.N ? n : g.N - 1;
-        w_src[it] = (size_t)n * 32 + c * 8;
-    }
-    auto issue = [&](int kt, int stage) {                    // this wave's share of tile kt
-        char* sb = smem + stage * STAGE;
-        const size_t ka = (size_t)kt * g.a_rows * 32, kw = (size_t)kt * g.N * 32;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int lo = (it * NT + (tid & ~63)) * 16;
-            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.Ahi + a_src[it] + ka), (RGN_AS3 void*)(sb + lo), 16, 0, 0);
-            if (X3)
-                __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.Alo + a_src[it] + ka), (RGN_AS3 void*)(sb + A_BYTES + lo), 16, 0, 0);
-        }
-#pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
-            const int lo = (it * NT + (tid & ~63)) * 16;
-            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.Whi + w_src[it] + kw), (RGN_AS3 void*)(sb + NPL * A_BYTES + lo), 16, 0, 0);
-            if (X3)
-                __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.Wlo + w_src[it] + kw), (RGN_AS3 void*)(sb + NPL * A_BYTES + W_BYTES + lo), 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-
-    const int l31 = lane & 31, kh = lane >> 5;
-    int a_off[TM][2], w_off[TN][2];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-        const int rr = mrow + t * 32 + l31;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) a_off[t][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
-    }
-#pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        const int rr = wn * 64 + t * 32 + l31;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) w_off[t][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
-    }
-    bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
-    auto read_frags = [&](int stage) {
-        const char* sb = smem + stage * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int t = 0; t < TM; ++t) {
-                ah[ks][t] = *reinterpret_cast<const bf16x8*>(sb + a_off[t][ks]);
-                if (X3) al[ks][t] = *reinterpret_cast<const bf16x8*>(sb + A_BYTES + a_off[t][ks]);
-            }
-#pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                bh[ks][t] = *reinterpret_cast<const bf16x8*>(sb + NPL * A_BYTES + w_off[t][ks]);
-                if (X3) bl[ks][t] = *reinterpret_cast<const bf16x8*>(sb + NPL * A_BYTES + W_BYTES + w_off[t][ks]);
-            }
-        }
-    };
-    auto mfmas = [&]() {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int ta = 0; ta < TM; ++ta)
-#pragma unroll
-                for (int tb = 0; tb < TN; ++tb) {
-                    if (X3) {
-                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][ta], bh[ks][tb], acc[ta][tb], 0, 0, 0);
-                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][ta], bl[ks][tb], acc[ta][tb], 0, 0, 0);
-                    }
-                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][ta], bh[ks][tb], acc[ta][tb], 0, 0, 0);
-                }
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    const int nk = g.Kp / 32;
-    // prologue: tiles 0 and 1 by everyone, tile 2 by group A (its off-phase "-1"); group A then reads tile 0
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    if (gA && nk > 2) issue(2, 2);
-    {
-        const int later = (nk > 1 ? 1 : 0) + ((gA && nk > 2) ? 1 : 0);   // tile groups younger than tile 0
-        if (later == 2) wait_vmcnt<2 * LPT>();
-        else if (later == 1) wait_vmcnt<LPT>();
-        else wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    if (gA || RGN_PP_ABLATE) read_frags(0);
-    int st_j = 0;                                            // stage of tile j
-    for (int j = 0; j < nk; ++j) {
-        const int st_j1 = st_j == 2 ? 0 : st_j + 1;         // stage of tile j+1 (and of tile j-2)
-        const int st_j2 = st_j1 == 2 ? 0 : st_j1 + 1;       // stage of tile j+2 (== stage of tile j-1)
-        // ---- even phase: A computes tile j; B reads its fragments of tile j and issues DMA(j+2)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads of the previous phase are done
-        if (RGN_PP_ABLATE != 2) __builtin_amdgcn_s_barrier();
-        if (gA) {
-            mfmas();
-        } else if (RGN_PP_ABLATE == 0) {
-            read_frags(st_j);
-            if (j + 2 < nk) issue(j + 2, st_j2);
-        }
-        // tile j+1 must have landed before anyone reads it (A: next phase, B: next even phase)
-        if (j + 2 < nk && RGN_PP_ABLATE == 0) wait_vmcnt<LPT>();
-        else wait_vmcnt<0>();
-        // ---- odd phase: B computes tile j; A reads its fragments of tile j+1 and issues DMA(j+3)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (RGN_PP_ABLATE != 2) __builtin_amdgcn_s_barrier();
-        if (gA) {
-            if (RGN_PP_ABLATE == 0) {
-                if (j + 1 < nk) read_frags(st_j1);
-                if (j + 3 < nk) issue(j + 3, st_j);         // stage of tile j: both groups are done reading it
-            }
-        } else {
-            mfmas();
-        }
-        st_j = st_j1;
-    }
-    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
-    if (interior) x3_epilogue<TM, TN, QKV, false>(g, acc, m0 + mrow, n0 + wn * 64, lane);
-    else x3_epilogue<TM, TN, QKV, true>(g, acc, m0 + mrow, n0 + wn * 64, lane);
-}
-
-static hipError_t x3_pp_launch(const GemmX3Args& g, bool x3, hipStream_t s, bool configure_only) {
-    const int lds = 3 * (x3 ? 2 : 1) * (256 * 64 + 128 * 64);
-    if (configure_only) {
-        hipError_t e;
-#define RGN_CFG(X3V, QV, BYTES)                                                                                          \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_x3_pp<X3V, QV>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES); \
-        if (e != hipSuccess) return e;
-        RGN_CFG(true, false, 147456) RGN_CFG(false, false, 73728) RGN_CFG(true, true, 147456) RGN_CFG(false, true, 73728)
-#undef RGN_CFG
-        return hipSuccess;
-    }
-    const int nbx = (g.N + 127) / 128, nby = (g.M + 255) / 256;
-    const dim3 grid(nbx * nby), block(512);
-    const bool qkv = g.Qhi != nullptr;
-    if (x3 && !qkv) hipLaunchKernelGGL((k_gemm_x3_pp<true, false>), grid, block, lds, s, g, nbx, nby);
-    else if (x3 && qkv) hipLaunchKernelGGL((k_gemm_x3_pp<true, true>), grid, block, lds, s, g, nbx, nby);
-    else if (!qkv) hipLaunchKernelGGL((k_gemm_x3_pp<false, false>), grid, block, lds, s, g, nbx, nby);
-    else hipLaunchKernelGGL((k_gemm_x3_pp<false, true>), grid, block, lds, s, g, nbx, nby);
-    return hipGetLastError();
-}
-
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 static hipError_t x3_launch(const GemmX3Args& g, bool x3, hipStream_t s, bool configure_only) {
     const int lds = NSTAGE * (x3 ? 2 : 1) * (BM * 64 + BN * 64);
@@ -552,18 +364,14 @@ static hipError_t x3_launch(const GemmX3Args& g, bool x3, hipStream_t s, bool co
     return hipGetLastError();
 }
 
-// variant: 0 = 128x128 / 4 waves / 2 stages (64 KiB: two workgroups per CU), 1 = 256x128 / 8 waves / 3 stages,
-//          2 = 256x128 / 8 waves / 3 stages, ping-pong wave groups (k_gemm_x3_pp)
+// variant: 0 = 128x128 / 4 waves / 2 stages (64 KiB: two workgroups per CU), 1 = 256x128 / 8 waves / 3 stages
 hipError_t launch_gemm_x3(const GemmX3Args& g, bool x3, int variant, hipStream_t s) {
-    if (variant == 2) return x3_pp_launch(g, x3, s, false);
     if (variant == 1) return x3_launch<256, 128, 4, 2, 3>(g, x3, s, false);
     return x3_launch<128, 128, 2, 2, 2>(g, x3, s, false);
 }
 hipError_t configure_gemm_x3() {
     GemmX3Args g{};
     hipError_t e = x3_launch<128, 128, 2, 2, 2>(g, true, nullptr, true);
-    if (e != hipSuccess) return e;
-    e = x3_pp_launch(g, true, nullptr, true);
     if (e != hipSuccess) return e;
     return x3_launch<256, 128, 4, 2, 3>(g, true, nullptr, true);
 }
