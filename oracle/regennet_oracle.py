@@ -99,10 +99,15 @@ def spaced_schedule(base_betas, use_timesteps):
     return tmap, diffusion_tables(np.array(new_betas))
 
 
-def make_schedule(noise_schedule="cosine", timestep_respacing="", steps=1000):
-    """utils/model_util.py:75-117 (steps hard-coded to 1000 at :78)."""
+def make_schedule(noise_schedule="cosine", timestep_respacing="", steps=1000, sigma_small=True):
+    """utils/model_util.py:75-117 (steps hard-coded to 1000 at :78). `model_log_variance` is the table p_mean_variance
+    picks for FIXED_SMALL / FIXED_LARGE (gaussian_diffusion.py:344-364)."""
     betas = get_named_beta_schedule(noise_schedule, steps, 1.0)
     tmap, tables = spaced_schedule(betas, space_timesteps(steps, timestep_respacing or [steps]))
+    if sigma_small:
+        tables["model_log_variance"] = tables["posterior_log_variance_clipped"]
+    else:
+        tables["model_log_variance"] = np.log(np.append(tables["posterior_variance"][1], tables["betas"][1:]))
     return tmap, tables
 
 
@@ -208,7 +213,8 @@ def cfg_forward(sd, cfg, x, timesteps, y):
 # --------------------------------------------------------------------------------------
 # a5-a10: sampling loops                      gaussian_diffusion.py:289-400,508-560,610-794,891-1005
 # --------------------------------------------------------------------------------------
-def sample_loop(sd, cfg, schedule, tape, y, mode="ddpm", guided=False, eta=0.0, trace=None):
+def sample_loop(sd, cfg, schedule, tape, y, mode="ddpm", guided=False, eta=0.0, trace=None, clip_denoised=False,
+                skip_timesteps=0, init_image=None):
     """Run p_sample_loop (mode='ddpm') or ddim_sample_loop (mode='ddim') with an injected noise tape.
 
     tape[0] = x_T, tape[k] = k-th per-step draw (drawn every step, gaussian_diffusion.py:544,785).
@@ -221,16 +227,25 @@ def sample_loop(sd, cfg, schedule, tape, y, mode="ddpm", guided=False, eta=0.0, 
     B = img.shape[0]
     fwd = cfg_forward if guided else cmdm_forward
     k = 1
+    if skip_timesteps and init_image is None:                                # gaussian_diffusion.py:708-709
+        init_image = torch.zeros_like(img)
+    first = S - 1 - skip_timesteps
+    if init_image is not None:                                               # :713-715 -> q_sample :248-266 with noise=img
+        t0 = torch.full((B,), first, dtype=torch.long)
+        img = _extract(tb["sqrt_alphas_cumprod"], t0, img.shape) * torch.as_tensor(init_image) + \
+            _extract(tb["sqrt_one_minus_alphas_cumprod"], t0, img.shape) * img
     with torch.no_grad():
-        for i in range(S - 1, -1, -1):
+        for i in range(first, -1, -1):
             t = torch.tensor([i] * B)                                        # gaussian_diffusion.py:724
             x0 = fwd(sd, cfg, img, tmap_t[t], y)                             # respace.py:124-129; START_X :381
+            if clip_denoised:
+                x0 = x0.clamp(-1, 1)                                         # process_xstart :366-372
             noise = torch.as_tensor(tape[k]); k += 1
             nz = (t != 0).float().view(-1, 1, 1, 1)
             if mode == "ddpm":                                               # p_sample :508-560; FIXED_SMALL :344-364
                 mean = _extract(tb["posterior_mean_coef1"], t, img.shape) * x0 + \
                        _extract(tb["posterior_mean_coef2"], t, img.shape) * img
-                logvar = _extract(tb["posterior_log_variance_clipped"], t, img.shape)
+                logvar = _extract(tb.get("model_log_variance", tb["posterior_log_variance_clipped"]), t, img.shape)
                 img = mean + nz * torch.exp(0.5 * logvar) * noise
             else:                                                            # ddim_sample :744-794
                 eps = (_extract(tb["sqrt_recip_alphas_cumprod"], t, img.shape) * img - x0) / \

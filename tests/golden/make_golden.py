@@ -113,10 +113,12 @@ def gen_forward(name, cfg_name, B, ts, guided=False, **over):
          out=np.stack(outs), sd_digest=sd_digest(sd), in_digest=digest(x.numpy(), y["cmotion"].numpy()))
 
 
-def gen_loop(name, cfg_name, B, resp, mode, guided=False, keep_trace=False, **over):
+def gen_loop(name, cfg_name, B, resp, mode, guided=False, keep_trace=False, opts=None, **over):
+    opts = dict(opts or {})
     cfg = synth.get_config(cfg_name, **over)
     sd = synth.make_state_dict(cfg, seed=0)
-    model, diffusion = build(cfg, resp, sd)
+    cfg_d = dict(cfg, noise_schedule=opts.get("noise_schedule", "cosine"), sigma_small=opts.get("sigma_small", True))
+    model, diffusion = build(cfg_d, resp, sd)
     S = diffusion.num_timesteps
     y = make_y(cfg, B, guided)
     if "text" in cfg["cond_mode"]:
@@ -139,16 +141,22 @@ def gen_loop(name, cfg_name, B, resp, mode, guided=False, keep_trace=False, **ov
 
     model.forward = spy
     t0 = time.time()
+    skip = int(opts.get("skip_timesteps", 0))
+    call_kw = dict(clip_denoised=bool(opts.get("clip_denoised", False)), model_kwargs={"y": y}, skip_timesteps=skip)
+    if opts.get("init_image", False):
+        call_kw["init_image"] = torch.from_numpy(synth.make_noise_tape(cfg, B, 0, seed=12)[0] * 0.5)
+    if mode == "ddim" and "eta" in opts:
+        call_kw["eta"] = float(opts["eta"])
     with _ref_import.NoiseTape(tape) as nt:
-        for out in fn(fmodel, shape, clip_denoised=False, model_kwargs={"y": y}):
+        for out in fn(fmodel, shape, **call_kw):
             if keep_trace:
                 x0s.append(out["pred_xstart"].numpy().copy())
                 xs.append(out["sample"].numpy().copy())
             final = out["sample"]
-        assert nt.pos == S + 1, (nt.pos, S)
+        assert nt.pos == S + 1 - skip, (nt.pos, S, skip)
     dt = time.time() - t0
     print(f"{name}: reference {mode} S={S} B={B} took {dt:.1f}s")
-    kw = dict(cfg_name=cfg_name, over=repr(over), B=B, resp=resp, mode=mode, guided=guided, S=S,
+    kw = dict(cfg_name=cfg_name, over=repr(over), opts=repr(opts), B=B, resp=resp, mode=mode, guided=guided, S=S,
               final=final.numpy(), model_t=np.stack(seen_t)[:, 0], ref_seconds=dt,
               sd_digest=sd_digest(sd), in_digest=digest(tape[0], tape[-1], y["cmotion"].numpy()))
     if keep_trace:
@@ -182,6 +190,11 @@ JOBS = {
     "tiny_text_fwd_cfg": lambda: gen_forward("tiny_text_fwd_cfg", "tiny_text", 3, [0, 321], guided=True),
     "tiny_ddpm10": lambda: gen_loop("tiny_ddpm10", "tiny", 2, "10", "ddpm", keep_trace=True),
     "tiny_ddim10_cfg": lambda: gen_loop("tiny_ddim10_cfg", "tiny", 2, "ddim10", "ddim", guided=True, keep_trace=True),
+    "tiny_opts_clip": lambda: gen_loop("tiny_opts_clip", "tiny", 2, "10", "ddpm", opts=dict(clip_denoised=True)),
+    "tiny_opts_large_linear": lambda: gen_loop("tiny_opts_large_linear", "tiny", 2, "20", "ddpm", opts=dict(sigma_small=False, noise_schedule="linear")),
+    "tiny_opts_skip_init": lambda: gen_loop("tiny_opts_skip_init", "tiny", 2, "10", "ddpm", opts=dict(skip_timesteps=3, init_image=True)),
+    "tiny_opts_skip_zero": lambda: gen_loop("tiny_opts_skip_zero", "tiny", 2, "ddim10", "ddim", opts=dict(skip_timesteps=4)),
+    "tiny_opts_eta": lambda: gen_loop("tiny_opts_eta", "tiny", 2, "ddim10", "ddim", guided=True, opts=dict(eta=0.7)),
     "tiny_add_ddpm1000": lambda: gen_loop("tiny_add_ddpm1000", "tiny_add", 2, "", "ddpm"),
     "tiny_text_ddim20_cfg": lambda: gen_loop("tiny_text_ddim20_cfg", "tiny_text", 3, "ddim20", "ddim", guided=True),
     "ntu_fwd": lambda: gen_forward("ntu_fwd", "ntu", 2, [0, 500, 999]),

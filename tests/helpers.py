@@ -23,6 +23,10 @@ def fixture_cfg(g):
     return synth.get_config(str(g["cfg_name"]), **over)
 
 
+def fixture_opts(g):
+    return ast.literal_eval(str(g["opts"])) if "opts" in g else {}
+
+
 def fixture_inputs(g, loop):
     """Returns (cfg, sd, y_numpy, tape_or_x). y_numpy holds numpy arrays."""
     cfg = fixture_cfg(g)
@@ -46,7 +50,7 @@ def fixture_inputs(g, loop):
 
 
 # ---- HIP-side construction (GPU tests) --------------------------------------------------------------
-def build_hip(cfg, sd, resp="", precision="f32", device="cuda:0"):
+def build_hip(cfg, sd, resp="", precision="f32", device="cuda:0", noise_schedule="cosine", sigma_small=True):
     """(model, diffusion) from regennet_amd for a synth config + synthetic checkpoint."""
     import torch
 
@@ -66,8 +70,9 @@ def build_hip(cfg, sd, resp="", precision="f32", device="cuda:0"):
     model.to(device)
     model.eval()
     diffusion = SpacedDiffusion(use_timesteps=space_timesteps(1000, resp or [1000]),
-                                betas=gd.get_named_beta_schedule("cosine", 1000, 1.0),
-                                model_mean_type=gd.ModelMeanType.START_X, model_var_type=gd.ModelVarType.FIXED_SMALL,
+                                betas=gd.get_named_beta_schedule(noise_schedule, 1000, 1.0),
+                                model_mean_type=gd.ModelMeanType.START_X,
+                                model_var_type=gd.ModelVarType.FIXED_SMALL if sigma_small else gd.ModelVarType.FIXED_LARGE,
                                 loss_type=gd.LossType.MSE, rescale_timesteps=False)
     return model, diffusion
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import build_hip, fixture_inputs, y_to_device
+from tests.helpers import build_hip, fixture_inputs, fixture_opts, y_to_device
 
 pytestmark = pytest.mark.gpu
 
@@ -295,3 +295,29 @@ def test_full_size_batch_is_row_independent():
         yb = {k: v[b:b + 1].contiguous() for k, v in y2.items()}
         one = diffusion2.ddim_sample_loop(g2, (1, 56, 6, 60), clip_denoised=False, model_kwargs={"y": yb}, seed=11, sample_offset=b)
         assert torch.allclose(full2[b:b + 1], one, atol=2e-5), (b, (full2[b:b + 1] - one).abs().max().item())
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("name", ["tiny_opts_clip", "tiny_opts_large_linear", "tiny_opts_skip_init", "tiny_opts_skip_zero",
+                                  "tiny_opts_eta"])
+def test_sampler_options(golden, name, precision):
+    """Options of p_sample_loop / ddim_sample_loop beyond the cgenerate defaults, against the reference:
+    clip_denoised=True, FIXED_LARGE variance + linear schedule, skip_timesteps (+ init_image), DDIM eta > 0."""
+    from regennet_amd import synth
+    g = golden(name)
+    cfg, sd, y, tape = fixture_inputs(g, loop=True)
+    o = fixture_opts(g)
+    model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision=precision,
+                                 noise_schedule=o.get("noise_schedule", "cosine"), sigma_small=o.get("sigma_small", True))
+    fm = _wrap(model, bool(g["guided"]))
+    shape = (int(g["B"]), cfg["njoints"], cfg["nfeats"], cfg["num_frames"])
+    kw = dict(clip_denoised=o.get("clip_denoised", False), model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape),
+              skip_timesteps=o.get("skip_timesteps", 0))
+    if o.get("init_image"):
+        kw["init_image"] = torch.from_numpy(synth.make_noise_tape(cfg, int(g["B"]), 0, seed=12)[0] * 0.5).cuda()
+    if str(g["mode"]) == "ddpm":
+        out = diffusion.p_sample_loop(fm, shape, **kw)
+    else:
+        out = diffusion.ddim_sample_loop(fm, shape, eta=o.get("eta", 0.0), **kw)
+    err = np.abs(out.cpu().numpy() - g["final"]).max()
+    assert err < 1e-3, (name, err)

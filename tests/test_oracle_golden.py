@@ -4,7 +4,8 @@ import pytest
 import torch
 
 from oracle import regennet_oracle as orc
-from tests.helpers import fixture_inputs
+from regennet_amd import synth
+from tests.helpers import fixture_inputs, fixture_opts
 
 FWD = ["tiny_fwd", "tiny_fwd_cfg", "tiny_add_fwd", "tiny_etd_fwd", "tiny_text_fwd_cfg", "ntu_fwd",
        "ntu_action_fwd_cfg", "chi3d_fwd"]
@@ -88,3 +89,20 @@ def test_postproc_rows_match_reference(golden):
     np.testing.assert_allclose(m, g["mats"], atol=1e-6)
     np.testing.assert_allclose(orc.gaussian_filter1d_lastaxis(g["x"]), g["gf"], atol=1e-6)
     np.testing.assert_allclose(orc.gaussian_filter1d_lastaxis(g["x3"]), g["gf3"], atol=1e-6)
+
+
+OPTS = ["tiny_opts_clip", "tiny_opts_large_linear", "tiny_opts_skip_init", "tiny_opts_skip_zero", "tiny_opts_eta"]
+
+
+@pytest.mark.parametrize("name", OPTS)
+def test_sampler_options_match_reference(golden, name):
+    """clip_denoised, FIXED_LARGE + linear schedule, skip_timesteps (+init_image), DDIM eta > 0."""
+    g = golden(name)
+    cfg, sd, y, tape = fixture_inputs(g, loop=True)
+    o = fixture_opts(g)
+    sched = orc.make_schedule(o.get("noise_schedule", "cosine"), str(g["resp"]), sigma_small=o.get("sigma_small", True))
+    init = synth.make_noise_tape(cfg, int(g["B"]), 0, seed=12)[0] * 0.5 if o.get("init_image") else None
+    out = orc.sample_loop(sd, cfg, sched, tape, _ty(y), mode=str(g["mode"]), guided=bool(g["guided"]), eta=o.get("eta", 0.0),
+                          clip_denoised=o.get("clip_denoised", False), skip_timesteps=o.get("skip_timesteps", 0),
+                          init_image=None if init is None else torch.from_numpy(init))
+    np.testing.assert_allclose(out.numpy(), g["final"], atol=1e-4, rtol=0)
