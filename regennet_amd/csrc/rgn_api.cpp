@@ -87,6 +87,7 @@ struct rgn_ctx {
     __bf16 *q_hi = nullptr, *q_lo = nullptr, *k_hi = nullptr, *k_lo = nullptr, *vt_hi = nullptr, *vt_lo = nullptr;   // attention-ready planes
     bool attn_x3 = false;
     int Tqp = 0;
+    bool fuse_qkv = false;             // in_proj GEMM + attention in one per-sample kernel (k_qkv_attn)
     bool fuse_ln = false;              // out_proj / linear2 GEMMs carry their LayerNorms (k_gemm_x3_ln)
     StepCoef* d_tab = nullptr;
     int* d_step = nullptr;
@@ -390,7 +391,17 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
     const size_t slab0 = (size_t)s0 * c->H * c->Tqp * dm.dh;      // attention-ready planes: first slab of this range
     for (int l = 0; l < c->L; ++l) {
         const LayerW& w = c->layers[l];
-        if (fast && c->attn_x3) {
+        if (fast && c->fuse_qkv) {
+            // in_proj + attention per sample in one kernel: q, k, v only ever exist in LDS
+            QkvAttnArgs g{};
+            g.Ahi = h_p.hi; g.Alo = h_p.lo; g.a_rows = h_p.rows;
+            g.Whi = c->dp<__bf16>(w.qkv.hi); g.Wlo = c->dp<__bf16>(w.qkv.lo);
+            g.bias = c->dp<float>(w.qkv.b);
+            g.out = att_p;
+            g.Bm = ns; g.Kp = w.qkv.Kp; g.d = d; g.H = c->H; g.Tq = dm.Tq;
+            g.qscale = 1.0f / sqrtf((float)dm.dh);
+            RGN_LAUNCH(c, KC_ATTN, s, launch_qkv_attn(g, x3, s));
+        } else if (fast && c->attn_x3) {
             // in_proj GEMM scatters q (pre-scaled), k and v as attention-ready split planes; no fp32 qkv round trip
             GemmX3Args g{};
             g.Ahi = h_p.hi; g.Alo = h_p.lo; g.a_rows = h_p.rows;
@@ -789,6 +800,8 @@ int rgn_finalize_weights(rgn_handle h) {
             }
             RGN_HIP(c, configure_attn_x3(c->Tq, d / c->H));
         }
+        c->fuse_qkv = qkv_attn_supported(c->Tq, d / c->H, d) && getenv("REGENNET_NO_FUSED_QKV") == nullptr;
+        if (c->fuse_qkv) RGN_HIP(c, configure_qkv_attn());
     }
     if ((rc = ws_alloc(c, &c->d_tab, (size_t)1024))) return rc;
     if ((rc = ws_alloc(c, &c->d_step, (size_t)4))) return rc;

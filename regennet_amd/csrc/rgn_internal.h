@@ -80,6 +80,26 @@ struct GemmX3Args {
     float qscale;
 };
 
+// Split-bf16 activation planes in the K32-blocked layout; hi == nullptr means "not requested".
+struct Planes {
+    __bf16* hi;
+    __bf16* lo;
+    int rows;     // row count of the plane (the M of the consuming GEMM)
+};
+
+// Fused in_proj GEMM + causal self-attention, one workgroup per sample (rgn_qkv_attn.hip)
+struct QkvAttnArgs {
+    const __bf16* Ahi; const __bf16* Alo; int a_rows;   // layer input planes [Kp/32][a_rows][32] (advanced to the first sample)
+    const __bf16* Whi; const __bf16* Wlo;               // in_proj weight planes [Kp/32][3d][32]
+    const float* bias;                                  // in_proj bias [3d]
+    Planes out;                                         // attention output planes (advanced to the first sample's row)
+    int Bm, Kp, d, H, Tq;
+    float qscale;
+};
+bool qkv_attn_supported(int Tq, int dh, int d);
+hipError_t configure_qkv_attn();
+hipError_t launch_qkv_attn(const QkvAttnArgs& g, bool x3, hipStream_t s);
+
 // Row-complete GEMM + fused residual LayerNorm(s) (rgn_gemm_ln.hip); N is fixed to 512.
 struct GemmLnArgs {
     const __bf16* Ahi; const __bf16* Alo; int a_rows;   // activation planes [Kp/32][a_rows][32]
@@ -98,13 +118,6 @@ struct GemmLnArgs {
 bool gemm_ln_supported(int N);
 hipError_t configure_gemm_ln();
 hipError_t launch_gemm_ln(const GemmLnArgs& g, bool x3, hipStream_t s);
-
-// Split-bf16 activation planes in the K32-blocked layout; hi == nullptr means "not requested".
-struct Planes {
-    __bf16* hi;
-    __bf16* lo;
-    int rows;     // row count of the plane (the M of the consuming GEMM)
-};
 
 struct Dims {
     int B;        // motions in the bound condition
