@@ -33,7 +33,13 @@ ALGO_GFLOP_PER_EVAL = {("ntu", "concat"): 2.154, ("ntu", "add"): 2.123, ("chi3d"
 PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
 
 
-def gemm_flops_per_eval(cfg, B, guided):
+def fused_qkv_attention(cfg, precision):
+    """Mirrors qkv_attn_supported() in rgn_qkv_attn.hip: the in_proj GEMM and the attention run as one kernel."""
+    return (precision != "f32" and cfg["num_frames"] + int(bool(cfg.get("emb_trans_dec"))) <= 64
+            and cfg["latent_dim"] // cfg["num_heads"] == 128 and not os.environ.get("REGENNET_NO_FUSED_QKV"))
+
+
+def gemm_flops_per_eval(cfg, B, guided, precision="bf16x3"):
     """Algorithmic FLOPs of the GEMM-class launches of one evaluation (everything except attention scores/AV; the
     timestep MLP and the folded 1-token cross-attention are per-schedule work, not per-step)."""
     T, d, ff, L, F = cfg["num_frames"], cfg["latent_dim"], cfg["ff_size"], cfg["layers"], cfg["njoints"] * cfg["nfeats"]
@@ -41,6 +47,8 @@ def gemm_flops_per_eval(cfg, B, guided):
     M = Bm * T
     mac = M * (3 * d * d + d * d + 2 * d * ff) * L          # qkv, out_proj, ffn1, ffn2
     mac += B * T * F * d + M * d * F                        # input embedding (folded fuse half), output projection
+    if fused_qkv_attention(cfg, precision):                 # k_qkv_attn carries the (full T x T) scores + AV work too
+        mac += M * 2 * T * d * L
     return 2.0 * mac
 
 
@@ -173,7 +181,7 @@ def main():
         eng.profile_enable(False)
         n_eval = min(a.profile_evals, S)
         gemm_ms, gemm_n = prof["gemm_mfma"]
-        fl = gemm_flops_per_eval(cfg, B, a.guided) * n_eval
+        fl = gemm_flops_per_eval(cfg, B, a.guided, a.precision) * n_eval
         achieved = fl / (gemm_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[a.precision]
         traffic = None   # HBM bytes per GEMM launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
@@ -185,7 +193,7 @@ def main():
             t1 = pj["k_gemm_x3"]["hbm_fetch_MB_per_launch_corrected"] + pj["k_gemm_x3"]["hbm_write_MB_per_launch"]
             t2 = pj["k_gemm_x3[qkv]"]["hbm_fetch_MB_per_launch_corrected"] + pj["k_gemm_x3[qkv]"]["hbm_write_MB_per_launch"]
             traffic = round((n1 * t1 + n2 * t2) / (n1 + n2) * 1e6)
-        roof = {"bound": "mfma", "kernel": "k_gemm (all MFMA GEMM launches of one denoiser evaluation)",
+        roof = {"bound": "mfma", "kernel": "k_gemm_x3 / k_qkv_attn (all MFMA GEMM launches of one denoiser evaluation)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic,
                 "note": "HIP events on the engine stream around every GEMM launch, single-chain eager pass; each bracket carries "

@@ -400,7 +400,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             g.out = att_p;
             g.Bm = ns; g.Kp = w.qkv.Kp; g.d = d; g.H = c->H; g.Tq = dm.Tq;
             g.qscale = 1.0f / sqrtf((float)dm.dh);
-            RGN_LAUNCH(c, KC_ATTN, s, launch_qkv_attn(g, x3, s));
+            RGN_LAUNCH(c, KC_GEMM, s, launch_qkv_attn(g, x3, s));   // 93 % of its MFMA work is the in_proj GEMM
         } else if (fast && c->attn_x3) {
             // in_proj GEMM scatters q (pre-scaled), k and v as attention-ready split planes; no fp32 qkv round trip
             GemmX3Args g{};
