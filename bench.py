@@ -189,9 +189,9 @@ def main():
         if os.path.exists(pmc) and (a.config, B, a.precision, a.guided) == ("ntu", 256, "bf16x3", False):
             with open(pmc) as fh:
                 pj = json.load(fh)
-            n1, n2 = pj["k_gemm_x3"]["FETCH_SIZE"]["launches"], pj["k_gemm_x3[qkv]"]["FETCH_SIZE"]["launches"]
+            n1, n2 = pj["k_gemm_x3"]["FETCH_SIZE"]["launches"], pj["k_qkv_attn"]["FETCH_SIZE"]["launches"]
             t1 = pj["k_gemm_x3"]["hbm_fetch_MB_per_launch_corrected"] + pj["k_gemm_x3"]["hbm_write_MB_per_launch"]
-            t2 = pj["k_gemm_x3[qkv]"]["hbm_fetch_MB_per_launch_corrected"] + pj["k_gemm_x3[qkv]"]["hbm_write_MB_per_launch"]
+            t2 = pj["k_qkv_attn"]["hbm_fetch_MB_per_launch_corrected"] + pj["k_qkv_attn"]["hbm_write_MB_per_launch"]
             traffic = round((n1 * t1 + n2 * t2) / (n1 + n2) * 1e6)
         roof = {"bound": "mfma", "kernel": "k_gemm_x3 / k_qkv_attn (all MFMA GEMM launches of one denoiser evaluation)",
                 "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
