@@ -8,8 +8,8 @@
 // HBM (saves a 4 B/element write + read and one launch per LayerNorm). A workgroup owns 64 COMPLETE rows:
 // tile 64 x 512, 8 waves as 2 (M) x 4 (N), wave tile 32 x 128 = 1 x 4 MFMA tiles (v_mfma_f32_32x32x16_bf16, three
 // products per tile pair as in k_gemm_x3), two LDS stages of 72 KiB fed by direct-to-LDS DMA from K32-blocked planes.
-// Row statistics: a lane holds 4 columns (one per N tile) of 16 rows; partial (sum, sum of squares) are reduced over
-// the 32 lanes of a half-wave with xor-shuffles and over the 4 N-waves through a small LDS table.
+// Epilogue: the accumulators are parked in an LDS row buffer (aliasing the dead stages); every wave then normalises
+// 8 complete rows with the one-wave-per-row scheme of k_layernorm and writes coalesced rows.
 #include "rgn_internal.h"
 
 #include <hip/hip_runtime.h>
@@ -18,7 +18,6 @@ namespace rgn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 #define RGN_AS1 __attribute__((address_space(1)))
 #define RGN_AS3 __attribute__((address_space(3)))
@@ -131,142 +130,91 @@ __global__ __launch_bounds__(LN_NT, 2) void k_gemm_x3_ln(GemmLnArgs g) {
     }
     static_assert(LPT_A + LPT_W == (X3 ? 10 : 5), "vmcnt literals above assume W_IT == 4");
 
-    // ---- epilogue: bias + residual, LayerNorm a, (+ vectors, LayerNorm b), stores ------------------------------------
-    // lane: columns n_t = wn*128 + t*32 + l31 (t = 0..3); rows mr(i) = m0 + wm*32 + (i&3) + 8*(i>>2) + 4*kh (i = 0..15)
-    float* stats = reinterpret_cast<float*>(smem);                     // [2 wm][4 wn][32 rows][2]  (stages are dead now)
-    const int mbase = m0 + wm * 32 + 4 * kh;
-    float bias[4], ga[4], ba[4];
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    // (1) accumulators (+ bias) go to an LDS row buffer [64][516] fp32 that aliases the dead pipeline stages: in the
+    //     C/D layout a half-wave writes 32 consecutive columns of one row (conflict-free);
+    // (2) every wave then owns 8 complete rows, one at a time, 8 columns per lane (lane + 64 j) exactly like k_layernorm:
+    //     + residual (coalesced fp32 row reads), two-pass LayerNorm a, (+ per-sample / per-step vectors, LayerNorm b),
+    //     coalesced stores of the fp32 residual stream and of the split planes.
+    constexpr int RLD = LN_BN + 4;
+    float* rowbuf = reinterpret_cast<float*>(smem);
+    __builtin_amdgcn_s_barrier();                                       // every wave is done reading the pipeline stages
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int n = wn * 128 + t * 32 + l31;
-        bias[t] = g.bias ? g.bias[n] : 0.f;
-        ga[t] = g.ga[n];
-        ba[t] = g.ba[n];
+        const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rowbuf[(wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh) * RLD + n] = acc[t][i] + bias;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    constexpr int VPL = LN_BN / 64;                                     // 8
+    float ga[VPL], ba[VPL], gb[VPL], bb[VPL], sv[VPL];
+    const int step = g.stepvec ? *g.d_step : 0;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int n = wn * 128 + t * 32 + l31;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int m = mbase + (i & 3) + 8 * (i >> 2);
-            const float r = (m < g.M) ? g.resid[(size_t)m * LN_BN + n] : 0.f;
-            acc[t][i] += bias[t] + r;
-        }
+    for (int j = 0; j < VPL; ++j) {
+        const int n = lane + 64 * j;
+        ga[j] = g.ga[n];
+        ba[j] = g.ba[n];
+        gb[j] = g.gb ? g.gb[n] : 0.f;
+        bb[j] = g.gb ? g.bb[n] : 0.f;
+        sv[j] = g.stepvec ? g.stepvec[(size_t)step * g.ldstep + n] : 0.f;
     }
     const float invn = 1.0f / (float)LN_BN;
-    auto row_stats = [&](float (&mean)[16], float (&rstd)[16]) {
-        // per-row (sum, sumsq) over this lane's 4 columns, then over the 32 lanes of the half-wave
+    for (int rr = 0; rr < LN_BM / 8; ++rr) {
+        const int r = wave * (LN_BM / 8) + rr, m = m0 + r;
+        if (m >= g.M) break;                                            // wave-uniform
+        float v[VPL], s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float s = 0.f, q = 0.f;
+        for (int j = 0; j < VPL; ++j) {
+            v[j] = rowbuf[r * RLD + lane + 64 * j] + g.resid[(size_t)m * LN_BN + lane + 64 * j];
+            s += v[j];
+        }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                s += acc[t][i];
-                q += acc[t][i] * acc[t][i];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        float mean = s * invn, q = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const float c = v[j] - mean;
+            q += c * c;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        float rstd = 1.0f / sqrtf(q * invn + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) v[j] = (v[j] - mean) * rstd * ga[j] + ba[j];
+        if (g.gb) {
+            const float* pv = g.pervec ? g.pervec + (size_t)(m / g.Tq) * g.ldper : nullptr;
+            s = 0.f;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                v[j] += sv[j] + (pv ? pv[lane + 64 * j] : 0.f);
+                s += v[j];
             }
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
-                s += __shfl_xor(s, o, 64);
-                q += __shfl_xor(q, o, 64);
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            mean = s * invn;
+            q = 0.f;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const float c = v[j] - mean;
+                q += c * c;
             }
-            mean[i] = s;
-            rstd[i] = q;
-        }
-        // combine the 4 N-waves: stats[wm][wn][row 0..31][2]
-        __builtin_amdgcn_s_barrier();                                   // previous users of `stats` are done
-        if (l31 == 0) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rl = (i & 3) + 8 * (i >> 2) + 4 * kh;
-                float* p = &stats[((wm * 4 + wn) * 32 + rl) * 2];
-                p[0] = mean[i];
-                p[1] = rstd[i];
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            rstd = 1.0f / sqrtf(q * invn + 1e-5f);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rl = (i & 3) + 8 * (i >> 2) + 4 * kh;
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) {
-                const float* p = &stats[((wm * 4 + w4) * 32 + rl) * 2];
-                s += p[0];
-                q += p[1];
-            }
-            const float mu = s * invn;
-            const float var = fmaxf(q * invn - mu * mu, 0.f);
-            mean[i] = mu;
-            rstd[i] = 1.0f / sqrtf(var + 1e-5f);
-        }
-    };
-    {
-        __builtin_amdgcn_s_barrier();                                   // every wave is done reading the pipeline stages
-        float mean[16], rstd[16];
-        row_stats(mean, rstd);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][i] = (acc[t][i] - mean[i]) * rstd[i] * ga[t] + ba[t];
-    }
-    if (g.gb) {
-        float sv[4], gbv[4], bbv[4];
-        const int step = g.stepvec ? *g.d_step : 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int n = wn * 128 + t * 32 + l31;
-            sv[t] = g.stepvec ? g.stepvec[(size_t)step * g.ldstep + n] : 0.f;
-            gbv[t] = g.gb[n];
-            bbv[t] = g.bb[n];
+            for (int j = 0; j < VPL; ++j) v[j] = (v[j] - mean) * rstd * gb[j] + bb[j];
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int m = mbase + (i & 3) + 8 * (i >> 2);
-            const int b = (m < g.M ? m : g.M - 1) / g.Tq;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float a = sv[t];
-                if (g.pervec) a += g.pervec[(size_t)b * g.ldper + wn * 128 + t * 32 + l31];
-                acc[t][i] += a;
-            }
-        }
-        float mean[16], rstd[16];
-        row_stats(mean, rstd);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][i] = (acc[t][i] - mean[i]) * rstd[i] * gbv[t] + bbv[t];
-    }
-    // stores: fp32 residual stream + split planes (K32-blocked; adjacent columns paired across lane^1 -> 4-byte stores)
-    const bool odd = lane & 1;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int n = wn * 128 + t * 32 + l31;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int m = mbase + (i & 3) + 8 * (i >> 2);
-            if (m < g.M) g.out[(size_t)m * LN_BN + n] = acc[t][i];
-        }
-        if (g.ohi) {
-            const size_t o = ((size_t)(n >> 5) * g.o_rows + mbase) * 32 + (n & 30);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float mine = odd ? acc[t][i + 8] : acc[t][i];
-                const float give = odd ? acc[t][i] : acc[t][i + 8];
-                const float got = __shfl_xor(give, 1, 64);
-                const float c0 = odd ? got : mine, c1 = odd ? mine : got;
-                const int ii = odd ? i + 8 : i;
-                const int ro = (ii & 3) + 8 * (ii >> 2);
-                if (mbase + ro < g.M) {
-                    const __bf16 h0 = (__bf16)c0, h1 = (__bf16)c1;
-                    bf16x2 hv = {h0, h1};
-                    *reinterpret_cast<bf16x2*>(g.ohi + o + ro * 32) = hv;
-                    if (g.olo) {
-                        bf16x2 lv = {(__bf16)(c0 - (float)h0), (__bf16)(c1 - (float)h1)};
-                        *reinterpret_cast<bf16x2*>(g.olo + o + ro * 32) = lv;
-                    }
-                }
+        for (int j = 0; j < VPL; ++j) {
+            const int n = lane + 64 * j;
+            g.out[(size_t)m * LN_BN + n] = v[j];
+            if (g.ohi) {
+                const size_t o = ((size_t)(n >> 5) * g.o_rows + m) * 32 + (n & 31);
+                const __bf16 h = (__bf16)v[j];
+                g.ohi[o] = h;
+                if (g.olo) g.olo[o] = (__bf16)(v[j] - (float)h);
             }
         }
     }

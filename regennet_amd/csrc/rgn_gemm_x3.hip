@@ -19,20 +19,17 @@
 // c ^ ((r>>2)&3): the permutation is applied to the per-lane global SOURCE address and again on the read
 // (both-sides-or-neither rule for global_load_lds).
 //
-// Pipeline: 3 LDS stages, ONE raw s_barrier per k-step. At step kt: counted wait (s_waitcnt vmcnt(LPT):
-// tile kt landed, tile kt+1 still in flight) -> barrier (tile kt visible to every wave AND every wave is
-// done reading tile kt-1) -> issue tile kt+2's DMA into the stage tile kt-1 occupied -> MFMAs on tile kt.
-// Each DMA therefore has two full k-steps of MFMA work to hide its latency; register fragments for the
-// second half of a k-step are fetched while the first half's MFMAs run.
+// Loop (shipped flavour): 128x128 tile, 4 waves, 2 LDS stages of 32 KiB -> two workgroups per CU, one hiding the
+// other's barriers and epilogue. Per k-step: issue tile kt+1's DMA, counted wait (vmcnt) for tile kt, barrier, fragments
+// + 24 MFMAs per wave, barrier. Measured with per-step cycle stamps (tools/gemm_bench -DRGN_GEMM_PROF): the step is
+// bound by the ~20 B/clk a CU can pull from L2 through the vector-memory path (the 64 KiB the two resident workgroups
+// request per step take ~3000 clk to land, the MFMAs ~1500), not by the matrix pipe. A 256x256 / 8-wave tile with one
+// barrier per step and the DMA issued between MFMA groups (ILV = true, tools only) halves the bytes per MFMA and its
+// loop runs at ~80 % MFMA occupancy, but at M = 15360 it leaves only 120-240 tiles for 256 CUs and nothing to hide its
+// 256 KiB-per-tile epilogue behind: end to end it only ties (70 vs 72 us on linear1), so it is not shipped.
 #include "rgn_internal.h"
 
 #include <hip/hip_runtime.h>
-
-#include <type_traits>
-
-#ifndef RGN_PP_ABLATE
-#define RGN_PP_ABLATE 0   // tools only: 1 = MFMA + barriers only, 2 = MFMA only (no barriers / LDS / DMA after prologue)
-#endif
 
 namespace rgn {
 
@@ -195,9 +192,16 @@ __device__ __forceinline__ void x3_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
     }
 }
 
+#ifdef RGN_GEMM_PROF
+__device__ long long g_prof[1024];   // tools only: per-k-step cycle stamps of one workgroup
+#endif
+
 // BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN) = TM x TN tiles of 32x32.
-template <int BM, int BN, int WM, int WN, bool X3, int NSTAGE, bool QKV>
-__global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_x3(GemmX3Args g, int nbx, int nby) {
+// ILV = false: two barriers per k-step, the whole next tile's DMA issued at the top of the step (128x128, 2 WG / CU).
+// ILV = true : one barrier per k-step, DMA pieces interleaved with the MFMAs of the first K half, fragments fetched one
+//              MFMA group ahead (256x256, 1 WG / CU).
+template <int BM, int BN, int WM, int WN, bool X3, bool ILV, bool QKV>
+__global__ __launch_bounds__(64 * WM * WN, (2 * 2 * (BM + BN) * 64 <= 80 * 1024) ? 2 : 1) void k_gemm_x3(GemmX3Args g, int nbx, int nby) {
     constexpr int NT = 64 * WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NPL = X3 ? 2 : 1;                         // planes per operand
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_x3(GemmX3Args g, int n
     constexpr int A_IT = BM * 4 / NT, W_IT = BN * 4 / NT;   // DMA instructions per thread per plane
     constexpr int LPT = NPL * (A_IT + W_IT);                // ... per thread per tile
     static_assert(BM * 4 % NT == 0 && BN * 4 % NT == 0, "tile/threads mismatch");
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][Ahi|Alo|Whi|Wlo]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Ahi|Alo|Whi|Wlo]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -216,39 +220,41 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_x3(GemmX3Args g, int n
     const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int m0 = (vid / nbx) * BM, n0 = (vid % nbx) * BN;
 
-    // per-thread DMA source offsets (elements), k-invariant part
-    size_t a_src[A_IT], w_src[W_IT];
+    // per-thread DMA source byte offsets inside one k-block of a plane (k-invariant, 32-bit: a plane k-block is
+    // rows x 64 B); the k-dependent part is a wave-uniform base pointer, so the DMA uses the SGPR-base + VGPR-offset form
+    unsigned a_src[A_IT], w_src[W_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         const int q = it * NT + tid, r = q >> 2, c = (q & 3) ^ ((r >> 2) & 3);
         int m = m0 + r;
         m = m < g.M ? m : g.M - 1;
-        a_src[it] = (size_t)m * 32 + c * 8;
+        a_src[it] = (unsigned)m * 64u + c * 16u;
     }
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
         const int q = it * NT + tid, r = q >> 2, c = (q & 3) ^ ((r >> 2) & 3);
         int n = n0 + r;
         n = n < g.N ? n : g.N - 1;
-        w_src[it] = (size_t)n * 32 + c * 8;
+        w_src[it] = (unsigned)n * 64u + c * 16u;
     }
-    auto issue = [&](int kt, int stage) {
-        char* sb = smem + stage * STAGE;
-        const size_t ka = (size_t)kt * g.a_rows * 32, kw = (size_t)kt * g.N * 32;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
+    // DMA piece idx of tile kt into stage buffer sb (idx is a compile-time constant after unrolling)
+    auto piece = [&](int idx, int kt, char* sb) {
+        const size_t ka = (size_t)kt * g.a_rows * 64, kw = (size_t)kt * g.N * 64;
+        if (idx < NPL * A_IT) {
+            const int it = idx / NPL, pl = idx % NPL;
             const int lo = (it * NT + (tid & ~63)) * 16;   // wave-uniform LDS byte offset of this 1 KiB piece
-            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.Ahi + a_src[it] + ka), (RGN_AS3 void*)(sb + lo), 16, 0, 0);
-            if (X3)
-                __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.Alo + a_src[it] + ka), (RGN_AS3 void*)(sb + A_BYTES + lo), 16, 0, 0);
-        }
-#pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
+            const char* base = reinterpret_cast<const char*>(pl ? g.Alo : g.Ahi) + ka;
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(base + a_src[it]), (RGN_AS3 void*)(sb + pl * A_BYTES + lo), 16, 0, 0);
+        } else {
+            const int j = idx - NPL * A_IT, it = j / NPL, pl = j % NPL;
             const int lo = (it * NT + (tid & ~63)) * 16;
-            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.Whi + w_src[it] + kw), (RGN_AS3 void*)(sb + NPL * A_BYTES + lo), 16, 0, 0);
-            if (X3)
-                __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.Wlo + w_src[it] + kw), (RGN_AS3 void*)(sb + NPL * A_BYTES + W_BYTES + lo), 16, 0, 0);
+            const char* base = reinterpret_cast<const char*>(pl ? g.Wlo : g.Whi) + kw;
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(base + w_src[it]), (RGN_AS3 void*)(sb + NPL * A_BYTES + pl * W_BYTES + lo), 16, 0, 0);
         }
+    };
+    auto issue = [&](int kt, int stage) {
+#pragma unroll
+        for (int idx = 0; idx < LPT; ++idx) piece(idx, kt, smem + stage * STAGE);
     };
 
     f32x16 acc[TM][TN];
@@ -274,106 +280,181 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void k_gemm_x3(GemmX3Args g, int n
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) w_off[t][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
     }
+    // the three products of one C tile (a.w ~ al.wh + ah.wl + ah.wh, small terms first)
+    auto mma3 = [&](f32x16& c, const bf16x8& a_h, const bf16x8& a_l, const bf16x8& w_h, const bf16x8& w_l) {
+        if (X3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, w_h, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_l, c, 0, 0, 0);
+        }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_h, c, 0, 0, 0);
+    };
 
+#ifdef RGN_GEMM_PROF
+    const bool prof = (bid == RGN_GEMM_PROF) && (tid == 0 || tid == NT - 64);
+    long long* pp = g_prof + (tid ? 512 : 0);
+#define RGN_T(i) if (prof) pp[kt * 6 + i] = clock64();
+#else
+#define RGN_T(i)
+#endif
     const int nk = g.Kp / 32;
-    auto compute = [&](const char* sb) {
-        bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
-        auto frags = [&](int ks, int buf) {
+    if constexpr (ILV) {
+        constexpr int NG = 2 * TN;                               // MFMA groups per k-step: (K half, N tile), TM tiles each
+        constexpr int PPG = (LPT + TN - 1) / TN;                 // DMA pieces after each group of the first K half
+        auto step = [&](int kt, bool more) {
+            const char* sb = smem + (kt & 1) * STAGE;
+            char* nb = smem + ((kt + 1) & 1) * STAGE;
+            bf16x8 ah[2][TM], al[2][TM], wh[2], wl[2];
+            auto fetch = [&](int grp) {                          // fragments of group grp = ks*TN + tb
+                const int ks = grp / TN, tb = grp % TN;
+                if (tb == 0) {
 #pragma unroll
-            for (int t = 0; t < TM; ++t) {
-                ah[buf][t] = *reinterpret_cast<const bf16x8*>(sb + a_off[t][ks]);
-                if (X3) al[buf][t] = *reinterpret_cast<const bf16x8*>(sb + A_BYTES + a_off[t][ks]);
-            }
+                    for (int t = 0; t < TM; ++t) {
+                        ah[ks][t] = *reinterpret_cast<const bf16x8*>(sb + a_off[t][ks]);
+                        if (X3) al[ks][t] = *reinterpret_cast<const bf16x8*>(sb + A_BYTES + a_off[t][ks]);
+                    }
+                }
+                wh[grp & 1] = *reinterpret_cast<const bf16x8*>(sb + NPL * A_BYTES + w_off[tb][ks]);
+                if (X3) wl[grp & 1] = *reinterpret_cast<const bf16x8*>(sb + NPL * A_BYTES + W_BYTES + w_off[tb][ks]);
+            };
+            fetch(0);
 #pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                bh[buf][t] = *reinterpret_cast<const bf16x8*>(sb + NPL * A_BYTES + w_off[t][ks]);
-                if (X3) bl[buf][t] = *reinterpret_cast<const bf16x8*>(sb + NPL * A_BYTES + W_BYTES + w_off[t][ks]);
+            for (int grp = 0; grp < NG; ++grp) {
+                if (grp + 1 < NG) fetch(grp + 1);
+#pragma unroll
+                for (int ta = 0; ta < TM; ++ta) mma3(acc[ta][grp % TN], ah[grp / TN][ta], al[grp / TN][ta], wh[grp & 1], wl[grp & 1]);
+                if (grp < TN && more) {
+#pragma unroll
+                    for (int q = 0; q < PPG; ++q)
+                        if (grp * PPG + q < LPT) piece(grp * PPG + q, kt + 1, nb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
-        frags(0, 0);
+        issue(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            RGN_T(0)
+            wait_vmcnt<0>();                      // my pieces of tile kt landed
+            RGN_T(1)
+            __builtin_amdgcn_s_barrier();         // ... everyone's did, and everyone is done reading tile kt-1's stage
+            RGN_T(2)
+            step(kt, kt + 1 < nk);
+            RGN_T(3)
+            RGN_T(4)
+            RGN_T(5)
+        }
+    } else {
+        auto compute = [&](const char* sb) {
+            bf16x8 ah[2][TM], al[2][TM], wh[2][TN], wl[2][TN];
+            auto frags = [&](int ks, int buf) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (ks == 0) frags(1, 1);
-#pragma unroll
-            for (int ta = 0; ta < TM; ++ta)
-#pragma unroll
-                for (int tb = 0; tb < TN; ++tb) {
-                    if (X3) {
-                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][ta], bh[ks][tb], acc[ta][tb], 0, 0, 0);
-                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][ta], bl[ks][tb], acc[ta][tb], 0, 0, 0);
-                    }
-                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][ta], bh[ks][tb], acc[ta][tb], 0, 0, 0);
+                for (int t = 0; t < TM; ++t) {
+                    ah[buf][t] = *reinterpret_cast<const bf16x8*>(sb + a_off[t][ks]);
+                    if (X3) al[buf][t] = *reinterpret_cast<const bf16x8*>(sb + A_BYTES + a_off[t][ks]);
                 }
-        }
-    };
-    if constexpr (NSTAGE == 3) {
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
+                    wh[buf][t] = *reinterpret_cast<const bf16x8*>(sb + NPL * A_BYTES + w_off[t][ks]);
+                    if (X3) wl[buf][t] = *reinterpret_cast<const bf16x8*>(sb + NPL * A_BYTES + W_BYTES + w_off[t][ks]);
+                }
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks == 0) frags(1, 1);
+#pragma unroll
+                for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < TN; ++tb) mma3(acc[ta][tb], ah[ks][ta], al[ks][ta], wh[ks][tb], wl[ks][tb]);
+            }
+        };
         issue(0, 0);
-        if (nk > 1) issue(1, 1);
-        int st_cur = 0, st_free = 2;          // stage of tile kt, stage that tile kt+2 goes to
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) wait_vmcnt<LPT>();   // tile kt landed (tile kt+1 may still be in flight)
-            else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (kt + 2 < nk) issue(kt + 2, st_free);
-            compute(smem + st_cur * STAGE);
-            st_free = st_cur;
-            st_cur = (st_cur == 2) ? 0 : st_cur + 1;
-        }
-    } else {   // 2 stages, two barriers per k-step; small enough for two workgroups per CU
-        issue(0, 0);
-        for (int kt = 0; kt < nk; ++kt) {
+            RGN_T(0)
             if (kt + 1 < nk) {
                 issue(kt + 1, (kt + 1) & 1);
-                wait_vmcnt<LPT>();
+                RGN_T(1)
+                wait_vmcnt<LPT>();                // tile kt landed, tile kt+1 stays in flight
             } else {
+                RGN_T(1)
                 wait_vmcnt<0>();
             }
+            RGN_T(2)
             __builtin_amdgcn_s_barrier();
+            RGN_T(3)
             compute(smem + (kt & 1) * STAGE);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();     // stage (kt&1) may now be overwritten by tile kt+2
+            RGN_T(4)
+            __builtin_amdgcn_s_barrier();         // stage (kt&1) may now be overwritten by tile kt+2
+            RGN_T(5)
         }
     }
+#undef RGN_T
 
     const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
     if (interior) x3_epilogue<TM, TN, QKV, false>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
     else x3_epilogue<TM, TN, QKV, true>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
+template <int BM, int BN, int WM, int WN, bool ILV>
 static hipError_t x3_launch(const GemmX3Args& g, bool x3, hipStream_t s, bool configure_only) {
-    const int lds = NSTAGE * (x3 ? 2 : 1) * (BM * 64 + BN * 64);
+    const int lds = 2 * (x3 ? 2 : 1) * (BM * 64 + BN * 64);
     if (configure_only) {
-        const int big = NSTAGE * 2 * (BM * 64 + BN * 64), small = NSTAGE * (BM * 64 + BN * 64);
+        const int big = 2 * 2 * (BM * 64 + BN * 64), small = 2 * (BM * 64 + BN * 64);
         hipError_t e;
 #define RGN_CFG(X3V, QV, BYTES)                                                                                        \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_x3<BM, BN, WM, WN, X3V, NSTAGE, QV>),                 \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_x3<BM, BN, WM, WN, X3V, ILV, QV>),                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);                                        \
         if (e != hipSuccess) return e;
-        RGN_CFG(true, false, big) RGN_CFG(false, false, small) RGN_CFG(true, true, big) RGN_CFG(false, true, small)
+        RGN_CFG(true, false, big) RGN_CFG(false, false, small)
+        if constexpr (BM == 128 && !ILV) { RGN_CFG(true, true, big) RGN_CFG(false, true, small) }
 #undef RGN_CFG
         return hipSuccess;
     }
     const int nbx = (g.N + BN - 1) / BN, nby = (g.M + BM - 1) / BM;
     const dim3 grid(nbx * nby), block(64 * WM * WN);
     const bool qkv = g.Qhi != nullptr;
-    if (x3 && !qkv) hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, true, NSTAGE, false>), grid, block, lds, s, g, nbx, nby);
-    else if (x3 && qkv) hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, true, NSTAGE, true>), grid, block, lds, s, g, nbx, nby);
-    else if (!qkv) hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, false, NSTAGE, false>), grid, block, lds, s, g, nbx, nby);
-    else hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, false, NSTAGE, true>), grid, block, lds, s, g, nbx, nby);
+    if constexpr (BM == 128 && !ILV) {   // the attention-ready scatter exists for the default tile only
+        if (qkv) {
+            if (x3) hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, true, ILV, true>), grid, block, lds, s, g, nbx, nby);
+            else hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, false, ILV, true>), grid, block, lds, s, g, nbx, nby);
+            return hipGetLastError();
+        }
+    } else if (qkv) {
+        return hipErrorInvalidValue;
+    }
+    if (x3) hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, true, ILV, false>), grid, block, lds, s, g, nbx, nby);
+    else hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, false, ILV, false>), grid, block, lds, s, g, nbx, nby);
     return hipGetLastError();
 }
 
-// variant: 0 = 128x128 / 4 waves / 2 stages (64 KiB: two workgroups per CU), 1 = 256x128 / 8 waves / 3 stages
+// variant 0 = 128x128 / 4 waves (two workgroups per CU) is the only one the library ships. tools/gemm_bench builds with
+// RGN_GEMM_TOOLS and can also time 1 = 256x256 / 8 waves / interleaved DMA (one workgroup per CU), 2 = 256x256 with
+// the two-barrier loop, 3 = 128x128 with the interleaved loop: at M = 15360 the 256x256 loop is ~1.7x faster per
+// output but leaves 120 (N = 512) / 240 (N = 1024) tiles for 256 CUs and cannot hide its 256 KiB-per-tile epilogue.
 hipError_t launch_gemm_x3(const GemmX3Args& g, bool x3, int variant, hipStream_t s) {
-    if (variant == 1) return x3_launch<256, 128, 4, 2, 3>(g, x3, s, false);
-    return x3_launch<128, 128, 2, 2, 2>(g, x3, s, false);
+#ifdef RGN_GEMM_TOOLS
+    if (variant == 1) return x3_launch<256, 256, 4, 2, true>(g, x3, s, false);
+    if (variant == 2) return x3_launch<256, 256, 4, 2, false>(g, x3, s, false);
+    if (variant == 3) return x3_launch<128, 128, 2, 2, true>(g, x3, s, false);
+#endif
+    return x3_launch<128, 128, 2, 2, false>(g, x3, s, false);
 }
 hipError_t configure_gemm_x3() {
     GemmX3Args g{};
-    hipError_t e = x3_launch<128, 128, 2, 2, 2>(g, true, nullptr, true);
+    hipError_t e = x3_launch<128, 128, 2, 2, false>(g, true, nullptr, true);
     if (e != hipSuccess) return e;
-    return x3_launch<256, 128, 4, 2, 3>(g, true, nullptr, true);
+#ifdef RGN_GEMM_TOOLS
+    e = x3_launch<256, 256, 4, 2, false>(g, true, nullptr, true);
+    if (e != hipSuccess) return e;
+    e = x3_launch<128, 128, 2, 2, true>(g, true, nullptr, true);
+    if (e != hipSuccess) return e;
+    e = x3_launch<256, 256, 4, 2, true>(g, true, nullptr, true);
+#endif
+    return e;
 }
+
+#ifdef RGN_GEMM_PROF
+void gemm_prof_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(long long) * 1024); }
+#endif
 
 }  // namespace rgn

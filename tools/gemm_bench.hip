@@ -1,5 +1,5 @@
 // Stand-alone micro-benchmark + refcheck of the split-bf16 GEMM (tools only; not part of the library).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I regennet_amd/csrc tools/gemm_bench.hip regennet_amd/csrc/rgn_gemm_x3.hip -o tools/bin/gemm_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRGN_GEMM_TOOLS -I regennet_amd/csrc tools/gemm_bench.hip regennet_amd/csrc/rgn_gemm_x3.hip -o tools/bin/gemm_bench
 #include "rgn_internal.h"
 
 #include <hip/hip_runtime.h>
@@ -12,6 +12,9 @@
 #include <vector>
 
 using namespace rgn;
+#ifdef RGN_GEMM_PROF
+namespace rgn { void gemm_prof_read(long long* out); }
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
 static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
@@ -68,6 +71,7 @@ int main(int argc, char** argv) {
             else maxerr = fmax(maxerr, fabs(ref - C[(size_t)m * N + n]));
             maxref = fmax(maxref, fabs(ref));
         }
+        if (getenv("PLANES_ONLY") && planes_out) g.C = nullptr;   // time the in-model linear1 form (planes out only)
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         for (int i = 0; i < 3; ++i) CK(launch_gemm_x3(g, true, variant, nullptr));
         CK(hipEventRecord(e0, nullptr));
@@ -77,6 +81,21 @@ int main(int argc, char** argv) {
         const double us = 1e3 * ms / iters, fl = 2.0 * M * N * K;
         printf("%-9s M=%5d N=%4d K=%4d  %8.1f us  %7.1f TF(alg) %7.1f TF(raw bf16)  maxerr %.2e (ref max %.2f)\n", sh.name, M, N, K, us, fl / us * 1e-6, 3 * fl / us * 1e-6, maxerr, maxref);
         if (M > 1000 && N >= 512 && K >= 512) { tot_us += us; tot_fl += fl; }
+#ifdef RGN_GEMM_PROF
+        if (!strcmp(sh.name, getenv("PROF_SHAPE") ? getenv("PROF_SHAPE") : "ffn1")) {
+            std::vector<long long> pr(1024);
+            gemm_prof_read(pr.data());
+            for (int w = 0; w < 2; ++w) {
+                printf("  wave %s: per k-step cycles [t1-t0 | t2-t1 | t3-t2 | t4-t3 | t5-t4 | total]\n", w ? "last" : "0");
+                const long long* q = pr.data() + w * 512;
+                for (int kt = 0; kt < Kp / 32; ++kt) {
+                    const long long* t = q + kt * 6;
+                    const long long nxt = kt + 1 < Kp / 32 ? t[6] : t[5];
+                    printf("   kt %2d: %5lld %5lld %5lld %5lld %5lld | %5lld\n", kt, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], nxt - t[0]);
+                }
+            }
+        }
+#endif
         hipFree(dAh); hipFree(dAl); hipFree(dWh); hipFree(dWl); hipFree(dC); hipFree(dB);
     }
     printf("layer GEMMs: %.1f us, %.1f TF(alg)\n", tot_us, tot_fl / tot_us * 1e-6);
