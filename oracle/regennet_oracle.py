@@ -262,6 +262,27 @@ def sample_loop(sd, cfg, schedule, tape, y, mode="ddpm", guided=False, eta=0.0, 
 
 
 # --------------------------------------------------------------------------------------
+# next-3 row: auto_regressive generation           eval/a2m/stgcn_eval.py:50-67
+# --------------------------------------------------------------------------------------
+def sample_auto_regressive(sd, cfg, schedule, tapes, y, setting="cmdm", mode="ddpm"):
+    """Literal restatement of the reference's frame loop: for frame f the actor's frames 0..f are revealed (the rest
+    stay zero), one complete sampler run is made with fresh noise (tapes[f]) and only frame f of the result is kept.
+    Returns `output` [B, J, 2F, T] for setting 'cmdm' (actor rows then reactor rows, stgcn_eval.py:62-63), else [B,J,F,T]."""
+    cm_full = torch.as_tensor(y["cmotion"])
+    B, J, Fe, T = cm_full.shape
+    cm = torch.zeros_like(cm_full)
+    out = torch.zeros((B, J, Fe * 2 if setting == "cmdm" else Fe, T))
+    for f in range(T):
+        cm[:, :, :, f] = cm_full[:, :, :, f]                                 # :58
+        yy = dict(y)
+        yy["cmotion"] = cm
+        sample = sample_loop(sd, cfg, schedule, tapes[f], yy, mode=mode, clip_denoised=False)   # :60
+        tmp = torch.cat((cm, sample), dim=2) if setting == "cmdm" else sample    # :61-64
+        out[:, :, :, f] = tmp[:, :, :, f]                                    # :65
+    return out
+
+
+# --------------------------------------------------------------------------------------
 # next-1 / next-2 rows (SURVEY.md §8f)
 # --------------------------------------------------------------------------------------
 def rotation_6d_to_matrix(d6):

@@ -165,6 +165,42 @@ def gen_loop(name, cfg_name, B, resp, mode, guided=False, keep_trace=False, opts
     save(name, **kw)
 
 
+def gen_autoreg(name, cfg_name, B, resp, **over):
+    """next-3 row: the auto_regressive generation of eval/a2m/stgcn_eval.py:50-67 (setting 'cmdm').
+
+    The frame loop below re-states those lines around the REFERENCE's own model and p_sample_loop (NewDataloader itself
+    needs the SMPL-X assets for rot2xyz, which the container lacks): for every frame index the actor's frames up to it are
+    revealed, a full sampler run is made with fresh noise (run f pops tape f) and only that frame of the result is kept.
+    """
+    cfg = synth.get_config(cfg_name, **over)
+    sd = synth.make_state_dict(cfg, seed=0)
+    model, diffusion = build(dict(cfg, noise_schedule="cosine", sigma_small=True), resp, sd)
+    S = diffusion.num_timesteps
+    y = make_y(cfg, B, False)
+    T = cfg["num_frames"]
+    shape = (B, cfg["njoints"], cfg["nfeats"], T)
+    cmotion_bak = y["cmotion"]
+    cmotion = torch.zeros_like(cmotion_bak)
+    output = torch.zeros((B, cfg["njoints"], cfg["nfeats"] * 2, T))
+    samples = []
+    t0 = time.time()
+    for f in range(T):
+        cmotion[:, :, :, f] = cmotion_bak[:, :, :, f]
+        y["cmotion"] = cmotion
+        tape = synth.make_noise_tape(cfg, B, S, seed=100 + f)
+        with _ref_import.NoiseTape(tape) as nt:
+            sample = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y})
+            assert nt.pos == S + 1
+        tmp = torch.cat((y["cmotion"], sample), axis=2)
+        output[:, :, :, f] = tmp[:, :, :, f]
+        samples.append(sample.numpy().copy())
+    dt = time.time() - t0
+    print(f"{name}: reference auto_regressive T={T} S={S} B={B} took {dt:.1f}s")
+    save(name, cfg_name=cfg_name, over=repr(over), B=B, resp=resp, S=S, T=T, guided=False, output=output.numpy(),
+         last_run=samples[-1], ref_seconds=dt, sd_digest=sd_digest(sd),
+         in_digest=digest(synth.make_noise_tape(cfg, B, S, seed=100)[0], cmotion_bak.numpy()))
+
+
 def gen_post():
     """next-1/next-2 rows: rotation_6d_to_matrix and the cgenerate.py:142 smoothing."""
     _ref_import.install()
@@ -197,6 +233,8 @@ JOBS = {
     "tiny_opts_eta": lambda: gen_loop("tiny_opts_eta", "tiny", 2, "ddim10", "ddim", guided=True, opts=dict(eta=0.7)),
     "tiny_add_ddpm1000": lambda: gen_loop("tiny_add_ddpm1000", "tiny_add", 2, "", "ddpm"),
     "tiny_text_ddim20_cfg": lambda: gen_loop("tiny_text_ddim20_cfg", "tiny_text", 3, "ddim20", "ddim", guided=True),
+    "tiny_autoreg_ddpm10": lambda: gen_autoreg("tiny_autoreg_ddpm10", "tiny", 2, "10"),
+    "tiny_add_autoreg_ddpm20": lambda: gen_autoreg("tiny_add_autoreg_ddpm20", "tiny_add", 3, "20"),
     "ntu_fwd": lambda: gen_forward("ntu_fwd", "ntu", 2, [0, 500, 999]),
     "ntu_action_fwd_cfg": lambda: gen_forward("ntu_action_fwd_cfg", "ntu_action", 2, [0, 990], guided=True),
     "ntu_ddpm50": lambda: gen_loop("ntu_ddpm50", "ntu", 2, "50", "ddpm"),

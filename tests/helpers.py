@@ -49,6 +49,20 @@ def fixture_inputs(g, loop):
     return cfg, sd, y, x
 
 
+def autoreg_inputs(g):
+    """Inputs of an auto_regressive fixture (make_golden.gen_autoreg): (cfg, sd, y_numpy, [tape_f for f in range(T)])."""
+    cfg = fixture_cfg(g)
+    sd = synth.make_state_dict(cfg, seed=0)
+    assert sd_digest(sd) == str(g["sd_digest"]), "synthetic checkpoint drifted from the golden fixtures"
+    B, S, T = int(g["B"]), int(g["S"]), int(g["T"])
+    y = {"cmotion": synth.make_cmotion(cfg, B, seed=1)}
+    if "action" in cfg["cond_mode"]:
+        y["action"] = synth.make_actions(cfg, B, seed=2)
+    tapes = [synth.make_noise_tape(cfg, B, S, seed=100 + f) for f in range(T)]
+    assert digest(tapes[0][0], y["cmotion"]) == str(g["in_digest"])
+    return cfg, sd, y, tapes
+
+
 # ---- HIP-side construction (GPU tests) --------------------------------------------------------------
 def build_hip(cfg, sd, resp="", precision="f32", device="cuda:0", noise_schedule="cosine", sigma_small=True):
     """(model, diffusion) from regennet_amd for a synth config + synthetic checkpoint."""

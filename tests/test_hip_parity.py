@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import build_hip, fixture_inputs, fixture_opts, y_to_device
+from tests.helpers import autoreg_inputs, build_hip, fixture_inputs, fixture_opts, y_to_device
 
 pytestmark = pytest.mark.gpu
 
@@ -321,3 +321,42 @@ def test_sampler_options(golden, name, precision):
         out = diffusion.ddim_sample_loop(fm, shape, eta=o.get("eta", 0.0), **kw)
     err = np.abs(out.cpu().numpy() - g["final"]).max()
     assert err < 1e-3, (name, err)
+
+
+# ---- next-3 row: auto_regressive generation (eval/a2m/stgcn_eval.py:50-67) --------------------------------------------
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("name", ["tiny_autoreg_ddpm10", "tiny_add_autoreg_ddpm20"])
+def test_auto_regressive_matches_reference(golden, name, precision):
+    """All T runs as one batch (and as several calls) against the reference's frame-by-frame loop on the same noise."""
+    from regennet_amd.eval import sample_auto_regressive
+
+    g = golden(name)
+    cfg, sd, y, tapes = autoreg_inputs(g)
+    model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision=precision)
+    B, T = int(g["B"]), int(g["T"])
+    shape = (B, cfg["njoints"], cfg["nfeats"], T)
+    tapes_t = [torch.from_numpy(t) for t in tapes]
+    for fpc in (T, 3, 1):
+        out = sample_auto_regressive(diffusion.p_sample_loop, model, shape, {"y": y_to_device(y)}, frames_per_call=fpc,
+                                     noise_tapes=tapes_t)
+        err = np.abs(out.cpu().numpy() - g["output"]).max()
+        assert err < 1e-3, (name, fpc, err)
+
+
+def test_auto_regressive_grouping_invariance_with_device_rng():
+    """Philox keyed by the global (frame, sample) index: the grouping of frames into sampler calls cannot change a bit."""
+    from regennet_amd import synth
+    from regennet_amd.eval import sample_auto_regressive
+
+    cfg = synth.get_config("tiny")
+    sd = synth.make_state_dict(cfg, seed=0)
+    model, diffusion = build_hip(cfg, sd, resp="10", precision="bf16x3")
+    B, T = 3, cfg["num_frames"]
+    y = y_to_device({"cmotion": synth.make_cmotion(cfg, B, seed=1), "action": synth.make_actions(cfg, B, seed=2)})
+    shape = (B, cfg["njoints"], cfg["nfeats"], T)
+    ref = sample_auto_regressive(diffusion.p_sample_loop, model, shape, {"y": y}, frames_per_call=T, seed=11)
+    for fpc in (1, 3):
+        out = sample_auto_regressive(diffusion.p_sample_loop, model, shape, {"y": y}, frames_per_call=fpc, seed=11)
+        assert torch.equal(out, ref), fpc
+    other = sample_auto_regressive(diffusion.p_sample_loop, model, shape, {"y": y}, frames_per_call=T, seed=12)
+    assert not torch.equal(other, ref)

@@ -116,3 +116,51 @@ def test_flag_quirks():
     assert cgenerate_args(["--sigma_small", "False"]).sigma_small is True      # type=bool quirk of the reference
     a = cgenerate_args([])
     assert (a.seed, a.batch_size, a.noise_schedule, a.latent_dim, a.layers, a.cm_mode) == (10, 64, "cosine", 512, 8, "concat")
+
+
+# ---- next-3 row: batched auto_regressive generation (host logic; the sampler is faked) -------------------------------
+def test_auto_regressive_batching_masks_orders_and_gathers():
+    import torch
+
+    from regennet_amd.eval import sample_auto_regressive
+
+    B, V, C, T = 3, 2, 4, 5
+    gen = torch.Generator().manual_seed(0)
+    cm = torch.randn(B, V, C, T, generator=gen)
+    y = {"cmotion": cm, "action": torch.arange(B).reshape(B, 1), "lengths": torch.full((B,), T), "action_text": ["a", "b", "c"]}
+    calls = []
+
+    def fake_sample_fn(model, shape, clip_denoised=True, model_kwargs=None, seed=None, sample_offset=0, noise_tape=None):
+        yy = model_kwargs["y"]
+        n = shape[0] // B
+        calls.append((shape, sample_offset, seed))
+        assert yy["cmotion"].shape == shape and yy["action"].shape == (n * B, 1) and len(yy["action_text"]) == n * B
+        assert clip_denoised is False
+        # sample (f, b) = masked actor motion + 1000 * (global sample index): lets the caller's gather be checked exactly
+        gidx = sample_offset + torch.arange(n * B).reshape(-1, 1, 1, 1)
+        assert torch.equal(yy["action"][:, 0], torch.arange(B).repeat(n))
+        return yy["cmotion"] + 1000.0 * gidx
+
+    for fpc in (1, 2, 5, None):
+        calls.clear()
+        out = sample_auto_regressive(fake_sample_fn, None, (B, V, C, T), {"y": y}, frames_per_call=fpc, seed=7)
+        assert out.shape == (B, V, 2 * C, T)
+        assert torch.equal(out[:, :, :C], cm)
+        for f in range(T):
+            for b in range(B):
+                # frame f of run f: the actor's frame f is revealed in that run, offset identifies (f, b)
+                assert torch.equal(out[b, :, C:, f], cm[b, :, :, f] + 1000.0 * (f * B + b))
+        assert [c[1] for c in calls] == list(range(0, T * B, (fpc or T) * B))
+        assert all(c[2] == 7 for c in calls)
+    # masking: run f must not see later actor frames
+    seen = []
+
+    def spy(model, shape, clip_denoised=True, model_kwargs=None, **kw):
+        seen.append(model_kwargs["y"]["cmotion"].clone())
+        return torch.zeros(shape)
+
+    out = sample_auto_regressive(spy, None, (B, V, C, T), {"y": y}, setting="other", frames_per_call=T, seed=1)
+    assert out.shape == (B, V, C, T)
+    m = seen[0].reshape(T, B, V, C, T)
+    for f in range(T):
+        assert torch.equal(m[f, :, :, :, : f + 1], cm[:, :, :, : f + 1]) and not m[f, :, :, :, f + 1:].any()

@@ -5,7 +5,7 @@ import torch
 
 from oracle import regennet_oracle as orc
 from regennet_amd import synth
-from tests.helpers import fixture_inputs, fixture_opts
+from tests.helpers import autoreg_inputs, fixture_inputs, fixture_opts
 
 FWD = ["tiny_fwd", "tiny_fwd_cfg", "tiny_add_fwd", "tiny_etd_fwd", "tiny_text_fwd_cfg", "ntu_fwd",
        "ntu_action_fwd_cfg", "chi3d_fwd"]
@@ -40,6 +40,20 @@ def test_sampling_loop_matches_reference(golden, name):
     if "x0" in g:
         np.testing.assert_allclose(torch.stack(trace["x0"]).numpy(), g["x0"], atol=1e-4, rtol=0)
         np.testing.assert_allclose(torch.stack(trace["x"]).numpy(), g["x"], atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["tiny_autoreg_ddpm10", "tiny_add_autoreg_ddpm20"])
+def test_auto_regressive_generation_matches_reference(golden, name):
+    """next-3 row: eval/a2m/stgcn_eval.py:50-67 run around the reference's own sampler (make_golden.gen_autoreg)."""
+    g = golden(name)
+    cfg, sd, y, tapes = autoreg_inputs(g)
+    sched = orc.make_schedule("cosine", str(g["resp"]))
+    out = orc.sample_auto_regressive(sd, cfg, sched, tapes, _ty(y)).numpy()
+    np.testing.assert_allclose(out, g["output"], atol=1e-4, rtol=0)
+    F = cfg["nfeats"]
+    assert np.array_equal(out[:, :, :F], y["cmotion"])                       # actor rows = the (fully revealed) actor motion
+    # the last run saw the whole actor motion: its last frame is the last column of the reactor rows
+    np.testing.assert_allclose(out[:, :, F:, -1], g["last_run"][:, :, :, -1], atol=1e-4, rtol=0)
 
 
 def test_schedule_tables_and_respacing_match_reference(golden):
