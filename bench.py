@@ -168,7 +168,7 @@ def main():
 
     # ---- roofline of the dominant kernel class: HIP events around every launch, eager mode -----------------
     roof = None
-    if rank == 0:
+    if rank == 0 and a.profile_evals > 0:   # (--profile-evals 0: tools/collect_pmc.sh wants the sampling call only)
         eng.profile_enable(True)
         x = torch.empty(shape, device=dev)
         st = torch.cuda.current_stream().cuda_stream

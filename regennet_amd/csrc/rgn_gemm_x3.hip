@@ -436,6 +436,8 @@ hipError_t launch_gemm_x3(const GemmX3Args& g, bool x3, int variant, hipStream_t
     if (variant == 1) return x3_launch<256, 256, 4, 2, true>(g, x3, s, false);
     if (variant == 2) return x3_launch<256, 256, 4, 2, false>(g, x3, s, false);
     if (variant == 3) return x3_launch<128, 128, 2, 2, true>(g, x3, s, false);
+    if (variant == 4) return x3_launch<128, 256, 2, 4, true>(g, x3, s, false);
+    if (variant == 5) return x3_launch<256, 128, 4, 2, true>(g, x3, s, false);
 #endif
     return x3_launch<128, 128, 2, 2, false>(g, x3, s, false);
 }
@@ -449,6 +451,10 @@ hipError_t configure_gemm_x3() {
     e = x3_launch<128, 128, 2, 2, true>(g, true, nullptr, true);
     if (e != hipSuccess) return e;
     e = x3_launch<256, 256, 4, 2, true>(g, true, nullptr, true);
+    if (e != hipSuccess) return e;
+    e = x3_launch<128, 256, 2, 4, true>(g, true, nullptr, true);
+    if (e != hipSuccess) return e;
+    e = x3_launch<256, 128, 4, 2, true>(g, true, nullptr, true);
 #endif
     return e;
 }
