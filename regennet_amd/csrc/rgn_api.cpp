@@ -392,7 +392,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
     for (int l = 0; l < c->L; ++l) {
         const LayerW& w = c->layers[l];
         if (fast && c->fuse_qkv) {
-            // in_proj + attention per sample in one kernel: q, k, v only ever exist in LDS
+            // in_proj + attention in one kernel (two samples x half the heads per workgroup): q, k, v only ever exist in LDS
             QkvAttnArgs g{};
             g.Ahi = h_p.hi; g.Alo = h_p.lo; g.a_rows = h_p.rows;
             g.Whi = c->dp<__bf16>(w.qkv.hi); g.Wlo = c->dp<__bf16>(w.qkv.lo);

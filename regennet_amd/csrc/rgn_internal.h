@@ -87,7 +87,7 @@ struct Planes {
     int rows;     // row count of the plane (the M of the consuming GEMM)
 };
 
-// Fused in_proj GEMM + causal self-attention, one workgroup per sample (rgn_qkv_attn.hip)
+// Fused in_proj GEMM + causal self-attention, one workgroup per (sample pair, half of the heads) (rgn_qkv_attn.hip)
 struct QkvAttnArgs {
     const __bf16* Ahi; const __bf16* Alo; int a_rows;   // layer input planes [Kp/32][a_rows][32] (advanced to the first sample)
     const __bf16* Whi; const __bf16* Wlo;               // in_proj weight planes [Kp/32][3d][32]
