@@ -337,7 +337,7 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn(QkvAttnArgs g) {
 }
 
 bool qkv_attn_supported(int Tq, int dh, int d) { return Tq <= QA_ROWS && dh == QA_DH && d % 32 == 0 && d / dh <= 8; }
-static int qa_lds(bool x3) { return 2 * (x3 ? 2 : 1) * (QA_NS * QA_ROWS * 64 + QA_WROWS * 64) + 4 * QA_WROWS * 4 /* biases of <= 4 heads */; }
+static int qa_lds(bool x3) { return 2 * (x3 ? 2 : 1) * (QA_NS * QA_ROWS * 64 + QA_WROWS * 64) + 8 * QA_WROWS * 4 /* biases of <= 8 heads (odd H: one workgroup runs them all) */; }
 hipError_t configure_qkv_attn() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, qa_lds(true));
     if (e != hipSuccess) return e;
