@@ -145,7 +145,7 @@ hipError_t launch_attn_x3(const AttnX3Args& a, hipStream_t s);
 hipError_t launch_attention(const float* qkv, float* out, Planes op, const Dims& dm, hipStream_t s);
 // h_out = LN_b( LN_a(in) + addvec[row/Tq] ) when ln_b != nullptr, else LN_a(in)
 // addvec: per-sample vector (row/Tq)*ldadd, may be nullptr; stepvec: per-step vector at (*d_step)*ldstep, may be nullptr
-hipError_t launch_layernorm(const float* in, float* out, Planes op, int M, int d, const float* ga, const float* ba,
+hipError_t launch_layernorm(const float* in, Planes resid, float* out, Planes op, int M, int d, const float* ga, const float* ba,
                             const float* addvec, int ldadd, const float* stepvec, int ldstep, const int* d_step, int Tq,
                             const float* gb, const float* bb, hipStream_t s);
 hipError_t launch_gather_pe(const float* pe, const StepCoef* tab, const int* d_step, const SampleParams* sp,

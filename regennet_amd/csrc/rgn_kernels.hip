@@ -581,14 +581,80 @@ hipError_t launch_attention(const float* qkv, float* out, Planes op, const Dims&
 }
 
 // =================================================================================================
-// Residual LayerNorm(s): one wave per token row, row held in registers.
-//   out = LN_b( LN_a(in) + addvec[row / Tq] )   or   out = LN_a(in)
-// `in` already contains residual + sublayer output (+bias) from the producing GEMM's epilogue.
+// Residual LayerNorm(s): one wave per token row, row held in registers (lane owns VPL = d/64 CONSECUTIVE columns, so
+// every access is one or two 16-byte vectors per lane: fp32 rows as float4, plane rows as 8 bf16).
+//   out = LN_b( LN_a(in + resid) + addvec[row / Tq] + stepvec[*d_step] )   or   out = LN_a(in + resid)
+// F32 mode: `in` already contains the residual (added in the producing GEMM's epilogue), resid is empty and the
+// result goes to the fp32 residual stream `out`. bf16 modes: the residual stream exists only as split planes; it is
+// added here (hi + lo) and the result is written as planes only (out == nullptr).
 // Replaces norm1/norm2/norm3 of TransformerDecoderLayer (post-norm, eps=1e-5) and the add of the
 // 1-token cross-attention result, which is constant over the sequence.
 // =================================================================================================
+template <int N>
+__device__ __forceinline__ void ld_f32(const float* __restrict__ p, float* v) {
+    if constexpr (N % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < N / 4; ++j) {
+            const f32x4 t = reinterpret_cast<const f32x4*>(p)[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * j + e] = t[e];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = p[j];
+    }
+}
+template <int N>
+__device__ __forceinline__ void st_f32(float* __restrict__ p, const float* v) {
+    if constexpr (N % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < N / 4; ++j) {
+            const f32x4 t = {v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
+            reinterpret_cast<f32x4*>(p)[j] = t;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) p[j] = v[j];
+    }
+}
+template <int N>
+__device__ __forceinline__ void ld_bf16_add(const __bf16* __restrict__ p, float* v) {   // v += p[0..N)
+    typedef __bf16 bf16xN __attribute__((ext_vector_type(N)));
+    if constexpr (N == 1) {
+        v[0] += (float)p[0];
+    } else if constexpr (N <= 8) {
+        const bf16xN t = *reinterpret_cast<const bf16xN*>(p);
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] += (float)t[e];
+    } else {
+        ld_bf16_add<8>(p, v);
+        ld_bf16_add<N - 8>(p + 8, v + 8);
+    }
+}
+template <int N>
+__device__ __forceinline__ void st_split(__bf16* __restrict__ hi, __bf16* __restrict__ lo, const float* v) {
+    typedef __bf16 bf16xN __attribute__((ext_vector_type(N)));
+    if constexpr (N == 1) {
+        const __bf16 h = (__bf16)v[0];
+        hi[0] = h;
+        if (lo) lo[0] = (__bf16)(v[0] - (float)h);
+    } else if constexpr (N <= 8) {
+        bf16xN h, l;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            h[e] = (__bf16)v[e];
+            l[e] = (__bf16)(v[e] - (float)h[e]);
+        }
+        *reinterpret_cast<bf16xN*>(hi) = h;
+        if (lo) *reinterpret_cast<bf16xN*>(lo) = l;
+    } else {
+        st_split<8>(hi, lo, v);
+        st_split<N - 8>(hi + 8, lo ? lo + 8 : nullptr, v + 8);
+    }
+}
+
 template <int VPL>
-__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in, float* __restrict__ out, Planes op, int M, int d,
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in, Planes resid, float* __restrict__ out, Planes op, int M, int d,
                                                     const float* __restrict__ ga, const float* __restrict__ ba,
                                                     const float* __restrict__ addvec, int ldadd,
                                                     const float* __restrict__ stepvec, int ldstep, const int* __restrict__ d_step,
@@ -601,14 +667,17 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
     const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int row = vid * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float* x = in + (size_t)row * d;
-    float v[VPL];
+    const int c0 = lane * VPL;                                   // first of this lane's VPL consecutive columns
+    float v[VPL], w[VPL], bsh[VPL];
+    ld_f32<VPL>(in + (size_t)row * d + c0, v);
+    if (resid.hi) {
+        const size_t o = plane_off(resid.rows, row, c0);          // VPL divides 32: the run stays inside one K32 block
+        ld_bf16_add<VPL>(resid.hi + o, v);
+        if (resid.lo) ld_bf16_add<VPL>(resid.lo + o, v);
+    }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        v[i] = x[lane + 64 * i];
-        s += v[i];
-    }
+    for (int i = 0; i < VPL; ++i) s += v[i];
     const float invd = 1.0f / (float)d;
     float mean = wave_sum(s) * invd;
     float q = 0.f;
@@ -618,19 +687,24 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
         q += c * c;
     }
     float rstd = 1.0f / sqrtf(wave_sum(q) * invd + 1e-5f);
+    ld_f32<VPL>(ga + c0, w);
+    ld_f32<VPL>(ba + c0, bsh);
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) v[i] = (v[i] - mean) * rstd * ga[lane + 64 * i] + ba[lane + 64 * i];
+    for (int i = 0; i < VPL; ++i) v[i] = (v[i] - mean) * rstd * w[i] + bsh[i];
     if (gb) {
-        const float* av = addvec ? addvec + (size_t)(row / Tq) * ldadd : nullptr;
-        const float* sv = stepvec ? stepvec + (size_t)(*d_step) * ldstep : nullptr;
+        if (stepvec) {
+            ld_f32<VPL>(stepvec + (size_t)(*d_step) * ldstep + c0, w);
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) v[i] += w[i];
+        }
+        if (addvec) {
+            ld_f32<VPL>(addvec + (size_t)(row / Tq) * ldadd + c0, w);
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) v[i] += w[i];
+        }
         s = 0.f;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            float a = sv ? sv[lane + 64 * i] : 0.f;
-            if (av) a += av[lane + 64 * i];
-            v[i] += a;
-            s += v[i];
-        }
+        for (int i = 0; i < VPL; ++i) s += v[i];
         mean = wave_sum(s) * invd;
         q = 0.f;
 #pragma unroll
@@ -639,23 +713,23 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
             q += c * c;
         }
         rstd = 1.0f / sqrtf(wave_sum(q) * invd + 1e-5f);
+        ld_f32<VPL>(gb + c0, w);
+        ld_f32<VPL>(bb + c0, bsh);
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) v[i] = (v[i] - mean) * rstd * gb[lane + 64 * i] + bb[lane + 64 * i];
+        for (int i = 0; i < VPL; ++i) v[i] = (v[i] - mean) * rstd * w[i] + bsh[i];
     }
-    float* y = out + (size_t)row * d;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) y[lane + 64 * i] = v[i];
+    if (out) st_f32<VPL>(out + (size_t)row * d + c0, v);
     if (op.hi) {
-#pragma unroll
-        for (int i = 0; i < VPL; ++i) plane_put(op, row, lane + 64 * i, v[i]);
+        const size_t o = plane_off(op.rows, row, c0);
+        st_split<VPL>(op.hi + o, op.lo ? op.lo + o : nullptr, v);
     }
 }
 
-hipError_t launch_layernorm(const float* in, float* out, Planes op, int M, int d, const float* ga, const float* ba,
+hipError_t launch_layernorm(const float* in, Planes resid, float* out, Planes op, int M, int d, const float* ga, const float* ba,
                             const float* addvec, int ldadd, const float* stepvec, int ldstep, const int* d_step, int Tq,
                             const float* gb, const float* bb, hipStream_t s) {
     dim3 grid((M + 3) / 4), block(256);
-#define RGN_LN(V) hipLaunchKernelGGL(k_layernorm<V>, grid, block, 0, s, in, out, op, M, d, ga, ba, addvec, ldadd, stepvec, ldstep, d_step, Tq, gb, bb)
+#define RGN_LN(V) hipLaunchKernelGGL(k_layernorm<V>, grid, block, 0, s, in, resid, out, op, M, d, ga, ba, addvec, ldadd, stepvec, ldstep, d_step, Tq, gb, bb)
     switch (d / 64) {
         case 1: RGN_LN(1); break;
         case 2: RGN_LN(2); break;
