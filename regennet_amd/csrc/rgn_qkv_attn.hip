@@ -345,7 +345,11 @@ hipError_t configure_qkv_attn() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, qa_lds(true));
 }
 hipError_t launch_qkv_attn(const QkvAttnArgs& g, bool x3, hipStream_t s) {
-    const dim3 grid((g.Bm + QA_NS - 1) / QA_NS, g.H % 2 == 0 ? 2 : 1);
+    // heads per workgroup: half of them (the weight stream per sample is what bounds the kernel), but one head each while
+    // the launch is small (<= 64 workgroups): a small batch is latency-bound and the heads of a workgroup run back to back
+    const int pairs = (g.Bm + QA_NS - 1) / QA_NS;
+    const int hsplit = (pairs * g.H <= 64) ? g.H : (g.H % 2 == 0 ? 2 : 1);
+    const dim3 grid(pairs, hsplit);
     if (x3)
         hipLaunchKernelGGL((k_qkv_attn<true>), grid, dim3(QA_NT), qa_lds(true), s, g);
     else

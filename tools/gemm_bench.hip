@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
     struct Shape { int M, N, K; const char* name; };
     std::vector<Shape> shapes = {{15360, 1536, 512, "qkv"}, {15360, 512, 512, "out_proj"}, {15360, 1024, 512, "ffn1"},
                                  {15360, 512, 1024, "ffn2"}, {15360, 336, 512, "pose_out"}, {15360, 512, 336, "pose_in"},
-                                 {150, 200, 72, "ragged"}, {15360, 512, 32, "fixed_k32"}, {15360, 512, 64, "fixed_k64"}, {15360, 1536, 32, "fixedq_k32"}};
+                                 {150, 200, 72, "ragged"}, {60, 512, 512, "b1_out"}, {60, 1024, 512, "b1_ffn1"}, {60, 512, 1024, "b1_ffn2"}, {600, 512, 512, "b10_out"}, {15360, 512, 32, "fixed_k32"}, {15360, 512, 64, "fixed_k64"}, {15360, 1536, 32, "fixedq_k32"}};
     std::mt19937 rng(1);
     std::uniform_real_distribution<float> U(-1.f, 1.f);
     double tot_us = 0, tot_fl = 0;
