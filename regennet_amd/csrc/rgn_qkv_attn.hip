@@ -1,23 +1,24 @@
-// Fused in_proj GEMM + causal self-attention (Tq <= 64 tokens, head dim 128): q, k, v never go to HBM.
+// Fused in_proj GEMM + causal self-attention (Tq <= 64 tokens, head dim 128): q, k, v never leave the register file.
 //
 // Replaces, per decoder layer, the packed in_proj Linear of nn.MultiheadAttention and the attention itself
 // (model/cmdm.py:227 -> TransformerDecoderLayer._sa_block with generate_square_subsequent_mask :168-171).
-// A workgroup owns TWO samples and H/2 heads (grid = ceil(Bm/2) x 2). For each of its heads it computes
-// [q_h | k_h | v_h] = x . W_h^T for both samples at once (128 x 384, split-bf16 MFMA, operands by direct-to-LDS DMA from
-// the K32-blocked planes exactly as in k_gemm_x3), then per sample converts the accumulators to hi/lo bf16 straight into
-// LDS (q, k token-major with padded rows; v transposed), runs the transposed attention of k_attn_x3 on them
-// (S^T = K.Q^T, in-register softmax, O^T = V^T.P^T) and stores the head's output as split planes in the K32-blocked
-// layout the out_proj GEMM consumes.
+// A workgroup owns TWO samples and H/2 heads (grid = ceil(Bm/2) x 2; one head each for small launches). For each of its
+// heads it computes [q_h | k_h | v_h] = x . W_h^T for both samples at once (128 x 384, split-bf16 MFMA, operands by
+// direct-to-LDS DMA from the K32-blocked planes exactly as in k_gemm_x3) and then runs the attention straight from the
+// accumulators: an MFMA contraction does not care in which order the reduction index is fed as long as both operands
+// agree, and the C/D layouts of q^T, k^T (accumulated transposed: W fragment as the MFMA A operand), v and the
+// softmaxed scores agree by construction, so S^T = K.Q^T and O^T = V^T.P^T take the accumulator registers as operands
+// with no LDS staging, no transposes and no fragment reads. The only exchange is the sum of the four dh-tile partials
+// of S^T through an fp32 LDS buffer that aliases the dead pipeline stages. The head's output is stored as split planes
+// in the K32-blocked layout the out_proj GEMM consumes.
 //
 // Why two samples x half the heads instead of one sample x all heads: the kernel is bound by the ~20 B/clk a CU pulls
 // from L2 into LDS (see rgn_gemm_x3.hip), and almost all of that is the in_proj weight stream. Pairing samples halves
 // the weight bytes per sample (2.0 MiB of DMA per workgroup instead of 3.5 MiB) at the same workgroup count.
 //
-// 8 waves. GEMM phase: wave = (sample, column tile wn of each of q, k, v), wave tile 64 x 96 (2 x 3 MFMA tiles; the q and k
-// tiles are accumulated transposed - W fragment as the MFMA A operand - so their conversion to LDS is 8-byte writes), two 64 KiB LDS stages
-// [A 128x32 | W_h 384x32] x {hi, lo}; tile rows 0-63 / 64-127 are the tokens of sample 0 / 1 (padding rows replicate
-// the last token and are masked). Attention phase (once per sample): wave = (query tile, dh tile); the three LDS operand
-// buffers (104 KiB) alias the dead pipeline stages.
+// 8 waves; wave = (sample wm, dh tile wn): wave tile 64 x 96 = both token tiles x the 32 columns wn of each of q, k, v;
+// two 64 KiB LDS stages [A 128x32 | W_h 384x32] x {hi, lo}; tile rows 0-63 / 64-127 are the tokens of sample 0 / 1
+// (padding rows replicate the last token and are masked).
 #include "rgn_internal.h"
 
 #include <hip/hip_runtime.h>
@@ -35,8 +36,6 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define RGN_AS3 __attribute__((address_space(3)))
 
 constexpr int QA_ROWS = 64, QA_NS = 2, QA_DH = 128, QA_WROWS = 3 * QA_DH, QA_NT = 512;
-constexpr int QA_KLD = QA_DH + 8;      // q / k row stride in LDS (bf16): conflict-free ds_read_b128
-constexpr int QA_VLD = QA_ROWS + 4;    // v^T row stride (bf16): conflict-free ds_read_b64
 
 #ifdef RGN_QA_PROF
 __device__ long long g_qa_prof[64];   // tools only: phase cycle stamps of one workgroup (wave 0)
@@ -51,18 +50,11 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn(QkvAttnArgs g) {
     constexpr int A_BYTES = QA_NS * QA_ROWS * 64, W_BYTES = QA_WROWS * 64;
     constexpr int STAGE = NPL * (A_BYTES + W_BYTES);                 // 64 KiB (x3)
     constexpr int W_IT = QA_WROWS * 4 / QA_NT;                       // 3
-    constexpr int QK_PLANE = QA_ROWS * QA_KLD, VT_PLANE = QA_DH * QA_VLD;   // elements
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __bf16* Qs = reinterpret_cast<__bf16*>(smem);                    // [NPL][64][136]
-    __bf16* Ks = Qs + 2 * QK_PLANE;                                  // [NPL][64][136]
-    __bf16* Vt = Ks + 2 * QK_PLANE;                                  // [NPL][128][68]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;                         // GEMM phase roles: wm = sample of the pair
-    // attention phase roles (query tile, dh tile); the causal query tile 1 does twice the score MFMAs of tile 0, so the
-    // two waves sharing a SIMD (wave, wave + 4) get one tile of each
-    const int qt = (wave ^ (wave >> 2)) & 1, dt = wave >> 1;
     const int l31 = lane & 31, kh = lane >> 5;
     const int b0 = blockIdx.x * QA_NS, Tq = g.Tq, d = g.d;
     const int hpb = g.H / (int)gridDim.y, hd0 = blockIdx.y * hpb;    // heads of this workgroup
@@ -89,7 +81,6 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn(QkvAttnArgs g) {
         for (int ks = 0; ks < 2; ++ks) w_off[t][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
     }
     const int nk = g.Kp / 32;
-    const int qrow = qt * 32 + l31;                                  // this lane's query in the attention phase
     float* bias_s = reinterpret_cast<float*>(smem + 4 * (A_BYTES + W_BYTES));   // [hpb][3][128] in_proj biases, past the stages / operand buffers
     for (int i = tid; i < hpb * QA_WROWS; i += QA_NT) {
         const int hh = i / QA_WROWS, r = i - hh * QA_WROWS;
@@ -184,155 +175,171 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn(QkvAttnArgs g) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // every wave is done reading the last stage
         RGN_QT((hd - hd0) * 8 + 1)
-#pragma unroll 1
-        for (int sm = 0; sm < nsamp; ++sm) {
-        const size_t row0 = (size_t)(b0 + sm) * Tq;
-        if (wm == sm) {
+        // ---------------- attention straight from the accumulators: q, k, v never leave the register file --------------
+        // Wave (wm, wn) holds, for its sample and the 32 dh columns of tile wn: q and k transposed (lane = token, the 16
+        // registers = dh (i&3) + 8(i>>2) + 4*kh) and v plain (lane = dh, registers = tokens in the same pattern), for both
+        // token tiles. An MFMA contraction does not care in which order the reduction index is fed as long as both
+        // operands agree, and here they do by construction: register i of lane half kh means the same dh in q and in k,
+        // and the same token in v and in p. So
+        //   S^T[keys, queries] (partial over this wave's 32 dh) = K-regs (A operand) x Q-regs (B operand),
+        //   O^T[dh tile, queries] = V-regs (A) x P^T-regs (B, the softmaxed S^T accumulators)
+        // need no LDS staging, no transposes and no ds_reads. The only exchange is the sum of the four dh-tile partials of
+        // S^T, done through an fp32 LDS buffer that aliases the dead pipeline stages (96 KiB: 2 samples x 3 causal tiles
+        // x 4 waves x 4 KiB). Both samples proceed at the same time on their own four waves.
+        const bool live = wm < nsamp;                               // (an odd batch: the second sample of the last pair is a dummy)
+        const size_t row0 = (size_t)(b0 + (live ? wm : 0)) * Tq;
+        const float* bias_h = bias_s + (hd - hd0) * QA_WROWS + wn * 32;
+        bf16x8 qh[2][2], ql[2][2], kfh[2][2], kfl[2][2], vh[2][2], vl[2][2];   // [token tile][16-slice of the register index]
+        {
+            const float bv = bias_h[2 * QA_DH + l31];
+            const float qs2 = g.qscale * 1.44269504088896340736f;   // scores in log2 units: softmax = exp2(s - max), one mul less per score
 #pragma unroll
-            for (int ta = 0; ta < 2; ++ta) {
+            for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {                        // q (pre-scaled), k: lane = token, register quads = 4 dh
-                    __bf16* dst = t == 0 ? Qs : Ks;
-                    const float sc = t == 0 ? g.qscale : 1.0f;
-                    const int tok = ta * 32 + l31;
+                for (int sl = 0; sl < 2; ++sl) {
+                    const f32x4 bq0 = *reinterpret_cast<const f32x4*>(bias_h + 16 * sl + 4 * kh);
+                    const f32x4 bq1 = *reinterpret_cast<const f32x4*>(bias_h + 16 * sl + 8 + 4 * kh);
+                    const f32x4 bk0 = *reinterpret_cast<const f32x4*>(bias_h + QA_DH + 16 * sl + 4 * kh);
+                    const f32x4 bk1 = *reinterpret_cast<const f32x4*>(bias_h + QA_DH + 16 * sl + 8 + 4 * kh);
 #pragma unroll
-                    for (int i4 = 0; i4 < 4; ++i4) {
-                        const int dhc = wn * 32 + 8 * i4 + 4 * kh;
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + (hd - hd0) * QA_WROWS + t * QA_DH + dhc);
-                        bf16x4 hv, lv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float x = (acc[ta][t][4 * i4 + e] + b4[e]) * sc;
-                            hv[e] = (__bf16)x;
-                            lv[e] = (__bf16)(x - (float)hv[e]);
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = 8 * sl + j;
+                        const float xq = (acc[ta][0][i] + (j < 4 ? bq0[j] : bq1[j - 4])) * qs2;
+                        const float xk = acc[ta][1][i] + (j < 4 ? bk0[j] : bk1[j - 4]);
+                        const float xv = acc[ta][2][i] + bv;
+                        qh[ta][sl][j] = (__bf16)xq;
+                        kfh[ta][sl][j] = (__bf16)xk;
+                        vh[ta][sl][j] = (__bf16)xv;
+                        if (X3) {
+                            ql[ta][sl][j] = (__bf16)(xq - (float)qh[ta][sl][j]);
+                            kfl[ta][sl][j] = (__bf16)(xk - (float)kfh[ta][sl][j]);
+                            vl[ta][sl][j] = (__bf16)(xv - (float)vh[ta][sl][j]);
                         }
-                        *reinterpret_cast<bf16x4*>(&dst[tok * QA_KLD + dhc]) = hv;
-                        if (X3) *reinterpret_cast<bf16x4*>(&dst[QK_PLANE + tok * QA_KLD + dhc]) = lv;
                     }
                 }
-                {                                                    // v: lane = dh, register quads = 4 tokens -> v^T rows
-                    const int dhc = wn * 32 + l31;
-                    const float bias = bias_s[(hd - hd0) * QA_WROWS + 2 * QA_DH + dhc];
+        }
+        // causal tiles of S^T: 0 = (keys 0-31, queries 0-31), 1 = (keys 0-31, queries 32-63), 2 = (keys 32-63, queries 32-63)
+        f32x16 st[3];
 #pragma unroll
-                    for (int i4 = 0; i4 < 4; ++i4) {
-                        const int tok = ta * 32 + 8 * i4 + 4 * kh;
-                        bf16x4 hv, lv;
+        for (int tl = 0; tl < 3; ++tl) {
+            const int kj = tl >> 1, qtile = tl ? 1 : 0;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float x = acc[ta][2][4 * i4 + e] + bias;
-                            hv[e] = (__bf16)x;
-                            lv[e] = (__bf16)(x - (float)hv[e]);
-                        }
-                        *reinterpret_cast<bf16x4*>(&Vt[dhc * QA_VLD + tok]) = hv;
-                        if (X3) *reinterpret_cast<bf16x4*>(&Vt[VT_PLANE + dhc * QA_VLD + tok]) = lv;
-                    }
+            for (int i = 0; i < 16; ++i) st[tl][i] = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                if (X3) {
+                    st[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl[kj][sl], qh[qtile][sl], st[tl], 0, 0, 0);
+                    st[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh[kj][sl], ql[qtile][sl], st[tl], 0, 0, 0);
                 }
+                st[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh[kj][sl], qh[qtile][sl], st[tl], 0, 0, 0);
             }
         }
+        // sum the partials of the four dh tiles: [sample][tile][wave wn][i/4][lane] float4
+        f32x4* sred = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+        for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const f32x4 v = {st[tl][4 * i4], st[tl][4 * i4 + 1], st[tl][4 * i4 + 2], st[tl][4 * i4 + 3]};
+                sred[(((wm * 3 + tl) * 4 + wn) * 4 + i4) * 64 + lane] = v;
+            }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        RGN_QT((hd - hd0) * 8 + 2 + 2 * sm)
-        // ---------------- attention for this head: wave = (query tile qt, dh tile dt) -----------------------------
-        f32x16 st[2];
+        RGN_QT((hd - hd0) * 8 + 2)
 #pragma unroll
-        for (int kj = 0; kj < 2; ++kj) {
+        for (int tl = 0; tl < 3; ++tl)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) st[kj][i] = 0.f;
-            if (kj <= qt) {
+            for (int i4 = 0; i4 < 4; ++i4) {
+                f32x4 v = sred[(((wm * 3 + tl) * 4 + 0) * 4 + i4) * 64 + lane];
 #pragma unroll
-                for (int s = 0; s < QA_DH / 16; ++s) {
-                    const int qo = qrow * QA_KLD + 16 * s + 8 * kh, ko = (32 * kj + l31) * QA_KLD + 16 * s + 8 * kh;
-                    const bf16x8 qh = *reinterpret_cast<const bf16x8*>(&Qs[qo]);
-                    const bf16x8 kfh = *reinterpret_cast<const bf16x8*>(&Ks[ko]);
-                    if (X3) {
-                        const bf16x8 ql = *reinterpret_cast<const bf16x8*>(&Qs[QK_PLANE + qo]);
-                        const bf16x8 kfl = *reinterpret_cast<const bf16x8*>(&Ks[QK_PLANE + ko]);
-                        st[kj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl, qh, st[kj], 0, 0, 0);
-                        st[kj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, ql, st[kj], 0, 0, 0);
-                    }
-                    st[kj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, qh, st[kj], 0, 0, 0);
+                for (int w = 1; w < 4; ++w) {
+                    const f32x4 u = sred[(((wm * 3 + tl) * 4 + w) * 4 + i4) * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += u[e];
                 }
-            }
-        }
-        float mx = -INFINITY;
 #pragma unroll
-        for (int kj = 0; kj < 2; ++kj)
-            if (kj <= qt) {
+                for (int e = 0; e < 4; ++e) st[tl][4 * i4 + e] = v[e];
+            }
+        RGN_QT((hd - hd0) * 8 + 4)
+        // softmax over keys for the lane's two queries (l31 and 32 + l31); every wave of the sample does the same work
+        float inv[2];
+#pragma unroll
+        for (int qtile = 0; qtile < 2; ++qtile) {
+            const int q = 32 * qtile + l31;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int tl = qtile; tl <= 2 * qtile; ++tl) {             // tiles {0} for query tile 0, {1, 2} for query tile 1
+                const int kj = tl >> 1;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int key = 32 * kj + (i & 3) + 8 * (i >> 2) + 4 * kh;
-                    const bool ok = (key <= qrow) && (key < Tq);
-                    st[kj][i] = ok ? st[kj][i] : -INFINITY;
-                    mx = fmaxf(mx, st[kj][i]);
+                    const bool ok = (tl == 1 || key <= q) && (key < Tq);   // tile 1 (keys 0-31, queries 32-63) lies below the diagonal
+                    st[tl][i] = ok ? st[tl][i] : -INFINITY;
+                    mx = fmaxf(mx, st[tl][i]);
                 }
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
 #pragma unroll
-        for (int kj = 0; kj < 2; ++kj)
-            if (kj <= qt) {
+            for (int tl = qtile; tl <= 2 * qtile; ++tl)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float e = __expf(st[kj][i] - mx);
-                    st[kj][i] = e;
+                    const float e = __builtin_amdgcn_exp2f(st[tl][i] - mx);
+                    st[tl][i] = e;
                     sum += e;
                 }
-            }
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-        f32x16 oa;
+            sum += __shfl_xor(sum, 32, 64);
+            inv[qtile] = 1.0f / sum;
+        }
+        RGN_QT((hd - hd0) * 8 + 5)
+        // O^T[dh tile wn, queries] = V (A operand, registers = keys) x P^T (B operand, registers = keys)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) oa[i] = 0.f;
+        for (int qtile = 0; qtile < 2; ++qtile) {
+            f32x16 oa;
 #pragma unroll
-        for (int kj = 0; kj < 2; ++kj) {
-            if (kj <= qt) {
+            for (int i = 0; i < 16; ++i) oa[i] = 0.f;
 #pragma unroll
-                for (int step = 0; step < 2; ++step) {
+            for (int tl = qtile; tl <= 2 * qtile; ++tl) {
+                const int kj = tl >> 1;
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
                     bf16x8 ph, pl;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float x = st[kj][8 * step + j];
+                        const float x = st[tl][8 * sl + j];
                         ph[j] = (__bf16)x;
                         pl[j] = (__bf16)(x - (float)ph[j]);
                     }
-                    const int o = (32 * dt + l31) * QA_VLD + 32 * kj + 16 * step + 4 * kh;   // keys o..o+3 and o+8..o+11
-                    u32x4 vh;
-                    vh.lo = *reinterpret_cast<const u32x2*>(&Vt[o]);
-                    vh.hi = *reinterpret_cast<const u32x2*>(&Vt[o + 8]);
-                    const bf16x8 vfh = __builtin_bit_cast(bf16x8, vh);
                     if (X3) {
-                        u32x4 vl;
-                        vl.lo = *reinterpret_cast<const u32x2*>(&Vt[VT_PLANE + o]);
-                        vl.hi = *reinterpret_cast<const u32x2*>(&Vt[VT_PLANE + o + 8]);
-                        const bf16x8 vfl = __builtin_bit_cast(bf16x8, vl);
-                        oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl, ph, oa, 0, 0, 0);
-                        oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, pl, oa, 0, 0, 0);
+                        oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[kj][sl], ph, oa, 0, 0, 0);
+                        oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[kj][sl], pl, oa, 0, 0, 0);
                     }
-                    oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh, ph, oa, 0, 0, 0);
+                    oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[kj][sl], ph, oa, 0, 0, 0);
+                }
+            }
+            // O^T tile: lane = query (column), registers = 16 dh indices -> 4 runs of 4 consecutive dh = 8-byte plane
+            // stores; the 32 x 32 tile is one contiguous 2 KiB run of the K32-blocked plane
+            const int q = 32 * qtile + l31;
+            if (live && q < Tq) {
+                const size_t o = ((size_t)(hd * (QA_DH / 32) + wn) * g.out.rows + row0 + q) * 32 + 4 * kh;
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    bf16x4 hv, lv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = oa[4 * i4 + e] * inv[qtile];
+                        hv[e] = (__bf16)x;
+                        lv[e] = (__bf16)(x - (float)hv[e]);
+                    }
+                    *reinterpret_cast<bf16x4*>(g.out.hi + o + 8 * i4) = hv;
+                    if (g.out.lo) *reinterpret_cast<bf16x4*>(g.out.lo + o + 8 * i4) = lv;
                 }
             }
         }
-        // O^T tile: lane = query (column), registers = 16 dh indices -> 4 runs of 4 consecutive dh = 8-byte plane stores;
-        // the 32 x 32 tile is one contiguous 2 KiB run of the K32-blocked plane
-        if (qrow < Tq) {
-            const size_t o = ((size_t)(hd * (QA_DH / 32) + dt) * g.out.rows + row0 + qrow) * 32 + 4 * kh;
-#pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                bf16x4 hv, lv;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x = oa[4 * i4 + e] * inv;
-                    hv[e] = (__bf16)x;
-                    lv[e] = (__bf16)(x - (float)hv[e]);
-                }
-                *reinterpret_cast<bf16x4*>(g.out.hi + o + 8 * i4) = hv;
-                if (g.out.lo) *reinterpret_cast<bf16x4*>(g.out.lo + o + 8 * i4) = lv;
-            }
-        }
+        RGN_QT((hd - hd0) * 8 + 6)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();      // the other sample's operands / the next head's DMA overwrite the buffers
-        RGN_QT((hd - hd0) * 8 + 3 + 2 * sm)
-        }
+        __builtin_amdgcn_s_barrier();      // the next head's DMA overwrites the reduction buffer
+        RGN_QT((hd - hd0) * 8 + 3)
     }
 }
 

@@ -2,7 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DRGN_QA_PROF=100] -I regennet_amd/csrc tools/qkv_attn_bench.hip \
 //         regennet_amd/csrc/rgn_qkv_attn.hip -o tools/bin/qkv_attn_bench
 // Times k_qkv_attn at Bm samples x Tq tokens (default 256 x 60, d = 512, H = 4); with -DRGN_QA_PROF=<block> it also
-// prints the cycle stamps of that workgroup's phases (GEMM loop / accumulators -> LDS / attention, per head and sample).
+// prints the cycle stamps of that workgroup's phases (GEMM loop / operand split + partial scores / reduction + softmax + PV).
 #include "rgn_internal.h"
 
 #include <hip/hip_runtime.h>
@@ -45,9 +45,10 @@ int main(int argc, char** argv) {
     long long pr[64]; qa_prof_read(pr);
     for (int h = 0; h < 2; ++h) {
         const long long* t = pr + h * 8;
-        printf("  head %d cycles: gemm %lld | conv s0 %lld | attn s0 %lld | conv s1 %lld | attn s1 %lld\n", h, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4]);
+        printf("  head %d cycles: gemm %lld | split + S partials + barrier %lld | reduce %lld | softmax %lld | PV + store %lld | barrier %lld\n", h,
+               t[1] - t[0], t[2] - t[1], t[4] - t[2], t[5] - t[4], t[6] - t[5], t[3] - t[6]);
     }
-    printf("  total cycles %lld\n", pr[8 + 5] - pr[0]);
+    printf("  total cycles %lld\n", pr[8 + 3] - pr[0]);
 #endif
     return 0;
 }
