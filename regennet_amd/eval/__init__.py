@@ -1,1 +1,2 @@
 from .auto_regressive import sample_auto_regressive  # noqa: F401
+from .fid import calculate_activation_statistics, calculate_fid, calculate_frechet_distance  # noqa: F401

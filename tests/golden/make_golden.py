@@ -216,9 +216,31 @@ def gen_post():
     save("postproc", d6=d6, mats=mats, x=x, gf=gf, x3=x3, gf3=gf3)
 
 
+def gen_fid():
+    """next-4 row: calculate_activation_statistics (eval/a2m/stgcn/evaluate.py:48-53) + calculate_frechet_distance
+    (eval/a2m/stgcn/fid.py:11-61) of the reference on seeded synthetic feature sets (only seeds and results are stored)."""
+    _ref_import.install()
+    from eval.a2m.stgcn.fid import calculate_fid
+    out = {}
+    for case, (n1, n2, dim, shift, scale) in enumerate([(400, 300, 32, 0.0, 1.0), (500, 500, 64, 0.3, 1.5), (256, 256, 16, 2.0, 0.5),
+                                                        (40, 60, 48, 0.1, 1.0)]):   # last: rank-deficient covariances
+        rng = np.random.Generator(np.random.PCG64(50 + case))
+        mix = rng.standard_normal((dim, dim)) / np.sqrt(dim)
+        a = (rng.standard_normal((n1, dim)) @ mix).astype(np.float32)
+        b = (rng.standard_normal((n2, dim)) @ mix * scale + shift).astype(np.float32)
+        stats = [(np.mean(x, axis=0), np.cov(x, rowvar=False)) for x in (a, b)]          # evaluate.py:50-52
+        out[f"fid_{case}"] = np.float64(calculate_fid(stats[0], stats[1]))
+        out[f"fid_same_{case}"] = np.float64(calculate_fid(stats[0], stats[0]))
+        out[f"cfg_{case}"] = np.array([n1, n2, dim, shift, scale], dtype=np.float64)
+        out[f"mu_{case}"] = stats[1][0]
+        out[f"sigma_diag_{case}"] = np.diag(stats[1][1])
+    save("fid", **out)
+
+
 JOBS = {
     "schedules": gen_schedules,
     "postproc": gen_post,
+    "fid": gen_fid,
     "tiny_fwd": lambda: gen_forward("tiny_fwd", "tiny", 3, [0, 1, 500, 999]),
     "tiny_fwd_cfg": lambda: gen_forward("tiny_fwd_cfg", "tiny", 3, [0, 700], guided=True),
     "tiny_add_fwd": lambda: gen_forward("tiny_add_fwd", "tiny_add", 2, [3, 999]),

@@ -164,3 +164,32 @@ def test_auto_regressive_batching_masks_orders_and_gathers():
     m = seen[0].reshape(T, B, V, C, T)
     for f in range(T):
         assert torch.equal(m[f, :, :, :, : f + 1], cm[:, :, :, : f + 1]) and not m[f, :, :, :, f + 1:].any()
+
+
+# ---- next-4 row: Frechet distance (torch, device-agnostic) vs the reference's numpy/scipy on seeded feature sets -----------
+def _fid_sets(g, case):
+    n1, n2, dim, shift, scale = g[f"cfg_{case}"]
+    n1, n2, dim = int(n1), int(n2), int(dim)
+    rng = np.random.Generator(np.random.PCG64(50 + case))
+    mix = rng.standard_normal((dim, dim)) / np.sqrt(dim)
+    a = (rng.standard_normal((n1, dim)) @ mix).astype(np.float32)
+    b = (rng.standard_normal((n2, dim)) @ mix * scale + shift).astype(np.float32)
+    return a, b
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_frechet_distance_matches_reference(golden, case):
+    import torch
+
+    from regennet_amd.eval import calculate_activation_statistics, calculate_fid
+
+    g = golden("fid")
+    a, b = _fid_sets(g, case)
+    s1 = calculate_activation_statistics(torch.from_numpy(a))
+    s2 = calculate_activation_statistics(torch.from_numpy(b))
+    np.testing.assert_allclose(s2[0].numpy(), g[f"mu_{case}"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(torch.diagonal(s2[1]).numpy(), g[f"sigma_diag_{case}"], rtol=1e-6)
+    ref = float(g[f"fid_{case}"])
+    got = float(calculate_fid(s1, s2))
+    assert abs(got - ref) <= 1e-6 * max(1.0, abs(ref)), (got, ref)
+    assert abs(float(calculate_fid(s1, s1))) < 1e-6 and abs(float(g[f"fid_same_{case}"])) < 1e-3
