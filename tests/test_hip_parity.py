@@ -90,6 +90,25 @@ def test_graph_replay_equals_eager(golden):
     assert torch.equal(a, b) and torch.equal(b, c)
 
 
+@pytest.mark.parametrize("frames,etd", [(16, False), (64, False), (63, True), (64, True)])
+def test_oracle_parity_sequence_length_edges(frames, etd):
+    """The fused in_proj+attention kernel takes Tq <= 64 tokens: one token tile only (16), exactly full tiles (64, and
+    63 + the emb_trans_dec token), and one token too many (64 + 1 -> the unfused GEMM + attention kernels)."""
+    from oracle import regennet_oracle as orc
+    from regennet_amd import synth
+    cfg = synth.get_config("ntu_action", layers=2, num_frames=frames, emb_trans_dec=etd)
+    sd = synth.make_state_dict(cfg, seed=9)
+    B = 3
+    model, diffusion = build_hip(cfg, sd, resp="ddim5", precision="bf16x3")
+    y = {"cmotion": synth.make_cmotion(cfg, B, seed=31), "action": synth.make_actions(cfg, B, seed=32)}
+    tape = synth.make_noise_tape(cfg, B, 5, seed=33)
+    ty = {k: torch.from_numpy(v) for k, v in y.items()}
+    ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", "ddim5"), tape, ty, mode="ddim").numpy()
+    out = diffusion.ddim_sample_loop(model, (B, 56, 6, frames), clip_denoised=False, model_kwargs={"y": y_to_device(y)},
+                                     noise_tape=torch.from_numpy(tape))
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-3
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_oracle_parity_random_inputs(precision):
     """HIP vs oracle on fresh seeded inputs (not the golden ones), ragged batch (odd: the fused in_proj+attention kernel
