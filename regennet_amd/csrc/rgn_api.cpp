@@ -505,18 +505,28 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
     const int per = dm.Bm / nch, extra = dm.Bm % nch;
     int s0 = per + (extra > 0 ? 1 : 0);                   // chain 0 (main stream) takes [0, s0) and is enqueued last
     const int first_n = s0;
+    // Without guidance a chain's samples are all the update kernel of that chain needs, so it runs at the end of the
+    // chain (overlapping the other chains' layers); with guidance the cond / uncond halves of a sample sit in different
+    // chains and the update waits for the join.
+    const Planes xin_p{fast ? c->xin_hi : nullptr, (fast && prec == RGN_PREC_BF16X3) ? c->xin_lo : nullptr, M};
+    const bool own_update = nch > 1 && !guided;
     for (int k = 1; k < nch; ++k) {
         const int n = per + (k < extra ? 1 : 0);
         RGN_HIP(c, hipStreamWaitEvent(c->side[k - 1], c->ev_fork, 0));
         if ((rc = run_layers(c, dm, guided, sampling, cond_rows, ccond_rows, s0, n, c->side[k - 1]))) return rc;
+        if (own_update)
+            RGN_LAUNCH(c, KC_UPDATE, c->side[k - 1],
+                       launch_update(c->x0tok, c->scale, c->d_tab, c->d_step, c->d_sp, nullptr, xin_p, dm, s0, n, c->side[k - 1]));
         RGN_HIP(c, hipEventRecord(c->ev_join[k - 1], c->side[k - 1]));
         s0 += n;
     }
     if ((rc = run_layers(c, dm, guided, sampling, cond_rows, ccond_rows, 0, first_n, s))) return rc;
+    if (own_update)
+        RGN_LAUNCH(c, KC_UPDATE, s, launch_update(c->x0tok, c->scale, c->d_tab, c->d_step, c->d_sp, nullptr, xin_p, dm, 0, first_n, s));
     for (int k = 1; k < nch; ++k) RGN_HIP(c, hipStreamWaitEvent(s, c->ev_join[k - 1], 0));
-    RGN_LAUNCH(c, KC_UPDATE, s,
-               launch_update(c->x0tok, c->scale, c->d_tab, c->d_step, c->d_sp, fast ? nullptr : c->xin,
-                             Planes{fast ? c->xin_hi : nullptr, (fast && prec == RGN_PREC_BF16X3) ? c->xin_lo : nullptr, M}, dm, s));
+    if (!own_update)
+        RGN_LAUNCH(c, KC_UPDATE, s,
+                   launch_update(c->x0tok, c->scale, c->d_tab, c->d_step, c->d_sp, fast ? nullptr : c->xin, xin_p, dm, 0, dm.B, s));
     return RGN_OK;
 }
 

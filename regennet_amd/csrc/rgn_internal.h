@@ -156,7 +156,7 @@ hipError_t launch_emb_rows(const float* emb, const float* stepemb, const int* d_
 hipError_t launch_add_pe(float* c0, const float* pe, const Dims& dm, hipStream_t s);
 hipError_t launch_pack_x(const float* x, float* xin, Planes xp, int copies, const Dims& dm, hipStream_t s);
 hipError_t launch_update(const float* x0tok, const float* scale, const StepCoef* tab, const int* d_step,
-                         const SampleParams* sp, float* xin, Planes xp, const Dims& dm, hipStream_t s);
+                         const SampleParams* sp, float* xin, Planes xp, const Dims& dm, int b0, int nb, hipStream_t s);
 hipError_t launch_advance(int* d_step, hipStream_t s);
 hipError_t launch_cond_rows(const float* table, const int64_t* action, float* out, int B, int d, hipStream_t s);
 hipError_t launch_fill_rows(float* out, const float* row, int rows, int d, hipStream_t s);

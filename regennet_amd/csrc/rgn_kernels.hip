@@ -880,11 +880,11 @@ hipError_t launch_randn(float* x, int B, int FT, unsigned long long seed, unsign
 __global__ __launch_bounds__(256) void k_update(const float* __restrict__ x0tok, const float* __restrict__ scale,
                                                  const StepCoef* __restrict__ tab, const int* __restrict__ d_step,
                                                  const SampleParams* __restrict__ spp, float* __restrict__ xin, Planes xp,
-                                                 Dims dm) {
+                                                 Dims dm, int b0) {
     __shared__ float tc[32][33];
     __shared__ float tu[32][33];
     const SampleParams sp = *spp;
-    const int b = blockIdx.z, f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int b = b0 + blockIdx.z, f0 = blockIdx.y * 32, t0 = blockIdx.x * 32;   // samples [b0, b0 + gridDim.z)
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const size_t half = (size_t)dm.B * dm.Tq * dm.F;
     for (int i = ty; i < 32; i += 8) {   // token-major read, coalesced along f
@@ -951,9 +951,9 @@ __global__ __launch_bounds__(256) void k_update(const float* __restrict__ x0tok,
     }
 }
 hipError_t launch_update(const float* x0tok, const float* scale, const StepCoef* tab, const int* d_step,
-                         const SampleParams* sp, float* xin, Planes xp, const Dims& dm, hipStream_t s) {
-    dim3 grid((dm.T + 31) / 32, (dm.F + 31) / 32, dm.B);
-    hipLaunchKernelGGL(k_update, grid, dim3(256), 0, s, x0tok, scale, tab, d_step, sp, xin, xp, dm);
+                         const SampleParams* sp, float* xin, Planes xp, const Dims& dm, int b0, int nb, hipStream_t s) {
+    dim3 grid((dm.T + 31) / 32, (dm.F + 31) / 32, nb);
+    hipLaunchKernelGGL(k_update, grid, dim3(256), 0, s, x0tok, scale, tab, d_step, sp, xin, xp, dm, b0);
     return hipGetLastError();
 }
 
