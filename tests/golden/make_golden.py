@@ -245,9 +245,13 @@ JOBS = {
     "tiny_fwd_cfg": lambda: gen_forward("tiny_fwd_cfg", "tiny", 3, [0, 700], guided=True),
     "tiny_add_fwd": lambda: gen_forward("tiny_add_fwd", "tiny_add", 2, [3, 999]),
     "tiny_etd_fwd": lambda: gen_forward("tiny_etd_fwd", "tiny", 2, [10, 999], emb_trans_dec=True),
+    "tiny_wope_fwd": lambda: gen_forward("tiny_wope_fwd", "tiny", 2, [7, 640], wo_pos_emb=True),
     "tiny_text_fwd_cfg": lambda: gen_forward("tiny_text_fwd_cfg", "tiny_text", 3, [0, 321], guided=True),
     "tiny_ddpm10": lambda: gen_loop("tiny_ddpm10", "tiny", 2, "10", "ddpm", keep_trace=True),
     "tiny_ddim10_cfg": lambda: gen_loop("tiny_ddim10_cfg", "tiny", 2, "ddim10", "ddim", guided=True, keep_trace=True),
+    "tiny_etd_ddim10_cfg": lambda: gen_loop("tiny_etd_ddim10_cfg", "tiny", 2, "ddim10", "ddim", guided=True, emb_trans_dec=True),
+    "tiny_wope_ddpm10": lambda: gen_loop("tiny_wope_ddpm10", "tiny", 2, "10", "ddpm", wo_pos_emb=True),
+    "ntu_add_etd_ddpm20": lambda: gen_loop("ntu_add_etd_ddpm20", "ntu", 2, "20", "ddpm", cm_mode="add", emb_trans_dec=True),
     "tiny_opts_clip": lambda: gen_loop("tiny_opts_clip", "tiny", 2, "10", "ddpm", opts=dict(clip_denoised=True)),
     "tiny_opts_large_linear": lambda: gen_loop("tiny_opts_large_linear", "tiny", 2, "20", "ddpm", opts=dict(sigma_small=False, noise_schedule="linear")),
     "tiny_opts_skip_init": lambda: gen_loop("tiny_opts_skip_init", "tiny", 2, "10", "ddpm", opts=dict(skip_timesteps=3, init_image=True)),

@@ -12,9 +12,10 @@ pytestmark = pytest.mark.gpu
 PRECISIONS = ["f32", "bf16x3"]
 TOL = {"f32": 2e-4, "bf16x3": 1e-3}       # abs; both inside the 1e-3 contract
 
-FWD = ["tiny_fwd", "tiny_fwd_cfg", "tiny_add_fwd", "tiny_etd_fwd", "tiny_text_fwd_cfg", "ntu_fwd",
+FWD = ["tiny_fwd", "tiny_fwd_cfg", "tiny_add_fwd", "tiny_etd_fwd", "tiny_wope_fwd", "tiny_text_fwd_cfg", "ntu_fwd",
        "ntu_action_fwd_cfg", "chi3d_fwd"]
-LOOPS = ["tiny_ddpm10", "tiny_ddim10_cfg", "tiny_add_ddpm1000", "tiny_text_ddim20_cfg", "ntu_ddpm50",
+LOOPS = ["tiny_ddpm10", "tiny_ddim10_cfg", "tiny_add_ddpm1000", "tiny_text_ddim20_cfg", "tiny_etd_ddim10_cfg",
+         "tiny_wope_ddpm10", "ntu_add_etd_ddpm20", "ntu_ddpm50",
          "ntu_action_ddim100_cfg", "text150_ddim50_cfg"]
 
 
