@@ -88,6 +88,7 @@ struct rgn_ctx {
     bool attn_x3 = false;
     int Tqp = 0;
     bool fuse_qkv = false;             // in_proj GEMM + attention in one per-sample kernel (k_qkv_attn)
+    int big_tile_rows = 7000;          // launches of at least this many rows per chain use the 256x256 GEMM tile
     bool fuse_ln = false;              // out_proj / linear2 GEMMs carry their LayerNorms (k_gemm_x3_ln)
     StepCoef* d_tab = nullptr;
     int* d_step = nullptr;
@@ -371,7 +372,11 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             g.C = C; g.ldc = ldc;
             g.Chi = Cp.hi; g.Clo = Cp.lo; g.c_rows = Cp.rows;
             g.M = rows; g.N = L.N; g.Kp = L.Kp; g.act = act;
-            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm_x3(g, x3, 0, s));
+            // tile choice: 256x256 (one workgroup per CU, ~1.45x faster loop) only when the chain's launch has enough
+            // tiles to take the CUs through more than one round, so that epilogues overlap the next round's loops:
+            // measured -13 % at 3840 rows per chain (B=256), +2 % at 7680 (B=512, CFG at B=256), +5 % at 15360 (B=1024)
+            const int variant = (rows >= c->big_tile_rows && L.N % 256 == 0) ? 1 : 0;
+            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm_x3(g, x3, variant, s));
         }
         return RGN_OK;
     };
@@ -815,6 +820,7 @@ int rgn_finalize_weights(rgn_handle h) {
             RGN_HIP(c, configure_attn_x3(c->Tq, d / c->H));
         }
         c->fuse_qkv = qkv_attn_supported(c->Tq, d / c->H, d) && getenv("REGENNET_NO_FUSED_QKV") == nullptr;
+        if (const char* e = getenv("REGENNET_BIG_TILE_ROWS")) c->big_tile_rows = atoi(e);
         if (c->fuse_qkv) RGN_HIP(c, configure_qkv_attn());
     }
     if ((rc = ws_alloc(c, &c->d_tab, (size_t)1024))) return rc;

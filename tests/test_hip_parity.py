@@ -288,6 +288,21 @@ def test_fused_layernorm_gemm_variant(golden, monkeypatch):
         model._engine.close()
 
 
+def test_big_gemm_tiles_meet_the_same_bound(golden, monkeypatch):
+    """Launches of >= 7000 rows per chain use the 256x256 GEMM tile; forced here on small goldens (edge tiles included)."""
+    monkeypatch.setenv("REGENNET_BIG_TILE_ROWS", "1")
+    for name in ("ntu_ddpm50", "ntu_action_ddim100_cfg", "text150_ddim50_cfg"):
+        g = golden(name)
+        cfg, sd, y, tape = fixture_inputs(g, loop=True)
+        model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision="bf16x3")
+        fm = _wrap(model, bool(g["guided"]))
+        fn = diffusion.p_sample_loop if str(g["mode"]) == "ddpm" else diffusion.ddim_sample_loop
+        out = fn(fm, (int(g["B"]), 56, 6, cfg["num_frames"]), clip_denoised=False, model_kwargs={"y": y_to_device(y)},
+                 noise_tape=torch.from_numpy(tape))
+        assert np.abs(out.cpu().numpy() - g["final"]).max() < 1e-3
+        model._engine.close()
+
+
 def test_full_size_batch_is_row_independent():
     """BASELINE configs[1] size (B=256, NTU): every sample's chain is independent, so sample b of a 256-batch must equal
     the same sample drawn alone with the same Philox key (sample_offset=b) — a size-independent property that checks
