@@ -1,7 +1,8 @@
 // Host side of libregennet_hip.so: the C-ABI declared in include/regennet_hip.h.
 // Owns the packed weight blob, the activation workspace, the per-step coefficient tables, the
-// step orchestration (one denoiser evaluation + sampler update = ~45 kernel launches) and its
-// hipGraph capture. All arithmetic on tensors happens in rgn_kernels.hip.
+// step orchestration (one denoiser evaluation + sampler update: 53 kernel launches per chain of samples at L = 8) and
+// its hipGraph capture. All arithmetic on tensors happens in the .hip files next to this one (rgn_gemm_x3: split-bf16
+// GEMM, rgn_qkv_attn: fused in_proj + attention, rgn_attn_x3: attention for long sequences, rgn_kernels: the rest).
 #include "../../include/regennet_hip.h"
 #include "rgn_internal.h"
 
