@@ -30,7 +30,7 @@ import torch.distributed as dist  # noqa: E402
 
 # minimal algorithmic work of ONE denoiser evaluation for ONE sample (FLOP = 2*MAC)
 ALGO_GFLOP_PER_EVAL = {("ntu", "concat"): 2.154, ("ntu", "add"): 2.123, ("chi3d", "concat"): 5.593, ("chi3d", "add"): 5.514}
-PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "bf16_x3tail": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
 
 
 def fused_qkv_attention(cfg, precision):
@@ -39,17 +39,34 @@ def fused_qkv_attention(cfg, precision):
             and cfg["latent_dim"] // cfg["num_heads"] == 128 and not os.environ.get("REGENNET_NO_FUSED_QKV"))
 
 
-def gemm_flops_per_eval(cfg, B, guided, precision="bf16x3"):
-    """Algorithmic FLOPs of the GEMM-class launches of one evaluation (everything except attention scores/AV; the
-    timestep MLP and the folded 1-token cross-attention are per-schedule work, not per-step)."""
+def rowgemm_phase(cfg, precision):
+    """Mirrors rgn_api.cpp: the plain-bf16 phase runs out_proj+LN / linear1+GELU / linear2+LN as row-complete kernels."""
+    return (precision == "bf16_x3tail" and cfg["latent_dim"] == 512 and cfg["ff_size"] in (384, 512, 1024)
+            and not os.environ.get("REGENNET_NO_ROWGEMM"))
+
+
+def flops_per_eval(cfg, B, guided, precision="bf16x3"):
+    """Algorithmic FLOPs (SURVEY.md §8d accounting: 2 x MAC, full T x T attention scores) of one denoiser evaluation in the
+    phase the profiled pass runs, per kernel class as the engine launches them. The timestep MLP and the folded 1-token
+    cross-attention are per-schedule work, not per-step."""
     T, d, ff, L, F = cfg["num_frames"], cfg["latent_dim"], cfg["ff_size"], cfg["layers"], cfg["njoints"] * cfg["nfeats"]
     Bm = 2 * B if guided else B
     M = Bm * T
-    mac = M * (3 * d * d + d * d + 2 * d * ff) * L          # qkv, out_proj, ffn1, ffn2
-    mac += B * T * F * d + M * d * F                        # input embedding (folded fuse half), output projection
-    if fused_qkv_attention(cfg, precision):                 # k_qkv_attn carries the (full T x T) scores + AV work too
-        mac += M * 2 * T * d * L
-    return 2.0 * mac
+    qkv = M * 3 * d * d * L
+    attn = M * 2 * T * d * L
+    embed = (B * T * F * d if precision == "f32" else M * F * d) + M * d * F       # input embedding, output projection
+    out = {"gemm_mfma": embed, "qkv_attn": 0, "attention": 0, "rowgemm_ln": 0, "rowgemm_act": 0}
+    if rowgemm_phase(cfg, precision):
+        out["rowgemm_ln"] = M * (d * d + d * ff) * L
+        out["rowgemm_act"] = M * d * ff * L
+    else:
+        out["gemm_mfma"] += M * (d * d + 2 * d * ff) * L
+    if fused_qkv_attention(cfg, precision):
+        out["qkv_attn"] = qkv + attn
+    else:
+        out["gemm_mfma"] += qkv
+        out["attention"] = attn
+    return {k: 2.0 * v for k, v in out.items()}
 
 
 def cpu_baseline(cfg, sd, steps_total, seconds_budget=20.0):
@@ -100,7 +117,9 @@ def main():
     ap.add_argument("--respacing", default="", help="timestep_respacing ('' = 1000-step DDPM)")
     ap.add_argument("--sampler", default="ddpm", choices=["ddpm", "ddim"])
     ap.add_argument("--guided", action="store_true")
-    ap.add_argument("--precision", default=os.environ.get("REGENNET_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"])
+    ap.add_argument("--precision", default=os.environ.get("REGENNET_PRECISION", "bf16_x3tail"),
+                    choices=["f32", "bf16x3", "bf16", "bf16_x3tail"])
+    ap.add_argument("--x3-tail", type=int, default=None, help="precision schedule: split-bf16 for the last N loop indices")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-evals", type=int, default=3)
@@ -109,7 +128,6 @@ def main():
     from regennet_amd import synth
     from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
     from regennet_amd.utils import dist_util
-    from tests.helpers import build_hip
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -121,7 +139,7 @@ def main():
     B = a.batch
     # rank 0 owns the checkpoint; other ranks start from a different seed and receive the packed blob via RCCL
     sd = synth.make_state_dict(cfg, seed=0 if rank == 0 else 1000 + rank)
-    model, diffusion = build_hip(cfg, sd, resp=a.respacing, precision=a.precision, device=str(dev))
+    model, diffusion = synth.build_model(cfg, sd, resp=a.respacing, precision=a.precision, device=str(dev), x3_tail=a.x3_tail)
     eng, _ = model._get_engine(B)
     if world > 1:
         ptr, nbytes = eng.weight_blob()
@@ -166,7 +184,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- roofline of the dominant kernel class: HIP events around every launch, eager mode -----------------
+    # ---- roofline: HIP events around every launch of a short eager single-chain pass on the engine's stream -----------
+    # (the first loop indices: the plain-bf16 phase under the precision schedule = where >= 97 % of the evaluations run)
     roof = None
     if rank == 0 and a.profile_evals > 0:   # (--profile-evals 0: tools/collect_pmc.sh wants the sampling call only)
         eng.profile_enable(True)
@@ -174,42 +193,69 @@ def main():
         st = torch.cuda.current_stream().cuda_stream
         eng.randn(x, B, 5, lo, st)
         first = S - 1
-        eng.profile_enable(True)                            # reset after the randn launch
-        eng.sample_range(a.sampler, a.guided, 0.0, x, None, 5, lo, first, min(a.profile_evals, S), None, False, False, st)
+        n_eval = min(a.profile_evals, S)
+        eng.sample_range(a.sampler, a.guided, 0.0, x, None, 5, lo, first, 1, None, False, False, st)   # warm (untimed)
+        torch.cuda.synchronize()
+        eng.profile_enable(True)                            # reset
+        eng.sample_range(a.sampler, a.guided, 0.0, x, None, 5, lo, first - 1, n_eval, None, False, False, st)
         torch.cuda.synchronize()
         prof = eng.profile_query()
+        ovh_ms = eng.profile_bracket_overhead_ms()
         eng.profile_enable(False)
-        n_eval = min(a.profile_evals, S)
-        gemm_ms, gemm_n = prof["gemm_mfma"]
-        fl = gemm_flops_per_eval(cfg, B, a.guided, a.precision) * n_eval
-        achieved = fl / (gemm_ms * 1e-3) / 1e12
+        fl = flops_per_eval(cfg, B, a.guided, a.precision)
         peak = PEAK_TFLOPS[a.precision]
-        traffic = None   # HBM bytes per GEMM launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_bench_streams1.json")   # FETCH x2 gfx950 correction), same workload only
-        if os.path.exists(pmc) and (a.config, B, a.precision, a.guided) == ("ntu", 256, "bf16x3", False):
+        names = {"gemm_mfma": "k_gemm_x3", "qkv_attn": "k_qkv_attn", "attention": "k_attn_x3", "layernorm": "k_layernorm",
+                 "update": "k_update", "rowgemm_ln": "k_rowgemm<LN>", "rowgemm_act": "k_rowgemm<ACT>"}
+        if a.precision == "f32":
+            names.update(gemm_mfma="k_gemm_f32", attention="k_attn_mfma")
+        per_kernel = []
+        for cls, (ms, n) in prof.items():
+            if n == 0 or cls not in names:
+                continue
+            # every event bracket carries the dispatch + event latency of an empty bracket (calibrated on a no-op kernel,
+            # whose own ~2 us of execution stay in the figure): subtract it, leaving ~ the rocprofv3 kernel duration
+            us = max(1e3 * (ms - n * ovh_ms) / n + 2.0, 0.1)
+            e = {"kernel": names[cls], "launches_per_eval": n // n_eval, "avg_us": round(us, 2),
+                 "ms_per_eval": round(us * (n // n_eval) * 1e-3, 4)}
+            if fl.get(cls, 0.0) > 0:
+                tf = fl[cls] * n_eval / n / (us * 1e-6) / 1e12
+                e.update(bound="mfma", algo_gflop_per_launch=round(fl[cls] * n_eval / n / 1e9, 3), achieved=round(tf, 1),
+                         peak=peak, unit="TFLOP/s", frac=round(tf / peak, 4))
+            per_kernel.append(e)
+        per_kernel.sort(key=lambda e: -e["ms_per_eval"])
+        dom = next(e for e in per_kernel if "frac" in e)     # the class with the largest share of the step that does MFMA work
+        phase = ""
+        if a.precision == "bf16_x3tail":
+            phase = " (plain-bf16 phase of the precision schedule: single-plane operands, one MFMA per product)"
+        roof = {"bound": "mfma", "kernel": dom["kernel"] + phase, "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s",
+                "frac": dom["frac"], "traffic": None,
+                "avg_launch_us": dom["avg_us"], "launches_per_eval": dom["launches_per_eval"],
+                "algo_gflop_per_launch": dom["algo_gflop_per_launch"],
+                "event_bracket_overhead_us": round(1e3 * ovh_ms, 2),
+                "note": "achieved = algorithmic FLOPs of the class's launches / their summed duration; duration = HIP-event "
+                        "bracket on the engine stream minus the calibrated empty-bracket latency (single-chain eager pass; "
+                        "matches rocprofv3 --kernel-trace durations, profiles/); the timed region replays 4-chain hipGraphs "
+                        "in which kernels of different chains overlap",
+                "per_kernel": per_kernel}
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")   # HBM bytes per launch from the committed PMC passes
+        if os.path.exists(pmc):
             with open(pmc) as fh:
                 pj = json.load(fh)
-            n1, n2 = pj["k_gemm_x3"]["FETCH_SIZE"]["launches"], pj["k_qkv_attn"]["FETCH_SIZE"]["launches"]
-            t1 = pj["k_gemm_x3"]["hbm_fetch_MB_per_launch_corrected"] + pj["k_gemm_x3"]["hbm_write_MB_per_launch"]
-            t2 = pj["k_qkv_attn"]["hbm_fetch_MB_per_launch_corrected"] + pj["k_qkv_attn"]["hbm_write_MB_per_launch"]
-            traffic = round((n1 * t1 + n2 * t2) / (n1 + n2) * 1e6)
-        roof = {"bound": "mfma", "kernel": "k_gemm_x3 / k_qkv_attn (all MFMA GEMM launches of one denoiser evaluation)",
-                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": traffic,
-                "note": "HIP events on the engine stream around every GEMM launch, single-chain eager pass; each bracket carries "
-                        "~8-10 us of dispatch/event latency that rocprofv3's kernel timestamps do not (profiles/*_streams1.csv); "
-                        "the timed region replays a 4-chain hipGraph in which kernels of different chains overlap",
-                "launches_per_eval": gemm_n // n_eval, "avg_launch_us": round(1e3 * gemm_ms / max(gemm_n, 1), 2),
-                "class_ms_per_eval": {k: round(v[0] / n_eval, 4) for k, v in prof.items()}}
+            key = f"{a.config}_B{B}_{a.precision}_{'cfg' if a.guided else 'plain'}"
+            roof["traffic"] = pj.get(key, {}).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
 
     if rank == 0:
         evals = S * (2 if a.guided else 1)
         algo = ALGO_GFLOP_PER_EVAL.get((cfg["dataset"], cfg["cm_mode"]), None)
         value = a.steps * B * world / dt
+        dtype = a.precision
+        if a.precision == "bf16_x3tail":
+            tail = a.x3_tail if a.x3_tail is not None else (S if S < 40 else max(8, (S + 39) // 40))
+            dtype = f"bf16 MFMA, fp32 accumulate/LayerNorm/softmax; split-bf16 (x3) for the last {min(tail, S)} of {S} steps"
         line = {
             "metric": "sampled motions/sec", "value": round(value, 3), "unit": "motions/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"{a.config}: [B={B}/GPU,56,6,{cfg['num_frames']}] online/{cfg['cm_mode']}/{cfg['cond_mode']} "
                                    f"L{cfg['layers']} d{cfg['latent_dim']}, {S}-step {a.sampler.upper()}"
                                    f"{' + CFG 2.5' if a.guided else ''}, Philox noise, hipGraph={'off' if a.no_graph else 'on'}",

@@ -40,7 +40,11 @@ enum { RGN_CM_ADD = 0, RGN_CM_CONCAT = 1 };                 /* --cm_mode, model/
 enum { RGN_COND_NONE = 0, RGN_COND_ACTION = 1, RGN_COND_TEXT = 2 }; /* cond_mode, model_util.py:25-30 */
 enum { RGN_PREC_F32 = 0,      /* fp32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products     */
        RGN_PREC_BF16X3 = 1,   /* split-bf16: a*b ~ ah*bh + ah*bl + al*bh on bf16 MFMA, fp32 accum  */
-       RGN_PREC_BF16 = 2 };   /* plain bf16 MFMA inputs (fastest; outside the 1e-3 parity bound)   */
+       RGN_PREC_BF16 = 2,     /* plain bf16 MFMA inputs (fastest; outside the 1e-3 parity bound)   */
+       RGN_PREC_BF16_X3TAIL = 3 }; /* precision schedule (default): plain-bf16 GEMM operands while the sampler
+                                 still contracts errors (large t), split-bf16 for the last steps of a sampling
+                                 loop (rgn_set_x3_tail) and for every rgn_denoise call; the residual stream and
+                                 LayerNorm/softmax stay hi+lo / fp32 throughout. Inside the 1e-3 parity bound. */
 enum { RGN_SAMPLER_DDPM = 0,  /* GaussianDiffusion.p_sample   diffusion/gaussian_diffusion.py:508  */
        RGN_SAMPLER_DDIM = 1 };/* GaussianDiffusion.ddim_sample diffusion/gaussian_diffusion.py:744 */
 enum { RGN_FLAG_UNCOND = 1,   /* y['uncond']=True  (model/cmdm.py:181, mask_cond :129-137)         */
@@ -132,6 +136,12 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
                      int32_t first_index, int32_t count, float* x0_dev, int32_t use_graph,
                      int32_t clip_denoised, void* stream);
 
+/* RGN_PREC_BF16_X3TAIL only: the last `tail_steps` loop indices (i < tail_steps) of every sampling loop run
+ * split-bf16, all earlier ones plain bf16. -1 restores the default (S < 40: all steps; otherwise max(8, ceil(S/40))); 0 = plain bf16 throughout;
+ * >= S = split-bf16 throughout. Why it is safe: p_sample scales the denoiser output by posterior_mean_coef1[t]
+ * (gaussian_diffusion.py:265-276; 0.0016 at t=999, -> 1 at t=0), so early-step rounding is contracted away. */
+int rgn_set_x3_tail(rgn_handle h, int32_t tail_steps);
+
 /* Fills x_dev [B,njoints,nfeats,T] with N(0,1) from the same Philox stream (x_T, gaussian_diffusion.py:706). */
 int rgn_randn(rgn_handle h, float* x_dev, int32_t B, uint64_t seed, uint64_t sample_offset, void* stream);
 
@@ -147,6 +157,9 @@ int rgn_gaussian_filter1d(rgn_handle h, const float* x_dev, float* out_dev, int6
  * internal kernel classes since the last reset; timing is only collected when enabled. */
 int rgn_profile_enable(rgn_handle h, int32_t on);
 int rgn_profile_query(rgn_handle h, int32_t idx, const char** name, double* total_ms, int64_t* launches);
+/* Time (ms) one event pair measures around a one-thread no-op kernel on this handle's stream: the dispatch + event
+ * latency every bracket of rgn_profile_query carries on top of the kernel itself (calibrated at the first enable). */
+int rgn_profile_bracket_overhead(rgn_handle h, double* ms);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,8 @@ RGN_OK = 0
 ERR_NAMES = {-1: "INVALID_ARG", -2: "BAD_KEY", -3: "BAD_SHAPE", -4: "MISSING_KEY", -5: "STATE", -6: "HIP", -7: "UNSUPPORTED"}
 CM = {"add": 0, "concat": 1}
 COND = {"no_cond": 0, "action": 1, "text": 2}
-PREC = {"f32": 0, "bf16x3": 1, "bf16": 2}
+PREC = {"f32": 0, "bf16x3": 1, "bf16": 2, "bf16_x3tail": 3}
+DEFAULT_PRECISION = "bf16_x3tail"
 SAMPLER = {"ddpm": 0, "ddim": 1}
 FLAG_UNCOND, FLAG_GUIDED = 1, 2
 
@@ -52,11 +53,13 @@ SYMBOLS = {
     "rgn_set_condition": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "rgn_denoise": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "rgn_sample_range": (C.c_int, [_vp, _i32, _i32, _f32, _vp, _vp, _u64, _u64, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "rgn_set_x3_tail": (C.c_int, [_vp, _i32]),
     "rgn_randn": (C.c_int, [_vp, _vp, _i32, _u64, _u64, _vp]),
     "rgn_rot6d_to_matrix": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "rgn_gaussian_filter1d": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "rgn_profile_enable": (C.c_int, [_vp, _i32]),
     "rgn_profile_query": (C.c_int, [_vp, _i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "rgn_profile_bracket_overhead": (C.c_int, [_vp, C.POINTER(C.c_double)]),
 }
 
 _lib = None
@@ -174,6 +177,10 @@ class Engine:
                                            int(seed) & (2 ** 64 - 1), int(sample_offset), int(first_index), int(count),
                                            _ptr(x0_out), int(bool(use_graph)), int(bool(clip_denoised)), C.c_void_p(stream)))
 
+    def set_x3_tail(self, tail_steps):
+        """Precision schedule ('bf16_x3tail'): split-bf16 for the last `tail_steps` loop indices (-1: default)."""
+        self._ck(self.lib.rgn_set_x3_tail(self.h, int(tail_steps)))
+
     def randn(self, x, B, seed, sample_offset, stream):
         self._ck(self.lib.rgn_randn(self.h, _ptr(x), int(B), int(seed) & (2 ** 64 - 1), int(sample_offset), C.c_void_p(stream)))
 
@@ -185,6 +192,11 @@ class Engine:
 
     def profile_enable(self, on):
         self._ck(self.lib.rgn_profile_enable(self.h, int(bool(on))))
+
+    def profile_bracket_overhead_ms(self):
+        ms = C.c_double()
+        self._ck(self.lib.rgn_profile_bracket_overhead(self.h, C.byref(ms)))
+        return ms.value
 
     def profile_query(self):
         out = {}

@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,7 +21,7 @@ using namespace rgn;
 
 namespace {
 
-std::string g_create_error;
+thread_local std::string g_create_error;   // text of the calling thread's last failed rgn_create
 
 struct HostTensor {
     std::vector<float> v;
@@ -29,6 +30,7 @@ struct HostTensor {
 
 struct Lin {  // one packed nn.Linear: offsets (bytes) into the weight blob
     size_t w = 0, hi = 0, lo = 0, b = 0;   // fp32 [N,Kp]; bf16 hi/lo planes (row-major [N,Kp] or K32-blocked)
+    size_t fr = 0;                         // bf16 hi plane in MFMA-fragment order (operand of k_rowgemm), optional
     int N = 0, K = 0, Kp = 0;
     bool has_bias = false;
     bool blocked = false;                  // hi/lo are K32-blocked [Kp/32][N][32] (operands of k_gemm_x3)
@@ -91,6 +93,7 @@ struct rgn_ctx {
     bool fuse_qkv = false;             // in_proj GEMM + attention in one per-sample kernel (k_qkv_attn)
     int big_tile_rows = 7000;          // launches of at least this many rows per chain use the 256x256 GEMM tile
     bool fuse_ln = false;              // out_proj / linear2 GEMMs carry their LayerNorms (k_gemm_x3_ln)
+    bool rowgemm = false;              // plain-bf16 phase: row-complete GEMMs with fused LayerNorm / GELU (k_rowgemm)
     StepCoef* d_tab = nullptr;
     int* d_step = nullptr;
     SampleParams* d_sp = nullptr;
@@ -101,6 +104,13 @@ struct rgn_ctx {
     hipStream_t side[MAX_SIDE] = {};   // extra chains of the multi-stream evaluation
     hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {};
     int nchains = 4;                   // REGENNET_STREAMS = 1 .. 16 (default 4)
+    // Precision schedule (RGN_PREC_BF16_X3TAIL): the loop indices i >= x3_tail run plain-bf16 GEMMs (one MFMA per
+    // product, hi planes only as GEMM operands), the last x3_tail indices and every rgn_denoise call the split-bf16 ones.
+    // phase_x3 is the phase of the evaluation being enqueued / captured.
+    bool phase_x3 = true;
+    int x3_tail = -1;                  // -1: default_tail(S)
+    bool bulk_resid_lo = false;        // bulk phase: residual stream as the hi plane only (REGENNET_BULK_RESID_LO=1: hi + lo; the switch-point
+                                       // sweeps measure the same final error either way, hi-only is ~6 % faster)
 
     // schedule (host copies)
     int S = 0;
@@ -114,7 +124,7 @@ struct rgn_ctx {
     int xin_rows = -1;                 // row count the xin planes are currently laid out for
     bool cond_has_scale = false;
 
-    // graphs: key = B | guided<<20 | sampler<<21
+    // graphs: key = B | guided<<20 | sampler<<21 | phase_x3<<23
     std::map<uint64_t, hipGraphExec_t> graphs;
 
     // profiling
@@ -122,6 +132,7 @@ struct rgn_ctx {
     std::vector<ProfEv> prof_pool;     // pre-created event pairs
     size_t prof_used = 0;
     double prof_ms[KC_COUNT] = {0};
+    double prof_bracket_ms = -1.0;     // event-pair time around a no-op kernel (calibrated on first enable)
     int64_t prof_n[KC_COUNT] = {0};
 
     int fail(int code, const std::string& m) {
@@ -134,7 +145,7 @@ struct rgn_ctx {
 
 namespace {
 
-const char* kclass_names[KC_COUNT] = {"gemm_mfma", "attention", "layernorm", "embed", "update", "misc"};
+const char* kclass_names[KC_COUNT] = {"gemm_mfma", "attention", "layernorm", "embed", "update", "misc", "qkv_attn", "rowgemm_ln", "rowgemm_act"};
 
 #define RGN_HIP(h, expr)                                                                                    \
     do {                                                                                                    \
@@ -225,7 +236,7 @@ size_t blob_put(rgn_ctx* c, const void* src, size_t bytes) {
 }
 
 // Pack W[N,K] (row-major fp32) into fp32 [N,Kp] plus bf16 hi/lo planes; bias optional.
-Lin pack_linear(rgn_ctx* c, const float* W, const float* bias, int N, int K, bool blocked = false) {
+Lin pack_linear(rgn_ctx* c, const float* W, const float* bias, int N, int K, bool blocked = false, bool frag = false) {
     Lin L;
     L.blocked = blocked;
     L.N = N;
@@ -245,6 +256,17 @@ Lin pack_linear(rgn_ctx* c, const float* W, const float* bias, int N, int K, boo
     L.w = blob_put(c, w.data(), w.size() * 4);
     L.hi = blob_put(c, hi.data(), hi.size() * 2);
     L.lo = blob_put(c, lo.data(), lo.size() * 2);
+    if (frag && N % 32 == 0) {
+        // fragment order [Kp/32][N/32][ks 2][lane 64][8]: lane = 32 * ((k % 16) / 8) + n % 32 holds its 8 consecutive k
+        std::vector<uint16_t> fr((size_t)N * L.Kp, 0);
+        const size_t nb_all = (size_t)N / 32;
+        for (int n = 0; n < N; ++n)
+            for (int k = 0; k < K; ++k) {
+                const size_t kt = k / 32, ks = (k % 32) / 16, lane = 32 * ((k % 16) / 8) + n % 32;
+                fr[(((kt * nb_all + n / 32) * 2 + ks) * 64 + lane) * 8 + k % 8] = f2bf(W[(size_t)n * K + k]);
+            }
+        L.fr = blob_put(c, fr.data(), fr.size() * 2);
+    }
     if (bias) {
         L.b = blob_put(c, bias, (size_t)N * 4);
         L.has_bias = true;
@@ -290,6 +312,26 @@ Dims make_dims(const rgn_ctx* c, int B, bool guided) {
     return dm;
 }
 
+// precision of the per-schedule / per-condition / rgn_denoise-only GEMMs (k_gemm_f32 / k_gemm_bf16): the schedule mode
+// runs them split-bf16 (they are once-per-call work)
+inline int small_prec(const rgn_ctx* c) { return c->cfg.precision == RGN_PREC_BF16_X3TAIL ? RGN_PREC_BF16X3 : c->cfg.precision; }
+// split-bf16 (three MFMAs per product) for the evaluation being enqueued?
+inline bool eval_x3(const rgn_ctx* c) {
+    return c->cfg.precision == RGN_PREC_BF16X3 || (c->cfg.precision == RGN_PREC_BF16_X3TAIL && c->phase_x3);
+}
+// do activation planes carry a lo part at all (allocation, sampler state, residual stream)?
+inline bool has_lo(const rgn_ctx* c) { return c->cfg.precision == RGN_PREC_BF16X3 || c->cfg.precision == RGN_PREC_BF16_X3TAIL; }
+inline int default_tail(int S) {
+    // What the bulk phase may cost is empirical (tests/test_hip_parity.py sweeps the switch point against the reference):
+    // a long schedule contracts early-step rounding (1000-step DDPM: 5 split-bf16 steps already reach 1.2e-4), a short
+    // DDIM schedule does not (every step carries a large share of the result: 20 guided steps with 8 of them split-bf16
+    // measured 3e-3 on a tiny model). So: schedules of fewer than 40 steps run split-bf16 throughout; longer ones keep
+    // 2.5 % of the steps, at least 8.
+    if (S < 40) return S;
+    const int t = (S + 39) / 40;
+    return t < 8 ? 8 : t;
+}
+
 GemmArgs gemm_args(const rgn_ctx* c, const Lin& L, const float* A, int lda, float* C, int ldc, int M) {
     GemmArgs g{};
     g.A = A;
@@ -316,7 +358,7 @@ int pack_state(rgn_ctx* c, const float* x, const Dims& dm, bool guided, hipStrea
     if (c->cfg.precision == RGN_PREC_F32) {
         RGN_LAUNCH(c, KC_UPDATE, s, launch_pack_x(x, c->xin, Planes{nullptr, nullptr, 0}, 1, dm, s));
     } else {
-        const Planes xp{c->xin_hi, c->cfg.precision == RGN_PREC_BF16X3 ? c->xin_lo : nullptr, dm.Bm * dm.Tq};
+        const Planes xp{c->xin_hi, has_lo(c) ? c->xin_lo : nullptr, dm.Bm * dm.Tq};
         if (xp.rows != c->xin_rows) {   // the blocked layout depends on the row count: K-padding columns must read as zero
             const size_t bytes = (size_t)2 * c->cfg.max_batch * c->Tq * align_up((size_t)c->F, 32) * 2;
             RGN_HIP(c, hipMemsetAsync(c->xin_hi, 0, bytes, s));
@@ -340,13 +382,16 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
     // ---- the big GEMMs: F32 mode keeps fp32 activations (k_gemm_f32); the bf16 modes chain pre-split
     //      K32-blocked planes between kernels (k_gemm_x3, DMA-fed). Plane pointers are advanced by row0 rows
     //      (32 elements each) while Planes::rows stays the row count of the whole evaluation.
-    const bool fast = prec != RGN_PREC_F32, x3 = prec == RGN_PREC_BF16X3;
-    auto pl = [&](__bf16* hi, __bf16* lo) {
-        return Planes{fast ? hi + (size_t)row0 * 32 : nullptr, (fast && x3) ? lo + (size_t)row0 * 32 : nullptr, Mtot};
+    // x3: this evaluation's GEMMs form three MFMAs per product and read hi + lo planes. In the bulk phase of the precision
+    // schedule every plane is written hi-only (the residual stream's lo plane is an option, bulk_resid_lo).
+    const bool fast = prec != RGN_PREC_F32, x3 = eval_x3(c);
+    auto pl = [&](__bf16* hi, __bf16* lo, bool with_lo) {
+        return Planes{fast ? hi + (size_t)row0 * 32 : nullptr, (fast && with_lo) ? lo + (size_t)row0 * 32 : nullptr, Mtot};
     };
     const Planes none{nullptr, nullptr, 0};
-    const Planes xin_p = pl(c->xin_hi, c->xin_lo), h_p = pl(c->h_hi, c->h_lo), att_p = pl(c->att_hi, c->att_lo),
-                 ffn_p = pl(c->ffn_hi, c->ffn_lo);
+    const bool h_lo = x3 || (has_lo(c) && c->bulk_resid_lo);
+    const Planes xin_p = pl(c->xin_hi, c->xin_lo, has_lo(c)), h_p = pl(c->h_hi, c->h_lo, h_lo), att_p = pl(c->att_hi, c->att_lo, x3),
+                 ffn_p = pl(c->ffn_hi, c->ffn_lo, x3);
     float* h = c->h + (size_t)row0 * d;
     float* tmp = c->tmp + (size_t)row0 * d;
     float* qkv = c->qkv + (size_t)row0 * 3 * d;
@@ -363,7 +408,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             g.add = add;
             g.ldadd = d;
             g.act = act;
-            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, small_prec(c), s));
         } else {
             GemmX3Args g{};
             g.Ahi = Ap.hi; g.Alo = Ap.lo; g.a_rows = Ap.rows;
@@ -410,7 +455,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             g.out = att_p;
             g.Bm = ns; g.Kp = w.qkv.Kp; g.d = d; g.H = c->H; g.Tq = dm.Tq;
             g.qscale = 1.0f / sqrtf((float)dm.dh);
-            RGN_LAUNCH(c, KC_GEMM, s, launch_qkv_attn(g, x3, s));   // 93 % of its MFMA work is the in_proj GEMM
+            RGN_LAUNCH(c, KC_QKV, s, launch_qkv_attn(g, x3, s));   // 93 % of its MFMA work is the in_proj GEMM
         } else if (fast && c->attn_x3) {
             // in_proj GEMM scatters q (pre-scaled), k and v as attention-ready split planes; no fp32 qkv round trip
             GemmX3Args g{};
@@ -437,6 +482,31 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
         const float* per_sample = sampling ? (ccond_rows ? ccond_rows + (size_t)s0 * Ld + (size_t)l * d : nullptr)
                                            : c->call + (size_t)s0 * Ld + (size_t)l * d;
         const float* step_vec = sampling ? c->call_time + (size_t)l * d : nullptr;
+        if (fast && !x3 && c->rowgemm) {
+            // plain-bf16 phase: out_proj + residual + norm1 + folded cross-attention + norm2 | linear1 + GELU |
+            // linear2 + residual + norm3, three row-complete kernels; the residual stream is updated in place as planes
+            RowGemmArgs g{};
+            g.A = att_p.hi; g.a_rows = att_p.rows;
+            g.W = c->dp<__bf16>(w.out.fr); g.bias = c->dp<float>(w.out.b);
+            g.M = M; g.N = d; g.Kp = w.out.Kp;
+            g.Rhi = h_p.hi; g.Rlo = h_p.lo; g.r_rows = h_p.rows; g.Ohi = h_p.hi; g.Olo = h_p.lo; g.o_rows = h_p.rows;
+            g.ga = c->dp<float>(w.ln[0]); g.ba = c->dp<float>(w.ln[1]); g.gb = c->dp<float>(w.ln[2]); g.bb = c->dp<float>(w.ln[3]);
+            g.pervec = per_sample; g.ldper = Ld; g.stepvec = step_vec; g.ldstep = Ld; g.d_step = c->d_step; g.Tq = dm.Tq;
+            RGN_LAUNCH(c, KC_ROWLN, s, launch_rowgemm(g, true, s));
+            RowGemmArgs f{};
+            f.A = h_p.hi; f.a_rows = h_p.rows;
+            f.W = c->dp<__bf16>(w.ff1.fr); f.bias = c->dp<float>(w.ff1.b);
+            f.M = M; f.N = c->ff; f.Kp = w.ff1.Kp; f.act = 1;
+            f.Chi = ffn_p.hi; f.Clo = ffn_p.lo; f.c_rows = ffn_p.rows;
+            RGN_LAUNCH(c, KC_ROWACT, s, launch_rowgemm(f, false, s));
+            g.A = ffn_p.hi; g.a_rows = ffn_p.rows;
+            g.W = c->dp<__bf16>(w.ff2.fr); g.bias = c->dp<float>(w.ff2.b);
+            g.Kp = w.ff2.Kp;
+            g.ga = c->dp<float>(w.ln[4]); g.ba = c->dp<float>(w.ln[5]); g.gb = nullptr; g.bb = nullptr;
+            g.pervec = nullptr; g.stepvec = nullptr;
+            RGN_LAUNCH(c, KC_ROWLN, s, launch_rowgemm(g, true, s));
+            continue;
+        }
         if (fast && c->fuse_ln) {
             // out_proj + residual + norm1 + folded cross-attention + norm2 in one kernel; then linear1 (GELU);
             // then linear2 + residual + norm3 in one kernel. The pre-norm tensors never reach HBM.
@@ -490,14 +560,14 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
         RGN_LAUNCH(c, KC_EMBED, s, launch_gather_pe(c->dp<float>(c->off_pe), c->d_tab, c->d_step, c->d_sp, c->pe_rows, dm.Bm, B, d, s));
         GemmArgs g = gemm_args(c, c->lin_t0, c->pe_rows, d, c->emb1, d, dm.Bm);
         g.act = 2;
-        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, small_prec(c), s));
         g = gemm_args(c, c->lin_t2, c->emb1, d, c->emb, d, dm.Bm);
         g.add = cond_rows;
         g.ldadd = d;
-        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, small_prec(c), s));
         // cross-attention onto the 1-token memory, all layers at once: call[b, l*d:(l+1)*d]
         g = gemm_args(c, c->lin_g, c->emb, d, c->call, Ld, dm.Bm);
-        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, prec, s));
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, small_prec(c), s));
     }
     // ---- layers. In the bf16 modes the samples of the evaluation are split into contiguous groups that run as
     //      independent kernel chains on separate streams (fork/join with events, also inside graph capture): the
@@ -514,7 +584,7 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
     // Without guidance a chain's samples are all the update kernel of that chain needs, so it runs at the end of the
     // chain (overlapping the other chains' layers); with guidance the cond / uncond halves of a sample sit in different
     // chains and the update waits for the join.
-    const Planes xin_p{fast ? c->xin_hi : nullptr, (fast && prec == RGN_PREC_BF16X3) ? c->xin_lo : nullptr, M};
+    const Planes xin_p{fast ? c->xin_hi : nullptr, (fast && has_lo(c)) ? c->xin_lo : nullptr, M};
     const bool own_update = nch > 1 && !guided;
     for (int k = 1; k < nch; ++k) {
         const int n = per + (k < extra ? 1 : 0);
@@ -565,6 +635,8 @@ int build_step_table(rgn_ctx* c, float eta) {
         k.t_model = (int32_t)c->tmap[i];
         tab[i] = k;
     }
+    // earlier sampling calls may still be reading the table on the engine's (non-blocking) stream
+    RGN_HIP(c, hipStreamSynchronize(c->stream));
     RGN_HIP(c, hipMemcpy(c->d_tab, tab.data(), tab.size() * sizeof(StepCoef), hipMemcpyHostToDevice));
     c->tab_eta = eta;
     c->tab_valid = true;
@@ -597,7 +669,7 @@ int rgn_create(const rgn_config* cfg, rgn_handle* out) {
         return bad(RGN_ERR_UNSUPPORTED, "rgn_create: head dim > 128 unsupported");
     if (cfg->cm_mode != RGN_CM_ADD && cfg->cm_mode != RGN_CM_CONCAT) return bad(RGN_ERR_INVALID_ARG, "rgn_create: cm_mode");
     if (cfg->cond_mode < RGN_COND_NONE || cfg->cond_mode > RGN_COND_TEXT) return bad(RGN_ERR_INVALID_ARG, "rgn_create: cond_mode");
-    if (cfg->precision < RGN_PREC_F32 || cfg->precision > RGN_PREC_BF16) return bad(RGN_ERR_INVALID_ARG, "rgn_create: precision");
+    if (cfg->precision < RGN_PREC_F32 || cfg->precision > RGN_PREC_BF16_X3TAIL) return bad(RGN_ERR_INVALID_ARG, "rgn_create: precision");
     if (cfg->cond_mode == RGN_COND_ACTION && cfg->num_actions <= 0) return bad(RGN_ERR_INVALID_ARG, "rgn_create: num_actions");
     if (cfg->cond_mode == RGN_COND_TEXT && cfg->clip_dim <= 0) return bad(RGN_ERR_INVALID_ARG, "rgn_create: clip_dim");
     int ndev = 0;
@@ -733,9 +805,10 @@ int rgn_finalize_weights(rgn_handle h) {
         const std::string p = "seqTransDecoder.layers." + std::to_string(l) + ".";
         LayerW& lw = c->layers[l];
         lw.qkv = pack_linear(c, W(p + "self_attn.in_proj_weight"), W(p + "self_attn.in_proj_bias"), 3 * d, d, true);
-        lw.out = pack_linear(c, W(p + "self_attn.out_proj.weight"), W(p + "self_attn.out_proj.bias"), d, d, true);
-        lw.ff1 = pack_linear(c, W(p + "linear1.weight"), W(p + "linear1.bias"), ff, d, true);
-        lw.ff2 = pack_linear(c, W(p + "linear2.weight"), W(p + "linear2.bias"), d, ff, true);
+        const bool fr = c->cfg.precision == RGN_PREC_BF16_X3TAIL;   // k_rowgemm operands (plain-bf16 phase)
+        lw.out = pack_linear(c, W(p + "self_attn.out_proj.weight"), W(p + "self_attn.out_proj.bias"), d, d, true, fr);
+        lw.ff1 = pack_linear(c, W(p + "linear1.weight"), W(p + "linear1.bias"), ff, d, true, fr);
+        lw.ff2 = pack_linear(c, W(p + "linear2.weight"), W(p + "linear2.bias"), d, ff, true, fr);
         const char* names[6] = {"norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "norm3.weight", "norm3.bias"};
         for (int i = 0; i < 6; ++i) lw.ln[i] = blob_put(c, W(p + names[i]), (size_t)d * 4);
         const float* wv = W(p + "multihead_attn.in_proj_weight") + (size_t)2 * d * d;
@@ -822,6 +895,10 @@ int rgn_finalize_weights(rgn_handle h) {
         }
         c->fuse_qkv = qkv_attn_supported(c->Tq, d / c->H, d) && getenv("REGENNET_NO_FUSED_QKV") == nullptr;
         if (const char* e = getenv("REGENNET_BIG_TILE_ROWS")) c->big_tile_rows = atoi(e);
+        c->rowgemm = c->cfg.precision == RGN_PREC_BF16_X3TAIL && getenv("REGENNET_NO_ROWGEMM") == nullptr &&
+                     rowgemm_supported(d, d, true) && rowgemm_supported(d, (int)align_up((size_t)ff, 32), true) &&
+                     rowgemm_supported(ff, d, false);
+        if (c->rowgemm) RGN_HIP(c, configure_rowgemm());
         if (c->fuse_qkv) RGN_HIP(c, configure_qkv_attn());
     }
     if ((rc = ws_alloc(c, &c->d_tab, (size_t)1024))) return rc;
@@ -836,6 +913,7 @@ int rgn_finalize_weights(rgn_handle h) {
         RGN_HIP(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
     RGN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    if (const char* e = getenv("REGENNET_BULK_RESID_LO")) c->bulk_resid_lo = atoi(e) != 0;
     if (const char* e = getenv("REGENNET_STREAMS")) c->nchains = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
     RGN_HIP(c, hipMemset(c->xin, 0, Mb * F * sizeof(float)));
     RGN_HIP(c, hipMemset(c->cmo_in, 0, Mb * F * sizeof(float)));
@@ -887,11 +965,11 @@ int rgn_set_schedule(rgn_handle h, const rgn_schedule* s) {
     RGN_LAUNCH(c, KC_EMBED, es, launch_gather_pe_all(c->dp<float>(c->off_pe), c->d_tab, c->sched_tmp, S, d, es));
     GemmArgs g = gemm_args(c, c->lin_t0, c->sched_tmp, d, c->sched_tmp + (size_t)1024 * d, d, S);
     g.act = 2;
-    RGN_LAUNCH(c, KC_GEMM, es, launch_gemm(g, c->cfg.precision, es));
+    RGN_LAUNCH(c, KC_GEMM, es, launch_gemm(g, small_prec(c), es));
     g = gemm_args(c, c->lin_t2, c->sched_tmp + (size_t)1024 * d, d, c->te_all, d, S);
-    RGN_LAUNCH(c, KC_GEMM, es, launch_gemm(g, c->cfg.precision, es));
+    RGN_LAUNCH(c, KC_GEMM, es, launch_gemm(g, small_prec(c), es));
     g = gemm_args(c, c->lin_g, c->te_all, d, c->call_time, c->L * d, S);
-    RGN_LAUNCH(c, KC_GEMM, es, launch_gemm(g, c->cfg.precision, es));
+    RGN_LAUNCH(c, KC_GEMM, es, launch_gemm(g, small_prec(c), es));
     RGN_HIP(c, hipStreamSynchronize(es));
     return RGN_OK;
 }
@@ -914,7 +992,7 @@ int rgn_set_condition(rgn_handle h, int32_t B, const float* cmotion, const int64
     // hoisted: c0 = cmo_process(cmotion) -> fuse half + all constant biases + positional encoding
     RGN_LAUNCH(c, KC_UPDATE, s, launch_pack_x(cmotion, c->cmo_in, Planes{nullptr, nullptr, 0}, 1, dm, s));
     GemmArgs g = gemm_args(c, c->lin_c, c->cmo_in, c->F, c->c0, d, B * dm.Tq);
-    RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, c->cfg.precision, s));
+    RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, small_prec(c), s));
     if (!c->cfg.wo_pos_emb) RGN_LAUNCH(c, KC_EMBED, s, launch_add_pe(c->c0, c->dp<float>(c->off_pe), dm, s));
     RGN_HIP(c, hipMemcpyAsync(c->c0 + (size_t)B * dm.Tq * d, c->c0, (size_t)B * dm.Tq * d * sizeof(float), hipMemcpyDeviceToDevice, s));   // uncond half
     // condition embedding rows: [0,B) conditional, [B,2B) what mask_cond(force_mask=True) leaves
@@ -923,13 +1001,13 @@ int rgn_set_condition(rgn_handle h, int32_t B, const float* cmotion, const int64
         RGN_LAUNCH(c, KC_EMBED, s, launch_fill_rows(c->condemb + (size_t)B * d, nullptr, B, d, s));
     } else if (c->cfg.cond_mode == RGN_COND_TEXT) {
         GemmArgs t = gemm_args(c, c->lin_text, text_feat, c->cfg.clip_dim, c->condemb, d, B);
-        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(t, c->cfg.precision, s));
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(t, small_prec(c), s));
         RGN_LAUNCH(c, KC_EMBED, s, launch_fill_rows(c->condemb + (size_t)B * d, c->dp<float>(c->off_bt), B, d, s));  // embed_text(0) = bias
     }
     if (c->cfg.cond_mode != RGN_COND_NONE) {   // folded cross-attention image of the condition rows (cond | uncond)
         GemmArgs cg = gemm_args(c, c->lin_g, c->condemb, d, c->call_cond, c->L * d, 2 * B);
         cg.bias = nullptr;
-        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(cg, c->cfg.precision, s));
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(cg, small_prec(c), s));
     }
     c->cond_has_scale = scale != nullptr;
     if (scale) RGN_HIP(c, hipMemcpyAsync(c->scale, scale, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -960,6 +1038,7 @@ int rgn_denoise(rgn_handle h, const float* x, const int64_t* t, int32_t flags, f
     RGN_HIP(c, hipMemcpyAsync(c->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
     rc = pack_state(c, x, dm, guided, s);
     if (rc) return rc;
+    c->phase_x3 = true;               // a single evaluation is always split-bf16 under the precision schedule
     rc = run_eval(c, c->B, guided, uncond, false, s);
     if (rc) return rc;
     return stream_exit(c, us);
@@ -1001,38 +1080,58 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
     RGN_HIP(c, hipMemcpyAsync(c->d_step, &first_index, sizeof(int), hipMemcpyHostToDevice, s));
     if ((rc = pack_state(c, x, dm, guided != 0, s))) return rc;
 
-    hipGraphExec_t gexec = nullptr;
-    if (use_graph && !c->prof) {
-        const uint64_t key = (uint64_t)c->B | ((uint64_t)(guided != 0) << 20) | ((uint64_t)sampler << 21);
+    // Precision schedule: loop indices >= tail run the plain-bf16 phase, the last `tail` indices the split-bf16 one.
+    // One captured step graph per phase; everything t-dependent is read on the device, so each serves all its steps.
+    const bool sched = c->cfg.precision == RGN_PREC_BF16_X3TAIL;
+    const int tail = !sched ? 0 : (c->x3_tail >= 0 ? c->x3_tail : default_tail(c->S));
+    auto graph_for = [&](bool x3, hipGraphExec_t* out) -> int {
+        const uint64_t key = (uint64_t)c->B | ((uint64_t)(guided != 0) << 20) | ((uint64_t)sampler << 21) | ((uint64_t)x3 << 23);
         auto it = c->graphs.find(key);
-        if (it == c->graphs.end()) {
-            hipGraph_t graph = nullptr;
-            RGN_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            rc = run_eval(c, c->B, guided != 0, false, true, s);
-            if (rc == RGN_OK && launch_advance(c->d_step, s) != hipSuccess) rc = c->fail(RGN_ERR_HIP, "launch_advance");
-            hipError_t e = hipStreamEndCapture(s, &graph);
-            if (rc) {
-                if (graph) (void)hipGraphDestroy(graph);
-                return rc;
-            }
-            RGN_HIP(c, e);
-            RGN_HIP(c, hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(graph);
-            c->graphs[key] = gexec;
-        } else {
-            gexec = it->second;
+        if (it != c->graphs.end()) {
+            *out = it->second;
+            return RGN_OK;
         }
-    }
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t ge = nullptr;
+        c->phase_x3 = x3;
+        RGN_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int r = run_eval(c, c->B, guided != 0, false, true, s);
+        if (r == RGN_OK && launch_advance(c->d_step, s) != hipSuccess) r = c->fail(RGN_ERR_HIP, "launch_advance");
+        hipError_t e = hipStreamEndCapture(s, &graph);
+        if (r) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return r;
+        }
+        RGN_HIP(c, e);
+        RGN_HIP(c, hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        c->graphs[key] = ge;
+        *out = ge;
+        return RGN_OK;
+    };
+    const bool graphs = use_graph && !c->prof;
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};   // [phase_x3]
     for (int k = 0; k < count; ++k) {
-        if (gexec) {
-            RGN_HIP(c, hipGraphLaunch(gexec, s));
+        const bool x3 = !sched || (first_index - k) < tail;
+        if (graphs) {
+            if (!gexec[x3] && (rc = graph_for(x3, &gexec[x3]))) return rc;
+            RGN_HIP(c, hipGraphLaunch(gexec[x3], s));
         } else {
+            c->phase_x3 = x3;
             rc = run_eval(c, c->B, guided != 0, false, true, s);
             if (rc) return rc;
             RGN_LAUNCH(c, KC_MISC, s, launch_advance(c->d_step, s));
         }
     }
+    c->phase_x3 = true;
     return stream_exit(c, us);
+}
+
+int rgn_set_x3_tail(rgn_handle h, int32_t tail_steps) {
+    if (!h) return RGN_ERR_INVALID_ARG;
+    if (tail_steps < -1) return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_x3_tail: tail_steps < -1");
+    h->x3_tail = tail_steps;
+    return RGN_OK;
 }
 
 int rgn_randn(rgn_handle h, float* x, int32_t B, uint64_t seed, uint64_t sample_offset, void* stream) {
@@ -1088,7 +1187,30 @@ int rgn_profile_enable(rgn_handle h, int32_t on) {
         h->prof_ms[i] = 0;
         h->prof_n[i] = 0;
     }
+    if (on && h->prof_bracket_ms < 0) {
+        // What an event pair adds around ANY kernel (dispatch + event latency): the same bracket around a one-thread
+        // no-op kernel, median of 64. rgn_profile_query reports it so that callers can subtract it per launch.
+        std::vector<float> v;
+        for (int i = 0; i < 64 && i < (int)h->prof_pool.size(); ++i) {
+            (void)hipEventRecord(h->prof_pool[i].a, h->stream);
+            (void)launch_advance(h->d_step + 3, h->stream);      // scratch slot of d_step[4]
+            (void)hipEventRecord(h->prof_pool[i].b, h->stream);
+        }
+        (void)hipStreamSynchronize(h->stream);
+        for (int i = 0; i < 64 && i < (int)h->prof_pool.size(); ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->prof_pool[i].a, h->prof_pool[i].b) == hipSuccess) v.push_back(ms);
+        }
+        std::sort(v.begin(), v.end());
+        h->prof_bracket_ms = v.empty() ? 0.0 : v[v.size() / 2];
+    }
     h->prof = on != 0;
+    return RGN_OK;
+}
+
+int rgn_profile_bracket_overhead(rgn_handle h, double* ms) {
+    if (!h || !ms) return RGN_ERR_INVALID_ARG;
+    *ms = h->prof_bracket_ms < 0 ? 0.0 : h->prof_bracket_ms;
     return RGN_OK;
 }
 

@@ -8,12 +8,15 @@ namespace rgn {
 
 // ---- kernel classes (for per-class HIP-event timing, rgn_profile_query) -------------------------
 enum KClass : int {
-    KC_GEMM = 0,      // all MFMA GEMMs (dominant)
+    KC_GEMM = 0,      // MFMA GEMM launches (k_gemm_x3 / k_gemm_f32 / k_gemm_bf16; dominant)
     KC_ATTN,          // causal self-attention
     KC_LN,            // residual LayerNorm kernels
     KC_EMBED,         // pe gather / emb rows
     KC_UPDATE,        // pack / sampler update / output transpose / philox
     KC_MISC,
+    KC_QKV,           // fused in_proj GEMM + attention (k_qkv_attn)
+    KC_ROWLN,         // row-complete GEMM + residual + LayerNorm(s) (k_rowgemm<0>)
+    KC_ROWACT,        // row-complete GEMM + activation (k_rowgemm<1>)
     KC_COUNT
 };
 
@@ -118,6 +121,30 @@ struct GemmLnArgs {
 bool gemm_ln_supported(int N);
 hipError_t configure_gemm_ln();
 hipError_t launch_gemm_ln(const GemmLnArgs& g, bool x3, hipStream_t s);
+
+// Row-complete plain-bf16 GEMM with the layer tail fused (rgn_rowgemm.hip): 64 complete rows x 512 columns per workgroup,
+// activation tile resident in LDS, weights streamed into registers.
+struct RowGemmArgs {
+    const __bf16* A; int a_rows;          // activation plane (hi) [Kp/32][a_rows][32], advanced to the first row
+    const __bf16* W;                      // weight plane (hi), fragment-ordered [Kp/32][N/32][2][64][8] (see rgn_rowgemm.hip)
+    const float* bias;                    // [N]
+    int M, N, Kp;
+    // ---- epilogue "act": out = act(A.W^T + bias) as bf16 planes (N % 32 == 0)
+    int act;                              // 0 none, 1 gelu(erf)
+    const float* add; int ldadd;          // (reserved, must be null)
+    float* C; int ldc;                    // (reserved, must be null)
+    __bf16* Chi; __bf16* Clo; int c_rows; // output planes [N/32][c_rows][32]; Clo nullable
+    // ---- epilogue "ln" (N == 512): out = LN_b(LN_a(A.W^T + bias + resid) + pervec[row / Tq] + stepvec[*d_step])
+    const __bf16* Rhi; const __bf16* Rlo; int r_rows;   // residual planes (Rlo nullable); may alias the output planes
+    __bf16* Ohi; __bf16* Olo; int o_rows;
+    const float *ga, *ba, *gb, *bb;       // gb == nullptr: single norm
+    const float* pervec; int ldper;
+    const float* stepvec; int ldstep; const int* d_step;
+    int Tq;
+};
+bool rowgemm_supported(int N, int Kp, bool ln);
+hipError_t configure_rowgemm();
+hipError_t launch_rowgemm(const RowGemmArgs& g, bool ln, hipStream_t s);
 
 struct Dims {
     int B;        // motions in the bound condition

@@ -161,18 +161,20 @@ class GaussianDiffusion:
         return {"mean": mean, "variance": _extract_into_tensor(var, t, x.shape),
                 "log_variance": _extract_into_tensor(logvar, t, x.shape), "pred_xstart": pred}
 
-    def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, const_noise=False):
+    def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, const_noise=False,
+                 *, _noise=None):
         """gaussian_diffusion.py:508-560."""
         if cond_fn is not None:
             raise NotImplementedError("classifier guidance (cond_fn) is outside the hot path")
         out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, model_kwargs=model_kwargs)
-        noise = th.randn_like(x)
+        noise = th.randn_like(x) if _noise is None else _noise
         if const_noise:
             noise = noise[[0]].repeat(x.shape[0], 1, 1, 1)
         nz = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
         return {"sample": out["mean"] + nz * th.exp(0.5 * out["log_variance"]) * noise, "pred_xstart": out["pred_xstart"]}
 
-    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0):
+    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0,
+                    *, _noise=None):
         """gaussian_diffusion.py:744-794."""
         if cond_fn is not None:
             raise NotImplementedError("classifier guidance (cond_fn) is outside the hot path")
@@ -182,7 +184,7 @@ class GaussianDiffusion:
         ab = _extract_into_tensor(self.alphas_cumprod, t, x.shape)
         abp = _extract_into_tensor(self.alphas_cumprod_prev, t, x.shape)
         sigma = eta * th.sqrt((1 - abp) / (1 - ab)) * th.sqrt(1 - ab / abp)
-        noise = th.randn_like(x)
+        noise = th.randn_like(x) if _noise is None else _noise
         mean = out["pred_xstart"] * th.sqrt(abp) + th.sqrt(1 - abp - sigma ** 2) * eps
         nz = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
         return {"sample": mean + nz * sigma * noise, "pred_xstart": out["pred_xstart"]}
@@ -204,7 +206,15 @@ class GaussianDiffusion:
         y = (model_kwargs or {}).get("y", None)
         if y is None:
             raise KeyError("model_kwargs['y'] with 'cmotion' is required (gaussian_diffusion.py:317, cmdm.py:189)")
-        eng, guided, dev = bind(B, y, device)
+        if "inpainting_mask" in y or "inpainted_motion" in y or y.get("uncond", False):
+            # keys the reference honours inside p_mean_variance on every step (gaussian_diffusion.py:319-323) / inside the
+            # denoiser (cmdm.py:181): the fused engine loop does not read them, so these calls take the per-step API
+            # (one HIP denoiser evaluation per step + torch elementwise glue) instead of being silently ignored
+            yield from self._loop_per_step(sampler, model, shape, noise, clip_denoised, model_kwargs, progress, skip_timesteps,
+                                           init_image, eta, noise_tape)
+            return
+        assert len(shape) == 4, "shape must be (B, njoints, nfeats, T)"
+        eng, guided, dev = bind(B, y, device, T=int(shape[3]))
         if tuple(shape[1:]) != (eng.cfg["njoints"], eng.cfg["nfeats"], eng.cfg["num_frames"]):
             raise AssertionError(f"shape {tuple(shape)} does not match the model ({eng.cfg['njoints']},{eng.cfg['nfeats']},{eng.cfg['num_frames']})")
         if eng.schedule_id is not self._sched_token:
@@ -252,6 +262,38 @@ class GaussianDiffusion:
             bar.close()
         if not progressive:
             yield {"sample": img, "pred_xstart": None}
+
+    def _loop_per_step(self, sampler, model, shape, noise, clip_denoised, model_kwargs, progress, skip_timesteps, init_image,
+                       eta, noise_tape):
+        """The reference's own loop structure (gaussian_diffusion.py:696-742 / 959-1005) around p_sample / ddim_sample:
+        for model_kwargs the fused loop does not cover (inpainting_mask / inpainted_motion, y['uncond'])."""
+        dev = next(model.parameters()).device
+        B, S = int(shape[0]), self.num_timesteps
+        if noise is not None:
+            img = noise.to(dev)
+        elif noise_tape is not None:
+            img = noise_tape[0].to(device=dev, dtype=th.float32)
+        else:
+            img = th.randn(*shape, device=dev)
+        if skip_timesteps and init_image is None:
+            init_image = th.zeros_like(img)
+        indices = list(range(S - int(skip_timesteps)))[::-1]
+        if init_image is not None:
+            my_t = th.ones([B], device=dev, dtype=th.long) * indices[0]
+            img = self.q_sample(init_image.to(dev), my_t, img)
+        if progress:
+            from tqdm.auto import tqdm
+            indices = tqdm(indices)
+        for k, i in enumerate(indices):
+            t = th.tensor([i] * B, device=dev)
+            eps = None if noise_tape is None else noise_tape[1 + k].to(device=dev, dtype=th.float32)
+            with th.no_grad():
+                if sampler == "ddpm":
+                    out = self.p_sample(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs, _noise=eps)
+                else:
+                    out = self.ddim_sample(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs, eta=eta, _noise=eps)
+            yield out
+            img = out["sample"]
 
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                       device=None, progress=False, skip_timesteps=0, init_image=None, randomize_class=False,

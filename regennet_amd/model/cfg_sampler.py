@@ -19,9 +19,9 @@ class ClassifierFreeSampleModel(nn.Module):
         self.data_rep = self.model.data_rep
         self.cond_mode = self.model.cond_mode
 
-    def _rgn_bind(self, B, y, device=None):
+    def _rgn_bind(self, B, y, device=None, T=None, cache=False):
         assert self.model.cond_mode in ["text", "action"]
-        return self.model._rgn_bind(B, y, device, guided=True)
+        return self.model._rgn_bind(B, y, device, guided=True, T=T, cache=cache)
 
     def forward(self, x, timesteps, y=None):
         assert self.model.cond_mode in ["text", "action"]

@@ -132,10 +132,13 @@ class CMDM(nn.Module):
         self.output_process = _Pose("poseFinal", d, self.input_feats)
         self.rot2xyz = _Rot2xyzUnavailable()
 
-        self.precision = os.environ.get("REGENNET_PRECISION", kargs.get("precision", "bf16x3"))
+        self.precision = os.environ.get("REGENNET_PRECISION", kargs.get("precision", _lib.DEFAULT_PRECISION))
+        # precision schedule: split-bf16 for the last x3_tail loop indices of a sampling loop (None: engine default)
+        self.x3_tail = kargs.get("x3_tail", None)
         self._engine = None
         self._engine_stale = True
         self._cond_key = None
+        self._keep = None
         for p in self.parameters():
             p.requires_grad_(False)
 
@@ -163,38 +166,51 @@ class CMDM(nn.Module):
         return torch.full((sz, sz), float("-inf")).triu(1)      # cmdm.py:168-171
 
     # ---- engine management ----------------------------------------------------------------------------
-    def engine_config(self):
-        return dict(njoints=self.njoints, nfeats=self.nfeats, num_frames=self.num_frames, latent_dim=self.latent_dim,
-                    ff_size=self.ff_size, num_heads=self.num_heads, layers=self.num_layers, cm_mode=self.cm_mode,
-                    cond_mode=self.cond_mode, num_actions=self.num_actions, clip_dim=self.clip_dim,
+    def engine_config(self, num_frames=None):
+        return dict(njoints=self.njoints, nfeats=self.nfeats, num_frames=int(num_frames or self.num_frames),
+                    latent_dim=self.latent_dim, ff_size=self.ff_size, num_heads=self.num_heads, layers=self.num_layers,
+                    cm_mode=self.cm_mode, cond_mode=self.cond_mode, num_actions=self.num_actions, clip_dim=self.clip_dim,
                     emb_trans_dec=self.emb_trans_dec, wo_pos_emb=self.wo_pos_emb)
 
-    def _get_engine(self, B):
+    def _get_engine(self, B, T=None):
+        """The engine for batches of up to B motions of T frames (default: num_frames). Like the reference's module, the
+        model itself is length-agnostic (the sequence length comes from x.shape, cmdm.py:176); the engine's workspace is
+        sized per (max batch, T), so a call with a different T or a larger B rebuilds it."""
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("regennet_amd CMDM runs on an AMD GPU only: call model.to(dist_util.dev()) first "
                                "(there is no CPU fallback; the CPU restatement lives in oracle/ as a test checker)")
+        T = int(T or (self._engine.cfg["num_frames"] if self._engine is not None and not self._engine_stale else self.num_frames))
         eng = self._engine
-        if eng is None or self._engine_stale or B > eng.max_batch or eng.precision != self.precision:
+        if eng is None or self._engine_stale or B > eng.max_batch or eng.precision != self.precision or eng.cfg["num_frames"] != T:
+            max_b = B
             if eng is not None:
                 torch.cuda.synchronize(dev)
+                if eng.cfg["num_frames"] == T:
+                    max_b = max(B, eng.max_batch)
                 eng.close()
-            max_b = max(B, eng.max_batch if eng is not None else 0)
-            eng = _lib.Engine(self.engine_config(), max_b, dev.index or 0, self.precision)
+            eng = _lib.Engine(self.engine_config(T), max_b, dev.index or 0, self.precision)
             for k, v in self.state_dict().items():
                 if k.startswith("clip_model."):
                     continue
                 eng.load_weight(k, v.detach().float().cpu().numpy())
             eng.finalize()
-            self._engine, self._engine_stale, self._cond_key = eng, False, None
+            self._engine, self._engine_stale, self._cond_key, self._keep = eng, False, None, None
+        tail = os.environ.get("REGENNET_X3_TAIL", self.x3_tail)
+        eng.set_x3_tail(-1 if tail is None else int(tail))
         return eng, dev
 
-    def _rgn_bind(self, B, y, device=None, guided=False):
-        """Bind model_kwargs['y'] on the engine (idempotent for an unchanged y). Returns (engine, guided, device)."""
-        eng, dev = self._get_engine(B)
+    def _rgn_bind(self, B, y, device=None, guided=False, T=None, cache=False):
+        """Bind model_kwargs['y'] on the engine. Returns (engine, guided, device).
+
+        Sampling loops rebind on every call (one pack kernel + one GEMM: nothing next to the step loop). Only the per-step
+        `forward()` API (cache=True) skips the bind for an unchanged y: the key is the identity and version counter of the
+        caller's own tensors, and those tensors are held until the next bind so that their ids cannot be recycled."""
+        T = int(T or self.num_frames)
+        eng, dev = self._get_engine(B, T)
         cm = y["cmotion"]
-        assert tuple(cm.shape) == (B, self.njoints, self.nfeats, self.num_frames), \
-            f"y['cmotion'] {tuple(cm.shape)} != {(B, self.njoints, self.nfeats, self.num_frames)}"
+        assert tuple(cm.shape) == (B, self.njoints, self.nfeats, T), \
+            f"y['cmotion'] {tuple(cm.shape)} != {(B, self.njoints, self.nfeats, T)}"
         action = text = scale = None
         if self.cond_mode == "action":
             action = y["action"]
@@ -204,21 +220,29 @@ class CMDM(nn.Module):
                 text = self.encode_text(y["text"])
         if guided:
             scale = y["scale"]
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) if t is not None else None
-                    for t in (cm, action, text, scale)) + (B,)
-        if key != self._cond_key:
-            cm = cm.to(device=dev, dtype=torch.float32).contiguous()
-            if action is not None:
-                action = action.to(device=dev).reshape(B, -1)[:, 0].to(torch.int64).contiguous()
-            if text is not None:
-                text = text.to(device=dev, dtype=torch.float32).contiguous()
-                assert tuple(text.shape) == (B, self.clip_dim)
-            if scale is not None:
-                scale = scale.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
-                assert tuple(scale.shape) == (B,)
-            eng.set_condition(B, cm, action, text, scale, torch.cuda.current_stream(dev).cuda_stream)
-            self._keep = (cm, action, text, scale)   # keep device copies alive until the stream consumed them
-            self._cond_key = key
+        src = (cm, action, text, scale)
+        key = tuple((id(t), t._version, tuple(t.shape)) if t is not None else None for t in src) + (B, T, guided)
+        if cache and key == self._cond_key:
+            return eng, guided, dev
+        cm_d = cm.to(device=dev, dtype=torch.float32).contiguous()
+        if action is not None:
+            action_d = action.to(device=dev).reshape(B, -1)[:, 0].to(torch.int64).contiguous()
+            lo, hi = int(action_d.min()), int(action_d.max())       # EmbedAction indexes a [num_actions, d] table (cmdm.py:363-365)
+            if lo < 0 or hi >= self.num_actions:
+                raise IndexError(f"y['action'] holds ids in [{lo}, {hi}] but the model has {self.num_actions} actions")
+        else:
+            action_d = None
+        text_d = scale_d = None
+        if text is not None:
+            text_d = text.to(device=dev, dtype=torch.float32).contiguous()
+            assert tuple(text_d.shape) == (B, self.clip_dim)
+        if scale is not None:
+            scale_d = scale.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+            assert tuple(scale_d.shape) == (B,)
+        eng.set_condition(B, cm_d, action_d, text_d, scale_d, torch.cuda.current_stream(dev).cuda_stream)
+        # device copies stay alive until the stream consumed them; the caller's tensors until the key is replaced
+        self._keep = (cm_d, action_d, text_d, scale_d) + (src if cache else ())
+        self._cond_key = key if cache else None
         return eng, guided, dev
 
     # ---- cmdm.py:173-252 -------------------------------------------------------------------------------
@@ -226,9 +250,11 @@ class CMDM(nn.Module):
         """x [B,njoints,nfeats,T] (x_t); timesteps [B] int; y dict with 'cmotion' (+ 'action'/'text_features',
         'uncond', 'scale'). Returns x0_hat [B,njoints,nfeats,T] on x's device."""
         bs, njoints, nfeats, nframes = x.shape
-        assert (njoints, nfeats, nframes) == (self.njoints, self.nfeats, self.num_frames)
-        eng, _, dev = self._rgn_bind(bs, y, guided=_guided)
+        assert (njoints, nfeats) == (self.njoints, self.nfeats)
+        eng, _, dev = self._rgn_bind(bs, y, guided=_guided, T=nframes, cache=True)
         assert tuple(timesteps.shape) == (bs,)
+        if timesteps.numel() and (int(timesteps.min()) < 0 or int(timesteps.max()) >= self.sequence_pos_encoder.pe.shape[0]):
+            raise IndexError("timesteps outside the positional table (TimestepEmbedder, cmdm.py:298)")
         xc = x.to(device=dev, dtype=torch.float32).contiguous()
         tc = timesteps.to(device=dev, dtype=torch.int64).contiguous()
         out = torch.empty_like(xc)

@@ -145,3 +145,32 @@ def make_text_features(cfg, batch, seed=3):
     f = rng.standard_normal((batch, cfg.get("clip_dim", 512)))
     f /= np.linalg.norm(f, axis=-1, keepdims=True)
     return f.astype(np.float32)
+
+
+def build_model(cfg, sd, resp="", precision=None, device="cuda:0", noise_schedule="cosine", sigma_small=True, x3_tail=None):
+    """(model, diffusion) from regennet_amd for a synth config + checkpoint dict (reference key names): the same
+    constructor calls the reference factory makes (utils/model_util.py:66-117), for tests, bench.py and tools."""
+    import torch
+
+    from .diffusion import gaussian_diffusion as gd
+    from .diffusion.respace import SpacedDiffusion, space_timesteps
+    from .model.cmdm import CMDM
+    from .utils.model_util import load_model_wo_clip
+
+    kw = {} if precision is None else {"precision": precision}
+    model = CMDM("", cfg["njoints"], cfg["nfeats"], cfg["num_actions"], True, "rot6d", True, True,
+                 num_frames=cfg["num_frames"], latent_dim=cfg["latent_dim"], ff_size=cfg["ff_size"],
+                 num_layers=cfg["layers"], num_heads=cfg["num_heads"], dropout=0.1, activation="gelu",
+                 data_rep="rot6d", dataset=cfg["dataset"], arch="online", cm_mode=cfg["cm_mode"], body_model="smplx",
+                 cond_mode=cfg["cond_mode"], cond_mask_prob=cfg["cond_mask_prob"], action_emb="tensor",
+                 emb_trans_dec=cfg.get("emb_trans_dec", False), wo_pos_emb=cfg.get("wo_pos_emb", False),
+                 x3_tail=x3_tail, **kw)
+    load_model_wo_clip(model, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.to(device)
+    model.eval()
+    diffusion = SpacedDiffusion(use_timesteps=space_timesteps(1000, resp or [1000]),
+                                betas=gd.get_named_beta_schedule(noise_schedule, 1000, 1.0),
+                                model_mean_type=gd.ModelMeanType.START_X,
+                                model_var_type=gd.ModelVarType.FIXED_SMALL if sigma_small else gd.ModelVarType.FIXED_LARGE,
+                                loss_type=gd.LossType.MSE, rescale_timesteps=False)
+    return model, diffusion

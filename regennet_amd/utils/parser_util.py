@@ -68,7 +68,7 @@ def add_generate_options(p):
     # inputs the reference takes from its (licence-restricted) h5 datasets; here an .npz or synthetic data
     g.add_argument("--cmotion_npz", default="", type=str, help="npz with 'cmotion' [N,56,6,T] (+ 'action' [N]) actor clips")
     g.add_argument("--synthetic", action="store_true", help="synthetic checkpoint + actor motions (no assets needed)")
-    g.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"], type=str)
+    g.add_argument("--precision", default="bf16_x3tail", choices=["f32", "bf16x3", "bf16", "bf16_x3tail"], type=str)
 
 
 def _group_keys(parser, args, title):

@@ -266,6 +266,9 @@ JOBS = {
     "ntu_ddpm50": lambda: gen_loop("ntu_ddpm50", "ntu", 2, "50", "ddpm"),
     "ntu_action_ddim100_cfg": lambda: gen_loop("ntu_action_ddim100_cfg", "ntu_action", 2, "ddim100", "ddim", guided=True),
     "chi3d_fwd": lambda: gen_forward("chi3d_fwd", "chi3d", 2, [0, 999]),
+    # Chi3D (T=150, 8 action classes) sampling loops: DDPM and guided DDIM
+    "chi3d_ddpm20": lambda: gen_loop("chi3d_ddpm20", "chi3d", 2, "20", "ddpm"),
+    "chi3d_ddim20_cfg": lambda: gen_loop("chi3d_ddim20_cfg", "chi3d", 2, "ddim20", "ddim", guided=True),
     "text150_ddim50_cfg": lambda: gen_loop("text150_ddim50_cfg", "text150", 2, "ddim50", "ddim", guided=True),
     # long: the headline configuration (1000-step DDPM), B=2
     "ntu_ddpm1000": lambda: gen_loop("ntu_ddpm1000", "ntu", 2, "", "ddpm"),

@@ -64,31 +64,10 @@ def autoreg_inputs(g):
 
 
 # ---- HIP-side construction (GPU tests) --------------------------------------------------------------
-def build_hip(cfg, sd, resp="", precision="f32", device="cuda:0", noise_schedule="cosine", sigma_small=True):
+def build_hip(cfg, sd, resp="", precision="f32", device="cuda:0", noise_schedule="cosine", sigma_small=True, x3_tail=None):
     """(model, diffusion) from regennet_amd for a synth config + synthetic checkpoint."""
-    import torch
-
-    from regennet_amd.diffusion import gaussian_diffusion as gd
-    from regennet_amd.diffusion.respace import SpacedDiffusion, space_timesteps
-    from regennet_amd.model.cmdm import CMDM
-    from regennet_amd.utils.model_util import load_model_wo_clip
-
-    model = CMDM("", cfg["njoints"], cfg["nfeats"], cfg["num_actions"], True, "rot6d", True, True,
-                 num_frames=cfg["num_frames"], latent_dim=cfg["latent_dim"], ff_size=cfg["ff_size"],
-                 num_layers=cfg["layers"], num_heads=cfg["num_heads"], dropout=0.1, activation="gelu",
-                 data_rep="rot6d", dataset=cfg["dataset"], arch="online", cm_mode=cfg["cm_mode"], body_model="smplx",
-                 cond_mode=cfg["cond_mode"], cond_mask_prob=cfg["cond_mask_prob"], action_emb="tensor",
-                 emb_trans_dec=cfg.get("emb_trans_dec", False), wo_pos_emb=cfg.get("wo_pos_emb", False),
-                 precision=precision)
-    load_model_wo_clip(model, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
-    model.to(device)
-    model.eval()
-    diffusion = SpacedDiffusion(use_timesteps=space_timesteps(1000, resp or [1000]),
-                                betas=gd.get_named_beta_schedule(noise_schedule, 1000, 1.0),
-                                model_mean_type=gd.ModelMeanType.START_X,
-                                model_var_type=gd.ModelVarType.FIXED_SMALL if sigma_small else gd.ModelVarType.FIXED_LARGE,
-                                loss_type=gd.LossType.MSE, rescale_timesteps=False)
-    return model, diffusion
+    return synth.build_model(cfg, sd, resp=resp, precision=precision, device=device, noise_schedule=noise_schedule,
+                             sigma_small=sigma_small, x3_tail=x3_tail)
 
 
 def y_to_device(y, device="cuda:0"):
