@@ -124,7 +124,8 @@ struct rgn_ctx {
     int xin_rows = -1;                 // row count the xin planes are currently laid out for
     bool cond_has_scale = false;
 
-    // graphs: key = B | guided<<20 | sampler<<21 | phase_x3<<23
+    // graphs: key = B | guided<<20 | sampler<<21 | phase_x3<<23 | steps<<24
+    int graph_steps = 10;              // loop iterations per captured graph for long ranges (REGENNET_GRAPH_STEPS)
     std::map<uint64_t, hipGraphExec_t> graphs;
 
     // profiling
@@ -914,6 +915,7 @@ int rgn_finalize_weights(rgn_handle h) {
     }
     RGN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     if (const char* e = getenv("REGENNET_BULK_RESID_LO")) c->bulk_resid_lo = atoi(e) != 0;
+    if (const char* e = getenv("REGENNET_GRAPH_STEPS")) c->graph_steps = atoi(e) < 1 ? 1 : (atoi(e) > 100 ? 100 : atoi(e));
     if (const char* e = getenv("REGENNET_STREAMS")) c->nchains = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
     RGN_HIP(c, hipMemset(c->xin, 0, Mb * F * sizeof(float)));
     RGN_HIP(c, hipMemset(c->cmo_in, 0, Mb * F * sizeof(float)));
@@ -1084,8 +1086,13 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
     // One captured step graph per phase; everything t-dependent is read on the device, so each serves all its steps.
     const bool sched = c->cfg.precision == RGN_PREC_BF16_X3TAIL;
     const int tail = !sched ? 0 : (c->x3_tail >= 0 ? c->x3_tail : default_tail(c->S));
-    auto graph_for = [&](bool x3, hipGraphExec_t* out) -> int {
-        const uint64_t key = (uint64_t)c->B | ((uint64_t)(guided != 0) << 20) | ((uint64_t)sampler << 21) | ((uint64_t)x3 << 23);
+    // A graph holds `steps` consecutive loop iterations (evaluation + sampler update + counter decrement each): the loop
+    // index lives on the device, so one instantiated graph serves any starting index. Long ranges replay the multi-step
+    // graph (graph_steps iterations per host launch; a 4-branch launch costs the host ~1 ms, as much as the GPU needs for
+    // a step at B = 256), the remainder single-step graphs.
+    auto graph_for = [&](bool x3, int steps, hipGraphExec_t* out) -> int {
+        const uint64_t key = (uint64_t)c->B | ((uint64_t)(guided != 0) << 20) | ((uint64_t)sampler << 21) | ((uint64_t)x3 << 23) |
+                             ((uint64_t)steps << 24);
         auto it = c->graphs.find(key);
         if (it != c->graphs.end()) {
             *out = it->second;
@@ -1095,8 +1102,11 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
         hipGraphExec_t ge = nullptr;
         c->phase_x3 = x3;
         RGN_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        int r = run_eval(c, c->B, guided != 0, false, true, s);
-        if (r == RGN_OK && launch_advance(c->d_step, s) != hipSuccess) r = c->fail(RGN_ERR_HIP, "launch_advance");
+        int r = RGN_OK;
+        for (int k = 0; k < steps && r == RGN_OK; ++k) {
+            r = run_eval(c, c->B, guided != 0, false, true, s);
+            if (r == RGN_OK && launch_advance(c->d_step, s) != hipSuccess) r = c->fail(RGN_ERR_HIP, "launch_advance");
+        }
         hipError_t e = hipStreamEndCapture(s, &graph);
         if (r) {
             if (graph) (void)hipGraphDestroy(graph);
@@ -1110,17 +1120,24 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
         return RGN_OK;
     };
     const bool graphs = use_graph && !c->prof;
-    hipGraphExec_t gexec[2] = {nullptr, nullptr};   // [phase_x3]
-    for (int k = 0; k < count; ++k) {
-        const bool x3 = !sched || (first_index - k) < tail;
+    const int multi = c->graph_steps;
+    int k = 0;
+    while (k < count) {
+        const int i = first_index - k;                       // loop index of the next step
+        const bool x3 = !sched || i < tail;
+        const int phase_left = x3 ? (count - k) : ((i - tail + 1) < (count - k) ? (i - tail + 1) : (count - k));   // steps left in this phase
         if (graphs) {
-            if (!gexec[x3] && (rc = graph_for(x3, &gexec[x3]))) return rc;
-            RGN_HIP(c, hipGraphLaunch(gexec[x3], s));
+            const int steps = (multi > 1 && phase_left >= multi) ? multi : 1;
+            hipGraphExec_t ge = nullptr;
+            if ((rc = graph_for(x3, steps, &ge))) return rc;
+            RGN_HIP(c, hipGraphLaunch(ge, s));
+            k += steps;
         } else {
             c->phase_x3 = x3;
             rc = run_eval(c, c->B, guided != 0, false, true, s);
             if (rc) return rc;
             RGN_LAUNCH(c, KC_MISC, s, launch_advance(c->d_step, s));
+            k += 1;
         }
     }
     c->phase_x3 = true;

@@ -48,7 +48,10 @@ template <bool X3>
 __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn(QkvAttnArgs g) {
     constexpr int NPL = X3 ? 2 : 1;
     constexpr int A_BYTES = QA_NS * QA_ROWS * 64, W_BYTES = QA_WROWS * 64;
-    constexpr int STAGE = NPL * (A_BYTES + W_BYTES);                 // 64 KiB (x3)
+    constexpr int STAGE = NPL * (A_BYTES + W_BYTES);                 // 64 KiB (x3), 32 KiB (plain bf16)
+    // pipeline depth: the same 128 KiB hold two split-bf16 stages or four plain-bf16 ones; what a CU pulls from L2 is set by
+    // the bytes it keeps in flight (tools/l2_paths_bench), so the plain-bf16 build prefetches three tiles ahead
+    constexpr int NSTG = X3 ? 2 : 4;
     constexpr int W_IT = QA_WROWS * 4 / QA_NT;                       // 3
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -120,17 +123,22 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn(QkvAttnArgs g) {
                 for (int i = 0; i < 16; ++i) acc[ta][t][i] = 0.f;
         RGN_QT((hd - hd0) * 8 + 0)
 #pragma unroll
-        for (int idx = 0; idx < LPT; ++idx) piece(idx, 0, smem);
+        for (int t0 = 0; t0 < NSTG - 1; ++t0)
+#pragma unroll
+            for (int idx = 0; idx < LPT; ++idx) piece(idx, t0, smem + t0 * STAGE);   // nk >= NSTG - 1 (host-checked)
         // One barrier per k-step: tile kt+1's pieces are issued two at a time behind the MFMA groups of the first K half of
         // tile kt (a back-to-back burst would stall the in-order wave for the whole queue of the CU's vector-memory
         // path), into the stage every wave finished reading before this step's barrier; fragments are fetched one MFMA
         // group (one W tile x both A tiles) ahead.
         for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my pieces of tile kt landed
+            // my pieces of tile kt landed; tiles kt+1 .. kt+NSTG-2 stay in flight (fewer near the end of the loop)
+            if (NSTG == 2 || kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (kt + 2 >= nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // LPT = 4 in the plain-bf16 build
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             __builtin_amdgcn_s_barrier();                          // ... everyone's did, and everyone left step kt-1
-            const char* sb = smem + (kt & 1) * STAGE;
-            char* nb = smem + ((kt + 1) & 1) * STAGE;
-            const bool more = kt + 1 < nk;
+            const char* sb = smem + (kt % NSTG) * STAGE;
+            char* nb = smem + ((kt + NSTG - 1) % NSTG) * STAGE;
+            const bool more = kt + NSTG - 1 < nk;
             bf16x8 ah[2][2], al[2][2], wh[2], wl[2];
             auto fetch = [&](int grp) {                             // grp = ks * 3 + t
                 const int ks = grp / 3, t = grp % 3;
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn(QkvAttnArgs g) {
                 }
                 if (more && grp < 4) {
 #pragma unroll
-                    for (int q = 0; q < LPT / 4; ++q) piece(grp * (LPT / 4) + q, kt + 1, nb);
+                    for (int q = 0; q < LPT / 4; ++q) piece(grp * (LPT / 4) + q, kt + NSTG - 1, nb);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn(QkvAttnArgs g) {
     }
 }
 
-bool qkv_attn_supported(int Tq, int dh, int d) { return Tq <= QA_ROWS && dh == QA_DH && d % 32 == 0 && d / dh <= 8; }
+bool qkv_attn_supported(int Tq, int dh, int d) { return Tq <= QA_ROWS && dh == QA_DH && d % 32 == 0 && d / dh <= 8 && d >= 128; }
 static int qa_lds(bool x3) { return 2 * (x3 ? 2 : 1) * (QA_NS * QA_ROWS * 64 + QA_WROWS * 64) + 8 * QA_WROWS * 4 /* biases of <= 8 heads (odd H: one workgroup runs them all) */; }
 hipError_t configure_qkv_attn() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, qa_lds(true));

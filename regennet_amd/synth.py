@@ -147,6 +147,42 @@ def make_text_features(cfg, batch, seed=3):
     return f.astype(np.float32)
 
 
+def make_stgcn_state_dict(A, num_class=26, in_channels=12, num_person=2, seed=0):
+    """Synthetic checkpoint of the ST-GCN evaluator with the reference's state_dict keys
+    (eval/a2m/recognition/models/stgcn.py:44-73,183-219; stgcnutils/tgcn.py:51-59). `A` [K, V, V] is the adjacency buffer
+    the reference registers (stgcn.py:42); BatchNorm running statistics are non-trivial so that folding them is exercised."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    K, V = int(A.shape[0]), int(A.shape[1])
+    sd = {"A": np.asarray(A, dtype=np.float32)}
+
+    def bn(prefix, c):
+        sd[prefix + ".weight"] = (1.0 + 0.2 * rng.standard_normal(c)).astype(np.float32)
+        sd[prefix + ".bias"] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+        sd[prefix + ".running_mean"] = (0.2 * rng.standard_normal(c)).astype(np.float32)
+        sd[prefix + ".running_var"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+        sd[prefix + ".num_batches_tracked"] = np.array(100, dtype=np.int64)
+
+    def conv(prefix, co, ci, kt, gain=1.0):
+        sd[prefix + ".weight"] = (rng.standard_normal((co, ci, kt, 1)) * (gain / np.sqrt(ci * kt))).astype(np.float32)
+        sd[prefix + ".bias"] = (0.05 * rng.standard_normal(co)).astype(np.float32)
+
+    bn("data_bn", in_channels * V)
+    chans = [(in_channels // num_person, 64, 1), (64, 64, 1), (64, 64, 1), (64, 64, 1), (64, 128, 2), (128, 128, 1), (128, 128, 1),
+             (128, 256, 2), (256, 256, 1), (256, 256, 1)]
+    for i, (ci, co, stride) in enumerate(chans):
+        p = f"st_gcn_networks.{i}."
+        conv(p + "gcn.conv", co * K, ci, 1, gain=1.5)
+        bn(p + "tcn.0", co)
+        conv(p + "tcn.2", co, co, 9, gain=1.5)
+        bn(p + "tcn.3", co)
+        if i > 0 and (ci != co or stride != 1):
+            conv(p + "residual.0", co, ci, 1)
+            bn(p + "residual.1", co)
+        sd[f"edge_importance.{i}"] = (1.0 + 0.3 * rng.standard_normal((K, V, V))).astype(np.float32)
+    conv("fcn", num_class, 256, 1)
+    return sd
+
+
 def build_model(cfg, sd, resp="", precision=None, device="cuda:0", noise_schedule="cosine", sigma_small=True, x3_tail=None):
     """(model, diffusion) from regennet_amd for a synth config + checkpoint dict (reference key names): the same
     constructor calls the reference factory makes (utils/model_util.py:66-117), for tests, bench.py and tools."""

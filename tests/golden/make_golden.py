@@ -237,10 +237,71 @@ def gen_fid():
     save("fid", **out)
 
 
+# SMPL-X kinematic tree (parent of joint i; 55 joints), the public skeleton layout the reference reads from the licensed
+# SMPLX_NEUTRAL.npz (eval/a2m/recognition/models/stgcnutils/graph.py:81-88). Only used to let the reference build its graph
+# here; the product takes the adjacency from the checkpoint's `A` buffer.
+SMPLX_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 15, 15, 15, 20, 25, 26, 20, 28, 29, 20, 31,
+                 32, 20, 34, 35, 20, 37, 38, 21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50, 21, 52, 53]
+
+
+def build_ref_stgcn(num_class):
+    _ref_import.install()
+    import tempfile
+    import utils.config as rc
+    d = tempfile.mkdtemp()
+    kt = np.stack([np.array(SMPLX_PARENTS, dtype=np.int64) % (2 ** 32), np.arange(55, dtype=np.int64)])
+    np.savez(os.path.join(d, "SMPLX_NEUTRAL.npz"), kintree_table=kt)
+    rc.SMPLX_KINTREE_PATH = os.path.join(d, "SMPLX_NEUTRAL.npz")
+    sys.modules.pop("eval.a2m.recognition.models.stgcnutils.graph", None)
+    from eval.a2m.recognition.models.stgcn import STGCN
+    return STGCN(in_channels=12, num_class=num_class, num_person=2, graph_args={"layout": "smplx", "strategy": "spatial"},
+                 edge_importance_weighting=True, device="cpu")
+
+
+def gen_stgcn():
+    """next-4 row: the ST-GCN feature extractor / classifier (eval/a2m/recognition/models/stgcn.py:76-123) on synthetic
+    weights (regennet_amd.synth.make_stgcn_state_dict, reference key names) + diversity / multimodality
+    (eval/a2m/stgcn/diversity.py:6) and accuracy (accuracy.py:4) on seeded activations."""
+    num_class = 26
+    model = build_ref_stgcn(num_class)
+    A = model.A.numpy().copy()
+    sd = synth.make_stgcn_state_dict(A, num_class=num_class, seed=0)
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.eval()
+    out = {"A": A, "sd_digest": sd_digest(sd)}
+    for tag, (N, T) in {"ntu": (5, 60), "chi3d": (2, 150), "one": (1, 60)}.items():
+        rng = np.random.Generator(np.random.PCG64(70 + T + N))
+        x = rng.standard_normal((N, 56, 12, T)).astype(np.float32)
+        with torch.no_grad():
+            b = model({"output": torch.from_numpy(x)})
+        out[f"x_{tag}"] = x
+        out[f"features_{tag}"] = b["features"].numpy().reshape(N, -1)
+        out[f"yhat_{tag}"] = b["yhat"].numpy()
+    from eval.a2m.stgcn.diversity import calculate_diversity_multimodality
+    from eval.a2m.stgcn.accuracy import calculate_accuracy
+    rng = np.random.Generator(np.random.PCG64(90))
+    act = rng.standard_normal((300, 256)).astype(np.float32)
+    labels = rng.integers(0, num_class, 300).astype(np.int64)
+    labels[labels == 7] = 8                                  # one class absent: its multimodality quota stays zero
+    div, mm = calculate_diversity_multimodality(torch.from_numpy(act), torch.from_numpy(labels), num_class, seed=123)
+    out.update(div_act=act, div_labels=labels, diversity=np.float64(div), multimodality=np.float64(mm))
+
+    class _Cls:      # stand-in classifier: yhat supplied per batch (accuracy.py only reads classifier(batch)["yhat"])
+        def __call__(self, batch):
+            return {"yhat": batch["yhat_in"]}
+    yh = rng.standard_normal((64, num_class)).astype(np.float32)
+    ys = rng.integers(0, num_class, 64).astype(np.int64)
+    loader = [{"yhat_in": torch.from_numpy(yh[i:i + 16]), "y": torch.from_numpy(ys[i:i + 16])} for i in range(0, 64, 16)]
+    acc, conf = calculate_accuracy(None, loader, num_class, _Cls(), "cpu")
+    out.update(acc_yhat=yh, acc_y=ys, accuracy=np.float64(acc), confusion=conf.numpy())
+    save("stgcn", **out)
+
+
 JOBS = {
     "schedules": gen_schedules,
     "postproc": gen_post,
     "fid": gen_fid,
+    "stgcn": gen_stgcn,
     "tiny_fwd": lambda: gen_forward("tiny_fwd", "tiny", 3, [0, 1, 500, 999]),
     "tiny_fwd_cfg": lambda: gen_forward("tiny_fwd_cfg", "tiny", 3, [0, 700], guided=True),
     "tiny_add_fwd": lambda: gen_forward("tiny_add_fwd", "tiny_add", 2, [3, 999]),

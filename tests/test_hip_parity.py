@@ -401,7 +401,7 @@ def test_chi3d_full_size_shard_is_row_independent(precision, tail):
 
 
 @pytest.mark.parametrize("precision,tail,tol", [("f32", None, 2e-4), ("bf16x3", None, 1e-3), ("bf16_x3tail", None, 1e-3),
-                                                 ("bf16_x3tail", 0, 6e-2)])
+                                                 ("bf16_x3tail", 0, 0.15)])
 def test_bench_shape_against_the_oracle(precision, tail, tol):
     """HIP vs oracle AT THE BENCH SHAPE (B=256, NTU): 3 DDPM steps unguided (4 kernel chains + the step graph) and 3 DDIM
     steps guided (512 rows per evaluation -> the 256x256 GEMM tile). The last case runs all three steps in the plain-bf16

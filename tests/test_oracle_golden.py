@@ -121,3 +121,30 @@ def test_sampler_options_match_reference(golden, name):
                           clip_denoised=o.get("clip_denoised", False), skip_timesteps=o.get("skip_timesteps", 0),
                           init_image=None if init is None else torch.from_numpy(init))
     np.testing.assert_allclose(out.numpy(), g["final"], atol=1e-4, rtol=0)
+
+
+# ---- next-4 row: ST-GCN evaluator, diversity / multimodality, accuracy ------------------------------------------------------
+def _stgcn_sd(g):
+    sd = synth.make_stgcn_state_dict(g["A"], num_class=26, seed=0)
+    from tests.helpers import sd_digest
+    assert sd_digest(sd) == str(g["sd_digest"]), "synthetic ST-GCN checkpoint drifted from the golden fixture"
+    return sd
+
+
+@pytest.mark.parametrize("tag", ["ntu", "chi3d", "one"])
+def test_stgcn_forward_matches_reference(golden, tag):
+    from oracle import stgcn_oracle as so
+    g = golden("stgcn")
+    feats, yhat = so.stgcn_forward(_stgcn_sd(g), g[f"x_{tag}"])
+    np.testing.assert_allclose(feats.numpy(), g[f"features_{tag}"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(yhat.numpy(), g[f"yhat_{tag}"], atol=2e-5, rtol=1e-5)
+
+
+def test_diversity_multimodality_accuracy_match_reference(golden):
+    from oracle import stgcn_oracle as so
+    g = golden("stgcn")
+    div, mm = so.calculate_diversity_multimodality(g["div_act"], g["div_labels"], 26, seed=123)
+    assert abs(div - float(g["diversity"])) < 1e-5 and abs(mm - float(g["multimodality"])) < 1e-5
+    yh, ys = g["acc_yhat"], g["acc_y"]
+    acc, conf = so.calculate_accuracy([yh[i:i + 16] for i in range(0, 64, 16)], [ys[i:i + 16] for i in range(0, 64, 16)], 26)
+    assert abs(acc - float(g["accuracy"])) < 1e-7 and np.array_equal(conf.numpy(), g["confusion"])

@@ -22,6 +22,7 @@ namespace rgn { void qa_prof_read(long long* out); }
 int main(int argc, char** argv) {
     const int Bm = argc > 1 ? atoi(argv[1]) : 256, Tq = argc > 2 ? atoi(argv[2]) : 60, iters = argc > 3 ? atoi(argv[3]) : 50;
     const int d = 512, H = 4, M = Bm * Tq, Kp = d;
+    const bool x3 = getenv("BF16") == nullptr;   // BF16=1: the plain-bf16 phase build (hi planes only)
     std::mt19937 rng(1);
     std::uniform_int_distribution<int> U(0x3c00, 0x3fff);   // bf16 bit patterns in [0.0078, 2)
     auto fill = [&](size_t n) { std::vector<uint16_t> v(n); for (auto& x : v) x = (uint16_t)U(rng); return v; };
@@ -31,12 +32,12 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&Ohi, (size_t)M * d * 2)); CK(hipMalloc(&Olo, (size_t)M * d * 2)); CK(hipMalloc(&bias, 3 * d * 4)); CK(hipMemset(bias, 0, 3 * d * 4));
     QkvAttnArgs g{};
     g.Ahi = Ahi; g.Alo = Alo; g.a_rows = M; g.Whi = Whi; g.Wlo = Wlo; g.bias = bias;
-    g.out.hi = Ohi; g.out.lo = Olo; g.out.rows = M; g.Bm = Bm; g.Kp = Kp; g.d = d; g.H = H; g.Tq = Tq; g.qscale = 0.0884f;
+    g.out.hi = Ohi; g.out.lo = x3 ? Olo : nullptr; g.out.rows = M; g.Bm = Bm; g.Kp = Kp; g.d = d; g.H = H; g.Tq = Tq; g.qscale = 0.0884f;
     CK(configure_qkv_attn());
-    for (int i = 0; i < 3; ++i) CK(launch_qkv_attn(g, true, nullptr));
+    for (int i = 0; i < 3; ++i) CK(launch_qkv_attn(g, x3, nullptr));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < iters; ++i) CK(launch_qkv_attn(g, true, nullptr));
+    for (int i = 0; i < iters; ++i) CK(launch_qkv_attn(g, x3, nullptr));
     CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = 1e3 * ms / iters, fl = 2.0 * M * 3 * d * d + 4.0 * Bm * H * Tq * Tq * 128;
