@@ -161,6 +161,32 @@ int rgn_profile_query(rgn_handle h, int32_t idx, const char** name, double* tota
  * latency every bracket of rgn_profile_query carries on top of the kernel itself (calibrated at the first enable). */
 int rgn_profile_bracket_overhead(rgn_handle h, double* ms);
 
+/* ---- Evaluation harness next to the sampler: the ST-GCN feature extractor / action classifier ----
+ * Replaces eval/a2m/recognition/models/stgcn.py:28-123 (STGCN) as used by eval/a2m/stgcn/evaluate.py:9-45: the features
+ * feed FID / diversity / multimodality, yhat the accuracy. Checkpoint keys are the reference's state_dict names
+ * ('A', 'data_bn.*', 'st_gcn_networks.<i>.{gcn.conv,tcn.0,tcn.2,tcn.3,residual.0,residual.1}.*', 'edge_importance.<i>',
+ * 'fcn.*'); '*.num_batches_tracked' entries are accepted and ignored. */
+typedef struct rgn_stgcn_ctx* rgn_stgcn_handle;
+typedef struct {
+    int32_t in_channels;    /* nfeats of batch['output'] = C * num_person (evaluate.py:15; 12 for two persons in rot6d) */
+    int32_t num_class;      /* evaluate.py:16 */
+    int32_t num_person;     /* evaluate.py:17 */
+    int32_t num_nodes;      /* V: graph nodes = joints (56 for the 'smplx' layout, stgcnutils/graph.py:81-82) */
+    int32_t num_frames;     /* T of batch['output'] */
+    int32_t max_batch;
+    int32_t device;
+} rgn_stgcn_config;
+int rgn_stgcn_create(const rgn_stgcn_config* cfg, rgn_stgcn_handle* out);
+int rgn_stgcn_destroy(rgn_stgcn_handle h);
+const char* rgn_stgcn_last_error(rgn_stgcn_handle h);
+/* host fp32 copies of the checkpoint tensors (model.load_state_dict, evaluate.py:24-25) */
+int rgn_stgcn_load_weight(rgn_stgcn_handle h, const char* ref_key, const float* host, const int64_t* shape, int32_t ndim);
+/* folds every BatchNorm (eval mode) and the edge importance into the convolutions; RGN_ERR_MISSING_KEY names what is absent */
+int rgn_stgcn_finalize(rgn_stgcn_handle h);
+/* STGCN.forward (stgcn.py:76-123): output_dev fp32 [N, num_nodes, in_channels, T] (batch['output']) ->
+ * features_dev fp32 [N, 256] (batch['features'], nullable) and yhat_dev fp32 [N, num_class] (batch['yhat'], nullable) */
+int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output_dev, float* features_dev, float* yhat_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

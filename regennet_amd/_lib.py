@@ -62,6 +62,19 @@ SYMBOLS = {
     "rgn_profile_bracket_overhead": (C.c_int, [_vp, C.POINTER(C.c_double)]),
 }
 
+class RgnStgcnConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("in_channels", "num_class", "num_person", "num_nodes", "num_frames", "max_batch", "device")]
+
+
+SYMBOLS.update({
+    "rgn_stgcn_create": (C.c_int, [C.POINTER(RgnStgcnConfig), C.POINTER(_vp)]),
+    "rgn_stgcn_destroy": (C.c_int, [_vp]),
+    "rgn_stgcn_last_error": (C.c_char_p, [_vp]),
+    "rgn_stgcn_load_weight": (C.c_int, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i32]),
+    "rgn_stgcn_finalize": (C.c_int, [_vp]),
+    "rgn_stgcn_forward": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
+})
+
 _lib = None
 
 
@@ -207,3 +220,45 @@ class Engine:
                 break
             out[name.value.decode()] = (ms.value, n.value)
         return out
+
+
+class StgcnEngine:
+    """Owns one rgn_stgcn_handle (the ST-GCN evaluator, include/regennet_hip.h)."""
+
+    def __init__(self, in_channels, num_class, num_person, num_nodes, num_frames, max_batch, device_index):
+        self.lib = load()
+        self.shape = (int(num_nodes), int(in_channels), int(num_frames))
+        self.num_class, self.max_batch = int(num_class), int(max_batch)
+        cfg = RgnStgcnConfig(in_channels=in_channels, num_class=num_class, num_person=num_person, num_nodes=num_nodes,
+                             num_frames=num_frames, max_batch=max_batch, device=int(device_index))
+        h = C.c_void_p()
+        code = self.lib.rgn_stgcn_create(C.byref(cfg), C.byref(h))
+        if code != RGN_OK:
+            raise RgnError(code, (self.lib.rgn_stgcn_last_error(None) or b"").decode())
+        self.h = h
+
+    def _ck(self, code):
+        if code != RGN_OK:
+            raise RgnError(code, (self.lib.rgn_stgcn_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rgn_stgcn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_weight(self, key, array):
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+        self._ck(self.lib.rgn_stgcn_load_weight(self.h, key.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+
+    def finalize(self):
+        self._ck(self.lib.rgn_stgcn_finalize(self.h))
+
+    def forward(self, N, output, features, yhat, stream):
+        self._ck(self.lib.rgn_stgcn_forward(self.h, int(N), _ptr(output), _ptr(features), _ptr(yhat), C.c_void_p(stream)))

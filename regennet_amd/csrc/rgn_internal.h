@@ -61,7 +61,7 @@ struct GemmArgs {
     int add_mod;                      // 0 -> r itself
     float* C; int ldc;
     int M, N, K, Kp;
-    int act;                          // 0 none, 1 gelu(erf), 2 silu
+    int act;                          // 0 none, 1 gelu(erf), 2 silu, 3 relu
 };
 
 // bf16 operand planes use the "K32-blocked" layout [Kp/32][rows][32] (see rgn_gemm_x3.hip).

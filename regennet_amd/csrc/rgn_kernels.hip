@@ -45,6 +45,7 @@ __device__ __forceinline__ void plane_put(const Planes& p, int row, int col, flo
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == 1) return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));  // F.gelu, exact erf
     if (act == 2) return v / (1.0f + __expf(-v));                                  // nn.SiLU (cmdm.py:293)
+    if (act == 3) return fmaxf(v, 0.f);                                            // nn.ReLU (ST-GCN evaluator)
     return v;
 }
 

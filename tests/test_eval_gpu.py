@@ -1,0 +1,107 @@
+"""GPU: the evaluation harness next to the sampler against outputs of the reference itself
+(tests/golden/stgcn.npz, fid.npz): ST-GCN features / logits through the C-ABI, diversity + multimodality, accuracy, FID."""
+import numpy as np
+import pytest
+import torch
+
+from regennet_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(g):
+    from regennet_amd.eval import STGCN
+    from tests.helpers import sd_digest
+    sd = synth.make_stgcn_state_dict(g["A"], num_class=26, seed=0)
+    assert sd_digest(sd) == str(g["sd_digest"])
+    model = STGCN(in_channels=12, num_class=26, num_person=2, graph_args={"layout": "smplx", "strategy": "spatial"},
+                  edge_importance_weighting=True, device="cuda:0")
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    assert not missing and not unexpected                       # the reference's key names, all of them
+    return model.to("cuda:0").eval(), sd
+
+
+@pytest.mark.parametrize("tag", ["ntu", "chi3d", "one"])
+def test_stgcn_features_and_logits_match_reference(golden, tag):
+    g = golden("stgcn")
+    model, _ = _model(g)
+    x = torch.from_numpy(g[f"x_{tag}"]).cuda()
+    batch = model({"output": x})
+    feats = batch["features"].reshape(x.shape[0], -1).cpu().numpy()
+    ref_f, ref_y = g[f"features_{tag}"], g[f"yhat_{tag}"]
+    assert np.abs(feats - ref_f).max() < 1e-4 * max(1.0, np.abs(ref_f).max()), np.abs(feats - ref_f).max()
+    assert np.abs(batch["yhat"].cpu().numpy() - ref_y).max() < 1e-4 * max(1.0, np.abs(ref_y).max())
+    assert batch["features"].shape == torch.from_numpy(ref_f).squeeze().shape           # N == 1 squeezes to [256] (stgcn.py:117)
+    assert torch.equal(batch["yhat"].max(dim=1).indices.cpu(), torch.from_numpy(ref_y).max(dim=1).indices)
+
+
+def test_stgcn_batching_and_errors(golden):
+    """A batch evaluated at once equals its samples evaluated one by one (rows are independent); a checkpoint with a
+    missing key is refused with the key named."""
+    from regennet_amd import _lib
+    g = golden("stgcn")
+    model, sd = _model(g)
+    x = torch.from_numpy(g["x_ntu"]).cuda()
+    full = model({"output": x})["features"]
+    for i in (0, 4):
+        one = model({"output": x[i:i + 1]})["features"]
+        assert torch.allclose(full[i], one, atol=1e-5)
+    eng = _lib.StgcnEngine(12, 26, 2, 56, 60, 2, 0)
+    for k, v in sd.items():
+        if k != "st_gcn_networks.3.tcn.2.weight" and not k.endswith("num_batches_tracked"):
+            eng.load_weight(k, v)
+    with pytest.raises(_lib.RgnError) as e:
+        eng.finalize()
+    assert e.value.code == -4 and "st_gcn_networks.3.tcn.2.weight" in str(e.value)
+    eng.close()
+
+
+def test_diversity_multimodality_accuracy_on_device(golden):
+    from regennet_amd.eval import calculate_accuracy, calculate_diversity_multimodality
+    g = golden("stgcn")
+    act, labels = torch.from_numpy(g["div_act"]).cuda(), torch.from_numpy(g["div_labels"]).cuda()
+    div, mm = calculate_diversity_multimodality(act, labels, 26, seed=123)
+    assert abs(div - float(g["diversity"])) < 1e-4 and abs(mm - float(g["multimodality"])) < 1e-4
+    yh, ys = g["acc_yhat"], g["acc_y"]
+    loader = [{"yhat_in": torch.from_numpy(yh[i:i + 16]).cuda(), "y": torch.from_numpy(ys[i:i + 16])} for i in range(0, 64, 16)]
+    acc, conf = calculate_accuracy(None, loader, 26, lambda b: {"yhat": b["yhat_in"]}, "cuda")
+    assert abs(acc - float(g["accuracy"])) < 1e-7 and np.array_equal(conf.numpy(), g["confusion"])
+
+
+def test_fid_on_device(golden):
+    """calculate_activation_statistics + calculate_frechet_distance (evaluate.py:48-53, fid.py:11-61) on GPU tensors."""
+    from regennet_amd.eval import calculate_activation_statistics, calculate_fid
+    g = golden("fid")
+    for case in range(4):
+        n1, n2, dim, shift, scale = g[f"cfg_{case}"]
+        rng = np.random.Generator(np.random.PCG64(50 + case))
+        mix = rng.standard_normal((int(dim), int(dim))) / np.sqrt(dim)
+        a = (rng.standard_normal((int(n1), int(dim))) @ mix).astype(np.float32)
+        b = (rng.standard_normal((int(n2), int(dim))) @ mix * scale + shift).astype(np.float32)
+        sa, sb = (calculate_activation_statistics(torch.from_numpy(x).cuda()) for x in (a, b))
+        assert sa[0].is_cuda
+        ref = float(g[f"fid_{case}"])
+        assert abs(float(calculate_fid(sa, sb)) - ref) < 1e-6 * max(1.0, abs(ref)) + 1e-6
+        assert abs(float(calculate_fid(sa, sa))) < 1e-6
+
+
+def test_evaluation_pipeline_end_to_end(golden):
+    """Evaluation.evaluate (evaluate.py:55-124) over synthetic 'gt' and 'gen' loaders: every metric is produced and the
+    ground truth's FID against itself is zero."""
+    from regennet_amd.eval import Evaluation
+    g = golden("stgcn")
+    sd = synth.make_stgcn_state_dict(g["A"], num_class=26, seed=0)
+    ev = Evaluation("ntu", "smplx", {"nfeats": 12, "num_classes": 26, "num_person": 2,
+                                     "state_dict": {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}}, "cuda:0", seed=7)
+    rng = np.random.Generator(np.random.PCG64(3))
+
+    def loader(shift):
+        return [{"output": torch.from_numpy((rng.standard_normal((16, 56, 12, 60)) + shift).astype(np.float32)).cuda(),
+                 "y": torch.from_numpy(rng.integers(0, 26, 16))} for _ in range(3)]
+
+    loaders = {"gt": {"train": loader(0.0), "test": loader(0.0)}, "gen": {"train": loader(0.3), "test": loader(0.3)}}
+    m = ev.evaluate(type("M", (), {"cond_mode": "action"})(), loaders, "cmdm")
+    for sets in ("train", "test"):
+        assert abs(m[f"fid_gt_{sets}"]) < 1e-6 and m[f"fid_gen_{sets}"] > 0
+        for key in ("accuracy", "diversity", "multimodality"):
+            assert np.isfinite(m[f"{key}_gen_{sets}"])

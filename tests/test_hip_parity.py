@@ -135,6 +135,25 @@ def test_graph_replay_equals_eager(golden, precision):
     assert torch.equal(a, b) and torch.equal(b, c)
 
 
+def test_multi_step_graphs_equal_single_step_replay(golden, monkeypatch):
+    """rgn_sample_range replays graphs that hold several loop iterations each (the loop index lives on the device): 1, 7
+    or 10 iterations per graph, or eager launches, must not change a bit — across the phase switch of the schedule too."""
+    g = golden("ntu_ddpm50")
+    cfg, sd, y, tape = fixture_inputs(g, loop=True)
+    outs = []
+    for steps in ("1", "7", "10"):
+        monkeypatch.setenv("REGENNET_GRAPH_STEPS", steps)
+        model, diffusion = build_hip(cfg, sd, resp="50", precision="bf16_x3tail")
+        kw = dict(clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
+        outs.append(diffusion.p_sample_loop(model, (2, 56, 6, 60), **kw))
+        if steps == "7":
+            outs.append(diffusion.p_sample_loop(model, (2, 56, 6, 60), use_graph=False, **kw))
+        model._engine.close()
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
+    assert np.abs(outs[0].cpu().numpy() - g["final"]).max() < 1e-3
+
+
 @pytest.mark.parametrize("frames,etd", [(16, False), (64, False), (63, True), (64, True)])
 def test_oracle_parity_sequence_length_edges(frames, etd):
     """The fused in_proj+attention kernel takes Tq <= 64 tokens: one token tile only (16), exactly full tiles (64, and
