@@ -141,12 +141,7 @@ def main():
     sd = synth.make_state_dict(cfg, seed=0 if rank == 0 else 1000 + rank)
     model, diffusion = synth.build_model(cfg, sd, resp=a.respacing, precision=a.precision, device=str(dev), x3_tail=a.x3_tail)
     eng, _ = model._get_engine(B)
-    if world > 1:
-        ptr, nbytes = eng.weight_blob()
-
-        blob = dist_util.device_view(ptr, nbytes, dev)      # zero-copy uint8 view of the packed weight blob
-        dist_util.broadcast_flat(blob, 0)                   # ONE collective over xGMI
-        torch.cuda.synchronize()
+    dist_util.broadcast_engine_weights(eng, dev, 0)         # ONE collective over xGMI (no-op at N = 1)
     fm = ClassifierFreeSampleModel(model) if a.guided else model
     lo = rank * B                                           # global sample index of this rank's shard
     y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1 + rank)).to(dev)}

@@ -666,6 +666,7 @@ int rgn_create(const rgn_config* cfg, rgn_handle* out) {
     if (cfg->latent_dim % cfg->num_heads) return bad(RGN_ERR_INVALID_ARG, "rgn_create: latent_dim % num_heads != 0");
     if (cfg->latent_dim % 64 || cfg->latent_dim > 1024 || (cfg->latent_dim / 64 & (cfg->latent_dim / 64 - 1)))
         return bad(RGN_ERR_UNSUPPORTED, "rgn_create: latent_dim must be 64*2^k <= 1024");
+    if (cfg->num_frames > 4096) return bad(RGN_ERR_UNSUPPORTED, "rgn_create: more than 4096 frames (Philox element counter)");
     if (cfg->latent_dim / cfg->num_heads > 128)
         return bad(RGN_ERR_UNSUPPORTED, "rgn_create: head dim > 128 unsupported");
     if (cfg->cm_mode != RGN_CM_ADD && cfg->cm_mode != RGN_CM_CONCAT) return bad(RGN_ERR_INVALID_ARG, "rgn_create: cm_mode");
@@ -1159,7 +1160,7 @@ int rgn_randn(rgn_handle h, float* x, int32_t B, uint64_t seed, uint64_t sample_
     hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = h->stream;
     int rc = stream_enter(h, us);
     if (rc) return rc;
-    RGN_LAUNCH(h, KC_UPDATE, s, launch_randn(x, B, h->F * h->cfg.num_frames, seed, sample_offset, s));
+    RGN_LAUNCH(h, KC_UPDATE, s, launch_randn(x, B, h->F * h->cfg.num_frames, h->cfg.num_frames, seed, sample_offset, s));
     return stream_exit(h, us);
 }
 

@@ -859,15 +859,18 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
     return rad * ((elem & 1) ? sn : cs);
 }
 
-__global__ void k_randn(float* __restrict__ x, int B, int FT, unsigned long long seed, unsigned long long off) {
+// The element counter is (feature * 4096 + frame), not the flat index: the draw for (sample, step, feature, frame) does
+// not depend on the sequence length, so a run truncated to the first frames (auto_regressive evaluation: frame f only
+// needs tokens 0..f of a causal decoder) sees the same noise as the full-length run.
+__global__ void k_randn(float* __restrict__ x, int B, int FT, int T, unsigned long long seed, unsigned long long off) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)B * FT) return;
     const int b = (int)(idx / FT), e = (int)(idx - (size_t)b * FT);
-    x[idx] = philox_normal(seed, off + b, 0xFFFFFFFFu, (uint32_t)e);   // stream 0xFFFFFFFF = x_T draw
+    x[idx] = philox_normal(seed, off + b, 0xFFFFFFFFu, (uint32_t)((e / T) * 4096 + e % T));   // stream 0xFFFFFFFF = x_T draw
 }
-hipError_t launch_randn(float* x, int B, int FT, unsigned long long seed, unsigned long long off, hipStream_t s) {
+hipError_t launch_randn(float* x, int B, int FT, int T, unsigned long long seed, unsigned long long off, hipStream_t s) {
     const size_t n = (size_t)B * FT;
-    hipLaunchKernelGGL(k_randn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, B, FT, seed, off);
+    hipLaunchKernelGGL(k_randn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, B, FT, T, seed, off);
     return hipGetLastError();
 }
 
@@ -923,7 +926,7 @@ __global__ __launch_bounds__(256) void k_update(const float* __restrict__ x0tok,
                 if (sp.noise)
                     eps = sp.noise[(size_t)(sp.first_index - step) * dm.B * FT + o];
                 else
-                    eps = philox_normal(sp.seed, sp.sample_offset + b, (uint32_t)step, (uint32_t)(f * dm.T + t));
+                    eps = philox_normal(sp.seed, sp.sample_offset + b, (uint32_t)step, (uint32_t)(f * 4096 + t));   // (feature, frame): independent of T
                 if (sp.sampler == 0) {
                     const float mean = __fadd_rn(__fmul_rn(k.c1, x0), __fmul_rn(k.c2, xv));
                     nv = __fadd_rn(mean, __fmul_rn(k.sig_ddpm, eps));

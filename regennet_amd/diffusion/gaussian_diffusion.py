@@ -219,7 +219,7 @@ class GaussianDiffusion:
             raise AssertionError(f"shape {tuple(shape)} does not match the model ({eng.cfg['njoints']},{eng.cfg['nfeats']},{eng.cfg['num_frames']})")
         if eng.schedule_id is not self._sched_token:
             eng.set_schedule(self.timestep_map, self._engine_tables(), self._sched_token)
-        stream = th.cuda.current_stream(dev).cuda_stream
+        stream = th.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
         if seed is None:   # derived from torch's default generator so fixseed() makes runs reproducible
             seed = int(th.randint(0, 2 ** 62, (1,), dtype=th.int64).item())
         S = self.num_timesteps
@@ -254,7 +254,8 @@ class GaussianDiffusion:
             eng.sample_range(sampler, guided, eta, img, tp, seed, sample_offset, i, n, x0, use_graph, clip_denoised, stream)
             i -= n
             if bar is not None:
-                th.cuda.synchronize(dev)
+                if dev.type == "cuda":
+                    th.cuda.synchronize(dev)
                 bar.update(n)
             if progressive:
                 yield {"sample": img, "pred_xstart": x0}

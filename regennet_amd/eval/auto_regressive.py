@@ -9,6 +9,11 @@ the samples of ONE larger batch: sample (f, b) carries the condition of b with t
 `frames_per_call` frames (B * frames_per_call samples) go through one `p_sample_loop` call, i.e. through the engine's
 batched kernels and a single captured hipGraph. With the on-device Philox stream, sample (f, b) is keyed by the global
 index f * B + b, so the result does not depend on how the frames are grouped into calls.
+
+Sequence truncation: the decoder is causal (cmdm.py:168-171,220-227) and only frame f of run f is kept, which depends on
+tokens 0..f alone at every diffusion step. A call that covers the frames [f0, f1) therefore samples sequences of f1 tokens
+instead of T (the model object is length-agnostic, like the reference's): about half the work over a whole evaluation. Noise
+is keyed by (sample, step, feature, frame), independent of the sequence length, so truncation does not change a bit either.
 """
 import torch as th
 
@@ -16,15 +21,20 @@ import torch as th
 _PER_SAMPLE = ("cmotion", "action", "action_cond", "text_features", "scale", "lengths", "mask", "trans_mask")
 
 
-def _expand_y(y, B, f0, f1, cm_full):
-    """model_kwargs['y'] for the samples (f, b), f in [f0, f1): index (f - f0) * B + b."""
+def _expand_y(y, B, f0, f1, cm_full, T_call=None):
+    """model_kwargs['y'] for the samples (f, b), f in [f0, f1): index (f - f0) * B + b; sequences cut to T_call frames."""
     n = f1 - f0
     T = cm_full.shape[-1]
+    T_call = T if T_call is None else T_call
     out = {}
     for k, v in y.items():
         if k == "cmotion":
             continue
         if th.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B:
+            if k in ("mask", "trans_mask") and v.shape[-1] == T:
+                v = v[..., :T_call]
+            if k == "lengths":
+                v = v.clamp(max=T_call)
             out[k] = v.repeat((n,) + (1,) * (v.dim() - 1))
         elif isinstance(v, (list, tuple)) and len(v) == B:
             out[k] = list(v) * n
@@ -33,13 +43,14 @@ def _expand_y(y, B, f0, f1, cm_full):
     # frame f sees the actor's frames 0..f; everything after is zero (stgcn_eval.py:52,58)
     frames = th.arange(T, device=cm_full.device)
     keep = (frames[None, :] <= th.arange(f0, f1, device=cm_full.device)[:, None]).to(cm_full.dtype)   # [n, T]
-    cm = cm_full[None] * keep[:, None, None, None, :]                                               # [n, B, V, C, T]
-    out["cmotion"] = cm.reshape((n * B,) + tuple(cm_full.shape[1:])).contiguous()
+    cm = (cm_full[None] * keep[:, None, None, None, :])[..., :T_call]                               # [n, B, V, C, T_call]
+    out["cmotion"] = cm.reshape((n * B,) + tuple(cm_full.shape[1:3]) + (T_call,)).contiguous()
     return out
 
 
 def sample_auto_regressive(sample_fn, model, shape, model_kwargs, setting="cmdm", frames_per_call=None,
-                           clip_denoised=False, noise_tapes=None, seed=None, max_samples_per_call=256, **sample_kw):
+                           clip_denoised=False, noise_tapes=None, seed=None, max_samples_per_call=256, truncate=True,
+                           **sample_kw):
     """Return the reference's `batch['output']` of the auto-regressive branch.
 
     sample_fn       diffusion.p_sample_loop or diffusion.ddim_sample_loop (regennet_amd.diffusion).
@@ -47,6 +58,7 @@ def sample_auto_regressive(sample_fn, model, shape, model_kwargs, setting="cmdm"
     model_kwargs    {'y': {...}} with y['cmotion'] [B, V, C, T] the full actor motion.
     setting         'cmdm': output = cat(actor, reactor) on axis 2 -> [B, V, 2C, T]; otherwise the reactor only.
     frames_per_call frames batched into one sampler call (default: as many as keep B * frames <= max_samples_per_call).
+    truncate        sample only the first f1 tokens in the call that covers frames [f0, f1) (see the module docstring).
     noise_tapes     optional sequence of T tapes [S+1, B, V, C, T] (run f consumes tape f; for parity tests),
     seed            otherwise the Philox seed (None: drawn from torch's generator, like the sampler itself).
     Remaining keyword arguments go to sample_fn (eta, skip_timesteps, use_graph, ...).
@@ -64,14 +76,15 @@ def sample_auto_regressive(sample_fn, model, shape, model_kwargs, setting="cmdm"
     for f0 in range(0, T, frames_per_call):
         f1 = min(T, f0 + frames_per_call)
         n = f1 - f0
-        yy = _expand_y(y, B, f0, f1, cm_full)
+        Tc = f1 if truncate else T
+        yy = _expand_y(y, B, f0, f1, cm_full, Tc)
         kw = dict(sample_kw)
         if noise_tapes is not None:
-            kw["noise_tape"] = th.cat([th.as_tensor(noise_tapes[f]) for f in range(f0, f1)], dim=1)   # batch axis
+            kw["noise_tape"] = th.cat([th.as_tensor(noise_tapes[f])[..., :Tc] for f in range(f0, f1)], dim=1).contiguous()   # batch axis
         else:
             kw.update(seed=seed, sample_offset=f0 * B + int(sample_kw.get("sample_offset", 0)))
-        sample = sample_fn(model, (n * B, V, C, T), clip_denoised=clip_denoised, model_kwargs={"y": yy}, **kw)
-        sample = sample.reshape(n, B, V, C, T)
+        sample = sample_fn(model, (n * B, V, C, Tc), clip_denoised=clip_denoised, model_kwargs={"y": yy}, **kw)
+        sample = sample.reshape(n, B, V, C, Tc)
         if output is None:
             output = th.zeros((B, V, C * 2 if setting == "cmdm" else C, T), device=sample.device, dtype=sample.dtype)
         idx = th.arange(f0, f1, device=sample.device)

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
+from ..utils import dist_util
 
 
 class _Pose(nn.Module):          # InputProcess / OutputProcess parameter holders (cmdm.py:301-355)
@@ -136,6 +137,7 @@ class CMDM(nn.Module):
         # precision schedule: split-bf16 for the last x3_tail loop indices of a sampling loop (None: engine default)
         self.x3_tail = kargs.get("x3_tail", None)
         self._engine = None
+        self._engines = {}
         self._engine_stale = True
         self._cond_key = None
         self._keep = None
@@ -172,30 +174,43 @@ class CMDM(nn.Module):
                     cm_mode=self.cm_mode, cond_mode=self.cond_mode, num_actions=self.num_actions, clip_dim=self.clip_dim,
                     emb_trans_dec=self.emb_trans_dec, wo_pos_emb=self.wo_pos_emb)
 
+    MAX_ENGINES = 16    # engines kept alive, one per sequence length (auto_regressive evaluation walks through many lengths)
+
     def _get_engine(self, B, T=None):
-        """The engine for batches of up to B motions of T frames (default: num_frames). Like the reference's module, the
-        model itself is length-agnostic (the sequence length comes from x.shape, cmdm.py:176); the engine's workspace is
-        sized per (max batch, T), so a call with a different T or a larger B rebuilds it."""
+        """The engine for batches of up to B motions of T frames (default: num_frames, or the length used last). Like the
+        reference's module the model itself is length-agnostic (the sequence length comes from x.shape, cmdm.py:176); an
+        engine's workspace is sized per (max batch, T), so engines are cached per T (least recently used evicted) and one is
+        rebuilt when a larger batch arrives."""
         dev = next(self.parameters()).device
-        if dev.type != "cuda":
+        if dev.type != "cuda" and getattr(_lib.Engine, "requires_gpu", True):
             raise RuntimeError("regennet_amd CMDM runs on an AMD GPU only: call model.to(dist_util.dev()) first "
                                "(there is no CPU fallback; the CPU restatement lives in oracle/ as a test checker)")
-        T = int(T or (self._engine.cfg["num_frames"] if self._engine is not None and not self._engine_stale else self.num_frames))
-        eng = self._engine
-        if eng is None or self._engine_stale or B > eng.max_batch or eng.precision != self.precision or eng.cfg["num_frames"] != T:
-            max_b = B
-            if eng is not None:
-                torch.cuda.synchronize(dev)
-                if eng.cfg["num_frames"] == T:
-                    max_b = max(B, eng.max_batch)
-                eng.close()
-            eng = _lib.Engine(self.engine_config(T), max_b, dev.index or 0, self.precision)
+        if self._engine_stale:                                # weights / device changed: every cached engine is obsolete
+            dist_util.synchronize(dev)
+            for e in self._engines.values():
+                e.close()
+            self._engines.clear()
+            self._engine, self._engine_stale = None, False
+        T = int(T or (self._engine.cfg["num_frames"] if self._engine is not None else self.num_frames))
+        eng = self._engines.pop(T, None)
+        if eng is not None and (B > eng.max_batch or eng.precision != self.precision):
+            dist_util.synchronize(dev)
+            B = max(B, eng.max_batch)
+            eng.close()
+            eng = None
+        if eng is None:
+            while len(self._engines) >= self.MAX_ENGINES:
+                dist_util.synchronize(dev)
+                self._engines.pop(next(iter(self._engines))).close()
+            eng = _lib.Engine(self.engine_config(T), B, dev.index or 0, self.precision)
             for k, v in self.state_dict().items():
                 if k.startswith("clip_model."):
                     continue
                 eng.load_weight(k, v.detach().float().cpu().numpy())
             eng.finalize()
-            self._engine, self._engine_stale, self._cond_key, self._keep = eng, False, None, None
+        self._engines[T] = eng                                # (re)inserted last = most recently used
+        if eng is not self._engine:
+            self._engine, self._cond_key, self._keep = eng, None, None
         tail = os.environ.get("REGENNET_X3_TAIL", self.x3_tail)
         eng.set_x3_tail(-1 if tail is None else int(tail))
         return eng, dev
@@ -239,7 +254,7 @@ class CMDM(nn.Module):
         if scale is not None:
             scale_d = scale.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
             assert tuple(scale_d.shape) == (B,)
-        eng.set_condition(B, cm_d, action_d, text_d, scale_d, torch.cuda.current_stream(dev).cuda_stream)
+        eng.set_condition(B, cm_d, action_d, text_d, scale_d, dist_util.stream_handle(dev))
         # device copies stay alive until the stream consumed them; the caller's tensors until the key is replaced
         self._keep = (cm_d, action_d, text_d, scale_d) + (src if cache else ())
         self._cond_key = key if cache else None
@@ -259,5 +274,5 @@ class CMDM(nn.Module):
         tc = timesteps.to(device=dev, dtype=torch.int64).contiguous()
         out = torch.empty_like(xc)
         flags = (_lib.FLAG_GUIDED if _guided else 0) | (_lib.FLAG_UNCOND if y.get("uncond", False) else 0)
-        eng.denoise(xc, tc, flags, out, torch.cuda.current_stream(dev).cuda_stream)
+        eng.denoise(xc, tc, flags, out, dist_util.stream_handle(dev))
         return out

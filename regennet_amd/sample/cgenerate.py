@@ -32,23 +32,33 @@ def _load_clips(args, cfg, n):
 
 
 def main(argv=None):
+    """Single process: one GPU samples `num_samples` motions per repetition. Under torchrun
+    (`python -m torch.distributed.run --nproc-per-node N -m regennet_amd.sample.cgenerate ...`): the `num_samples` of every
+    repetition are sharded over the N ranks (contiguous shards, `dist_util.shard_bounds`), rank 0's packed weights are
+    broadcast once over RCCL, every rank samples its shard with the Philox stream keyed by the GLOBAL sample index (so the
+    result does not depend on N), and rank 0 gathers and saves. No collective inside the sampling loop."""
     args = cgenerate_args(argv)
     fixseed(args.seed)
     max_frames = 150 if args.dataset == "chi3d" else 60
     n_frames = min(max_frames, int(args.motion_length))
     dev = dist_util.setup_dist()
+    rank, world = dist_util.world()
     assert args.num_samples <= args.batch_size, \
         f"Please either increase batch_size({args.batch_size}) or reduce num_samples({args.num_samples})"
     args.batch_size = args.num_samples
     cfg = synth.get_config("chi3d" if args.dataset == "chi3d" else ("ntu" if args.unconstrained else "ntu_action"))
     data = types.SimpleNamespace(dataset=types.SimpleNamespace(num_actions=cfg["num_actions"], num_person=2))
-    print("Creating model and diffusion...")
+    if rank == 0:
+        print("Creating model and diffusion...")
     model, diffusion = create_model_and_diffusion(args, data)
     model.precision = args.precision
     if args.synthetic or not args.model_path:
-        sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(model.engine_config() | {"layers": model.num_layers}, seed=0).items()}
+        # rank 0 owns "the checkpoint"; other ranks start from different values and receive rank 0's packed blob
+        sd = {k: torch.from_numpy(v) for k, v in
+              synth.make_state_dict(model.engine_config() | {"layers": model.num_layers}, seed=0 if rank == 0 else 1000 + rank).items()}
     else:
-        print(f"Loading checkpoints from [{args.model_path}]...")
+        if rank == 0:
+            print(f"Loading checkpoints from [{args.model_path}]...")
         sd = torch.load(args.model_path, map_location="cpu")
     load_model_wo_clip(model, sd)
     if args.guidance_param != 1:
@@ -56,46 +66,63 @@ def main(argv=None):
     model.to(dev)
     model.eval()
     clips, actions = _load_clips(args, cfg, args.num_samples)
-    assert clips.shape[1:] == (56, 6, max_frames) or clips.shape[1:3] == (cfg["njoints"], cfg["nfeats"])
+    assert clips.shape[1:3] == (cfg["njoints"], cfg["nfeats"]) and clips.shape[3] >= n_frames, \
+        f"actor clips {clips.shape} do not cover [N, {cfg['njoints']}, {cfg['nfeats']}, {n_frames}]"
+    clips = clips[..., :n_frames]                           # --motion_length shorter than the dataset length (cgenerate.py:40,126)
     B = args.batch_size
+    lo, hi = dist_util.shard_bounds(B)                      # this rank's samples of every repetition
+    Bl = hi - lo
     sample_fn = diffusion.p_sample_loop if not args.use_ddim else diffusion.ddim_sample_loop
     inner = model.model if isinstance(model, ClassifierFreeSampleModel) else model
-    eng, _ = inner._get_engine(B)
+    eng, _ = inner._get_engine(max(Bl, 1), n_frames)
+    dist_util.broadcast_engine_weights(eng, dev, 0)
     all_outputs, all_cmotions, time_all = [], [], 0.0
     for rep_i in range(args.num_repetitions):
-        print(f"### Sampling [repetitions #{rep_i}]")
-        idx = (np.arange(B) + rep_i * B) % len(clips)
-        y = {"cmotion": torch.from_numpy(clips[idx]).to(dev), "lengths": torch.full((B,), n_frames),
-             "mask": torch.ones(B, 1, 1, n_frames, dtype=torch.bool)}
+        if rank == 0:
+            print(f"### Sampling [repetitions #{rep_i}]")
+        idx = (np.arange(lo, hi) + rep_i * B) % len(clips)
+        y = {"cmotion": torch.from_numpy(np.ascontiguousarray(clips[idx])).to(dev), "lengths": torch.full((Bl,), n_frames),
+             "mask": torch.ones(Bl, 1, 1, n_frames, dtype=torch.bool)}
         if inner.cond_mode == "action":
             y["action"] = torch.from_numpy(actions[idx]).to(dev)
         if args.guidance_param != 1:
-            y["scale"] = torch.ones(B, device=dev) * args.guidance_param
-        torch.cuda.synchronize()
+            y["scale"] = torch.ones(Bl, device=dev) * args.guidance_param
+        dist_util.synchronize()
         t_start = time.time()
-        sample = sample_fn(model, (B, inner.njoints, inner.nfeats, n_frames), clip_denoised=False, model_kwargs={"y": y},
-                           skip_timesteps=0, init_image=None, progress=True, dump_steps=None, noise=None, const_noise=False)
-        torch.cuda.synchronize()
+        shape = (Bl, inner.njoints, inner.nfeats, n_frames)
+        if Bl > 0:
+            sample = sample_fn(model, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=0, init_image=None,
+                               progress=(rank == 0), dump_steps=None, noise=None, const_noise=False,
+                               seed=args.seed * 1000003 + rep_i, sample_offset=rep_i * B + lo)
+            smooth = torch.empty_like(sample)      # scipy.ndimage.gaussian_filter1d(sigma=1, axis=-1) on the device (cgenerate.py:142)
+            eng.gaussian_filter1d(sample.contiguous(), smooth, sample.numel() // n_frames, n_frames, 1.0, dist_util.stream_handle(dev))
+        else:
+            smooth = torch.empty(shape, device=dev)
+        dist_util.synchronize()
         t_end = time.time()
         if rep_i >= 1:
             time_all += (t_end - t_start) * 1000
-        print("Generating time consumption: %s ms" % ((t_end - t_start) * 1000))
-        smooth = torch.empty_like(sample)      # scipy.ndimage.gaussian_filter1d(sigma=1, axis=-1) on the device
-        eng.gaussian_filter1d(sample.contiguous(), smooth, sample.numel() // n_frames, n_frames, 1.0,
-                              torch.cuda.current_stream().cuda_stream)
-        all_outputs.append(smooth.cpu().numpy())
-        all_cmotions.append(y["cmotion"].cpu().numpy())
-        print(f"created {len(all_outputs) * B} samples")
-    if args.num_repetitions != 1:
-        print("Average Time Consumption: %s ms" % (time_all / (args.num_repetitions - 1)))
-    out_path = args.output_dir or os.path.join(os.path.dirname(args.model_path) or ".", f"samples_seed{args.seed}")
-    os.makedirs(out_path, exist_ok=True)
-    npy_path = os.path.join(out_path, "results.npy")
-    print(f"saving results file to [{npy_path}]")
-    np.save(npy_path, {"output": np.concatenate(all_outputs), "cmotion": np.concatenate(all_cmotions),
-                       "lengths": np.full((len(all_outputs) * B,), n_frames), "num_samples": args.num_samples,
-                       "num_repetitions": args.num_repetitions})
-    print(f"[Done] Results are at [{os.path.abspath(out_path)}]")
+        if rank == 0:
+            print("Generating time consumption: %s ms" % ((t_end - t_start) * 1000))
+        all_outputs.append(dist_util.all_gather_samples(smooth, B).cpu().numpy())
+        all_cmotions.append(dist_util.all_gather_samples(y["cmotion"], B).cpu().numpy())
+        if rank == 0:
+            print(f"created {len(all_outputs) * B} samples")
+    npy_path = None
+    if rank == 0:
+        if args.num_repetitions != 1:
+            print("Average Time Consumption: %s ms" % (time_all / (args.num_repetitions - 1)))
+        out_path = args.output_dir or os.path.join(os.path.dirname(args.model_path) or ".", f"samples_seed{args.seed}")
+        os.makedirs(out_path, exist_ok=True)
+        npy_path = os.path.join(out_path, "results.npy")
+        print(f"saving results file to [{npy_path}]")
+        np.save(npy_path, {"output": np.concatenate(all_outputs), "cmotion": np.concatenate(all_cmotions),
+                           "lengths": np.full((len(all_outputs) * B,), n_frames), "num_samples": args.num_samples,
+                           "num_repetitions": args.num_repetitions, "world_size": world})
+        print(f"[Done] Results are at [{os.path.abspath(out_path)}]")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     return npy_path
 
 

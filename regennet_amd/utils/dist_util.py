@@ -71,6 +71,32 @@ def broadcast_flat(buf, src=0):
     return buf
 
 
+def stream_handle(device):
+    """hipStream_t of torch's current stream on `device` as an int (0 on a CPU-only host: gloo tests with a stub engine)."""
+    device = torch.device(device)
+    return torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+
+
+def synchronize(device=None):
+    if torch.cuda.is_available():
+        torch.cuda.synchronize(device)
+
+
+def broadcast_engine_weights(engine, device, src=0):
+    """Start-up collective of a multi-GPU run: rank `src`'s packed weight blob (rgn_weight_blob: ONE flat device buffer)
+    is broadcast into every rank's blob over RCCL / xGMI — replaces the per-tensor `sync_params` of the reference
+    (utils/dist_util.py:77-83). Callers must re-derive everything computed FROM the weights afterwards (the per-schedule
+    tables: `engine.schedule_id = None`; the hoisted condition is rebound by every sampling call anyway)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    ptr, nbytes = engine.weight_blob()
+    view = ptr if torch.is_tensor(ptr) else device_view(ptr, nbytes, device)   # (a stub engine hands over a tensor)
+    synchronize(device)
+    dist.broadcast(view, src)
+    synchronize(device)
+    engine.schedule_id = None
+
+
 def sync_params(params):
     """dist_util.py:77-83, but as a single flattened broadcast instead of one per tensor."""
     params = list(params)

@@ -67,3 +67,91 @@ def test_single_process_helpers_are_noops():
     assert dist_util.all_gather_samples(t, 4) is t
     dist_util.sync_params([t])
     assert dist_util.shard_bounds(10, 0, 1) == (0, 10)
+
+
+# ---- the multi-GPU sampling entry point (sample/cgenerate.py under torchrun) with the engine stubbed at _lib.Engine -----------
+class FakeEngine:
+    """Stands in for regennet_amd._lib.Engine on a CPU-only host: same methods, deterministic arithmetic that depends on
+    everything the real engine's result depends on (weights blob, condition, seed, GLOBAL sample index, step index)."""
+    requires_gpu = False
+
+    def __init__(self, cfg, max_batch, device_index, precision="f32"):
+        self.cfg, self.max_batch, self.precision = dict(cfg), int(max_batch), precision
+        self.schedule_id, self._w, self.blob, self.calls = None, {}, None, []
+
+    def load_weight(self, key, array):
+        self._w[key] = float(np.asarray(array, dtype=np.float64).sum())
+
+    def finalize(self):
+        vals = np.array([self._w[k] for k in sorted(self._w)], dtype=np.float32)
+        self.blob = torch.from_numpy(vals.view(np.uint8).copy())
+
+    def weight_blob(self):
+        self.calls.clear()                       # whoever takes the blob may overwrite it: schedule and condition must follow
+        return self.blob, self.blob.numel()
+
+    def set_x3_tail(self, n):
+        pass
+
+    def set_schedule(self, tmap, tables, sched_id=None):
+        self.schedule_id = sched_id
+        self.calls.append("schedule")
+
+    def set_condition(self, B, cm, action, text, scale, stream):
+        self.cond = cm.reshape(B, -1).mean(dim=1).clone()
+        self.calls.append("condition")
+
+    def _wsum(self):
+        return float(self.blob.view(torch.float32).double().sum()) * 1e-3
+
+    def randn(self, x, B, seed, sample_offset, stream):
+        idx = torch.arange(x[0].numel(), dtype=torch.float32).reshape(x[0].shape)
+        for b in range(B):
+            x[b] = torch.sin(idx * 0.37 + float(seed % 1000) + (sample_offset + b) * 1.7)
+
+    def sample_range(self, sampler, guided, eta, x, noise, seed, sample_offset, first_index, count, x0, use_graph, clip, stream):
+        assert "condition" in self.calls and "schedule" in self.calls, "sampling before condition / schedule were (re)bound"
+        self.calls.append("range")
+        B = x.shape[0]
+        for i in range(first_index, first_index - count, -1):
+            for b in range(B):
+                x[b] = 0.9 * x[b] + 0.1 * (self._wsum() + float(self.cond[b]) + 0.01 * i + 0.001 * ((sample_offset + b) % 97))
+
+    def gaussian_filter1d(self, x, out, rows, T, sigma, stream):
+        out.copy_(x)
+
+    def close(self):
+        pass
+
+
+def _cgen_args(out_dir):
+    return ["--synthetic", "--unconstrained", "--guidance_param", "1", "--num_samples", "5", "--num_repetitions", "2", "--layers", "1",
+            "--timestep_respacing", "ddim5", "--use_ddim", "--motion_length", "40", "--output_dir", out_dir]
+
+
+def _cgen_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from regennet_amd import _lib
+    from regennet_amd.sample import cgenerate
+    _lib.Engine = FakeEngine
+    path = cgenerate.main(_cgen_args(out_dir))
+    assert (path is not None) == (rank == 0)
+    dist.destroy_process_group()
+
+
+def test_cgenerate_entry_point_shards_broadcasts_and_gathers(tmp_path, monkeypatch):
+    """`torchrun -m regennet_amd.sample.cgenerate` control flow on 2 gloo ranks: contiguous shards of num_samples, rank 0's
+    weight blob broadcast (rank 1 starts from a different checkpoint), per-rank sampling keyed by the global sample index,
+    gather + save on rank 0 — and the saved result equals the single-process run (world-size invariance)."""
+    from regennet_amd import _lib
+    from regennet_amd.sample import cgenerate
+    monkeypatch.setattr(_lib, "Engine", FakeEngine)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    one = np.load(cgenerate.main(_cgen_args(str(tmp_path / "w1"))), allow_pickle=True).item()
+    mp.spawn(_cgen_worker, args=(2, _free_port(), str(tmp_path / "w2")), nprocs=2, join=True)
+    two = np.load(str(tmp_path / "w2" / "results.npy"), allow_pickle=True).item()
+    assert one["output"].shape == (10, 56, 6, 40) and two["world_size"] == 2 and one["world_size"] == 1
+    assert np.array_equal(one["cmotion"], two["cmotion"])
+    assert np.allclose(one["output"], two["output"], atol=1e-6), np.abs(one["output"] - two["output"]).max()
+    assert np.abs(one["output"][0] - one["output"][3]).max() > 1e-4      # samples differ (global index, condition)

@@ -322,6 +322,32 @@ def test_weight_blob_view_transfers_a_checkpoint():
     assert torch.equal(out_a, out_b1)
 
 
+def test_two_shards_after_a_blob_transfer_reproduce_the_unsharded_batch():
+    """What two ranks of a multi-GPU run do, on one GPU: engine B starts from another checkpoint, receives engine A's packed
+    blob (the RCCL broadcast), then A samples shard [0, B/2) and B shard [B/2, B) with the global sample offset: together
+    they must equal the unsharded B-batch BIT FOR BIT (schedule tables and hoisted condition re-derived after the transfer)."""
+    from regennet_amd import synth
+    from regennet_amd.utils import dist_util
+    cfg = synth.get_config("ntu_action", layers=2)
+    ma, da = build_hip(cfg, synth.make_state_dict(cfg, seed=0), resp="50", precision="bf16_x3tail")
+    mb, db = build_hip(cfg, synth.make_state_dict(cfg, seed=77), resp="50", precision="bf16_x3tail")
+    B, half = 6, 3
+    y = y_to_device({"cmotion": synth.make_cmotion(cfg, B, seed=8), "action": synth.make_actions(cfg, B, seed=9)})
+    shape = lambda n: (n, 56, 6, 60)   # noqa: E731
+    full = da.p_sample_loop(ma, shape(B), clip_denoised=False, model_kwargs={"y": y}, seed=21)
+    ea, _ = ma._get_engine(B)
+    eb, _ = mb._get_engine(half)
+    (pa, na), (pb, nb) = ea.weight_blob(), eb.weight_blob()
+    dist_util.device_view(pb, nb, "cuda:0").copy_(dist_util.device_view(pa, na, "cuda:0"))
+    torch.cuda.synchronize()
+    eb.schedule_id = None                                    # what dist_util.broadcast_engine_weights does after the collective
+    ya = {k: v[:half].contiguous() for k, v in y.items()}
+    yb = {k: v[half:].contiguous() for k, v in y.items()}
+    sa = da.p_sample_loop(ma, shape(half), clip_denoised=False, model_kwargs={"y": ya}, seed=21, sample_offset=0)
+    sb = db.p_sample_loop(mb, shape(B - half), clip_denoised=False, model_kwargs={"y": yb}, seed=21, sample_offset=half)
+    assert torch.equal(torch.cat([sa, sb]), full)
+
+
 def test_chain_count_does_not_change_results(golden, monkeypatch):
     """1, 2 or 4 concurrent kernel chains (REGENNET_STREAMS) are a scheduling choice only: bit-identical samples."""
     g = golden("ntu_ddpm50")
@@ -577,11 +603,11 @@ def test_auto_regressive_matches_reference(golden, name, precision):
     B, T = int(g["B"]), int(g["T"])
     shape = (B, cfg["njoints"], cfg["nfeats"], T)
     tapes_t = [torch.from_numpy(t) for t in tapes]
-    for fpc in (T, 3, 1):
+    for fpc, trunc in ((T, True), (3, True), (1, True), (3, False)):   # truncated sequences (frame f needs tokens 0..f only) and full ones
         out = sample_auto_regressive(diffusion.p_sample_loop, model, shape, {"y": y_to_device(y)}, frames_per_call=fpc,
-                                     noise_tapes=tapes_t)
+                                     noise_tapes=tapes_t, truncate=trunc)
         err = np.abs(out.cpu().numpy() - g["output"]).max()
-        assert err < 1e-3, (name, fpc, err)
+        assert err < 1e-3, (name, fpc, trunc, err)
 
 
 def test_auto_regressive_grouping_invariance_with_device_rng():
@@ -596,8 +622,8 @@ def test_auto_regressive_grouping_invariance_with_device_rng():
     y = y_to_device({"cmotion": synth.make_cmotion(cfg, B, seed=1), "action": synth.make_actions(cfg, B, seed=2)})
     shape = (B, cfg["njoints"], cfg["nfeats"], T)
     ref = sample_auto_regressive(diffusion.p_sample_loop, model, shape, {"y": y}, frames_per_call=T, seed=11)
-    for fpc in (1, 3):
-        out = sample_auto_regressive(diffusion.p_sample_loop, model, shape, {"y": y}, frames_per_call=fpc, seed=11)
-        assert torch.equal(out, ref), fpc
+    for fpc, trunc in ((1, True), (3, True), (3, False)):    # grouping and sequence truncation: neither changes a bit
+        out = sample_auto_regressive(diffusion.p_sample_loop, model, shape, {"y": y}, frames_per_call=fpc, seed=11, truncate=trunc)
+        assert torch.equal(out, ref), (fpc, trunc)
     other = sample_auto_regressive(diffusion.p_sample_loop, model, shape, {"y": y}, frames_per_call=T, seed=12)
     assert not torch.equal(other, ref)
