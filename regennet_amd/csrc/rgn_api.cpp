@@ -324,12 +324,12 @@ inline bool eval_x3(const rgn_ctx* c) {
 inline bool has_lo(const rgn_ctx* c) { return c->cfg.precision == RGN_PREC_BF16X3 || c->cfg.precision == RGN_PREC_BF16_X3TAIL; }
 inline int default_tail(int S) {
     // What the bulk phase may cost is empirical (tests/test_hip_parity.py sweeps the switch point against the reference):
-    // a long schedule contracts early-step rounding (1000-step DDPM: 5 split-bf16 steps already reach 1.2e-4), a short
-    // DDIM schedule does not (every step carries a large share of the result: 20 guided steps with 8 of them split-bf16
-    // measured 3e-3 on a tiny model). So: schedules of fewer than 40 steps run split-bf16 throughout; longer ones keep
-    // 2.5 % of the steps, at least 8.
+    // a long schedule contracts early-step rounding (1000-step DDPM: 5 split-bf16 steps reach 1.2e-4, 10 reach 6.7e-5, the
+    // uniform split-bf16 floor is 4.8e-5), a short DDIM schedule does not (every step carries a large share of the result:
+    // 20 guided steps with 8 of them split-bf16 measured 3e-3 on a tiny model). So: schedules of fewer than 40 steps run
+    // split-bf16 throughout; longer ones keep 1 % of the steps, at least 8.
     if (S < 40) return S;
-    const int t = (S + 39) / 40;
+    const int t = (S + 99) / 100;
     return t < 8 ? 8 : t;
 }
 

@@ -23,7 +23,7 @@ LOOPS = ["tiny_ddpm10", "tiny_ddim10_cfg", "tiny_add_ddpm1000", "tiny_text_ddim2
 
 def default_tail(S):
     """rgn_api.cpp default_tail(): loop indices below this run split-bf16 under the precision schedule."""
-    return S if S < 40 else max(8, (S + 39) // 40)
+    return S if S < 40 else max(8, (S + 99) // 100)
 
 
 def _wrap(model, guided):

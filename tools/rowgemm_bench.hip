@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
         g.A = dA; g.a_rows = M; g.W = dW; g.bias = dB; g.M = M; g.N = N; g.Kp = K;
         auto reset = [&] { if (sh.ln) { CK(hipMemcpy(dRh, Rh.data(), Rh.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dRl, Rl.data(), Rl.size() * 2, hipMemcpyHostToDevice)); } };
         if (sh.ln) {
-            g.Rhi = dRh; g.Rlo = dRl; g.r_rows = M; g.Ohi = dRh; g.Olo = dRl; g.o_rows = M;
+            g.Rhi = dRh; g.Rlo = getenv("HI_ONLY") ? nullptr : dRl; g.r_rows = M; g.Ohi = dRh; g.Olo = getenv("HI_ONLY") ? nullptr : dRl; g.o_rows = M;
             g.ga = dga; g.ba = dba; g.gb = sh.two ? dgb : nullptr; g.bb = sh.two ? dbb : nullptr;
             g.pervec = sh.two ? dpv : nullptr; g.ldper = N; g.stepvec = sh.two ? dsv : nullptr; g.ldstep = N; g.d_step = dstep; g.Tq = Tq;
         } else {
