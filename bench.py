@@ -64,7 +64,7 @@ def flops_per_eval(cfg, B, guided, precision="bf16x3"):
     if fused_qkv_attention(cfg, precision):
         out["qkv_attn"] = qkv + attn
     else:
-        out["gemm_mfma"] += qkv
+        out["rowgemm_act" if rowgemm_phase(cfg, precision) else "gemm_mfma"] += qkv   # long sequences: in_proj GEMM + k_attn_x3
         out["attention"] = attn
     return {k: 2.0 * v for k, v in out.items()}
 

@@ -457,6 +457,21 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             g.Bm = ns; g.Kp = w.qkv.Kp; g.d = d; g.H = c->H; g.Tq = dm.Tq;
             g.qscale = 1.0f / sqrtf((float)dm.dh);
             RGN_LAUNCH(c, KC_QKV, s, launch_qkv_attn(g, x3, s));   // 93 % of its MFMA work is the in_proj GEMM
+        } else if (fast && c->attn_x3 && !x3 && c->rowgemm && dm.dh % 32 == 0 && w.qkv.fr) {
+            // plain-bf16 phase, long sequence: packed in_proj as a row-complete GEMM that scatters q (pre-scaled), k, v as
+            // attention-ready planes (weights streamed to registers, output through an LDS image), then k_attn_x3
+            RowGemmArgs g{};
+            g.A = h_p.hi; g.a_rows = h_p.rows;
+            g.W = c->dp<__bf16>(w.qkv.fr); g.bias = c->dp<float>(w.qkv.b);
+            g.M = M; g.N = 3 * d; g.Kp = w.qkv.Kp; g.act = 2;
+            g.Qhi = c->q_hi + slab0; g.Khi = c->k_hi + slab0; g.Vhi = c->vt_hi + slab0;
+            g.H = c->H; g.dh = dm.dh; g.Tq = dm.Tq; g.Tqp = c->Tqp; g.qscale = 1.0f / sqrtf((float)dm.dh);
+            RGN_LAUNCH(c, KC_ROWACT, s, launch_rowgemm(g, false, s));
+            AttnX3Args a{};
+            a.Qhi = g.Qhi; a.Qlo = c->q_lo + slab0; a.Khi = g.Khi; a.Klo = c->k_lo + slab0; a.Vthi = g.Vhi; a.Vtlo = c->vt_lo + slab0;
+            a.out = att_p;
+            a.Bm = ns; a.H = c->H; a.dh = dm.dh; a.d = d; a.Tq = dm.Tq; a.Tqp = c->Tqp; a.x3 = false;
+            RGN_LAUNCH(c, KC_ATTN, s, launch_attn_x3(a, s));
         } else if (fast && c->attn_x3) {
             // in_proj GEMM scatters q (pre-scaled), k and v as attention-ready split planes; no fp32 qkv round trip
             GemmX3Args g{};
@@ -806,7 +821,8 @@ int rgn_finalize_weights(rgn_handle h) {
     for (int l = 0; l < c->L; ++l) {
         const std::string p = "seqTransDecoder.layers." + std::to_string(l) + ".";
         LayerW& lw = c->layers[l];
-        lw.qkv = pack_linear(c, W(p + "self_attn.in_proj_weight"), W(p + "self_attn.in_proj_bias"), 3 * d, d, true);
+        lw.qkv = pack_linear(c, W(p + "self_attn.in_proj_weight"), W(p + "self_attn.in_proj_bias"), 3 * d, d, true,
+                             c->cfg.precision == RGN_PREC_BF16_X3TAIL && !qkv_attn_supported(c->Tq, d / c->H, d));
         const bool fr = c->cfg.precision == RGN_PREC_BF16_X3TAIL;   // k_rowgemm operands (plain-bf16 phase)
         lw.out = pack_linear(c, W(p + "self_attn.out_proj.weight"), W(p + "self_attn.out_proj.bias"), d, d, true, fr);
         lw.ff1 = pack_linear(c, W(p + "linear1.weight"), W(p + "linear1.bias"), ff, d, true, fr);

@@ -130,7 +130,9 @@ struct RowGemmArgs {
     const float* bias;                    // [N]
     int M, N, Kp;
     // ---- epilogue "act": out = act(A.W^T + bias) as bf16 planes (N % 32 == 0)
-    int act;                              // 0 none, 1 gelu(erf)
+    int act;                              // 0 none, 1 gelu(erf), 2 packed in_proj -> attention-ready q (pre-scaled) / k / v planes
+    __bf16 *Qhi, *Khi, *Vhi;              // act == 2: [Bm*H][Tqp][dh] planes (N = 3 * 512: one column chunk each)
+    int H, dh, Tqp; float qscale;         // act == 2 (Tq below)
     const float* add; int ldadd;          // (reserved, must be null)
     float* C; int ldc;                    // (reserved, must be null)
     __bf16* Chi; __bf16* Clo; int c_rows; // output planes [N/32][c_rows][32]; Clo nullable

@@ -245,6 +245,9 @@ __global__ __launch_bounds__(RG_NT, (EPI == 1 && NK <= 16) ? RGN_RG_ACT_WAVES : 
                     if (g.act == 1) {
                         const f32x2 g0 = rg_gelu2(f32x2{v[0], v[1]}), g1 = rg_gelu2(f32x2{v[2], v[3]});
                         v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
+                    } else if (g.act == 2 && blockIdx.y == 0) {       // packed in_proj: column chunk 0 = q, pre-scaled by 1/sqrt(dh)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= g.qscale;
                     }
                     bf16x4 h, l;
 #pragma unroll
@@ -266,15 +269,33 @@ __global__ __launch_bounds__(RG_NT, (EPI == 1 && NK <= 16) ? RGN_RG_ACT_WAVES : 
         //     every wave-instruction moves 1 KiB (16 rows)
         const int nblk_tile = (((g.N - nblk0) < RG_BN ? (g.N - nblk0) : RG_BN) + 31) >> 5;   // column blocks that exist
         const int r16 = lane >> 2, c = lane & 3;
+        if (g.act == 2) {
+            // packed in_proj of a long sequence (N = 3 d, d = 512 = one column chunk each for q, k, v): the "attention-ready"
+            // layout [sample * H + head][Tqp][dh] k_attn_x3 reads; a row's 32-column block is a 64-byte run of its head's row
+            __bf16* dst = blockIdx.y == 0 ? g.Qhi : (blockIdx.y == 1 ? g.Khi : g.Vhi);
+            const int bpk = g.dh >> 5;                                 // 32-column blocks per head
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int p = wave * 8 + j, blk = p >> 2, r = (p & 3) * 16 + r16;
-            const int m = m0 + r;
-            if (blk < nblk_tile && m < g.M) {
-                const int off = blk * 4096 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
-                const size_t o = ((size_t)((nblk0 >> 5) + blk) * g.c_rows + m) * 32 + c * 8;
-                *reinterpret_cast<bf16x8*>(g.Chi + o) = *reinterpret_cast<const bf16x8*>(img_hi + off);
-                if (g.Clo) *reinterpret_cast<bf16x8*>(g.Clo + o) = *reinterpret_cast<const bf16x8*>(img_lo + off);
+            for (int j = 0; j < 8; ++j) {
+                const int p = wave * 8 + j, blk = p >> 2, r = (p & 3) * 16 + r16;
+                const int m = m0 + r;
+                if (m < g.M) {
+                    const int b = m / g.Tq, t = m - b * g.Tq, head = blk / bpk, cc = (blk - head * bpk) * 32 + c * 8;
+                    const int off = blk * 4096 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
+                    const size_t o = (((size_t)b * g.H + head) * g.Tqp + t) * g.dh + cc;
+                    *reinterpret_cast<bf16x8*>(dst + o) = *reinterpret_cast<const bf16x8*>(img_hi + off);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = wave * 8 + j, blk = p >> 2, r = (p & 3) * 16 + r16;
+                const int m = m0 + r;
+                if (blk < nblk_tile && m < g.M) {
+                    const int off = blk * 4096 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
+                    const size_t o = ((size_t)((nblk0 >> 5) + blk) * g.c_rows + m) * 32 + c * 8;
+                    *reinterpret_cast<bf16x8*>(g.Chi + o) = *reinterpret_cast<const bf16x8*>(img_hi + off);
+                    if (g.Clo) *reinterpret_cast<bf16x8*>(g.Clo + o) = *reinterpret_cast<const bf16x8*>(img_lo + off);
+                }
             }
         }
         RGN_RT(7)
@@ -449,7 +470,11 @@ hipError_t configure_rowgemm() {
 }
 hipError_t launch_rowgemm(const RowGemmArgs& g, bool ln, hipStream_t s) {
     if (!rowgemm_supported(g.N, g.Kp, ln)) return hipErrorInvalidValue;
-    if (!ln && (g.add || g.C || !g.Chi || g.N % 32)) return hipErrorInvalidValue;   // EPI_ACT writes planes only
+    if (!ln && g.act == 2) {                                         // attention-ready q / k / v scatter of the packed in_proj
+        if (g.N != 3 * RG_BN || !g.Qhi || !g.Khi || !g.Vhi || g.Clo || g.dh % 32 || g.H * g.dh != RG_BN || g.Tq <= 0) return hipErrorInvalidValue;
+    } else if (!ln && (g.add || g.C || !g.Chi || g.N % 32)) {
+        return hipErrorInvalidValue;                                 // EPI_ACT writes planes only
+    }
     return ln ? rg_nk<0>(g, g.Kp / 32, s, false) : rg_nk<1>(g, g.Kp / 32, s, false);
 }
 
