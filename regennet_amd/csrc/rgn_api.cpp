@@ -94,6 +94,7 @@ struct rgn_ctx {
     int big_tile_rows = 7000;          // launches of at least this many rows per chain use the 256x256 GEMM tile
     bool fuse_ln = false;              // out_proj / linear2 GEMMs carry their LayerNorms (k_gemm_x3_ln)
     bool rowgemm = false;              // plain-bf16 phase: row-complete GEMMs with fused LayerNorm / GELU (k_rowgemm)
+    bool mlp = false;                  // plain-bf16 phase: the whole layer tail in one row-persistent kernel (k_mlp)
     StepCoef* d_tab = nullptr;
     int* d_step = nullptr;
     SampleParams* d_sp = nullptr;
@@ -146,7 +147,7 @@ struct rgn_ctx {
 
 namespace {
 
-const char* kclass_names[KC_COUNT] = {"gemm_mfma", "attention", "layernorm", "embed", "update", "misc", "qkv_attn", "rowgemm_ln", "rowgemm_act"};
+const char* kclass_names[KC_COUNT] = {"gemm_mfma", "attention", "layernorm", "embed", "update", "misc", "qkv_attn", "rowgemm_ln", "rowgemm_act", "mlp"};
 
 #define RGN_HIP(h, expr)                                                                                    \
     do {                                                                                                    \
@@ -498,6 +499,19 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
         const float* per_sample = sampling ? (ccond_rows ? ccond_rows + (size_t)s0 * Ld + (size_t)l * d : nullptr)
                                            : c->call + (size_t)s0 * Ld + (size_t)l * d;
         const float* step_vec = sampling ? c->call_time + (size_t)l * d : nullptr;
+        if (fast && !x3 && c->mlp && !h_p.lo) {
+            // plain-bf16 phase, d = 512 / ff = 1024: the whole layer tail (out_proj + norm1 + folded cross-attention + norm2 +
+            // linear1 + GELU + linear2 + norm3) as ONE row-persistent kernel; residual stream updated in place (hi plane)
+            MlpArgs g{};
+            g.att = att_p.hi; g.h = h_p.hi; g.out = h_p.hi; g.rows = h_p.rows; g.M = M;
+            g.Wo = c->dp<__bf16>(w.out.fr); g.W1 = c->dp<__bf16>(w.ff1.fr); g.W2 = c->dp<__bf16>(w.ff2.fr);
+            g.bo = c->dp<float>(w.out.b); g.bf1 = c->dp<float>(w.ff1.b); g.bf2 = c->dp<float>(w.ff2.b);
+            g.g1 = c->dp<float>(w.ln[0]); g.b1 = c->dp<float>(w.ln[1]); g.g2 = c->dp<float>(w.ln[2]); g.b2 = c->dp<float>(w.ln[3]);
+            g.g3 = c->dp<float>(w.ln[4]); g.b3 = c->dp<float>(w.ln[5]);
+            g.pervec = per_sample; g.ldper = Ld; g.stepvec = step_vec; g.ldstep = Ld; g.d_step = c->d_step; g.Tq = dm.Tq;
+            RGN_LAUNCH(c, KC_MLP, s, launch_mlp(g, s));
+            continue;
+        }
         if (fast && !x3 && c->rowgemm) {
             // plain-bf16 phase: out_proj + residual + norm1 + folded cross-attention + norm2 | linear1 + GELU |
             // linear2 + residual + norm3, three row-complete kernels; the residual stream is updated in place as planes
@@ -917,6 +931,8 @@ int rgn_finalize_weights(rgn_handle h) {
                      rowgemm_supported(d, d, true) && rowgemm_supported(d, (int)align_up((size_t)ff, 32), true) &&
                      rowgemm_supported(ff, d, false);
         if (c->rowgemm) RGN_HIP(c, configure_rowgemm());
+        c->mlp = c->rowgemm && mlp_supported(d, ff) && getenv("REGENNET_NO_MLP") == nullptr;
+        if (c->mlp) RGN_HIP(c, configure_mlp());
         if (c->fuse_qkv) RGN_HIP(c, configure_qkv_attn());
     }
     if ((rc = ws_alloc(c, &c->d_tab, (size_t)1024))) return rc;

@@ -17,6 +17,7 @@ enum KClass : int {
     KC_QKV,           // fused in_proj GEMM + attention (k_qkv_attn)
     KC_ROWLN,         // row-complete GEMM + residual + LayerNorm(s) (k_rowgemm<0>)
     KC_ROWACT,        // row-complete GEMM + activation (k_rowgemm<1>)
+    KC_MLP,           // row-persistent layer tail (k_mlp)
     KC_COUNT
 };
 
@@ -147,6 +148,25 @@ struct RowGemmArgs {
 bool rowgemm_supported(int N, int Kp, bool ln);
 hipError_t configure_rowgemm();
 hipError_t launch_rowgemm(const RowGemmArgs& g, bool ln, hipStream_t s);
+
+// Row-persistent decoder-layer tail (rgn_mlp.hip): out_proj + norm1 + folded cross-attention + norm2 + linear1 + GELU + linear2 + norm3
+// for 64-row tiles, plain-bf16 phase, d = 512, ff = 1024. All planes are hi-only K32-blocked [16][rows][32]; weights fragment-ordered.
+struct MlpArgs {
+    const __bf16* att;                    // attention output planes (A operand of out_proj), advanced to the first row
+    const __bf16* h;                      // layer input planes (residual of norm1)
+    __bf16* out;                          // layer output planes (may alias h)
+    int rows;                             // plane row count (stride), M rows processed
+    int M;
+    const __bf16 *Wo, *W1, *W2;           // out_proj [512x512], linear1 [1024x512], linear2 [512x1024]
+    const float *bo, *bf1, *bf2;
+    const float *g1, *b1, *g2, *b2, *g3, *b3;
+    const float* pervec; int ldper;       // + pervec[(row / Tq) * ldper + n]     (nullable)
+    const float* stepvec; int ldstep; const int* d_step;   // + stepvec[(*d_step) * ldstep + n] (nullable)
+    int Tq;
+};
+bool mlp_supported(int d, int ff);
+hipError_t configure_mlp();
+hipError_t launch_mlp(const MlpArgs& g, hipStream_t s);
 
 struct Dims {
     int B;        // motions in the bound condition

@@ -40,7 +40,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define RGN_AS1 __attribute__((address_space(1)))
 #define RGN_AS3 __attribute__((address_space(3)))
 
-constexpr int RG_BM = 64, RG_BN = 512, RG_NT = 512, RG_D = 3;   // D = weight prefetch distance in k-steps (ring of D + 1)
+#ifndef RGN_RG_D_LN
+#define RGN_RG_D_LN 3
+#endif
+constexpr int RG_BM = 64, RG_BN = 512, RG_NT = 512;
+// weight prefetch distance in k-steps (register ring of D + 1 slots of 16 VGPRs): per epilogue kind, the ACT build has to fit 128 VGPRs
+template <int EPI> struct RgDepth { static constexpr int D = EPI == 0 ? RGN_RG_D_LN : 3; };
 
 // GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) for the plain-bf16 phase: erf as an odd degree-15 polynomial in u = clamp(x / sqrt 2,
 // +-3.2) (weighted least-squares fit, max abs error 1.6e-4 -> relative GELU error <= 8e-5, 25x below the bf16 rounding of the
@@ -85,6 +90,9 @@ __device__ __forceinline__ void rg_wait_vmcnt() {
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     else static_assert(N == 0, "add the vmcnt literal");
 }
 
@@ -111,7 +119,8 @@ __global__ __launch_bounds__(RG_NT, (EPI == 1 && NK <= 16) ? RGN_RG_ACT_WAVES : 
     const int m0 = blockIdx.x * RG_BM, nblk0 = blockIdx.y * RG_BN;
     const int nw = nblk0 + wave * 64;                                // first column of this wave
     constexpr int nk = NK;
-    static_assert(NK >= 4 && NK % 4 == 0 && NK <= 32, "ring unroll; activation image <= 128 KiB");
+    constexpr int RG_D = RgDepth<EPI>::D, RING = RG_D + 1;
+    static_assert(NK > RG_D && NK <= 32, "prefetch distance; activation image <= 128 KiB");
 
     RGN_RT(0)
     // ---- activation tile -> LDS, once: k-block kb = 4 wave-instructions of 1 KiB (16 rows each); wave w issues the
@@ -212,11 +221,10 @@ __global__ __launch_bounds__(RG_NT, (EPI == 1 && NK <= 16) ? RGN_RG_ACT_WAVES : 
     };
     // fully unrolled (ring slots are compile-time: slot = k-step % 4)
 #pragma unroll
-    for (int kt = 0; kt < nk - RG_D; ++kt) step(kt, kt & 3, kt + RG_D, (kt + RG_D) & 3, [] { rg_wait_vmcnt<4 * RG_D>(); });
+    for (int kt = 0; kt < nk - RG_D; ++kt) step(kt, kt % RING, kt + RG_D, (kt + RG_D) % RING, [] { rg_wait_vmcnt<4 * RG_D>(); });
     if constexpr (EPI == 0) load_resid();                             // behind the last weight prefetch; the drain steps cover its latency
-    step(nk - 3, (nk - 3) & 3, -1, 0, [] {});                         // drain: straight-line code, the compiler's own counts are exact
-    step(nk - 2, (nk - 2) & 3, -1, 0, [] {});
-    step(nk - 1, (nk - 1) & 3, -1, 0, [] {});
+#pragma unroll
+    for (int kt = nk - RG_D; kt < nk; ++kt) step(kt, kt % RING, -1, 0, [] {});   // drain: straight-line code, the compiler's own counts are exact
     RGN_RT(4)
 
     // ---- epilogue. Accumulator layout: lane (l31, kh) holds, for token m = m0 + 32 mt + l31, the columns
