@@ -247,7 +247,7 @@ def main():
         value = a.steps * B * world / dt
         dtype = a.precision
         if a.precision == "bf16_x3tail":
-            tail = a.x3_tail if a.x3_tail is not None else (S if S < 40 else max(8, (S + 99) // 100))
+            tail = a.x3_tail if a.x3_tail is not None else (S if S < 40 else min(S, -(-max(8, (S + 99) // 100) * 8 // min(8, cfg['layers']))))
             dtype = f"bf16 MFMA, fp32 accumulate/LayerNorm/softmax; split-bf16 (x3) for the last {min(tail, S)} of {S} steps"
         line = {
             "metric": "sampled motions/sec", "value": round(value, 3), "unit": "motions/s", "n_gpus": world,

@@ -323,15 +323,21 @@ inline bool eval_x3(const rgn_ctx* c) {
 }
 // do activation planes carry a lo part at all (allocation, sampler state, residual stream)?
 inline bool has_lo(const rgn_ctx* c) { return c->cfg.precision == RGN_PREC_BF16X3 || c->cfg.precision == RGN_PREC_BF16_X3TAIL; }
-inline int default_tail(int S) {
-    // What the bulk phase may cost is empirical (tests/test_hip_parity.py sweeps the switch point against the reference):
-    // a long schedule contracts early-step rounding (1000-step DDPM: 5 split-bf16 steps reach 1.2e-4, 10 reach 6.7e-5, the
-    // uniform split-bf16 floor is 4.8e-5), a short DDIM schedule does not (every step carries a large share of the result:
-    // 20 guided steps with 8 of them split-bf16 measured 3e-3 on a tiny model). So: schedules of fewer than 40 steps run
-    // split-bf16 throughout; longer ones keep 1 % of the steps, at least 8.
+inline int default_tail(int S, int layers, bool etd = false) {
+    if (etd) return S;   // emb_trans_dec feeds the timestep/condition embedding in as a token: measured 10x more sensitive
+                         // to bulk-phase rounding under guidance (2 layers, 50-step DDIM + CFG: 1.9e-3 with 40 of 50 steps split)
+    // What the bulk phase may cost is empirical (tests/test_hip_parity.py sweeps the switch point against the reference, and
+    // DESIGN.md §6 tabulates models of other depths): the last step returns the denoiser's own prediction (coef1[0] = 1,
+    // coef2[0] = 0), so earlier rounding reaches the result only through the network's sensitivity to x_t, which the
+    // LayerNorm stack damps - the deeper the model the more. Measured with 10 (of 1000 DDPM) / 8 (of 100 DDIM + CFG) split
+    // steps: 8 layers 6.7e-5 / 1.1e-4, 4 layers 1.6e-4, 2 layers 5.2e-4 / 8.3e-4; a 20-step DDIM schedule with 8 of them
+    // split measured 3e-3 on a tiny model. So: schedules of fewer than 40 steps run split-bf16 throughout; longer ones keep
+    // max(8, S / 100) split-bf16 steps, scaled by 8 / layers for models shallower than the shipped 8 layers.
     if (S < 40) return S;
-    const int t = (S + 99) / 100;
-    return t < 8 ? 8 : t;
+    int t = (S + 99) / 100;
+    t = t < 8 ? 8 : t;
+    if (layers < 8) t = (t * 8 + layers - 1) / (layers > 0 ? layers : 1);
+    return t < S ? t : S;
 }
 
 GemmArgs gemm_args(const rgn_ctx* c, const Lin& L, const float* A, int lda, float* C, int ldc, int M) {
@@ -927,11 +933,11 @@ int rgn_finalize_weights(rgn_handle h) {
         }
         c->fuse_qkv = qkv_attn_supported(c->Tq, d / c->H, d) && getenv("REGENNET_NO_FUSED_QKV") == nullptr;
         if (const char* e = getenv("REGENNET_BIG_TILE_ROWS")) c->big_tile_rows = atoi(e);
-        c->rowgemm = c->cfg.precision == RGN_PREC_BF16_X3TAIL && getenv("REGENNET_NO_ROWGEMM") == nullptr &&
+        c->rowgemm = c->cfg.precision == RGN_PREC_BF16_X3TAIL && getenv("REGENNET_NO_ROWGEMM") == nullptr && c->Tq >= 8 &&   // (8 rows of a wave: <= 2 samples)
                      rowgemm_supported(d, d, true) && rowgemm_supported(d, (int)align_up((size_t)ff, 32), true) &&
                      rowgemm_supported(ff, d, false);
         if (c->rowgemm) RGN_HIP(c, configure_rowgemm());
-        c->mlp = c->rowgemm && mlp_supported(d, ff) && getenv("REGENNET_NO_MLP") == nullptr;
+        c->mlp = c->rowgemm && mlp_supported(d, ff, c->Tq) && getenv("REGENNET_NO_MLP") == nullptr;
         if (c->mlp) RGN_HIP(c, configure_mlp());
         if (c->fuse_qkv) RGN_HIP(c, configure_qkv_attn());
     }
@@ -1118,7 +1124,7 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
     // Precision schedule: loop indices >= tail run the plain-bf16 phase, the last `tail` indices the split-bf16 one.
     // One captured step graph per phase; everything t-dependent is read on the device, so each serves all its steps.
     const bool sched = c->cfg.precision == RGN_PREC_BF16_X3TAIL;
-    const int tail = !sched ? 0 : (c->x3_tail >= 0 ? c->x3_tail : default_tail(c->S));
+    const int tail = !sched ? 0 : (c->x3_tail >= 0 ? c->x3_tail : default_tail(c->S, c->L, c->etd != 0));
     // A graph holds `steps` consecutive loop iterations (evaluation + sampler update + counter decrement each): the loop
     // index lives on the device, so one instantiated graph serves any starting index. Long ranges replay the multi-step
     // graph (graph_steps iterations per host launch; a 4-branch launch costs the host ~1 ms, as much as the GPU needs for

@@ -164,7 +164,7 @@ struct MlpArgs {
     const float* stepvec; int ldstep; const int* d_step;   // + stepvec[(*d_step) * ldstep + n] (nullable)
     int Tq;
 };
-bool mlp_supported(int d, int ff);
+bool mlp_supported(int d, int ff, int Tq);
 hipError_t configure_mlp();
 hipError_t launch_mlp(const MlpArgs& g, hipStream_t s);
 

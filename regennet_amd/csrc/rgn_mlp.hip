@@ -35,9 +35,10 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ML_BM = 64, ML_D = 512, ML_NT = 512, ML_PF = 3;   // PF = weight prefetch distance (ring of PF + 1)
 // LDS map: X | Y | reduction scratch (2 x 2 KiB) | per-column vectors: bo g1 b1 g2 b2 bf2 g3 b3 (8 x 512) + bf1 (1024) floats |
-// sv + pv of the (at most 3) samples a tile touches (3 x 512 floats)  = 158 KiB
+// sv + pv of the (at most ML_NSAMP) samples a 64-row tile touches (Tq >= 22)  = 160 KiB
+constexpr int ML_NSAMP = 4;
 constexpr int ML_X = 0, ML_Y = 64 * 1024, ML_RED = 128 * 1024, ML_VEC = ML_RED + 2 * 2048, ML_SPV = ML_VEC + (8 * 512 + 1024) * 4,
-              ML_LDS = ML_SPV + 3 * 512 * 4;
+              ML_LDS = ML_SPV + ML_NSAMP * 512 * 4;
 static_assert(ML_LDS <= 160 * 1024, "LDS map");
 enum { V_BO = 0, V_G1 = 512, V_B1 = 1024, V_G2 = 1536, V_B2 = 2048, V_BF2 = 2560, V_G3 = 3072, V_B3 = 3584, V_BF1 = 4096 };
 
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
         const float sv = g.stepvec ? g.stepvec[(size_t)(*g.d_step) * g.ldstep + tid] : 0.f;
         const int s0 = m0 / g.Tq, slast = (g.M - 1) / g.Tq;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < ML_NSAMP; ++j) {
             const int sidx = s0 + j < slast ? s0 + j : slast;
             spv[j * 512 + tid] = sv + (g.pervec ? g.pervec[(size_t)sidx * g.ldper + tid] : 0.f);
         }
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
 void ml_prof_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ml_prof), sizeof(long long) * 16); }
 #endif
 
-bool mlp_supported(int d, int ff) { return d == ML_D && ff == 2 * ML_D; }
+bool mlp_supported(int d, int ff, int Tq) { return d == ML_D && ff == 2 * ML_D && 63 / Tq + 2 <= ML_NSAMP; }   // samples a 64-row tile can touch
 hipError_t configure_mlp() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp), hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
 }

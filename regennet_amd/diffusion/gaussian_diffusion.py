@@ -214,6 +214,7 @@ class GaussianDiffusion:
                                            init_image, eta, noise_tape)
             return
         assert len(shape) == 4, "shape must be (B, njoints, nfeats, T)"
+        self._maybe_calibrate_tail(sampler, model, shape, y, eta)
         eng, guided, dev = bind(B, y, device, T=int(shape[3]))
         if tuple(shape[1:]) != (eng.cfg["njoints"], eng.cfg["nfeats"], eng.cfg["num_frames"]):
             raise AssertionError(f"shape {tuple(shape)} does not match the model ({eng.cfg['njoints']},{eng.cfg['nfeats']},{eng.cfg['num_frames']})")
@@ -263,6 +264,55 @@ class GaussianDiffusion:
             bar.close()
         if not progressive:
             yield {"sample": img, "pred_xstart": None}
+
+    # ---- precision-schedule calibration (x3_tail="auto") -------------------------------------------------------------------
+    def _maybe_calibrate_tail(self, sampler, model, shape, y, eta):
+        inner = getattr(model, "model", model)
+        if getattr(inner, "x3_tail", None) != "auto" or getattr(inner, "precision", "") != "bf16_x3tail" or getattr(self, "_calibrating", False):
+            return
+        key = (id(self._sched_token), sampler, inner is not model, int(shape[3]), float(eta))
+        if key not in inner._auto_tails:
+            inner._auto_tails[key] = self.calibrate_x3_tail(model, shape, {"y": y}, sampler=sampler, eta=eta)
+        inner._auto_tail = inner._auto_tails[key]
+
+    def calibrate_x3_tail(self, model, shape, model_kwargs, sampler="ddpm", eta=0.0, tol=2.5e-4, max_batch=4, seed=1234, verbose=False):
+        """How many split-bf16 steps THIS checkpoint needs at the end of THIS schedule: the precision schedule's validity
+        depends on how strongly the model damps early-step rounding, so it can be measured instead of assumed.
+        Samples the first min(B, max_batch) motions of the given condition with the uniform split-bf16 arithmetic (tail = S)
+        and with growing tails (engine default, x2, x4, ...), all from the same Philox noise, and returns the smallest tail
+        whose result stays within `tol` (max abs) of the uniform run. Cost: a few small sampling runs, once."""
+        inner = getattr(model, "model", model)
+        y = model_kwargs["y"]
+        B, nb, S = int(shape[0]), min(int(shape[0]), max_batch), self.num_timesteps
+        ys = {k: (v[:nb].contiguous() if th.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B else (v[:nb] if isinstance(v, (list, tuple)) and len(v) == B else v))
+              for k, v in y.items()}
+        saved, self._calibrating = (inner.x3_tail, inner._auto_tail), True
+        fn = self.p_sample_loop if sampler == "ddpm" else self.ddim_sample_loop
+        kw = dict(clip_denoised=False, model_kwargs={"y": ys}, seed=seed)
+        if sampler == "ddim":
+            kw["eta"] = eta
+
+        def run(tail):
+            inner.x3_tail = tail
+            return fn(model, (nb,) + tuple(shape[1:]), **kw)
+
+        try:
+            ref = run(S)
+            L = max(1, int(getattr(inner, "num_layers", 8)))
+            t = S if S < 40 else min(S, -(-max(8, (S + 99) // 100) * 8 // min(8, L)))
+            chosen = S
+            while t < S:
+                dev = float((run(t) - ref).abs().max())
+                if verbose:
+                    print(f"[calibrate_x3_tail] tail {t} of {S}: max |dev| vs uniform split-bf16 = {dev:.2e}")
+                if dev <= tol:
+                    chosen = t
+                    break
+                t *= 2
+        finally:
+            inner.x3_tail, inner._auto_tail = saved
+            self._calibrating = False
+        return chosen
 
     def _loop_per_step(self, sampler, model, shape, noise, clip_denoised, model_kwargs, progress, skip_timesteps, init_image,
                        eta, noise_tape):

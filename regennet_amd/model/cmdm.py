@@ -134,8 +134,10 @@ class CMDM(nn.Module):
         self.rot2xyz = _Rot2xyzUnavailable()
 
         self.precision = os.environ.get("REGENNET_PRECISION", kargs.get("precision", _lib.DEFAULT_PRECISION))
-        # precision schedule: split-bf16 for the last x3_tail loop indices of a sampling loop (None: engine default)
+        # precision schedule: split-bf16 for the last x3_tail loop indices of a sampling loop (None: engine default rule;
+        # "auto": measured on this checkpoint at the first sampling call, see diffusion.calibrate_x3_tail)
         self.x3_tail = kargs.get("x3_tail", None)
+        self._auto_tail, self._auto_tails = None, {}
         self._engine = None
         self._engines = {}
         self._engine_stale = True
@@ -212,6 +214,8 @@ class CMDM(nn.Module):
         if eng is not self._engine:
             self._engine, self._cond_key, self._keep = eng, None, None
         tail = os.environ.get("REGENNET_X3_TAIL", self.x3_tail)
+        if tail == "auto":                                    # filled in per (schedule, sampler, guidance, T) by calibrate_x3_tail
+            tail = self._auto_tail
         eng.set_x3_tail(-1 if tail is None else int(tail))
         return eng, dev
 

@@ -21,9 +21,14 @@ LOOPS = ["tiny_ddpm10", "tiny_ddim10_cfg", "tiny_add_ddpm1000", "tiny_text_ddim2
          "ntu_action_ddim100_cfg", "text150_ddim50_cfg", "chi3d_ddpm20", "chi3d_ddim20_cfg"]
 
 
-def default_tail(S):
+def default_tail(S, layers=8):
     """rgn_api.cpp default_tail(): loop indices below this run split-bf16 under the precision schedule."""
-    return S if S < 40 else max(8, (S + 99) // 100)
+    if S < 40:
+        return S
+    t = max(8, (S + 99) // 100)
+    if layers < 8:
+        t = -(-t * 8 // layers)
+    return min(t, S)
 
 
 def _wrap(model, guided):
@@ -109,7 +114,7 @@ def test_precision_schedule_switch_point_sweep(golden, name):
         out = fn(fm, shape, clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
         errs[tail] = float(np.abs(out.cpu().numpy() - g["final"]).max())
         model._engine.close()
-    print(f"\n[x3-tail sweep] {name} (default tail {default_tail(S)}): " + ", ".join(f"{k}: {v:.2e}" for k, v in errs.items()))
+    print(f"\n[x3-tail sweep] {name} (default tail {default_tail(S, cfg['layers'])}): " + ", ".join(f"{k}: {v:.2e}" for k, v in errs.items()))
     for tail, e in errs.items():
         if tail is None or tail >= 8:
             assert e < 1e-3, (name, tail, e)
@@ -133,6 +138,42 @@ def test_graph_replay_equals_eager(golden, precision):
     b = diffusion.p_sample_loop(model, shape, use_graph=True, **kw)
     c = diffusion.p_sample_loop(model, shape, use_graph=True, **kw)   # replays the cached graph
     assert torch.equal(a, b) and torch.equal(b, c)
+
+
+def test_precision_schedule_auto_calibration_and_conservative_defaults():
+    """The schedule's validity depends on how strongly a checkpoint damps early-step rounding (depth, emb_trans_dec,
+    guidance: DESIGN.md §6). (1) `x3_tail="auto"` measures it on the checkpoint itself: a shallow guided model gets a longer
+    split-bf16 tail than the depth-scaled default would need to be trusted blindly, and ends inside the parity bound;
+    (2) emb_trans_dec models default to split-bf16 throughout (bit-identical to the uniform mode)."""
+    from oracle import regennet_oracle as orc
+    from regennet_amd import synth
+    from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    cfg = synth.get_config("ntu_action", layers=2)
+    sd = synth.make_state_dict(cfg, seed=5)
+    B = 2
+    y = {"cmotion": synth.make_cmotion(cfg, B, seed=61), "action": synth.make_actions(cfg, B, seed=62), "scale": np.full((B,), 2.5, np.float32)}
+    tape = synth.make_noise_tape(cfg, B, 100, seed=63)
+    ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", "ddim100"), tape, {k: torch.from_numpy(v) for k, v in y.items()},
+                          mode="ddim", guided=True).numpy()
+    model, diffusion = build_hip(cfg, sd, resp="ddim100", precision="bf16_x3tail", x3_tail="auto")
+    fm = ClassifierFreeSampleModel(model)
+    out = diffusion.ddim_sample_loop(fm, (B, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
+    chosen = model._auto_tail
+    err = float(np.abs(out.cpu().numpy() - ref).max())
+    print(f"\n[auto tail] 2 layers, ddim100 + CFG: chose {chosen} of 100, error vs oracle {err:.2e}")
+    assert 8 <= chosen <= 100 and err < 1e-3
+    again = diffusion.ddim_sample_loop(fm, (B, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
+    assert torch.equal(out, again) and model._auto_tail == chosen            # calibrated once, cached per (schedule, sampler, guidance, T)
+    # emb_trans_dec: default = uniform split-bf16
+    cfg2 = synth.get_config("ntu_action", layers=2, emb_trans_dec=True)
+    sd2 = synth.make_state_dict(cfg2, seed=5)
+    tape2 = torch.from_numpy(synth.make_noise_tape(cfg2, B, 50, seed=63))
+    outs = []
+    for prec in ("bf16_x3tail", "bf16x3"):
+        m2, d2 = build_hip(cfg2, sd2, resp="ddim50", precision=prec)
+        outs.append(d2.ddim_sample_loop(ClassifierFreeSampleModel(m2), (B, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y_to_device(y)},
+                                        noise_tape=tape2))
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_multi_step_graphs_equal_single_step_replay(golden, monkeypatch):
@@ -171,6 +212,29 @@ def test_oracle_parity_sequence_length_edges(frames, etd):
     out = diffusion.ddim_sample_loop(model, (B, 56, 6, frames), clip_denoised=False, model_kwargs={"y": y_to_device(y)},
                                      noise_tape=torch.from_numpy(tape))
     assert np.abs(out.cpu().numpy() - ref).max() < 1e-3
+
+
+@pytest.mark.parametrize("over", [dict(ff_size=512), dict(ff_size=2048), dict(latent_dim=256, ff_size=1024), dict(num_frames=24, emb_trans_dec=True)])
+def test_oracle_parity_across_kernel_dispatch_paths(over):
+    """The plain-bf16 phase picks its kernels by shape: d = 512 / ff = 1024 -> k_mlp; d = 512 with another ff -> k_rowgemm
+    (ff = 512) or the generic tiles (ff = 2048: activation image too large); other widths -> generic tiles. Each path against
+    the oracle under the default precision schedule (2 layers, 50 steps: 18 plain-bf16 + 32 split-bf16) and with guidance."""
+    from oracle import regennet_oracle as orc
+    from regennet_amd import synth
+    from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    cfg = synth.get_config("ntu_action", layers=2, **over)
+    sd = synth.make_state_dict(cfg, seed=5)
+    B, T = 3, cfg["num_frames"]
+    model, diffusion = build_hip(cfg, sd, resp="ddim50", precision="bf16_x3tail")
+    y = {"cmotion": synth.make_cmotion(cfg, B, seed=61), "action": synth.make_actions(cfg, B, seed=62), "scale": np.full((B,), 2.5, np.float32)}
+    tape = synth.make_noise_tape(cfg, B, 50, seed=63)
+    ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", "ddim50"), tape, {k: torch.from_numpy(v) for k, v in y.items()},
+                          mode="ddim", guided=True).numpy()
+    out = diffusion.ddim_sample_loop(ClassifierFreeSampleModel(model), (B, 56, 6, T), clip_denoised=False,
+                                     model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
+    err = float(np.abs(out.cpu().numpy() - ref).max())
+    print(f"\n[dispatch path] {over}: {err:.2e}")
+    assert err < 1e-3, (over, err)
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
