@@ -89,7 +89,7 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
 #pragma unroll
         for (int j = 0; j < ML_NSAMP; ++j) {
             const int sidx = s0 + j < slast ? s0 + j : slast;
-            spv[j * 512 + tid] = sv + (g.pervec ? g.pervec[(size_t)sidx * g.ldper + tid] : 0.f);
+            spv[j * 512 + tid] = sv + g.b1[tid] + (g.pervec ? g.pervec[(size_t)sidx * g.ldper + tid] : 0.f);   // norm1's beta folded in
         }
     }
 
@@ -156,13 +156,18 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto zero = [](f32x16 (&acc)[2][2]) {
+    // accumulators start from the bias of their columns (vec: the LDS copy of the per-column vectors)
+    auto init_bias = [&](f32x16 (&acc)[2][2], const float* bias) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 64 * wave + 32 * nt + 8 * i4 + 4 * kh);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[nt][mt][4 * i4 + e] = b[e];
+            }
     };
     // element (token 32 mt + l31, column 64 wave + 32 nt + 8 i4 + 4 kh + e) <-> register acc[nt][mt][4 i4 + e]; its 8-byte
     // run inside a [16 column blocks][64 rows][64 B] swizzled image:
@@ -178,18 +183,16 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
         for (int mt = 0; mt < 2; ++mt) v[mt] += __shfl_xor(v[mt], 32, 64);
         float* buf = red + (red_slot & 1) * 512;   // two alternating buffers suffice: a barrier separates each write from its reads
         ++red_slot;
-        if (kh == 0) {
-            buf[wave * 64 + l31] = v[0];
-            buf[wave * 64 + 32 + l31] = v[1];
+        if (kh == 0) {                                                // [token][wave]: a token's 8 partials are two float4
+            buf[l31 * 8 + wave] = v[0];
+            buf[(32 + l31) * 8 + wave] = v[1];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            s0 += buf[w * 64 + l31];
-            s1 += buf[w * 64 + 32 + l31];
-        }
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(buf + l31 * 8), a1 = *reinterpret_cast<const f32x4*>(buf + l31 * 8 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(buf + (32 + l31) * 8), b1 = *reinterpret_cast<const f32x4*>(buf + (32 + l31) * 8 + 4);
+        const float s0 = ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a1[0] + a1[1]) + (a1[2] + a1[3]));
+        const float s1 = ((b0[0] + b0[1]) + (b0[2] + b0[3])) + ((b1[0] + b1[1]) + (b1[2] + b1[3]));
         v[0] = s0;
         v[1] = s1;
     };
@@ -216,32 +219,43 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
                 }
         row_sum(q);
         const float rstd[2] = {__builtin_amdgcn_rsqf(q[0] * invn + 1e-5f), __builtin_amdgcn_rsqf(q[1] * invn + 1e-5f)};
+        f32x4 ga[2][4], be[2][4];                                     // all the LDS reads first, then the arithmetic
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
-                const int n = col4(nt, i4);
-                const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + n), be = *reinterpret_cast<const f32x4*>(bet + n);
+                ga[nt][i4] = *reinterpret_cast<const f32x4*>(gam + col4(nt, i4));
+                if (bet) be[nt][i4] = *reinterpret_cast<const f32x4*>(bet + col4(nt, i4));
+            }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[nt][mt][4 * i4 + e] = fmaf(acc[nt][mt][4 * i4 + e], rstd[mt] * ga[e], be[e]);
-            }
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = acc[nt][mt][4 * i4 + e] * (rstd[mt] * ga[nt][i4][e]);
+                        acc[nt][mt][4 * i4 + e] = bet ? a + be[nt][i4][e] : a;
+                    }
     };
-    // acc += bias[n] + bf16 image value (the residual)
-    auto add_bias_resid = [&](f32x16 (&acc)[2][2], const float* bias, const char* img) {
+    // acc += bf16 image value (the residual); all sixteen 8-byte reads first, then the adds
+    auto add_resid = [&](f32x16 (&acc)[2][2], const char* img) {
+        bf16x4 r[2][4][2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(bias + col4(nt, i4));
+            for (int i4 = 0; i4 < 4; ++i4)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const bf16x4 r = *reinterpret_cast<const bf16x4*>(img + img_off(nt, i4, mt));
+                for (int mt = 0; mt < 2; ++mt) r[nt][i4][mt] = *reinterpret_cast<const bf16x4*>(img + img_off(nt, i4, mt));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[nt][mt][4 * i4 + e] += b[e] + (float)r[e];
-                }
-            }
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[nt][mt][4 * i4 + e] += (float)r[nt][i4][mt][e];
     };
     auto store_img = [&](const f32x16 (&acc)[2][2], char* img) {
 #pragma unroll
@@ -259,16 +273,17 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
 
     // =============== stage 1: out_proj + residual + norm1 + folded cross-attention + norm2 -> h' (Y) ====================
     f32x16 acc[2][2];
-    zero(acc);
     gemm_prefetch(g.Wo, 16, 2 * wave, 0);
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                // in order: both tile images landed, the weight prefetch may still fly
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // ... and this thread's share of the vectors is written
     __builtin_amdgcn_s_barrier();
+    init_bias(acc, vec + V_BO);
     RGN_MT(1)
     gemm16(acc, smem + ML_X, g.Wo, 16, 2 * wave, 0);
     RGN_MT(2)
-    add_bias_resid(acc, vec + V_BO, smem + ML_Y);
-    layernorm(acc, vec + V_G1, vec + V_B1);
-    {   // + call_time[step] + call_cond[sample of the token] (pre-summed per sample in LDS)
+    add_resid(acc, smem + ML_Y);
+    layernorm(acc, vec + V_G1, nullptr);                              // beta of norm1 rides in the per-sample vector below
+    {   // + norm1.beta + call_time[step] + call_cond[sample of the token] (pre-summed per sample in LDS)
         const int s0 = m0 / g.Tq;
         int sj[2];
 #pragma unroll
@@ -297,27 +312,22 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
 
     // =============== stage 2: linear1 + GELU + linear2, the hidden 1024 columns in two halves ==============================
     f32x16 acc2[2][2];
-    zero(acc2);
+    init_bias(acc2, vec + V_BF2);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        zero(acc);
+        init_bias(acc, vec + V_BF1 + 512 * c);
         gemm_prefetch(g.W1, 32, 16 * c + 2 * wave, 0);
         gemm16(acc, smem + ML_Y, g.W1, 32, 16 * c + 2 * wave, 0);    // hidden columns [512 c, 512 c + 512)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(vec + V_BF1 + 512 * c + col4(nt, i4));
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const f32x2 g0 = ml_gelu2(f32x2{acc[nt][mt][4 * i4] + b[0], acc[nt][mt][4 * i4 + 1] + b[1]});
-                    const f32x2 g1 = ml_gelu2(f32x2{acc[nt][mt][4 * i4 + 2] + b[2], acc[nt][mt][4 * i4 + 3] + b[3]});
-                    acc[nt][mt][4 * i4] = g0[0];
-                    acc[nt][mt][4 * i4 + 1] = g0[1];
-                    acc[nt][mt][4 * i4 + 2] = g1[0];
-                    acc[nt][mt][4 * i4 + 3] = g1[1];
+                for (int i = 0; i < 16; i += 2) {
+                    const f32x2 gl = ml_gelu2(f32x2{acc[nt][mt][i], acc[nt][mt][i + 1]});
+                    acc[nt][mt][i] = gl[0];
+                    acc[nt][mt][i + 1] = gl[1];
                 }
-            }
         if (c == 1) __builtin_amdgcn_s_barrier();                     // every wave is done reading the first half's image
         store_img(acc, smem + ML_X);                                  // (c == 0: X still holds the att tile, dead since stage 1)
         gemm_prefetch(g.W2, 16, 2 * wave, 16 * c);                   // flies while the barrier passes (acc is dead: no extra registers)
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
     RGN_MT(4)
 
     // =============== stage 3: + bias + residual h' + norm3 -> output planes ===============================================
-    add_bias_resid(acc2, vec + V_BF2, smem + ML_Y);
+    add_resid(acc2, smem + ML_Y);
     layernorm(acc2, vec + V_G3, vec + V_B3);                                      // (its barriers also fence the last reads of X)
     store_img(acc2, smem + ML_X);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
