@@ -593,7 +593,7 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
     const float* cond_rows = !has_cond ? nullptr : ((uncond && !guided) ? c->condemb + (size_t)B * d : c->condemb);
     const float* ccond_rows = !has_cond ? nullptr : ((uncond && !guided) ? c->call_cond + (size_t)B * Ld : c->call_cond);
     if (!sampling) {
-        RGN_LAUNCH(c, KC_EMBED, s, launch_gather_pe(c->dp<float>(c->off_pe), c->d_tab, c->d_step, c->d_sp, c->pe_rows, dm.Bm, B, d, s));
+        RGN_LAUNCH(c, KC_EMBED, s, launch_gather_pe(c->dp<float>(c->off_pe), c->d_tab, c->d_step, c->d_sp, c->pe_rows, dm.Bm, B, d, c->pe_len, s));
         GemmArgs g = gemm_args(c, c->lin_t0, c->pe_rows, d, c->emb1, d, dm.Bm);
         g.act = 2;
         RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, small_prec(c), s));
@@ -1038,7 +1038,7 @@ int rgn_set_condition(rgn_handle h, int32_t B, const float* cmotion, const int64
     RGN_HIP(c, hipMemcpyAsync(c->c0 + (size_t)B * dm.Tq * d, c->c0, (size_t)B * dm.Tq * d * sizeof(float), hipMemcpyDeviceToDevice, s));   // uncond half
     // condition embedding rows: [0,B) conditional, [B,2B) what mask_cond(force_mask=True) leaves
     if (c->cfg.cond_mode == RGN_COND_ACTION) {
-        RGN_LAUNCH(c, KC_EMBED, s, launch_cond_rows(c->dp<float>(c->off_action), action, c->condemb, B, d, s));
+        RGN_LAUNCH(c, KC_EMBED, s, launch_cond_rows(c->dp<float>(c->off_action), action, c->condemb, B, d, c->cfg.num_actions, s));
         RGN_LAUNCH(c, KC_EMBED, s, launch_fill_rows(c->condemb + (size_t)B * d, nullptr, B, d, s));
     } else if (c->cfg.cond_mode == RGN_COND_TEXT) {
         GemmArgs t = gemm_args(c, c->lin_text, text_feat, c->cfg.clip_dim, c->condemb, d, B);

@@ -198,7 +198,7 @@ hipError_t launch_layernorm(const float* in, Planes resid, float* out, Planes op
                             const float* addvec, int ldadd, const float* stepvec, int ldstep, const int* d_step, int Tq,
                             const float* gb, const float* bb, hipStream_t s);
 hipError_t launch_gather_pe(const float* pe, const StepCoef* tab, const int* d_step, const SampleParams* sp,
-                            float* out, int Bm, int B, int d, hipStream_t s);
+                            float* out, int Bm, int B, int d, int pe_len, hipStream_t s);
 hipError_t launch_gather_pe_all(const float* pe, const StepCoef* tab, float* out, int S, int d, hipStream_t s);
 hipError_t launch_emb_rows(const float* emb, const float* stepemb, const int* d_step, const float* pe, float* h, Planes hp,
                            const Dims& dm, int wo_pos, hipStream_t s);
@@ -207,7 +207,7 @@ hipError_t launch_pack_x(const float* x, float* xin, Planes xp, int copies, cons
 hipError_t launch_update(const float* x0tok, const float* scale, const StepCoef* tab, const int* d_step,
                          const SampleParams* sp, float* xin, Planes xp, const Dims& dm, int b0, int nb, hipStream_t s);
 hipError_t launch_advance(int* d_step, hipStream_t s);
-hipError_t launch_cond_rows(const float* table, const int64_t* action, float* out, int B, int d, hipStream_t s);
+hipError_t launch_cond_rows(const float* table, const int64_t* action, float* out, int B, int d, int num_actions, hipStream_t s);
 hipError_t launch_fill_rows(float* out, const float* row, int rows, int d, hipStream_t s);
 hipError_t launch_randn(float* x, int B, int FT, int T, unsigned long long seed, unsigned long long sample_offset,
                         hipStream_t s);

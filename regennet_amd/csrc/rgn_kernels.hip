@@ -749,18 +749,19 @@ hipError_t launch_layernorm(const float* in, Planes resid, float* out, Planes op
 // _WrappedModel.__call__, respace.py:124-129) or from external int64 timesteps (rgn_denoise).
 // =================================================================================================
 __global__ void k_gather_pe(const float* __restrict__ pe, const StepCoef* __restrict__ tab, const int* __restrict__ d_step,
-                            const SampleParams* __restrict__ sp, float* __restrict__ out, int Bm, int B, int d) {
+                            const SampleParams* __restrict__ sp, float* __restrict__ out, int Bm, int B, int d, int pe_len) {
     const int r = blockIdx.x;
     long long t;
     if (sp->t_ext)
         t = sp->t_ext[r % B];
     else
         t = tab[*d_step].t_model;
+    t = t < 0 ? 0 : (t >= pe_len ? pe_len - 1 : t);   // never read outside the table (the Python boundary raises IndexError first)
     for (int c = threadIdx.x; c < d; c += blockDim.x) out[(size_t)r * d + c] = pe[(size_t)t * d + c];
 }
 hipError_t launch_gather_pe(const float* pe, const StepCoef* tab, const int* d_step, const SampleParams* sp,
-                            float* out, int Bm, int B, int d, hipStream_t s) {
-    hipLaunchKernelGGL(k_gather_pe, dim3(Bm), dim3(d >= 256 ? 256 : 64), 0, s, pe, tab, d_step, sp, out, Bm, B, d);
+                            float* out, int Bm, int B, int d, int pe_len, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_pe, dim3(Bm), dim3(d >= 256 ? 256 : 64), 0, s, pe, tab, d_step, sp, out, Bm, B, d, pe_len);
     return hipGetLastError();
 }
 
@@ -969,13 +970,14 @@ hipError_t launch_advance(int* d_step, hipStream_t s) {
 
 // EmbedAction.forward (cmdm.py:363-365): out[b,:] = table[action[b],:]
 __global__ void k_cond_rows(const float* __restrict__ table, const int64_t* __restrict__ action, float* __restrict__ out,
-                            int B, int d) {
+                            int B, int d, int num_actions) {
     const int b = blockIdx.x;
-    const long long a = action[b];
+    long long a = action[b];
+    a = a < 0 ? 0 : (a >= num_actions ? num_actions - 1 : a);   // never read outside the table (the Python boundary raises IndexError first)
     for (int c = threadIdx.x; c < d; c += blockDim.x) out[(size_t)b * d + c] = table[(size_t)a * d + c];
 }
-hipError_t launch_cond_rows(const float* table, const int64_t* action, float* out, int B, int d, hipStream_t s) {
-    hipLaunchKernelGGL(k_cond_rows, dim3(B), dim3(256), 0, s, table, action, out, B, d);
+hipError_t launch_cond_rows(const float* table, const int64_t* action, float* out, int B, int d, int num_actions, hipStream_t s) {
+    hipLaunchKernelGGL(k_cond_rows, dim3(B), dim3(256), 0, s, table, action, out, B, d, num_actions);
     return hipGetLastError();
 }
 __global__ void k_fill_rows(float* __restrict__ out, const float* __restrict__ row, int rows, int d) {
