@@ -142,6 +142,14 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
  * (gaussian_diffusion.py:265-276; 0.0016 at t=999, -> 1 at t=0), so early-step rounding is contracted away. */
 int rgn_set_x3_tail(rgn_handle h, int32_t tail_steps);
 
+/* Evaluations of at most `rows` token rows (motions x tokens, doubled under guidance) run the small-batch engine:
+ * column-split GEMMs that spread one row tile over 16-48 workgroups (rgn_sb.hip; d = 512 models, bf16 modes), the
+ * latency-bound regime of the reference CLI's own default batch (sample/cgenerate.py:109-135, BASELINE configs[0]).
+ * Larger evaluations run the row-complete throughput kernels. -1 restores the default (768, or REGENNET_SB_ROWS);
+ * 0 switches the small-batch engine off. Results of the two engines agree within the precision mode's error (both are
+ * checked against the same goldens), not bit for bit. */
+int rgn_set_small_batch_rows(rgn_handle h, int32_t rows);
+
 /* Fills x_dev [B,njoints,nfeats,T] with N(0,1) from the same Philox stream (x_T, gaussian_diffusion.py:706). */
 int rgn_randn(rgn_handle h, float* x_dev, int32_t B, uint64_t seed, uint64_t sample_offset, void* stream);
 

@@ -54,6 +54,7 @@ SYMBOLS = {
     "rgn_denoise": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "rgn_sample_range": (C.c_int, [_vp, _i32, _i32, _f32, _vp, _vp, _u64, _u64, _i32, _i32, _vp, _i32, _i32, _vp]),
     "rgn_set_x3_tail": (C.c_int, [_vp, _i32]),
+    "rgn_set_small_batch_rows": (C.c_int, [_vp, _i32]),
     "rgn_randn": (C.c_int, [_vp, _vp, _i32, _u64, _u64, _vp]),
     "rgn_rot6d_to_matrix": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "rgn_gaussian_filter1d": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
@@ -193,6 +194,10 @@ class Engine:
     def set_x3_tail(self, tail_steps):
         """Precision schedule ('bf16_x3tail'): split-bf16 for the last `tail_steps` loop indices (-1: default)."""
         self._ck(self.lib.rgn_set_x3_tail(self.h, int(tail_steps)))
+
+    def set_small_batch_rows(self, rows):
+        """Evaluations of at most `rows` token rows run the small-batch (column-split) kernels; -1: default, 0: off."""
+        self._ck(self.lib.rgn_set_small_batch_rows(self.h, int(rows)))
 
     def randn(self, x, B, seed, sample_offset, stream):
         self._ck(self.lib.rgn_randn(self.h, _ptr(x), int(B), int(seed) & (2 ** 64 - 1), int(sample_offset), C.c_void_p(stream)))

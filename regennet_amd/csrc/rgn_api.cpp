@@ -95,6 +95,9 @@ struct rgn_ctx {
     bool fuse_ln = false;              // out_proj / linear2 GEMMs carry their LayerNorms (k_gemm_x3_ln)
     bool rowgemm = false;              // plain-bf16 phase: row-complete GEMMs with fused LayerNorm / GELU (k_rowgemm)
     bool mlp = false;                  // plain-bf16 phase: the whole layer tail in one row-persistent kernel (k_mlp)
+    bool sb = false;                   // small-batch engine: column-split GEMMs with consumer-side LayerNorm (k_sb_gemm)
+    int sb_rows = 768;                 // evaluations of at most this many token rows take it (rgn_set_small_batch_rows; 0 disables)
+    int sb_rows_default = 768;         // (REGENNET_SB_ROWS): measured crossover with the throughput kernels at 60 tokens: B = 12 .. 16
     StepCoef* d_tab = nullptr;
     int* d_step = nullptr;
     SampleParams* d_sp = nullptr;
@@ -147,7 +150,7 @@ struct rgn_ctx {
 
 namespace {
 
-const char* kclass_names[KC_COUNT] = {"gemm_mfma", "attention", "layernorm", "embed", "update", "misc", "qkv_attn", "rowgemm_ln", "rowgemm_act", "mlp"};
+const char* kclass_names[KC_COUNT] = {"gemm_mfma", "attention", "layernorm", "embed", "update", "misc", "qkv_attn", "rowgemm_ln", "rowgemm_act", "mlp", "sb_gemm"};
 
 #define RGN_HIP(h, expr)                                                                                    \
     do {                                                                                                    \
@@ -378,6 +381,85 @@ int pack_state(rgn_ctx* c, const float* x, const Dims& dm, bool guided, hipStrea
     return RGN_OK;
 }
 
+// Small-batch evaluation (rgn_sb.hip): the same embedding GEMM + L decoder layers + output projection as run_layers for ALL
+// rows of the evaluation on one stream, as column-split kernels: 5 launches per layer, pre-norm sums in `tmp` (fp32), the
+// residual stream in `h` (fp32), LayerNorms applied by the consuming GEMM.
+bool use_sb(const rgn_ctx* c, int rows) { return c->sb && c->cfg.precision != RGN_PREC_F32 && rows <= c->sb_rows; }
+
+int run_layers_sb(rgn_ctx* c, const Dims& dm, bool sampling, const float* cond_rows, const float* ccond_rows, hipStream_t s) {
+    const int d = c->d, Ld = c->L * c->d, M = dm.Bm * dm.Tq;
+    const bool x3 = eval_x3(c);
+    auto base = [&](const Lin& L) {
+        SbArgs g{};
+        g.Whi = c->dp<__bf16>(L.hi); g.Wlo = c->dp<__bf16>(L.lo); g.w_rows = L.N;
+        g.bias = L.has_bias ? c->dp<float>(L.b) : nullptr;
+        g.M = M; g.N = L.N; g.Kp = L.Kp; g.Tq = dm.Tq;
+        return g;
+    };
+    {   // input embedding + hoisted condition part: tmp = xin . Wx'^T + c0
+        SbArgs g = base(c->lin_x);
+        g.Ahi = c->xin_hi; g.Alo = c->xin_lo; g.a_rows = M;
+        g.resid = c->c0; g.ldr = d; g.C = c->tmp; g.ldc = d;
+        RGN_LAUNCH(c, KC_SB, s, launch_sb_gemm(g, 0, 0, x3, s));
+    }
+    if (c->etd) {
+        const Planes none{nullptr, nullptr, 0};
+        if (sampling)
+            RGN_LAUNCH(c, KC_EMBED, s, launch_emb_rows(cond_rows, c->te_all, c->d_step, c->dp<float>(c->off_pe), c->tmp, none, dm, c->cfg.wo_pos_emb, s));
+        else
+            RGN_LAUNCH(c, KC_EMBED, s, launch_emb_rows(c->emb, nullptr, nullptr, c->dp<float>(c->off_pe), c->tmp, none, dm, c->cfg.wo_pos_emb, s));
+    }
+    const Planes att_p{c->att_hi, x3 ? c->att_lo : nullptr, M};
+    for (int l = 0; l < c->L; ++l) {
+        const LayerW& w = c->layers[l];
+        {   // layer input = norm3 of the previous layer (layer 0: the embedding itself); in_proj -> q (pre-scaled), k, v
+            SbArgs g = base(w.qkv);
+            g.src = c->tmp; g.xout = c->h;
+            if (l) { g.ga = c->dp<float>(c->layers[l - 1].ln[4]); g.ba = c->dp<float>(c->layers[l - 1].ln[5]); }
+            g.Qhi = c->q_hi; g.Khi = c->k_hi; g.Vhi = c->vt_hi;
+            if (x3) { g.Qlo = c->q_lo; g.Klo = c->k_lo; g.Vlo = c->vt_lo; }
+            g.d = d; g.H = c->H; g.dh = dm.dh; g.Tqp = c->Tqp; g.qscale = 1.0f / sqrtf((float)dm.dh);
+            RGN_LAUNCH(c, KC_SB, s, launch_sb_gemm(g, 1, 2, x3, s));
+        }
+        {
+            AttnX3Args a{};
+            a.Qhi = c->q_hi; a.Qlo = c->q_lo; a.Khi = c->k_hi; a.Klo = c->k_lo; a.Vthi = c->vt_hi; a.Vtlo = c->vt_lo;
+            a.out = att_p;
+            a.Bm = dm.Bm; a.H = c->H; a.dh = dm.dh; a.d = d; a.Tq = dm.Tq; a.Tqp = c->Tqp; a.x3 = x3;
+            RGN_LAUNCH(c, KC_ATTN, s, launch_attn_x3(a, s));
+        }
+        {   // tmp = attention . Wo^T + bo + h
+            SbArgs g = base(w.out);
+            g.Ahi = c->att_hi; g.Alo = c->att_lo; g.a_rows = M;
+            g.resid = c->h; g.ldr = d; g.C = c->tmp; g.ldc = d;
+            RGN_LAUNCH(c, KC_SB, s, launch_sb_gemm(g, 0, 0, x3, s));
+        }
+        {   // h = norm2(norm1(tmp) + folded cross-attention); ffn = gelu(h . W1^T + b1)
+            SbArgs g = base(w.ff1);
+            g.src = c->tmp; g.xout = c->h;
+            g.ga = c->dp<float>(w.ln[0]); g.ba = c->dp<float>(w.ln[1]); g.gb = c->dp<float>(w.ln[2]); g.bb = c->dp<float>(w.ln[3]);
+            g.pervec = sampling ? (ccond_rows ? ccond_rows + (size_t)l * d : nullptr) : c->call + (size_t)l * d;
+            g.ldper = Ld;
+            g.stepvec = sampling ? c->call_time + (size_t)l * d : nullptr;
+            g.ldstep = Ld; g.d_step = c->d_step;
+            g.Chi = c->ffn_hi; g.Clo = x3 ? c->ffn_lo : nullptr; g.c_rows = M;
+            RGN_LAUNCH(c, KC_SB, s, launch_sb_gemm(g, 1, 1, x3, s));
+        }
+        {   // tmp = ffn . W2^T + b2 + h
+            SbArgs g = base(w.ff2);
+            g.Ahi = c->ffn_hi; g.Alo = c->ffn_lo; g.a_rows = M;
+            g.resid = c->h; g.ldr = d; g.C = c->tmp; g.ldc = d;
+            RGN_LAUNCH(c, KC_SB, s, launch_sb_gemm(g, 0, 0, x3, s));
+        }
+    }
+    SbArgs g = base(c->lin_out);   // x0tok = norm3(tmp) . Wout^T + bout
+    g.src = c->tmp;
+    g.ga = c->dp<float>(c->layers[c->L - 1].ln[4]); g.ba = c->dp<float>(c->layers[c->L - 1].ln[5]);
+    g.C = c->x0tok; g.ldc = c->F;
+    RGN_LAUNCH(c, KC_SB, s, launch_sb_gemm(g, 1, 0, x3, s));
+    return RGN_OK;
+}
+
 // Embedding GEMM + the L decoder layers + output projection for samples [s0, s0+ns) of the evaluation's sample list
 // (row range [s0*Tq, (s0+ns)*Tq)), enqueued on stream s. F32 mode is always called with the full range.
 int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const float* cond_rows, const float* ccond_rows,
@@ -385,6 +467,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
     const int prec = c->cfg.precision;
     const int d = c->d, Ld = c->L * c->d, Mtot = dmf.Bm * dmf.Tq, Mb = dmf.B * dmf.Tq;
     const int row0 = s0 * dmf.Tq, M = ns * dmf.Tq;
+    if (use_sb(c, Mtot)) return run_layers_sb(c, dmf, sampling, cond_rows, ccond_rows, s);   // (called with the full range)
     Dims dm = dmf;
     dm.Bm = ns;
     // ---- the big GEMMs: F32 mode keeps fp32 activations (k_gemm_f32); the bf16 modes chain pre-split
@@ -612,6 +695,7 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
     const bool fast = prec != RGN_PREC_F32;
     int rc;
     int nch = (fast && !c->prof) ? c->nchains : 1;       // per-kernel event timing wants un-overlapped kernels
+    if (use_sb(c, M)) nch = 1;                            // small-batch engine: one chain of column-split kernels
     if (nch > dm.Bm) nch = dm.Bm;
     if (nch > 1) RGN_HIP(c, hipEventRecord(c->ev_fork, s));
     const int per = dm.Bm / nch, extra = dm.Bm % nch;
@@ -940,6 +1024,9 @@ int rgn_finalize_weights(rgn_handle h) {
         c->mlp = c->rowgemm && mlp_supported(d, ff, c->Tq) && getenv("REGENNET_NO_MLP") == nullptr;
         if (c->mlp) RGN_HIP(c, configure_mlp());
         if (c->fuse_qkv) RGN_HIP(c, configure_qkv_attn());
+        c->sb = c->attn_x3 && sb_supported(d, ff, d / c->H);
+        if (const char* e = getenv("REGENNET_SB_ROWS")) c->sb_rows = c->sb_rows_default = atoi(e) < 0 ? 0 : atoi(e);
+        if (c->sb) RGN_HIP(c, configure_sb());
     }
     if ((rc = ws_alloc(c, &c->d_tab, (size_t)1024))) return rc;
     if ((rc = ws_alloc(c, &c->d_step, (size_t)4))) return rc;
@@ -1187,6 +1274,19 @@ int rgn_set_x3_tail(rgn_handle h, int32_t tail_steps) {
     if (!h) return RGN_ERR_INVALID_ARG;
     if (tail_steps < -1) return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_x3_tail: tail_steps < -1");
     h->x3_tail = tail_steps;
+    return RGN_OK;
+}
+
+int rgn_set_small_batch_rows(rgn_handle h, int32_t rows) {
+    if (!h) return RGN_ERR_INVALID_ARG;
+    if (rows < -1) return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_small_batch_rows: rows < -1");
+    const int v = rows < 0 ? h->sb_rows_default : rows;
+    if (v != h->sb_rows) {   // captured graphs hold the kernels of the engine that was selected when they were recorded
+        if (h->stream) RGN_HIP(h, hipStreamSynchronize(h->stream));
+        for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+        h->graphs.clear();
+        h->sb_rows = v;
+    }
     return RGN_OK;
 }
 

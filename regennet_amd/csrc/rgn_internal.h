@@ -18,6 +18,7 @@ enum KClass : int {
     KC_ROWLN,         // row-complete GEMM + residual + LayerNorm(s) (k_rowgemm<0>)
     KC_ROWACT,        // row-complete GEMM + activation (k_rowgemm<1>)
     KC_MLP,           // row-persistent layer tail (k_mlp)
+    KC_SB,            // small-batch column-split GEMMs (k_sb_gemm)
     KC_COUNT
 };
 
@@ -167,6 +168,33 @@ struct MlpArgs {
 bool mlp_supported(int d, int ff, int Tq);
 hipError_t configure_mlp();
 hipError_t launch_mlp(const MlpArgs& g, hipStream_t s);
+
+// Small-batch column-split GEMM (rgn_sb.hip): 64 rows x 32 output columns per workgroup; LayerNorm applied by the consumer.
+struct SbArgs {
+    // PRE 1: A = LN_b(LN_a(src) + stepvec[*d_step] + pervec[row / Tq]) of fp32 rows [M, 512]; ga == nullptr: A = src; gb == nullptr: one norm
+    const float* src;
+    const float *ga, *ba, *gb, *bb;
+    const float* pervec; int ldper;
+    const float* stepvec; int ldstep; const int* d_step;
+    int Tq;                                             // tokens per sample (pervec row, q/k/v scatter)
+    float* xout;                                        // normalised rows [M, 512] (written by the first 16 column slices), nullable
+    // PRE 0: A = K32-blocked planes [Kp/32][a_rows][32]
+    const __bf16 *Ahi, *Alo; int a_rows;
+    const __bf16 *Whi, *Wlo; int w_rows;                // weight planes [Kp/32][w_rows][32]
+    const float* bias;                                  // [N], nullable
+    int M, N, Kp;
+    // POST 0: C = A.W^T + bias + resid (fp32 rows)
+    const float* resid; int ldr;
+    float* C; int ldc;
+    // POST 1: gelu(A.W^T + bias) as K32-blocked planes [N/32][c_rows][32]
+    __bf16 *Chi, *Clo; int c_rows;
+    // POST 2: packed in_proj -> attention-ready q (pre-scaled) / k / v planes [Bm*H][Tqp][dh]
+    __bf16 *Qhi, *Qlo, *Khi, *Klo, *Vhi, *Vlo;
+    int d, H, dh, Tqp; float qscale;
+};
+bool sb_supported(int d, int ff, int dh);
+hipError_t configure_sb();
+hipError_t launch_sb_gemm(const SbArgs& g, int pre, int post, bool x3, hipStream_t s);
 
 struct Dims {
     int B;        // motions in the bound condition

@@ -1,0 +1,397 @@
+// Small-batch ("latency") GEMMs of the decoder layers: the denoiser evaluation for a handful of motions.
+//
+// At B = 1 (BASELINE configs[0], the reference CLI's own default range) one evaluation has 60 token rows: a single 64-row
+// tile. The throughput kernels (k_qkv_attn, k_mlp, k_rowgemm) give every tile ALL columns of a layer, so one workgroup
+// streams whole weight matrices through one CU (~4 MB per layer at the ~30-60 B/clk a CU pulls from L2): 0.5 ms per step
+// with 255 CUs idle. Here the split is the other way round: a workgroup owns 64 rows x 32 output columns, a launch has
+// N/32 (16-48) workgroups per row tile, each reads a 32-64 KiB weight slice, and the step becomes a chain of short
+// kernels whose cost is the dependent-launch boundary (~1.5 us, MI355X_MICROARCH.md "boundary") plus one L2 round trip.
+// In-kernel grid barriers are priced at 4-7 us on this chip, so kernel boundaries ARE the cheap barrier.
+//
+// LayerNorm cannot sit in the epilogue of a column-split GEMM (a row's statistics span all workgroups), so it moves to the
+// CONSUMER: the producing GEMM writes the pre-norm sum (GEMM + bias + residual) as fp32 rows, and every workgroup of the
+// next GEMM re-normalises the full 64 x 512 tile on its way into LDS (128 KiB of L2 reads, 8 rows per wave, DPP sums)
+// before it forms its A fragments. The first 16 column slices also write their 32 columns of the normalised rows back as
+// the fp32 residual stream of the next pre-norm sum.
+//
+//   per layer:  qkv  = PRE_LN(norm3 of the previous layer | identity) -> in_proj -> attention-ready q/k/v planes
+//               attn = k_attn_x3 (rgn_attn_x3.hip)
+//               proj = PRE_PLANES(attention output) -> out_proj + bias + residual -> fp32 pre-norm rows
+//               ff1  = PRE_LN(norm1, + folded cross-attention vectors, norm2) -> linear1 + GELU -> planes
+//               ff2  = PRE_PLANES -> linear2 + bias + residual -> fp32 pre-norm rows
+//
+// MFMA: v_mfma_f32_32x32x16_bf16, computed transposed (weights are the A operand, activations the B operand) so a lane
+// holds runs of 4 consecutive output columns. 8 waves = 2 row patches of 32 x 4 quarters of K: a wave's whole operand set
+// (its 32 x K/4 weight and activation fragments, straight from the K32-blocked planes [K/32][rows][32]) is in flight at
+// once, 64-128 VGPRs. The four k-quarters are summed through LDS in a fixed order, so every output element is accumulated
+// in an order that does not depend on which rows share its tile: results are bit-identical under any batch composition
+// (sharding, chains).
+// Precision follows the phase of the schedule: X3 = three MFMAs per product on hi/lo planes, else hi planes only.
+#include "rgn_internal.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+namespace rgn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int SB_D = 512;        // model width of the PRE_LN variants (row = 64 lanes x 8 floats)
+static int g_sb_small_rows = 128;             // tools: SB_SMALL_ROWS overrides (read once in configure_sb)
+
+template <int CTRL>
+__device__ __forceinline__ float sb_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// wave-wide sum on the VALU (DPP inside rows of 16 lanes, the four row totals through SGPRs), as in rgn_rowgemm.hip
+__device__ __forceinline__ float sb_wave_sum(float v) {
+    v += sb_dpp<0xB1>(v);
+    v += sb_dpp<0x4E>(v);
+    v += sb_dpp<0x141>(v);
+    v += sb_dpp<0x140>(v);
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+}
+
+// erf: Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), the split-bf16 GEMM epilogue's form
+__device__ __forceinline__ float sb_gelu(float v) {
+    const float x = v * 0.70710678118654752440f, ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = copysignf(1.0f - p * t * __expf(-ax * ax), x);
+    return v * 0.5f * (1.0f + e);
+}
+
+__device__ __forceinline__ void sb_ld8(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+
+// LayerNorm phase register layout: a 512-wide row lives in ONE 16-lane DPP row (lane c of it holds columns
+// 128 j + 8 c .. + 8 for j = 0..3), a wave normalises 4 rows at once, and a row's sum is 4 DPP adds with the result
+// in every lane of the row: no cross-row traffic, no SGPR round trips.
+__device__ __forceinline__ float sb_row16_sum(float v) {
+    v += sb_dpp<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += sb_dpp<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += sb_dpp<0x141>(v);    // row_half_mirror
+    v += sb_dpp<0x140>(v);    // row_mirror
+    return v;
+}
+// two-pass LayerNorm, eps = 1e-5, like k_layernorm; gamma / beta from the workgroup's LDS copy (pointers at this lane's columns)
+__device__ __forceinline__ void sb_ln_row(float (&v)[4][8], const float* gv, const float* bv) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[j][i];
+    const float mean = sb_row16_sum(s) * (1.0f / SB_D);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float c = v[j][i] - mean;
+            q += c * c;
+        }
+    const float rstd = 1.0f / sqrtf(sb_row16_sum(q) * (1.0f / SB_D) + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float ga[8], ba[8];
+        sb_ld8(gv + j * 128, ga);
+        sb_ld8(bv + j * 128, ba);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[j][i] = (v[j][i] - mean) * rstd * ga[i] + ba[i];
+    }
+}
+__device__ __forceinline__ void sb_ldvec(const float* p, int lc, float (&v)[4][8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sb_ld8(p + j * 128 + lc * 8, v[j]);
+}
+
+}  // namespace
+
+// PRE: 0 = A fragments from K32-blocked planes, 1 = A = LayerNorm(s) of fp32 rows (through an LDS image)
+// POST: 0 = fp32 rows (+ bias + residual), 1 = GELU -> K32-blocked planes, 2 = attention-ready q / k / v planes
+// NP: row patches of 32 per workgroup (1: 32-row tiles / 4 waves for the smallest evaluations, 2: 64-row tiles / 8 waves)
+template <int PRE, int POST, bool X3, int NP>
+__global__ __launch_bounds__(256 * NP) void k_sb_gemm(SbArgs g) {
+    constexpr int CH = (X3 || PRE == 1) ? 4 : 8;                     // k32-blocks per register chunk of a wave (PRE 1: K = 512, 4 per wave)
+    constexpr int ROWS = 32 * NP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int patch = w % NP, kq = w / NP, l31 = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.y * ROWS, n0 = blockIdx.x * 32;
+    const int KB = g.Kp >> 5;
+    const int kb0 = (kq * KB) >> 2, kb1 = ((kq + 1) * KB) >> 2;      // this wave's quarter of the k32-blocks
+    const int mrow = min(m0 + patch * 32 + l31, g.M - 1);            // the rows / weight rows whose fragments this lane loads
+    const int nrow = min(n0 + l31, g.N - 1);                         // (clamped: the surplus is masked at the store)
+    const int m = m0 + (tid >> 3), n = n0 + (tid & 7) * 4;           // this THREAD's outputs after the reduction: row m, columns n .. n+3
+
+    // ---- weight fragments of the first chunk: nothing depends on them until the MFMAs, so their L2 round trip overlaps
+    //      the LayerNorm phase / the activation fragment loads
+    bf16x8 wh[CH][2], wl[X3 ? CH : 1][2];
+    auto load_w = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (kc + j < kb1) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const unsigned o = ((unsigned)(kc + j) * g.w_rows + nrow) * 32 + ks * 16 + kh * 8;   // (32-bit offsets: SGPR base + one VGPR per address)
+                    wh[j][ks] = *reinterpret_cast<const bf16x8*>(g.Whi + o);
+                    if constexpr (X3) wl[j][ks] = *reinterpret_cast<const bf16x8*>(g.Wlo + o);
+                }
+            }
+    };
+    load_w(kb0);
+
+    // ---- epilogue operands, requested up front as well
+    float bias[4] = {0.f, 0.f, 0.f, 0.f}, res[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (n + i < g.N) bias[i] = g.bias[n + i];
+    }
+    if constexpr (POST == 0) {
+        if (g.resid && m < g.M) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (n + i < g.N) res[i] = g.resid[(size_t)m * g.ldr + n + i];
+        }
+    }
+
+    __bf16* img = reinterpret_cast<__bf16*>(smem);                   // PRE 1: [planes][16][ROWS][32], 16-byte chunk c of row r at c ^ ((r >> 2) & 3)
+    if constexpr (PRE == 1) {
+        // ---- LayerNorm phase: wave w owns rows 8w .. 8w+7 of the tile, 4 at a time (one per 16-lane row)
+        const int rr = lane >> 4, lc = lane & 15;
+        float x[2][4][8];
+        int mr[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            mr[p] = m0 + w * 8 + p * 4 + rr;
+            sb_ldvec(g.src + (unsigned)min(mr[p], g.M - 1) * SB_D, lc, x[p]);
+        }
+        // gamma / beta of both norms and the per-step vector: one LDS copy per workgroup (each lane reads 32 values of each;
+        // as per-lane global loads they cost up to 160 VGPRs of live range and four redundant fetches per wave)
+        float* vec = reinterpret_cast<float*>(smem + (size_t)(X3 ? 2 : 1) * 16 * ROWS * 32 * 2);   // [5][512]: ga, ba, gb, bb, stepvec
+        if (tid < 128) {
+            const float* srcs[5] = {g.ga, g.ba, g.gb, g.bb, (g.gb && g.stepvec) ? g.stepvec + (size_t)(*g.d_step) * g.ldstep : nullptr};
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                if (srcs[k]) *reinterpret_cast<f32x4*>(vec + k * SB_D + tid * 4) = *reinterpret_cast<const f32x4*>(srcs[k] + tid * 4);
+        }
+        __syncthreads();
+        const float* lv = vec + lc * 8;
+        if (g.ga) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) sb_ln_row(x[p], lv, lv + SB_D);
+        }
+        if (g.gb) {
+            if (g.stepvec) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float sv[8];
+                    sb_ld8(lv + 4 * SB_D + j * 128, sv);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) x[p][j][i] += sv[i];
+                }
+            }
+            if (g.pervec) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    float pv[4][8];
+                    sb_ldvec(g.pervec + (unsigned)(min(mr[p], g.M - 1) / g.Tq) * g.ldper, lc, pv);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) x[p][j][i] += pv[j][i];
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) sb_ln_row(x[p], lv + 2 * SB_D, lv + 3 * SB_D);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = w * 8 + p * 4 + rr;
+            const bool valid = mr[p] < g.M;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // this slice's 32 columns of the residual stream: columns 32 bx .. = chunk j = bx / 4 of lanes lc / 4 == bx % 4
+                if (g.xout && valid && j == (int)(blockIdx.x >> 2) && (lc >> 2) == (int)(blockIdx.x & 3)) {
+                    float* xo = g.xout + (size_t)mr[p] * SB_D + j * 128 + lc * 8;
+                    *reinterpret_cast<f32x4*>(xo) = f32x4{x[p][j][0], x[p][j][1], x[p][j][2], x[p][j][3]};
+                    *reinterpret_cast<f32x4*>(xo + 4) = f32x4{x[p][j][4], x[p][j][5], x[p][j][6], x[p][j][7]};
+                }
+                bf16x8 h, l;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float v = valid ? x[p][j][i] : 0.f;
+                    h[i] = (__bf16)v;
+                    l[i] = (__bf16)(v - (float)h[i]);
+                }
+                const int o = ((j * 4 + (lc >> 2)) * ROWS + r) * 32 + (((lc & 3) ^ ((r >> 2) & 3)) * 8);
+                *reinterpret_cast<bf16x8*>(img + o) = h;
+                if constexpr (X3) *reinterpret_cast<bf16x8*>(img + 16 * ROWS * 32 + o) = l;
+            }
+        }
+        __syncthreads();
+    }
+
+    f32x16 a0, a1, a2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a0[i] = a1[i] = a2[i] = 0.f;
+    for (int kc = kb0; kc < kb1; kc += CH) {
+        if (kc != kb0) load_w(kc);
+        bf16x8 ah[CH][2], al[X3 ? CH : 1][2];
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (kc + j < kb1) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    if constexpr (PRE == 0) {
+                        const unsigned o = ((unsigned)(kc + j) * g.a_rows + mrow) * 32 + ks * 16 + kh * 8;
+                        ah[j][ks] = *reinterpret_cast<const bf16x8*>(g.Ahi + o);
+                        if constexpr (X3) al[j][ks] = *reinterpret_cast<const bf16x8*>(g.Alo + o);
+                    } else {
+                        const int r = patch * 32 + l31;
+                        const int o = ((kc + j) * ROWS + r) * 32 + (((ks * 2 + kh) ^ ((r >> 2) & 3)) * 8);
+                        ah[j][ks] = *reinterpret_cast<const bf16x8*>(img + o);
+                        if constexpr (X3) al[j][ks] = *reinterpret_cast<const bf16x8*>(img + 16 * ROWS * 32 + o);
+                    }
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (kc + j < kb1) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[j][ks], ah[j][ks], a0, 0, 0, 0);
+                    if constexpr (X3) {
+                        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[j][ks], al[j][ks], a1, 0, 0, 0);
+                        a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[j][ks], ah[j][ks], a2, 0, 0, 0);
+                    }
+                }
+            }
+    }
+    if constexpr (X3) a0 += a1 + a2;
+
+    // ---- sum the four k-quarters through LDS in a fixed order. Computed transposed: a lane holds row (= lane & 31) of its
+    //      patch and the output columns (i & 3) + 8 (i >> 2) + 4 kh of the slice, i.e. four runs of 4 consecutive columns.
+    constexpr int RLD = 36;                                          // padded row stride (floats) of a partial patch
+    float* red = reinterpret_cast<float*>(smem);                     // [kq 4][patch NP][32][RLD] (PRE 1: over the dead image)
+    if constexpr (PRE == 1) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(red + ((kq * NP + patch) * 32 + l31) * RLD + 8 * q + 4 * kh) =
+            f32x4{a0[4 * q], a0[4 * q + 1], a0[4 * q + 2], a0[4 * q + 3]};
+    __syncthreads();
+    if (m >= g.M || n >= g.N) return;
+    float v[4];
+    {
+        const float* rp = red + (tid >> 3) * RLD + (tid & 7) * 4;    // (tid >> 3 = patch * 32 + row in the patch)
+        f32x4 sum = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) sum += *reinterpret_cast<const f32x4*>(rp + k * NP * 32 * RLD);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = sum[i] + bias[i];
+    }
+    if constexpr (POST == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += res[i];
+        float* cp = g.C + (size_t)m * g.ldc + n;
+        if (n + 3 < g.N && (g.ldc & 3) == 0) {
+            *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (n + i < g.N) cp[i] = v[i];
+        }
+    } else {
+        float sc = 1.0f;
+        __bf16 *ph, *pl;
+        size_t o;
+        if constexpr (POST == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = sb_gelu(v[i]);
+            ph = g.Chi; pl = g.Clo;
+            o = ((size_t)(n >> 5) * g.c_rows + m) * 32 + (n & 31);
+        } else {
+            const int which = n / g.d, cin = n - which * g.d, hd = cin / g.dh, c = cin - hd * g.dh;
+            const int b = m / g.Tq, t = m - b * g.Tq;
+            ph = which == 0 ? g.Qhi : (which == 1 ? g.Khi : g.Vhi);
+            pl = which == 0 ? g.Qlo : (which == 1 ? g.Klo : g.Vlo);
+            if (which == 0) sc = g.qscale;
+            o = (((size_t)b * g.H + hd) * g.Tqp + t) * g.dh + c;
+        }
+        bf16x4 h, l;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x = v[i] * sc;
+            h[i] = (__bf16)x;
+            l[i] = (__bf16)(x - (float)h[i]);
+        }
+        *reinterpret_cast<bf16x4*>(ph + o) = h;
+        if (pl) *reinterpret_cast<bf16x4*>(pl + o) = l;
+    }
+}
+
+bool sb_supported(int d, int ff, int dh) { return d == SB_D && ff % 32 == 0 && dh % 4 == 0; }
+
+template <int PRE, int POST, bool X3, int NP>
+static hipError_t sb_launch(const SbArgs& g, hipStream_t s, bool cfg) {
+    const size_t red = (size_t)4 * NP * 32 * 36 * 4, img = (size_t)(X3 ? 2 : 1) * 16 * 32 * NP * 32 * 2;
+    const size_t lds = PRE == 1 ? (img + 5 * 512 * 4 > red ? img + 5 * 512 * 4 : red) : red;
+    if (cfg) return hipFuncSetAttribute(reinterpret_cast<const void*>(k_sb_gemm<PRE, POST, X3, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_sb_gemm<PRE, POST, X3, NP>), dim3((g.N + 31) / 32, (g.M + 32 * NP - 1) / (32 * NP)), dim3(256 * NP), lds, s, g);
+    return hipGetLastError();
+}
+// 32-row tiles while the evaluation has at most 128 rows (B <= 2 at 60 frames: twice the workgroups, half the LayerNorm
+// phase each); 64-row tiles beyond (half the weight-slice re-reads)
+template <int PRE, int POST>
+static hipError_t sb_go(const SbArgs& g, bool x3, hipStream_t s, bool cfg) {
+    if (cfg) {
+        hipError_t e = sb_launch<PRE, POST, true, 1>(g, s, true);
+        if (e == hipSuccess) e = sb_launch<PRE, POST, true, 2>(g, s, true);
+        if (e == hipSuccess) e = sb_launch<PRE, POST, false, 1>(g, s, true);
+        if (e == hipSuccess) e = sb_launch<PRE, POST, false, 2>(g, s, true);
+        return e;
+    }
+    const bool small = g.M <= g_sb_small_rows;
+    if (x3) return small ? sb_launch<PRE, POST, true, 1>(g, s, false) : sb_launch<PRE, POST, true, 2>(g, s, false);
+    return small ? sb_launch<PRE, POST, false, 1>(g, s, false) : sb_launch<PRE, POST, false, 2>(g, s, false);
+}
+static hipError_t sb_dispatch(const SbArgs& g, int pre, int post, bool x3, hipStream_t s, bool cfg) {
+    if (pre == 0 && post == 0) return sb_go<0, 0>(g, x3, s, cfg);
+    if (pre == 1 && post == 0) return sb_go<1, 0>(g, x3, s, cfg);
+    if (pre == 1 && post == 1) return sb_go<1, 1>(g, x3, s, cfg);
+    if (pre == 1 && post == 2) return sb_go<1, 2>(g, x3, s, cfg);
+    return hipErrorInvalidValue;
+}
+hipError_t configure_sb() {
+    if (const char* e = getenv("REGENNET_SB_SMALL_ROWS")) g_sb_small_rows = atoi(e);
+    SbArgs g{};
+    const int combos[4][2] = {{0, 0}, {1, 0}, {1, 1}, {1, 2}};
+    for (auto& c : combos) {
+        hipError_t e = sb_dispatch(g, c[0], c[1], false, nullptr, true);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+hipError_t launch_sb_gemm(const SbArgs& g, int pre, int post, bool x3, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0 || (g.Kp & 31) || (pre == 1 && g.Kp != SB_D) || (post != 0 && (g.N & 31))) return hipErrorInvalidValue;
+    return sb_dispatch(g, pre, post, x3, s, false);
+}
+
+}  // namespace rgn

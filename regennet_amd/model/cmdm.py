@@ -137,6 +137,8 @@ class CMDM(nn.Module):
         # precision schedule: split-bf16 for the last x3_tail loop indices of a sampling loop (None: engine default rule;
         # "auto": measured on this checkpoint at the first sampling call, see diffusion.calibrate_x3_tail)
         self.x3_tail = kargs.get("x3_tail", None)
+        # evaluations of at most this many token rows run the small-batch engine (None: engine default, 0: never)
+        self.small_batch_rows = kargs.get("small_batch_rows", None)
         self._auto_tail, self._auto_tails = None, {}
         self._engine = None
         self._engines = {}
@@ -217,6 +219,7 @@ class CMDM(nn.Module):
         if tail == "auto":                                    # filled in per (schedule, sampler, guidance, T) by calibrate_x3_tail
             tail = self._auto_tail
         eng.set_x3_tail(-1 if tail is None else int(tail))
+        eng.set_small_batch_rows(-1 if self.small_batch_rows is None else int(self.small_batch_rows))
         return eng, dev
 
     def _rgn_bind(self, B, y, device=None, guided=False, T=None, cache=False):

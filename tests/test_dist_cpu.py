@@ -90,6 +90,9 @@ class FakeEngine:
         self.calls.clear()                       # whoever takes the blob may overwrite it: schedule and condition must follow
         return self.blob, self.blob.numel()
 
+    def set_small_batch_rows(self, n):
+        pass
+
     def set_x3_tail(self, n):
         pass
 

@@ -9,10 +9,18 @@ from tests.helpers import autoreg_inputs, build_hip, fixture_inputs, fixture_opt
 
 pytestmark = pytest.mark.gpu
 
-PRECISIONS = ["f32", "bf16x3", "bf16_x3tail"]
+# "<mode>/throughput" (tests/helpers.py build_hip): small-batch engine off, i.e. the kernels of a full-size batch. Without
+# it, evaluations of <= 768 token rows of a d = 512 model (every d = 512 golden here) run the column-split small-batch
+# kernels (rgn_sb.hip).
+PRECISIONS = ["f32", "bf16x3", "bf16_x3tail", "bf16_x3tail/throughput", "bf16x3/throughput"]
 # abs; all inside the 1e-3 contract. "bf16_x3tail" (the default) = the precision schedule: plain-bf16 GEMM operands for
 # the bulk of a sampling loop, split-bf16 for its last steps and for single evaluations.
-TOL = {"f32": 2e-4, "bf16x3": 1e-3, "bf16_x3tail": 1e-3}
+TOL = {"f32": 2e-4, "bf16x3": 1e-3, "bf16_x3tail": 1e-3, "bf16_x3tail/throughput": 1e-3, "bf16x3/throughput": 1e-3}
+
+
+def _skip_redundant(name, precision):
+    if "/" in precision and name.startswith("tiny"):
+        pytest.skip("the small-batch engine only takes d = 512 models: same kernels as the plain mode")
 
 FWD = ["tiny_fwd", "tiny_fwd_cfg", "tiny_add_fwd", "tiny_etd_fwd", "tiny_wope_fwd", "tiny_text_fwd_cfg", "ntu_fwd",
        "ntu_action_fwd_cfg", "chi3d_fwd"]
@@ -41,6 +49,7 @@ def _wrap(model, guided):
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", FWD)
 def test_denoiser_forward(golden, name, precision):
+    _skip_redundant(name, precision)
     g = golden(name)
     cfg, sd, y, x = fixture_inputs(g, loop=False)
     model, _ = build_hip(cfg, sd, precision=precision)
@@ -57,6 +66,7 @@ def test_denoiser_forward(golden, name, precision):
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", LOOPS)
 def test_sampling_loop(golden, name, precision):
+    _skip_redundant(name, precision)
     g = golden(name)
     cfg, sd, y, tape = fixture_inputs(g, loop=True)
     model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision=precision)
@@ -75,7 +85,7 @@ def test_sampling_loop(golden, name, precision):
         S = int(g["S"])
         for k, o in enumerate(pfn(fm, shape, clip_denoised=False, model_kwargs={"y": y_to_device(y)},
                                   noise_tape=torch.from_numpy(tape))):
-            if precision == "bf16_x3tail" and k < S - 1:
+            if precision.startswith("bf16_x3tail") and k < S - 1:
                 continue    # precision schedule: intermediate states carry the bulk phase's bf16-level error by design;
                             # the contract (and the check) is the state after the last step
             assert np.abs(o["pred_xstart"].cpu().numpy() - g["x0"][k]).max() < TOL[precision]
@@ -96,8 +106,9 @@ def test_headline_1000_step_ddpm(golden, precision):
     assert err < TOL[precision], err
 
 
+@pytest.mark.parametrize("engine", ["throughput", "small-batch"])
 @pytest.mark.parametrize("name", ["ntu_ddpm1000", "ntu_action_ddim100_cfg", "text150_ddim50_cfg"])
-def test_precision_schedule_switch_point_sweep(golden, name):
+def test_precision_schedule_switch_point_sweep(golden, name, engine):
     """Precision schedule (RGN_PREC_BF16_X3TAIL): plain-bf16 GEMMs for loop indices >= tail, split-bf16 below. Early-step
     error is contracted by the sampler (posterior_mean_coef1 -> 0 at large t, gaussian_diffusion.py:265-276), so a short
     split-bf16 tail recovers the parity bound. Sweeps the switch point against the reference's 1000-step DDPM and guided
@@ -108,19 +119,19 @@ def test_precision_schedule_switch_point_sweep(golden, name):
     errs = {}
     shape = (int(g["B"]), cfg["njoints"], cfg["nfeats"], cfg["num_frames"])
     for tail in (0, 2, 5, 10, 25, None, S):
-        model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision="bf16_x3tail", x3_tail=tail)
+        model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision="bf16_x3tail/" + engine, x3_tail=tail)
         fm = _wrap(model, bool(g["guided"]))
         fn = diffusion.p_sample_loop if str(g["mode"]) == "ddpm" else diffusion.ddim_sample_loop
         out = fn(fm, shape, clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
         errs[tail] = float(np.abs(out.cpu().numpy() - g["final"]).max())
         model._engine.close()
-    print(f"\n[x3-tail sweep] {name} (default tail {default_tail(S, cfg['layers'])}): " + ", ".join(f"{k}: {v:.2e}" for k, v in errs.items()))
+    print(f"\n[x3-tail sweep] {name} {engine} (default tail {default_tail(S, cfg['layers'])}): " + ", ".join(f"{k}: {v:.2e}" for k, v in errs.items()))
     for tail, e in errs.items():
         if tail is None or tail >= 8:
             assert e < 1e-3, (name, tail, e)
     assert errs[None] < 3.5e-4, errs        # the default keeps a 3x margin on these goldens
     # tail = S is the uniform split-bf16 mode
-    model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision="bf16x3")
+    model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision="bf16x3/" + engine)
     fm = _wrap(model, bool(g["guided"]))
     fn = diffusion.p_sample_loop if str(g["mode"]) == "ddpm" else diffusion.ddim_sample_loop
     ref = fn(fm, shape, clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
@@ -176,7 +187,8 @@ def test_precision_schedule_auto_calibration_and_conservative_defaults():
     assert torch.equal(outs[0], outs[1])
 
 
-def test_multi_step_graphs_equal_single_step_replay(golden, monkeypatch):
+@pytest.mark.parametrize("engine", ["throughput", "small-batch"])
+def test_multi_step_graphs_equal_single_step_replay(golden, monkeypatch, engine):
     """rgn_sample_range replays graphs that hold several loop iterations each (the loop index lives on the device): 1, 7
     or 10 iterations per graph, or eager launches, must not change a bit — across the phase switch of the schedule too."""
     g = golden("ntu_ddpm50")
@@ -184,7 +196,7 @@ def test_multi_step_graphs_equal_single_step_replay(golden, monkeypatch):
     outs = []
     for steps in ("1", "7", "10"):
         monkeypatch.setenv("REGENNET_GRAPH_STEPS", steps)
-        model, diffusion = build_hip(cfg, sd, resp="50", precision="bf16_x3tail")
+        model, diffusion = build_hip(cfg, sd, resp="50", precision="bf16_x3tail/" + engine)
         kw = dict(clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
         outs.append(diffusion.p_sample_loop(model, (2, 56, 6, 60), **kw))
         if steps == "7":
@@ -195,8 +207,9 @@ def test_multi_step_graphs_equal_single_step_replay(golden, monkeypatch):
     assert np.abs(outs[0].cpu().numpy() - g["final"]).max() < 1e-3
 
 
+@pytest.mark.parametrize("engine", ["throughput", "small-batch"])
 @pytest.mark.parametrize("frames,etd", [(16, False), (64, False), (63, True), (64, True)])
-def test_oracle_parity_sequence_length_edges(frames, etd):
+def test_oracle_parity_sequence_length_edges(frames, etd, engine):
     """The fused in_proj+attention kernel takes Tq <= 64 tokens: one token tile only (16), exactly full tiles (64, and
     63 + the emb_trans_dec token), and one token too many (64 + 1 -> the unfused GEMM + attention kernels)."""
     from oracle import regennet_oracle as orc
@@ -204,7 +217,7 @@ def test_oracle_parity_sequence_length_edges(frames, etd):
     cfg = synth.get_config("ntu_action", layers=2, num_frames=frames, emb_trans_dec=etd)
     sd = synth.make_state_dict(cfg, seed=9)
     B = 3
-    model, diffusion = build_hip(cfg, sd, resp="ddim5", precision="bf16x3")
+    model, diffusion = build_hip(cfg, sd, resp="ddim5", precision="bf16x3/" + engine)
     y = {"cmotion": synth.make_cmotion(cfg, B, seed=31), "action": synth.make_actions(cfg, B, seed=32)}
     tape = synth.make_noise_tape(cfg, B, 5, seed=33)
     ty = {k: torch.from_numpy(v) for k, v in y.items()}
@@ -214,18 +227,22 @@ def test_oracle_parity_sequence_length_edges(frames, etd):
     assert np.abs(out.cpu().numpy() - ref).max() < 1e-3
 
 
+@pytest.mark.parametrize("engine", ["throughput", "small-batch"])
 @pytest.mark.parametrize("over", [dict(ff_size=512), dict(ff_size=2048), dict(latent_dim=256, ff_size=1024), dict(num_frames=24, emb_trans_dec=True)])
-def test_oracle_parity_across_kernel_dispatch_paths(over):
+def test_oracle_parity_across_kernel_dispatch_paths(over, engine):
     """The plain-bf16 phase picks its kernels by shape: d = 512 / ff = 1024 -> k_mlp; d = 512 with another ff -> k_rowgemm
     (ff = 512) or the generic tiles (ff = 2048: activation image too large); other widths -> generic tiles. Each path against
-    the oracle under the default precision schedule (2 layers, 50 steps: 18 plain-bf16 + 32 split-bf16) and with guidance."""
+    the oracle under the default precision schedule (2 layers, 50 steps: 18 plain-bf16 + 32 split-bf16) and with guidance.
+    engine "small-batch": the same shapes through the column-split kernels (any ff % 32 == 0; d = 512 only)."""
+    if engine == "small-batch" and over.get("latent_dim", 512) != 512:
+        pytest.skip("small-batch engine: d = 512 only")
     from oracle import regennet_oracle as orc
     from regennet_amd import synth
     from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
     cfg = synth.get_config("ntu_action", layers=2, **over)
     sd = synth.make_state_dict(cfg, seed=5)
     B, T = 3, cfg["num_frames"]
-    model, diffusion = build_hip(cfg, sd, resp="ddim50", precision="bf16_x3tail")
+    model, diffusion = build_hip(cfg, sd, resp="ddim50", precision="bf16_x3tail/" + engine)
     y = {"cmotion": synth.make_cmotion(cfg, B, seed=61), "action": synth.make_actions(cfg, B, seed=62), "scale": np.full((B,), 2.5, np.float32)}
     tape = synth.make_noise_tape(cfg, B, 50, seed=63)
     ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", "ddim50"), tape, {k: torch.from_numpy(v) for k, v in y.items()},
@@ -233,7 +250,7 @@ def test_oracle_parity_across_kernel_dispatch_paths(over):
     out = diffusion.ddim_sample_loop(ClassifierFreeSampleModel(model), (B, 56, 6, T), clip_denoised=False,
                                      model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
     err = float(np.abs(out.cpu().numpy() - ref).max())
-    print(f"\n[dispatch path] {over}: {err:.2e}")
+    print(f"\n[dispatch path] {over} {engine}: {err:.2e}")
     assert err < 1e-3, (over, err)
 
 
@@ -419,7 +436,7 @@ def test_chain_count_does_not_change_results(golden, monkeypatch):
     outs = []
     for n in ("1", "2", "4"):
         monkeypatch.setenv("REGENNET_STREAMS", n)
-        model, diffusion = build_hip(cfg, sd, resp="50", precision="bf16x3")
+        model, diffusion = build_hip(cfg, sd, resp="50", precision="bf16x3/throughput")
         outs.append(diffusion.p_sample_loop(model, (2, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y_to_device(y)},
                                             noise_tape=torch.from_numpy(tape)))
         model._engine.close()
@@ -433,7 +450,7 @@ def test_fused_layernorm_gemm_variant(golden, monkeypatch):
     for name in ("ntu_ddpm50", "ntu_action_ddim100_cfg"):
         g = golden(name)
         cfg, sd, y, tape = fixture_inputs(g, loop=True)
-        model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision="bf16x3")
+        model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision="bf16x3/throughput")
         fm = _wrap(model, bool(g["guided"]))
         fn = diffusion.p_sample_loop if str(g["mode"]) == "ddpm" else diffusion.ddim_sample_loop
         out = fn(fm, (2, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
@@ -447,7 +464,7 @@ def test_big_gemm_tiles_meet_the_same_bound(golden, monkeypatch):
     for name in ("ntu_ddpm50", "ntu_action_ddim100_cfg", "text150_ddim50_cfg"):
         g = golden(name)
         cfg, sd, y, tape = fixture_inputs(g, loop=True)
-        model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision="bf16x3")
+        model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision="bf16x3/throughput")
         fm = _wrap(model, bool(g["guided"]))
         fn = diffusion.p_sample_loop if str(g["mode"]) == "ddpm" else diffusion.ddim_sample_loop
         out = fn(fm, (int(g["B"]), 56, 6, cfg["num_frames"]), clip_denoised=False, model_kwargs={"y": y_to_device(y)},
@@ -465,7 +482,7 @@ def test_full_size_batch_is_row_independent(precision, tail):
     from regennet_amd import synth
     cfg = synth.get_config("ntu")
     sd = synth.make_state_dict(cfg, seed=0)
-    model, diffusion = build_hip(cfg, sd, resp="ddim5", precision=precision, x3_tail=tail)
+    model, diffusion = build_hip(cfg, sd, resp="ddim5", precision=precision + "/throughput", x3_tail=tail)   # (the B = 1 runs too)
     B = 256
     cm = torch.from_numpy(synth.make_cmotion(cfg, B, seed=1)).cuda()
     full = diffusion.ddim_sample_loop(model, (B, 56, 6, 60), clip_denoised=False, model_kwargs={"y": {"cmotion": cm}}, seed=9)
@@ -476,7 +493,7 @@ def test_full_size_batch_is_row_independent(precision, tail):
         assert torch.allclose(full[b:b + 1], one, atol=2e-5), (b, (full[b:b + 1] - one).abs().max().item())
     # guided, ragged batch that does not divide into the chains evenly
     cfg2 = synth.get_config("ntu_action")
-    model2, diffusion2 = build_hip(cfg2, synth.make_state_dict(cfg2, seed=0), resp="ddim5", precision=precision, x3_tail=tail)
+    model2, diffusion2 = build_hip(cfg2, synth.make_state_dict(cfg2, seed=0), resp="ddim5", precision=precision + "/throughput", x3_tail=tail)
     from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
     g2 = ClassifierFreeSampleModel(model2)
     B2 = 37
@@ -489,6 +506,26 @@ def test_full_size_batch_is_row_independent(precision, tail):
         assert torch.allclose(full2[b:b + 1], one, atol=2e-5), (b, (full2[b:b + 1] - one).abs().max().item())
 
 
+@pytest.mark.parametrize("config,B,T", [("ntu_action", 6, 60), ("chi3d", 2, 150)])
+def test_small_batch_engine_is_bit_exact_under_batch_composition(config, B, T):
+    """The small-batch kernels (rgn_sb.hip) accumulate every output element in a fixed order that does not depend on which
+    rows share its tile, so sample b of a batch equals the same sample drawn alone BIT FOR BIT — guided (2B rows: up to
+    720 of the 768 the engine takes; 32- and 64-row tiles) and unguided, across both phases of the precision schedule."""
+    from regennet_amd import synth
+    from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    cfg = synth.get_config(config)
+    model, diffusion = build_hip(cfg, synth.make_state_dict(cfg, seed=0), resp="ddim5", precision="bf16_x3tail", x3_tail=2)
+    y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1)).cuda(),
+         "action": torch.from_numpy(synth.make_actions(cfg, B, seed=2)).cuda(), "scale": torch.full((B,), 2.5, device="cuda")}
+    for fm in (model, ClassifierFreeSampleModel(model)):
+        full = diffusion.ddim_sample_loop(fm, (B, 56, 6, T), clip_denoised=False, model_kwargs={"y": y}, seed=13)
+        assert torch.isfinite(full).all()
+        for b in (0, 1, B - 1):
+            yb = {k: v[b:b + 1].contiguous() for k, v in y.items()}
+            one = diffusion.ddim_sample_loop(fm, (1, 56, 6, T), clip_denoised=False, model_kwargs={"y": yb}, seed=13, sample_offset=b)
+            assert torch.equal(full[b:b + 1], one), (b, (full[b:b + 1] - one).abs().max().item())
+
+
 @pytest.mark.parametrize("precision,tail", [("bf16x3", None), ("bf16_x3tail", 2)])
 def test_chi3d_full_size_shard_is_row_independent(precision, tail):
     """BASELINE configs[3] per-GPU shard (Chi3D T=150, B=128 = 1024 / 8): the long-sequence kernels (in_proj GEMM with the
@@ -496,7 +533,7 @@ def test_chi3d_full_size_shard_is_row_independent(precision, tail):
     from regennet_amd import synth
     from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
     cfg = synth.get_config("chi3d")
-    model, diffusion = build_hip(cfg, synth.make_state_dict(cfg, seed=0), resp="ddim5", precision=precision, x3_tail=tail)
+    model, diffusion = build_hip(cfg, synth.make_state_dict(cfg, seed=0), resp="ddim5", precision=precision + "/throughput", x3_tail=tail)
     B = 128
     y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1)).cuda(),
          "action": torch.from_numpy(synth.make_actions(cfg, B, seed=2)).cuda(), "scale": torch.full((B,), 2.5, device="cuda")}
