@@ -95,6 +95,7 @@ struct rgn_ctx {
     bool fuse_ln = false;              // out_proj / linear2 GEMMs carry their LayerNorms (k_gemm_x3_ln)
     bool rowgemm = false;              // plain-bf16 phase: row-complete GEMMs with fused LayerNorm / GELU (k_rowgemm)
     bool mlp = false;                  // plain-bf16 phase: the whole layer tail in one row-persistent kernel (k_mlp)
+    bool qkv_rs = true;                // plain-bf16 phase: k_qkv_attn with register-streamed weights (REGENNET_NO_QKV_RS=1: the DMA-fed loop)
     bool sb = false;                   // small-batch engine: column-split GEMMs with consumer-side LayerNorm (k_sb_gemm)
     int sb_rows = 768;                 // evaluations of at most this many token rows take it (rgn_set_small_batch_rows; 0 disables)
     int sb_rows_default = 768;         // (REGENNET_SB_ROWS): measured crossover with the throughput kernels at 60 tokens: B = 12 .. 16
@@ -542,6 +543,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             QkvAttnArgs g{};
             g.Ahi = h_p.hi; g.Alo = h_p.lo; g.a_rows = h_p.rows;
             g.Whi = c->dp<__bf16>(w.qkv.hi); g.Wlo = c->dp<__bf16>(w.qkv.lo);
+            g.Wfr = (w.qkv.fr && c->qkv_rs) ? c->dp<__bf16>(w.qkv.fr) : nullptr;   // plain-bf16 phase: weights streamed to registers
             g.bias = c->dp<float>(w.qkv.b);
             g.out = att_p;
             g.Bm = ns; g.Kp = w.qkv.Kp; g.d = d; g.H = c->H; g.Tq = dm.Tq;
@@ -926,7 +928,7 @@ int rgn_finalize_weights(rgn_handle h) {
         const std::string p = "seqTransDecoder.layers." + std::to_string(l) + ".";
         LayerW& lw = c->layers[l];
         lw.qkv = pack_linear(c, W(p + "self_attn.in_proj_weight"), W(p + "self_attn.in_proj_bias"), 3 * d, d, true,
-                             c->cfg.precision == RGN_PREC_BF16_X3TAIL && !qkv_attn_supported(c->Tq, d / c->H, d));
+                             c->cfg.precision == RGN_PREC_BF16_X3TAIL);   // fragment order: k_rowgemm (long sequences) / k_qkv_attn_rs
         const bool fr = c->cfg.precision == RGN_PREC_BF16_X3TAIL;   // k_rowgemm operands (plain-bf16 phase)
         lw.out = pack_linear(c, W(p + "self_attn.out_proj.weight"), W(p + "self_attn.out_proj.bias"), d, d, true, fr);
         lw.ff1 = pack_linear(c, W(p + "linear1.weight"), W(p + "linear1.bias"), ff, d, true, fr);
@@ -1024,6 +1026,7 @@ int rgn_finalize_weights(rgn_handle h) {
         c->mlp = c->rowgemm && mlp_supported(d, ff, c->Tq) && getenv("REGENNET_NO_MLP") == nullptr;
         if (c->mlp) RGN_HIP(c, configure_mlp());
         if (c->fuse_qkv) RGN_HIP(c, configure_qkv_attn());
+        c->qkv_rs = getenv("REGENNET_NO_QKV_RS") == nullptr;
         c->sb = c->attn_x3 && sb_supported(d, ff, d / c->H);
         if (const char* e = getenv("REGENNET_SB_ROWS")) c->sb_rows = c->sb_rows_default = atoi(e) < 0 ? 0 : atoi(e);
         if (c->sb) RGN_HIP(c, configure_sb());
@@ -1205,7 +1208,8 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
     sp.guided = guided != 0;
     sp.clip = clip_denoised != 0;
     RGN_HIP(c, hipMemcpyAsync(c->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
-    RGN_HIP(c, hipMemcpyAsync(c->d_step, &first_index, sizeof(int), hipMemcpyHostToDevice, s));
+    const int step_init[2] = {first_index, 0};                   // loop index, k_update's ticket counter
+    RGN_HIP(c, hipMemcpyAsync(c->d_step, step_init, sizeof(step_init), hipMemcpyHostToDevice, s));
     if ((rc = pack_state(c, x, dm, guided != 0, s))) return rc;
 
     // Precision schedule: loop indices >= tail run the plain-bf16 phase, the last `tail` indices the split-bf16 one.
@@ -1230,8 +1234,7 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
         RGN_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         int r = RGN_OK;
         for (int k = 0; k < steps && r == RGN_OK; ++k) {
-            r = run_eval(c, c->B, guided != 0, false, true, s);
-            if (r == RGN_OK && launch_advance(c->d_step, s) != hipSuccess) r = c->fail(RGN_ERR_HIP, "launch_advance");
+            r = run_eval(c, c->B, guided != 0, false, true, s);   // (its k_update also moves the device-side loop index on)
         }
         hipError_t e = hipStreamEndCapture(s, &graph);
         if (r) {
@@ -1262,7 +1265,6 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
             c->phase_x3 = x3;
             rc = run_eval(c, c->B, guided != 0, false, true, s);
             if (rc) return rc;
-            RGN_LAUNCH(c, KC_MISC, s, launch_advance(c->d_step, s));
             k += 1;
         }
     }

@@ -96,6 +96,7 @@ struct Planes {
 struct QkvAttnArgs {
     const __bf16* Ahi; const __bf16* Alo; int a_rows;   // layer input planes [Kp/32][a_rows][32] (advanced to the first sample)
     const __bf16* Whi; const __bf16* Wlo;               // in_proj weight planes [Kp/32][3d][32]
+    const __bf16* Wfr;                                  // the hi plane in MFMA-fragment order [Kp/32][3d/32][2][64][8] (plain-bf16 phase, d = 512), nullable
     const float* bias;                                  // in_proj bias [3d]
     Planes out;                                         // attention output planes (advanced to the first sample's row)
     int Bm, Kp, d, H, Tq;
@@ -232,7 +233,7 @@ hipError_t launch_emb_rows(const float* emb, const float* stepemb, const int* d_
                            const Dims& dm, int wo_pos, hipStream_t s);
 hipError_t launch_add_pe(float* c0, const float* pe, const Dims& dm, hipStream_t s);
 hipError_t launch_pack_x(const float* x, float* xin, Planes xp, int copies, const Dims& dm, hipStream_t s);
-hipError_t launch_update(const float* x0tok, const float* scale, const StepCoef* tab, const int* d_step,
+hipError_t launch_update(const float* x0tok, const float* scale, const StepCoef* tab, int* d_step,
                          const SampleParams* sp, float* xin, Planes xp, const Dims& dm, int b0, int nb, hipStream_t s);
 hipError_t launch_advance(int* d_step, hipStream_t s);
 hipError_t launch_cond_rows(const float* table, const int64_t* action, float* out, int B, int d, int num_actions, hipStream_t s);

@@ -882,8 +882,11 @@ hipError_t launch_randn(float* x, int B, int FT, int T, unsigned long long seed,
 //   DDIM  e = (sr*x - x0)/srm1 ; x' = (x0*ca + cb*e) + sig*eps   gaussian_diffusion.py:419-423,785-793
 // Products and sums are rounded separately (no FMA contraction) to follow the reference's op order.
 // Writes the new state in boundary layout [B,F,T] and token-major xin for the next step's GEMM.
+// In sampling mode the LAST block to finish (of all k_update launches of the step: the chains' launches together cover the
+// B samples once) also moves the device-side loop index on: *d_step -= 1. Every block read *d_step before it took its
+// ticket, and every other reader of *d_step (the layer kernels of a chain) precedes that chain's k_update in stream order.
 __global__ __launch_bounds__(256) void k_update(const float* __restrict__ x0tok, const float* __restrict__ scale,
-                                                 const StepCoef* __restrict__ tab, const int* __restrict__ d_step,
+                                                 const StepCoef* __restrict__ tab, int* d_step,
                                                  const SampleParams* __restrict__ spp, float* __restrict__ xin, Planes xp,
                                                  Dims dm, int b0) {
     __shared__ float tc[32][33];
@@ -954,8 +957,15 @@ __global__ __launch_bounds__(256) void k_update(const float* __restrict__ x0tok,
             }
         }
     }
+    if (threadIdx.x == 0) {   // d_step[1]: tickets of this step
+        const int total = (int)(gridDim.x * gridDim.y) * dm.B;
+        if (atomicAdd(d_step + 1, 1) == total - 1) {
+            d_step[1] = 0;
+            d_step[0] = step - 1;
+        }
+    }
 }
-hipError_t launch_update(const float* x0tok, const float* scale, const StepCoef* tab, const int* d_step,
+hipError_t launch_update(const float* x0tok, const float* scale, const StepCoef* tab, int* d_step,
                          const SampleParams* sp, float* xin, Planes xp, const Dims& dm, int b0, int nb, hipStream_t s) {
     dim3 grid((dm.T + 31) / 32, (dm.F + 31) / 32, nb);
     hipLaunchKernelGGL(k_update, grid, dim3(256), 0, s, x0tok, scale, tab, d_step, sp, xin, xp, dm, b0);

@@ -44,6 +44,175 @@ __device__ long long g_qa_prof[64];   // tools only: phase cycle stamps of one w
 #define RGN_QT(i)
 #endif
 
+// Attention straight from the in_proj accumulators of one head (see the file header); shared by the DMA-fed and the
+// register-streamed GEMM phases. acc[token tile][q | k | v]; smem: the 96 KiB fp32 exchange buffer for the S^T partials.
+template <bool X3>
+__device__ __forceinline__ void qa_attention(f32x16 (&acc)[2][3], const QkvAttnArgs& g, char* smem, const float* bias_h, int hd, int hslot,
+                                             int wm, int wn, int nsamp, int b0, int lane, int tid) {
+    const int l31 = lane & 31, kh = lane >> 5, Tq = g.Tq;
+    (void)tid; (void)hslot;
+    // ---------------- attention straight from the accumulators: q, k, v never leave the register file --------------
+    // Wave (wm, wn) holds, for its sample and the 32 dh columns of tile wn: q and k transposed (lane = token, the 16
+    // registers = dh (i&3) + 8(i>>2) + 4*kh) and v plain (lane = dh, registers = tokens in the same pattern), for both
+    // token tiles. An MFMA contraction does not care in which order the reduction index is fed as long as both
+    // operands agree, and here they do by construction: register i of lane half kh means the same dh in q and in k,
+    // and the same token in v and in p. So
+    //   S^T[keys, queries] (partial over this wave's 32 dh) = K-regs (A operand) x Q-regs (B operand),
+    //   O^T[dh tile, queries] = V-regs (A) x P^T-regs (B, the softmaxed S^T accumulators)
+    // need no LDS staging, no transposes and no ds_reads. The only exchange is the sum of the four dh-tile partials of
+    // S^T, done through an fp32 LDS buffer that aliases the dead pipeline stages (96 KiB: 2 samples x 3 causal tiles
+    // x 4 waves x 4 KiB). Both samples proceed at the same time on their own four waves.
+    const bool live = wm < nsamp;                               // (an odd batch: the second sample of the last pair is a dummy)
+    const size_t row0 = (size_t)(b0 + (live ? wm : 0)) * Tq;
+        bf16x8 qh[2][2], ql[2][2], kfh[2][2], kfl[2][2], vh[2][2], vl[2][2];   // [token tile][16-slice of the register index]
+    {
+        const float bv = bias_h[2 * QA_DH + l31];
+        const float qs2 = g.qscale * 1.44269504088896340736f;   // scores in log2 units: softmax = exp2(s - max), one mul less per score
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const f32x4 bq0 = *reinterpret_cast<const f32x4*>(bias_h + 16 * sl + 4 * kh);
+                const f32x4 bq1 = *reinterpret_cast<const f32x4*>(bias_h + 16 * sl + 8 + 4 * kh);
+                const f32x4 bk0 = *reinterpret_cast<const f32x4*>(bias_h + QA_DH + 16 * sl + 4 * kh);
+                const f32x4 bk1 = *reinterpret_cast<const f32x4*>(bias_h + QA_DH + 16 * sl + 8 + 4 * kh);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = 8 * sl + j;
+                    const float xq = (acc[ta][0][i] + (j < 4 ? bq0[j] : bq1[j - 4])) * qs2;
+                    const float xk = acc[ta][1][i] + (j < 4 ? bk0[j] : bk1[j - 4]);
+                    const float xv = acc[ta][2][i] + bv;
+                    qh[ta][sl][j] = (__bf16)xq;
+                    kfh[ta][sl][j] = (__bf16)xk;
+                    vh[ta][sl][j] = (__bf16)xv;
+                    if (X3) {
+                        ql[ta][sl][j] = (__bf16)(xq - (float)qh[ta][sl][j]);
+                        kfl[ta][sl][j] = (__bf16)(xk - (float)kfh[ta][sl][j]);
+                        vl[ta][sl][j] = (__bf16)(xv - (float)vh[ta][sl][j]);
+                    }
+                }
+            }
+    }
+    // causal tiles of S^T: 0 = (keys 0-31, queries 0-31), 1 = (keys 0-31, queries 32-63), 2 = (keys 32-63, queries 32-63)
+    f32x16 st[3];
+#pragma unroll
+    for (int tl = 0; tl < 3; ++tl) {
+        const int kj = tl >> 1, qtile = tl ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[tl][i] = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            if (X3) {
+                st[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl[kj][sl], qh[qtile][sl], st[tl], 0, 0, 0);
+                st[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh[kj][sl], ql[qtile][sl], st[tl], 0, 0, 0);
+            }
+            st[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh[kj][sl], qh[qtile][sl], st[tl], 0, 0, 0);
+        }
+    }
+    // sum the partials of the four dh tiles: [sample][tile][wave wn][i/4][lane] float4
+    f32x4* sred = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+    for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const f32x4 v = {st[tl][4 * i4], st[tl][4 * i4 + 1], st[tl][4 * i4 + 2], st[tl][4 * i4 + 3]};
+            sred[(((wm * 3 + tl) * 4 + wn) * 4 + i4) * 64 + lane] = v;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    RGN_QT(hslot * 8 + 2)
+#pragma unroll
+    for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            f32x4 v = sred[(((wm * 3 + tl) * 4 + 0) * 4 + i4) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const f32x4 u = sred[(((wm * 3 + tl) * 4 + w) * 4 + i4) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += u[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[tl][4 * i4 + e] = v[e];
+        }
+    RGN_QT(hslot * 8 + 4)
+    // softmax over keys for the lane's two queries (l31 and 32 + l31); every wave of the sample does the same work
+    float inv[2];
+#pragma unroll
+    for (int qtile = 0; qtile < 2; ++qtile) {
+        const int q = 32 * qtile + l31;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int tl = qtile; tl <= 2 * qtile; ++tl) {             // tiles {0} for query tile 0, {1, 2} for query tile 1
+            const int kj = tl >> 1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = 32 * kj + (i & 3) + 8 * (i >> 2) + 4 * kh;
+                const bool ok = (tl == 1 || key <= q) && (key < Tq);   // tile 1 (keys 0-31, queries 32-63) lies below the diagonal
+                st[tl][i] = ok ? st[tl][i] : -INFINITY;
+                mx = fmaxf(mx, st[tl][i]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int tl = qtile; tl <= 2 * qtile; ++tl)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = __builtin_amdgcn_exp2f(st[tl][i] - mx);
+                st[tl][i] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        inv[qtile] = 1.0f / sum;
+    }
+    RGN_QT(hslot * 8 + 5)
+    // O^T[dh tile wn, queries] = V (A operand, registers = keys) x P^T (B operand, registers = keys)
+#pragma unroll
+    for (int qtile = 0; qtile < 2; ++qtile) {
+        f32x16 oa;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oa[i] = 0.f;
+#pragma unroll
+        for (int tl = qtile; tl <= 2 * qtile; ++tl) {
+            const int kj = tl >> 1;
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                bf16x8 ph, pl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = st[tl][8 * sl + j];
+                    ph[j] = (__bf16)x;
+                    pl[j] = (__bf16)(x - (float)ph[j]);
+                }
+                if (X3) {
+                    oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[kj][sl], ph, oa, 0, 0, 0);
+                    oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[kj][sl], pl, oa, 0, 0, 0);
+                }
+                oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[kj][sl], ph, oa, 0, 0, 0);
+            }
+        }
+        // O^T tile: lane = query (column), registers = 16 dh indices -> 4 runs of 4 consecutive dh = 8-byte plane
+        // stores; the 32 x 32 tile is one contiguous 2 KiB run of the K32-blocked plane
+        const int q = 32 * qtile + l31;
+        if (live && q < Tq) {
+            const size_t o = ((size_t)(hd * (QA_DH / 32) + wn) * g.out.rows + row0 + q) * 32 + 4 * kh;
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                bf16x4 hv, lv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = oa[4 * i4 + e] * inv[qtile];
+                    hv[e] = (__bf16)x;
+                    lv[e] = (__bf16)(x - (float)hv[e]);
+                }
+                *reinterpret_cast<bf16x4*>(g.out.hi + o + 8 * i4) = hv;
+                if (g.out.lo) *reinterpret_cast<bf16x4*>(g.out.lo + o + 8 * i4) = lv;
+            }
+        }
+    }
+}
+
 template <bool X3>
 __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn(QkvAttnArgs g) {
     constexpr int NPL = X3 ? 2 : 1;
@@ -183,170 +352,128 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn(QkvAttnArgs g) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // every wave is done reading the last stage
         RGN_QT((hd - hd0) * 8 + 1)
-        // ---------------- attention straight from the accumulators: q, k, v never leave the register file --------------
-        // Wave (wm, wn) holds, for its sample and the 32 dh columns of tile wn: q and k transposed (lane = token, the 16
-        // registers = dh (i&3) + 8(i>>2) + 4*kh) and v plain (lane = dh, registers = tokens in the same pattern), for both
-        // token tiles. An MFMA contraction does not care in which order the reduction index is fed as long as both
-        // operands agree, and here they do by construction: register i of lane half kh means the same dh in q and in k,
-        // and the same token in v and in p. So
-        //   S^T[keys, queries] (partial over this wave's 32 dh) = K-regs (A operand) x Q-regs (B operand),
-        //   O^T[dh tile, queries] = V-regs (A) x P^T-regs (B, the softmaxed S^T accumulators)
-        // need no LDS staging, no transposes and no ds_reads. The only exchange is the sum of the four dh-tile partials of
-        // S^T, done through an fp32 LDS buffer that aliases the dead pipeline stages (96 KiB: 2 samples x 3 causal tiles
-        // x 4 waves x 4 KiB). Both samples proceed at the same time on their own four waves.
-        const bool live = wm < nsamp;                               // (an odd batch: the second sample of the last pair is a dummy)
-        const size_t row0 = (size_t)(b0 + (live ? wm : 0)) * Tq;
-        const float* bias_h = bias_s + (hd - hd0) * QA_WROWS + wn * 32;
-        bf16x8 qh[2][2], ql[2][2], kfh[2][2], kfl[2][2], vh[2][2], vl[2][2];   // [token tile][16-slice of the register index]
-        {
-            const float bv = bias_h[2 * QA_DH + l31];
-            const float qs2 = g.qscale * 1.44269504088896340736f;   // scores in log2 units: softmax = exp2(s - max), one mul less per score
-#pragma unroll
-            for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-                for (int sl = 0; sl < 2; ++sl) {
-                    const f32x4 bq0 = *reinterpret_cast<const f32x4*>(bias_h + 16 * sl + 4 * kh);
-                    const f32x4 bq1 = *reinterpret_cast<const f32x4*>(bias_h + 16 * sl + 8 + 4 * kh);
-                    const f32x4 bk0 = *reinterpret_cast<const f32x4*>(bias_h + QA_DH + 16 * sl + 4 * kh);
-                    const f32x4 bk1 = *reinterpret_cast<const f32x4*>(bias_h + QA_DH + 16 * sl + 8 + 4 * kh);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int i = 8 * sl + j;
-                        const float xq = (acc[ta][0][i] + (j < 4 ? bq0[j] : bq1[j - 4])) * qs2;
-                        const float xk = acc[ta][1][i] + (j < 4 ? bk0[j] : bk1[j - 4]);
-                        const float xv = acc[ta][2][i] + bv;
-                        qh[ta][sl][j] = (__bf16)xq;
-                        kfh[ta][sl][j] = (__bf16)xk;
-                        vh[ta][sl][j] = (__bf16)xv;
-                        if (X3) {
-                            ql[ta][sl][j] = (__bf16)(xq - (float)qh[ta][sl][j]);
-                            kfl[ta][sl][j] = (__bf16)(xk - (float)kfh[ta][sl][j]);
-                            vl[ta][sl][j] = (__bf16)(xv - (float)vh[ta][sl][j]);
-                        }
-                    }
-                }
-        }
-        // causal tiles of S^T: 0 = (keys 0-31, queries 0-31), 1 = (keys 0-31, queries 32-63), 2 = (keys 32-63, queries 32-63)
-        f32x16 st[3];
-#pragma unroll
-        for (int tl = 0; tl < 3; ++tl) {
-            const int kj = tl >> 1, qtile = tl ? 1 : 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) st[tl][i] = 0.f;
-#pragma unroll
-            for (int sl = 0; sl < 2; ++sl) {
-                if (X3) {
-                    st[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl[kj][sl], qh[qtile][sl], st[tl], 0, 0, 0);
-                    st[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh[kj][sl], ql[qtile][sl], st[tl], 0, 0, 0);
-                }
-                st[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh[kj][sl], qh[qtile][sl], st[tl], 0, 0, 0);
-            }
-        }
-        // sum the partials of the four dh tiles: [sample][tile][wave wn][i/4][lane] float4
-        f32x4* sred = reinterpret_cast<f32x4*>(smem);
-#pragma unroll
-        for (int tl = 0; tl < 3; ++tl)
-#pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                const f32x4 v = {st[tl][4 * i4], st[tl][4 * i4 + 1], st[tl][4 * i4 + 2], st[tl][4 * i4 + 3]};
-                sred[(((wm * 3 + tl) * 4 + wn) * 4 + i4) * 64 + lane] = v;
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        RGN_QT((hd - hd0) * 8 + 2)
-#pragma unroll
-        for (int tl = 0; tl < 3; ++tl)
-#pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                f32x4 v = sred[(((wm * 3 + tl) * 4 + 0) * 4 + i4) * 64 + lane];
-#pragma unroll
-                for (int w = 1; w < 4; ++w) {
-                    const f32x4 u = sred[(((wm * 3 + tl) * 4 + w) * 4 + i4) * 64 + lane];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += u[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) st[tl][4 * i4 + e] = v[e];
-            }
-        RGN_QT((hd - hd0) * 8 + 4)
-        // softmax over keys for the lane's two queries (l31 and 32 + l31); every wave of the sample does the same work
-        float inv[2];
-#pragma unroll
-        for (int qtile = 0; qtile < 2; ++qtile) {
-            const int q = 32 * qtile + l31;
-            float mx = -INFINITY;
-#pragma unroll
-            for (int tl = qtile; tl <= 2 * qtile; ++tl) {             // tiles {0} for query tile 0, {1, 2} for query tile 1
-                const int kj = tl >> 1;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int key = 32 * kj + (i & 3) + 8 * (i >> 2) + 4 * kh;
-                    const bool ok = (tl == 1 || key <= q) && (key < Tq);   // tile 1 (keys 0-31, queries 32-63) lies below the diagonal
-                    st[tl][i] = ok ? st[tl][i] : -INFINITY;
-                    mx = fmaxf(mx, st[tl][i]);
-                }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float sum = 0.f;
-#pragma unroll
-            for (int tl = qtile; tl <= 2 * qtile; ++tl)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float e = __builtin_amdgcn_exp2f(st[tl][i] - mx);
-                    st[tl][i] = e;
-                    sum += e;
-                }
-            sum += __shfl_xor(sum, 32, 64);
-            inv[qtile] = 1.0f / sum;
-        }
-        RGN_QT((hd - hd0) * 8 + 5)
-        // O^T[dh tile wn, queries] = V (A operand, registers = keys) x P^T (B operand, registers = keys)
-#pragma unroll
-        for (int qtile = 0; qtile < 2; ++qtile) {
-            f32x16 oa;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oa[i] = 0.f;
-#pragma unroll
-            for (int tl = qtile; tl <= 2 * qtile; ++tl) {
-                const int kj = tl >> 1;
-#pragma unroll
-                for (int sl = 0; sl < 2; ++sl) {
-                    bf16x8 ph, pl;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float x = st[tl][8 * sl + j];
-                        ph[j] = (__bf16)x;
-                        pl[j] = (__bf16)(x - (float)ph[j]);
-                    }
-                    if (X3) {
-                        oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[kj][sl], ph, oa, 0, 0, 0);
-                        oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[kj][sl], pl, oa, 0, 0, 0);
-                    }
-                    oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[kj][sl], ph, oa, 0, 0, 0);
-                }
-            }
-            // O^T tile: lane = query (column), registers = 16 dh indices -> 4 runs of 4 consecutive dh = 8-byte plane
-            // stores; the 32 x 32 tile is one contiguous 2 KiB run of the K32-blocked plane
-            const int q = 32 * qtile + l31;
-            if (live && q < Tq) {
-                const size_t o = ((size_t)(hd * (QA_DH / 32) + wn) * g.out.rows + row0 + q) * 32 + 4 * kh;
-#pragma unroll
-                for (int i4 = 0; i4 < 4; ++i4) {
-                    bf16x4 hv, lv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x = oa[4 * i4 + e] * inv[qtile];
-                        hv[e] = (__bf16)x;
-                        lv[e] = (__bf16)(x - (float)hv[e]);
-                    }
-                    *reinterpret_cast<bf16x4*>(g.out.hi + o + 8 * i4) = hv;
-                    if (g.out.lo) *reinterpret_cast<bf16x4*>(g.out.lo + o + 8 * i4) = lv;
-                }
-            }
-        }
+        qa_attention<X3>(acc, g, smem, bias_s + (hd - hd0) * QA_WROWS + wn * 32, hd, hd - hd0, wm, wn, nsamp, b0, lane, tid);
         RGN_QT((hd - hd0) * 8 + 6)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();      // the next head's DMA overwrites the reduction buffer
+        RGN_QT((hd - hd0) * 8 + 3)
+    }
+}
+
+// ---- plain-bf16 phase, d = 512: the same kernel with the in_proj weights streamed into REGISTERS -------------------------
+// The DMA-fed loop above moves 112 KiB through LDS per k-step (32 KiB of DMA writes + 80 KiB of fragment reads, of which
+// 48 KiB are the W fragments) against the 128 B/clk the LDS delivers: ~1400 clk per k-step for 768 clk of MFMA work
+// (tools/qkv_attn_bench -DRGN_QA_PROF). Here every wave loads its own q/k/v weight fragments straight from the
+// fragment-ordered plane ([Kp/32][3d/32][2 ks][64 lanes][8], one contiguous 1 KiB run per wave-load, as in k_rowgemm)
+// into a 4-slot register ring, 3 k-steps ahead; only the activation tile (8 KiB per k-step, loaded to registers 3 steps
+// ahead as well and written to a 2-stage LDS ring one step ahead) still passes through LDS. No direct-to-LDS DMA in the
+// loop, and the 16 k-steps are fully unrolled: the compiler's own s_waitcnt bookkeeping then stays exact (it drains
+// vmcnt at loop back-edges and before the first LDS read behind a DMA).
+constexpr int QR_NK = 16, QR_D = 2, QR_RING = QR_D + 1;     // weights: issued QR_D k-steps ahead of the MFMAs that consume them
+constexpr int QR_DA = 4, QR_ARING = QR_DA + 1;                // activation pieces: QR_DA ahead (they must be in LDS one step early)
+constexpr int QR_ABUF = 96 * 1024;                                   // activation ring [2][128 rows][64 B], behind the exchange buffer
+__global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn_rs(QkvAttnArgs g, const __bf16* __restrict__ Wfr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int b0 = blockIdx.x * QA_NS, Tq = g.Tq, d = g.d;
+    const int hpb = g.H / (int)gridDim.y, hd0 = blockIdx.y * hpb;
+    const int nsamp = g.Bm - b0 < QA_NS ? g.Bm - b0 : QA_NS;
+    const int nb_all = 3 * d / 32;
+
+    unsigned a_voff;                                                 // this thread's 16 bytes of every activation k-block (elements)
+    {
+        const int r = tid >> 2, c = (tid & 3) ^ ((r >> 2) & 3);      // tile row r: sample r / 64, token r % 64
+        const int sm = (r >> 6) < nsamp ? (r >> 6) : 0, tk = r & 63;
+        const int rr = tk < Tq ? tk : Tq - 1;                        // padding rows replicate the last token (masked later)
+        a_voff = (unsigned)((b0 + sm) * Tq + rr) * 32u + c * 8;
+    }
+    // buffer loads: descriptor + uniform k-step offset in SGPRs, one 32-bit VGPR per lane address (with flat addresses the
+    // compiler materialises a 64-bit address pair per unrolled k-step and spills)
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(g.Ahi), 0, (int)((size_t)g.a_rows * g.Kp * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Wfr), 0, 3 * d * g.Kp * 2, 0x00020000);
+    const unsigned a_kbytes = (unsigned)g.a_rows * 64u;
+    int a_off[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int rr = wm * 64 + t * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a_off[t][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
+    }
+    float* bias_s = reinterpret_cast<float*>(smem + 4 * (QA_NS * QA_ROWS * 64 + QA_WROWS * 64));   // same place as in k_qkv_attn
+    for (int i = tid; i < hpb * QA_WROWS; i += QA_NT) {
+        const int hh = i / QA_WROWS, r = i - hh * QA_WROWS;
+        bias_s[i] = g.bias[(r >> 7) * d + (hd0 + hh) * QA_DH + (r & 127)];
+    }
+    char* abuf = smem + QR_ABUF;
+
+    for (int hd = hd0; hd < hd0 + hpb; ++hd) {
+        unsigned wofs[3];                                            // fragment block of this wave's 32 columns of q / k / v (elements)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) wofs[t] = (unsigned)((t * d + hd * QA_DH) / 32 + wn) * 1024u + lane * 8;
+        f32x16 acc[2][3];
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[ta][t][i] = 0.f;
+        RGN_QT((hd - hd0) * 8 + 0)
+        bf16x8 wf[QR_RING][3][2];                                    // [slot][q | k | v][ks]
+        u32x4 areg[QR_ARING];
+        auto issue_a = [&](int kt) { areg[kt % QR_ARING] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_voff * 2, kt * a_kbytes, 0)); };
+        auto issue = [&](int kt) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    wf[kt % QR_RING][t][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, wofs[t] * 2, (kt * nb_all * 1024 + ks * 512) * 2, 0));
+        };
+#pragma unroll
+        for (int kt = 0; kt < QR_DA; ++kt) issue_a(kt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kt = 0; kt < QR_D; ++kt) {
+            issue(kt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        *reinterpret_cast<u32x4*>(abuf + tid * 16) = areg[0];        // stage 0 <- k-block 0
+#pragma unroll
+        for (int kt = 0; kt < QR_NK; ++kt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                            // k-block kt is in its stage; everyone left stage (kt + 1) % 2
+            const char* sb = abuf + (kt & 1) * 8192;
+            bf16x8 af[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta) af[ks][ta] = *reinterpret_cast<const bf16x8*>(sb + a_off[ta][ks]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + QR_DA < QR_NK) issue_a(kt + QR_DA);
+            if (kt + QR_D < QR_NK) issue(kt + QR_D);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int grp = 0; grp < 6; ++grp) {
+                const int ks = grp / 3, t = grp % 3;
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta) {
+                    if (t < 2)     // q, k tiles transposed (lane = token, registers = dh)
+                        acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kt % QR_RING][t][ks], af[ks][ta], acc[ta][t], 0, 0, 0);
+                    else           // v tile: lane = dh, registers = tokens
+                        acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][ta], wf[kt % QR_RING][t][ks], acc[ta][t], 0, 0, 0);
+                }
+                if (grp == 2 && kt + 1 < QR_NK)                      // next k-block of the activation tile -> the other stage
+                    *reinterpret_cast<u32x4*>(abuf + ((kt + 1) & 1) * 8192 + tid * 16) = areg[(kt + 1) % QR_ARING];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        RGN_QT((hd - hd0) * 8 + 1)
+        qa_attention<false>(acc, g, smem, bias_s + (hd - hd0) * QA_WROWS + wn * 32, hd, hd - hd0, wm, wn, nsamp, b0, lane, tid);
+        RGN_QT((hd - hd0) * 8 + 6)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         RGN_QT((hd - hd0) * 8 + 3)
     }
 }
@@ -357,9 +484,17 @@ hipError_t configure_qkv_attn() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, qa_lds(true));
     if (e != hipSuccess) return e;
     // (the plain-bf16 build is given the same allocation: its operand buffers, one plane each, alias its 64 KiB of stages)
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, qa_lds(true));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, qa_lds(true));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_rs), hipFuncAttributeMaxDynamicSharedMemorySize, qa_lds(true));
 }
 hipError_t launch_qkv_attn(const QkvAttnArgs& g, bool x3, hipStream_t s) {
+    if (!x3 && g.Wfr && g.Kp == 32 * QR_NK && g.d == 512) {   // plain-bf16 phase: weights streamed to registers
+        const int pairs = (g.Bm + QA_NS - 1) / QA_NS;
+        const int hsplit = (pairs * g.H <= 64) ? g.H : (g.H % 2 == 0 ? 2 : 1);
+        hipLaunchKernelGGL(k_qkv_attn_rs, dim3(pairs, hsplit), dim3(QA_NT), qa_lds(true), s, g, g.Wfr);
+        return hipGetLastError();
+    }
     // heads per workgroup: half of them (the weight stream per sample is what bounds the kernel), but one head each while
     // the launch is small (<= 64 workgroups): a small batch is latency-bound and the heads of a workgroup run back to back
     const int pairs = (g.Bm + QA_NS - 1) / QA_NS;

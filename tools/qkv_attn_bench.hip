@@ -32,6 +32,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&Ohi, (size_t)M * d * 2)); CK(hipMalloc(&Olo, (size_t)M * d * 2)); CK(hipMalloc(&bias, 3 * d * 4)); CK(hipMemset(bias, 0, 3 * d * 4));
     QkvAttnArgs g{};
     g.Ahi = Ahi; g.Alo = Alo; g.a_rows = M; g.Whi = Whi; g.Wlo = Wlo; g.bias = bias;
+    if (getenv("RS")) g.Wfr = Whi;   // RS=1 (with BF16=1): the register-streamed weight loop (any bytes do for timing)
     g.out.hi = Ohi; g.out.lo = x3 ? Olo : nullptr; g.out.rows = M; g.Bm = Bm; g.Kp = Kp; g.d = d; g.H = H; g.Tq = Tq; g.qscale = 0.0884f;
     CK(configure_qkv_attn());
     for (int i = 0; i < 3; ++i) CK(launch_qkv_attn(g, x3, nullptr));
