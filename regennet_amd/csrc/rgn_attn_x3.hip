@@ -79,6 +79,29 @@ __global__ __launch_bounds__(64 * NT) void k_attn_x3(AttnX3Args a) {
             ql[s] = __builtin_bit_cast(bf16x8, vl);
         }
     }
+    // ---- V rows -> registers now (two keys x 8 dh per item): their global round trip overlaps the K staging and the S^T
+    //      phase instead of following the softmax; they go to LDS (transposed) once every wave is done with K
+    //      (sequences of up to 64 tokens only: the latency-bound small launches; at 150 tokens the kernel is HBM-bound and
+    //      the 32-64 extra live VGPRs cost more occupancy than the overlap returns: 27.3 -> 28.8 us at B=128)
+    constexpr int V_IT = ((TQP / 2) * (DH / 8) + 64 * NT - 1) / (64 * NT);
+    constexpr bool V_EARLY = NT <= 2;
+    u32x4 vreg[NPL][V_IT][2];
+    auto load_v = [&] {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+        for (int it = 0; it < V_IT; ++it) {
+            const int idx = tid + it * 64 * NT;
+            const int kp = idx % (TQP / 2), c = (idx / (TQP / 2)) * 8, k0 = 2 * kp;
+            const bool in = idx < (TQP / 2) * (DH / 8);
+            u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+            if (in && k0 < Tq) v0 = *reinterpret_cast<const u32x4*>(gV[p] + (size_t)k0 * DH + c);
+            if (in && k0 + 1 < Tq) v1 = *reinterpret_cast<const u32x4*>(gV[p] + (size_t)(k0 + 1) * DH + c);
+            vreg[p][it][0] = v0;
+            vreg[p][it][1] = v1;
+        }
+    };
+    if constexpr (V_EARLY) load_v();
     __syncthreads();
     f32x16 st[NT];
 #pragma unroll
@@ -135,13 +158,16 @@ __global__ __launch_bounds__(64 * NT) void k_attn_x3(AttnX3Args a) {
             reinterpret_cast<unsigned int*>(&sh[p * PLANE + DH * VLD])[o] = 0u;
         }
     }
+    if constexpr (!V_EARLY) load_v();
+#pragma unroll
     for (int p = 0; p < NPL; ++p)
-        for (int idx = tid; idx < (TQP / 2) * (DH / 8); idx += 64 * NT) {
+#pragma unroll
+        for (int it = 0; it < V_IT; ++it) {
+            const int idx = tid + it * 64 * NT;
+            if (idx >= (TQP / 2) * (DH / 8)) continue;
             const int kp = idx % (TQP / 2), c = (idx / (TQP / 2)) * 8;
             const int k0 = 2 * kp;
-            u32x4 v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
-            if (k0 < Tq) v0 = *reinterpret_cast<const u32x4*>(gV[p] + (size_t)k0 * DH + c);
-            if (k0 + 1 < Tq) v1 = *reinterpret_cast<const u32x4*>(gV[p] + (size_t)(k0 + 1) * DH + c);
+            const u32x4 v0 = vreg[p][it][0], v1 = vreg[p][it][1];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const unsigned int e0 = (v0[j >> 1] >> (16 * (j & 1))) & 0xffffu;
