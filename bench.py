@@ -39,6 +39,13 @@ def fused_qkv_attention(cfg, precision):
             and cfg["latent_dim"] // cfg["num_heads"] == 128 and not os.environ.get("REGENNET_NO_FUSED_QKV"))
 
 
+def fused_qkv_attention_long(cfg, precision):
+    """Mirrors qkv_attn_long_supported() + the dispatch in rgn_api.cpp: plain-bf16 phase, 65 .. 160 tokens, d = 512, dh = 128."""
+    Tq = cfg["num_frames"] + int(bool(cfg.get("emb_trans_dec")))
+    return (precision == "bf16_x3tail" and 64 < Tq <= 160 and cfg["latent_dim"] == 512 and cfg["latent_dim"] // cfg["num_heads"] == 128
+            and not os.environ.get("REGENNET_NO_QKV_LONG"))
+
+
 def rowgemm_phase(cfg, precision):
     """Mirrors rgn_api.cpp: the plain-bf16 phase runs out_proj+LN / linear1+GELU / linear2+LN as row-complete kernels."""
     return (precision == "bf16_x3tail" and cfg["latent_dim"] == 512 and cfg["ff_size"] in (384, 512, 1024)
@@ -70,7 +77,7 @@ def flops_per_eval(cfg, B, guided, precision="bf16x3"):
         out["rowgemm_act"] = M * d * ff * L
     else:
         out["gemm_mfma"] += M * (d * d + 2 * d * ff) * L
-    if fused_qkv_attention(cfg, precision):
+    if fused_qkv_attention(cfg, precision) or fused_qkv_attention_long(cfg, precision):
         out["qkv_attn"] = qkv + attn
     else:
         out["rowgemm_act" if rowgemm_phase(cfg, precision) else "gemm_mfma"] += qkv   # long sequences: in_proj GEMM + k_attn_x3

@@ -96,6 +96,7 @@ struct rgn_ctx {
     bool rowgemm = false;              // plain-bf16 phase: row-complete GEMMs with fused LayerNorm / GELU (k_rowgemm)
     bool mlp = false;                  // plain-bf16 phase: the whole layer tail in one row-persistent kernel (k_mlp)
     bool qkv_rs = true;                // plain-bf16 phase: k_qkv_attn with register-streamed weights (REGENNET_NO_QKV_RS=1: the DMA-fed loop)
+    bool qkv_long = false;             // plain-bf16 phase, 65 .. 160 tokens: fused in_proj + attention per (sample, head) (REGENNET_NO_QKV_LONG=1: in_proj GEMM + k_attn_x3)
     bool sb = false;                   // small-batch engine: column-split GEMMs with consumer-side LayerNorm (k_sb_gemm)
     int sb_rows = 768;                 // evaluations of at most this many token rows take it (rgn_set_small_batch_rows; 0 disables)
     int sb_rows_default = 768;         // (REGENNET_SB_ROWS): measured crossover with the throughput kernels at 60 tokens: B = 12 .. 16
@@ -549,6 +550,15 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             g.Bm = ns; g.Kp = w.qkv.Kp; g.d = d; g.H = c->H; g.Tq = dm.Tq;
             g.qscale = 1.0f / sqrtf((float)dm.dh);
             RGN_LAUNCH(c, KC_QKV, s, launch_qkv_attn(g, x3, s));   // 93 % of its MFMA work is the in_proj GEMM
+        } else if (fast && c->qkv_long && !x3 && w.qkv.fr && !att_p.lo) {
+            // plain-bf16 phase, long sequence: in_proj + attention of one (sample, head) per workgroup, q / k / v stay in LDS
+            QkvAttnArgs g{};
+            g.Ahi = h_p.hi; g.a_rows = h_p.rows;
+            g.Wfr = c->dp<__bf16>(w.qkv.fr); g.bias = c->dp<float>(w.qkv.b);
+            g.out = att_p;
+            g.Bm = ns; g.Kp = w.qkv.Kp; g.d = d; g.H = c->H; g.Tq = dm.Tq;
+            g.qscale = 1.0f / sqrtf((float)dm.dh);
+            RGN_LAUNCH(c, KC_QKV, s, launch_qkv_attn_long(g, s));
         } else if (fast && c->attn_x3 && !x3 && c->rowgemm && dm.dh % 32 == 0 && w.qkv.fr) {
             // plain-bf16 phase, long sequence: packed in_proj as a row-complete GEMM that scatters q (pre-scaled), k, v as
             // attention-ready planes (weights streamed to registers, output through an LDS image), then k_attn_x3
@@ -1027,12 +1037,14 @@ int rgn_finalize_weights(rgn_handle h) {
         if (c->mlp) RGN_HIP(c, configure_mlp());
         if (c->fuse_qkv) RGN_HIP(c, configure_qkv_attn());
         c->qkv_rs = getenv("REGENNET_NO_QKV_RS") == nullptr;
+        c->qkv_long = c->cfg.precision == RGN_PREC_BF16_X3TAIL && qkv_attn_long_supported(c->Tq, d / c->H, d) && getenv("REGENNET_NO_QKV_LONG") == nullptr;
+        if (c->qkv_long) RGN_HIP(c, configure_qkv_attn_long());
         c->sb = c->attn_x3 && sb_supported(d, ff, d / c->H);
         if (const char* e = getenv("REGENNET_SB_ROWS")) c->sb_rows = c->sb_rows_default = atoi(e) < 0 ? 0 : atoi(e);
         if (c->sb) RGN_HIP(c, configure_sb());
     }
     if ((rc = ws_alloc(c, &c->d_tab, (size_t)1024))) return rc;
-    if ((rc = ws_alloc(c, &c->d_step, (size_t)4))) return rc;
+    if ((rc = ws_alloc(c, &c->d_step, (size_t)4 + 1 + B))) return rc;   // [0] loop index, [3] scratch, [4 ..] k_update's ticket counters
     if ((rc = ws_alloc(c, &c->d_sp, (size_t)1))) return rc;
     RGN_HIP(c, configure_attention(c->Tq, c->d / c->H));
     RGN_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -1048,7 +1060,7 @@ int rgn_finalize_weights(rgn_handle h) {
     if (const char* e = getenv("REGENNET_STREAMS")) c->nchains = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
     RGN_HIP(c, hipMemset(c->xin, 0, Mb * F * sizeof(float)));
     RGN_HIP(c, hipMemset(c->cmo_in, 0, Mb * F * sizeof(float)));
-    RGN_HIP(c, hipMemset(c->d_step, 0, 4 * sizeof(int)));
+    RGN_HIP(c, hipMemset(c->d_step, 0, (4 + 1 + B) * sizeof(int)));
     c->finalized = true;
     return RGN_OK;
 }
@@ -1208,8 +1220,7 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
     sp.guided = guided != 0;
     sp.clip = clip_denoised != 0;
     RGN_HIP(c, hipMemcpyAsync(c->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
-    const int step_init[2] = {first_index, 0};                   // loop index, k_update's ticket counter
-    RGN_HIP(c, hipMemcpyAsync(c->d_step, step_init, sizeof(step_init), hipMemcpyHostToDevice, s));
+    RGN_HIP(c, hipMemcpyAsync(c->d_step, &first_index, sizeof(int), hipMemcpyHostToDevice, s));
     if ((rc = pack_state(c, x, dm, guided != 0, s))) return rc;
 
     // Precision schedule: loop indices >= tail run the plain-bf16 phase, the last `tail` indices the split-bf16 one.

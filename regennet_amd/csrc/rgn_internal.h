@@ -105,6 +105,10 @@ struct QkvAttnArgs {
 bool qkv_attn_supported(int Tq, int dh, int d);
 hipError_t configure_qkv_attn();
 hipError_t launch_qkv_attn(const QkvAttnArgs& g, bool x3, hipStream_t s);
+// long sequences (65 .. 160 tokens), plain-bf16 phase, d = 512: one workgroup per (sample, head) (rgn_qkv_attn_long.hip)
+bool qkv_attn_long_supported(int Tq, int dh, int d);
+hipError_t configure_qkv_attn_long();
+hipError_t launch_qkv_attn_long(const QkvAttnArgs& g, hipStream_t s);
 
 // Row-complete GEMM + fused residual LayerNorm(s) (rgn_gemm_ln.hip); N is fixed to 512.
 struct GemmLnArgs {

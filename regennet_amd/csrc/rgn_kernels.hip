@@ -883,7 +883,7 @@ hipError_t launch_randn(float* x, int B, int FT, int T, unsigned long long seed,
 // Products and sums are rounded separately (no FMA contraction) to follow the reference's op order.
 // Writes the new state in boundary layout [B,F,T] and token-major xin for the next step's GEMM.
 // In sampling mode the LAST block to finish (of all k_update launches of the step: the chains' launches together cover the
-// B samples once) also moves the device-side loop index on: *d_step -= 1. Every block read *d_step before it took its
+// B samples once) also moves the device-side loop index on: *d_step -= 1 (ticket counters behind d_step[4]). Every block read *d_step before it took its
 // ticket, and every other reader of *d_step (the layer kernels of a chain) precedes that chain's k_update in stream order.
 __global__ __launch_bounds__(256) void k_update(const float* __restrict__ x0tok, const float* __restrict__ scale,
                                                  const StepCoef* __restrict__ tab, int* d_step,
@@ -957,11 +957,14 @@ __global__ __launch_bounds__(256) void k_update(const float* __restrict__ x0tok,
             }
         }
     }
-    if (threadIdx.x == 0) {   // d_step[1]: tickets of this step
-        const int total = (int)(gridDim.x * gridDim.y) * dm.B;
-        if (atomicAdd(d_step + 1, 1) == total - 1) {
-            d_step[1] = 0;
-            d_step[0] = step - 1;
+    if (threadIdx.x == 0) {   // two-level tickets (one address takes ~88 atomics per us: 5632 blocks on one counter cost 60 us)
+        int* tick = d_step + 4;                                       // [0]: samples done this step, [1 + b]: blocks of sample b done
+        if (atomicAdd(tick + 1 + b, 1) == (int)(gridDim.x * gridDim.y) - 1) {
+            tick[1 + b] = 0;
+            if (atomicAdd(tick, 1) == dm.B - 1) {
+                tick[0] = 0;
+                d_step[0] = step - 1;
+            }
         }
     }
 }

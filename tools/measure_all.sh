@@ -9,7 +9,8 @@ head -c 400 $O/bench_cfg2.json; echo
 python bench.py --config ntu_action --sampler ddim --respacing ddim100 --guided --no-cpu-baseline --steps 5 --warmup 1 > $O/bench_cfg3.json 2>/dev/null; head -c 200 $O/bench_cfg3.json; echo
 python bench.py --config chi3d --batch 128 --no-cpu-baseline --steps 2 --warmup 1 > $O/bench_cfg4.json 2>/dev/null; head -c 200 $O/bench_cfg4.json; echo
 python bench.py --config text150 --batch 256 --sampler ddim --respacing ddim50 --guided --no-cpu-baseline --steps 5 --warmup 1 > $O/bench_cfg5.json 2>/dev/null; head -c 200 $O/bench_cfg5.json; echo
-python bench.py --batch 1 --no-cpu-baseline --steps 2 --warmup 1 --profile-evals 0 > $O/bench_cfg1_B1.json 2>/dev/null; head -c 200 $O/bench_cfg1_B1.json; echo
+python bench.py --batch 1 --no-cpu-baseline --steps 3 --warmup 1 > $O/bench_cfg1_B1.json 2>/dev/null; head -c 200 $O/bench_cfg1_B1.json; echo
+python bench.py --batch 10 --no-cpu-baseline --steps 3 --warmup 1 > $O/bench_B10.json 2>/dev/null; head -c 200 $O/bench_B10.json; echo
 python bench.py --precision bf16x3 --no-cpu-baseline --steps 1 --warmup 1 --profile-evals 0 > $O/bench_cfg2_uniform_x3.json 2>/dev/null; head -c 200 $O/bench_cfg2_uniform_x3.json; echo
 cd /tmp && export TMPDIR=/tmp
 prof() {  # name, streams, bench flags...
@@ -19,6 +20,7 @@ prof() {  # name, streams, bench flags...
 prof cfg2_bulk_s1 1 --respacing 50 --x3-tail 0
 prof cfg2_bulk_s4 4 --respacing 50 --x3-tail 0
 prof cfg2_tail_s1 1 --respacing 50 --x3-tail 50
+prof cfg1_B1 1 --batch 1 --respacing 50 --x3-tail 0
 prof cfg3_s4 4 --config ntu_action --sampler ddim --respacing ddim100 --guided
 prof cfg4_s4 4 --config chi3d --batch 128 --respacing 50
 prof cfg4_s1 1 --config chi3d --batch 128 --respacing 50 --x3-tail 0
