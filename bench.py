@@ -238,6 +238,8 @@ def main():
                  "update": "k_update", "rowgemm_ln": "k_rowgemm<LN>", "rowgemm_act": "k_rowgemm<ACT>", "mlp": "k_mlp", "sb_gemm": "k_sb_gemm"}
         if a.precision == "f32":
             names.update(gemm_mfma="k_gemm_f32", attention="k_attn_mfma")
+        if fused_qkv_attention_long(cfg, a.precision):
+            names.update(qkv_attn="k_qkv_attn_long")
         per_kernel = []
         for cls, (ms, n) in prof.items():
             if n == 0 or cls not in names:
@@ -280,7 +282,7 @@ def main():
         value = a.steps * B * world / dt
         dtype = a.precision
         if a.precision == "bf16_x3tail":
-            tail = a.x3_tail if a.x3_tail is not None else (S if S < 40 else min(S, -(-max(8, (S + 99) // 100) * 8 // min(8, cfg['layers']))))
+            tail = a.x3_tail if a.x3_tail is not None else min(S, -(-max(8, (S + 99) // 100) * 8 // min(8, cfg['layers'])))
             dtype = f"bf16 MFMA, fp32 accumulate/LayerNorm/softmax; split-bf16 (x3) for the last {min(tail, S)} of {S} steps"
         line = {
             "metric": "sampled motions/sec", "value": round(value, 3), "unit": "motions/s", "n_gpus": world,

@@ -336,9 +336,9 @@ inline int default_tail(int S, int layers, bool etd = false) {
     // coef2[0] = 0), so earlier rounding reaches the result only through the network's sensitivity to x_t, which the
     // LayerNorm stack damps - the deeper the model the more. Measured with 10 (of 1000 DDPM) / 8 (of 100 DDIM + CFG) split
     // steps: 8 layers 6.7e-5 / 1.1e-4, 4 layers 1.6e-4, 2 layers 5.2e-4 / 8.3e-4; a 20-step DDIM schedule with 8 of them
-    // split measured 3e-3 on a tiny model. So: schedules of fewer than 40 steps run split-bf16 throughout; longer ones keep
-    // max(8, S / 100) split-bf16 steps, scaled by 8 / layers for models shallower than the shipped 8 layers.
-    if (S < 40) return S;
+    // split measured 3e-3 on a tiny 2-layer model (which the depth scaling now keeps split-bf16 throughout), while the 8-layer
+    // 20-step goldens measure 1.2e-4 with 5 and 1.0e-4 with all 20 steps split. So: max(8, S / 100) split-bf16 steps, scaled by
+    // 8 / layers for models shallower than the shipped 8 layers.
     int t = (S + 99) / 100;
     t = t < 8 ? 8 : t;
     if (layers < 8) t = (t * 8 + layers - 1) / (layers > 0 ? layers : 1);

@@ -44,6 +44,14 @@ static_assert(QL_TT * 32 * QL_OLD * 4 <= QL_V, "output patches alias the Q and K
 static_assert(QL_LDS <= 160 * 1024, "LDS");
 }  // namespace
 
+#ifdef RGN_QL_PROF
+__device__ long long g_ql_prof[16 * 8];   // tools only: phase cycle stamps of the waves of workgroup RGN_QL_PROF
+#define RGN_LT(i) if (blockIdx.x == RGN_QL_PROF && lane == 0) g_ql_prof[wave * 8 + (i)] = clock64();
+void ql_prof_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ql_prof), sizeof(long long) * 16 * 8); }
+#else
+#define RGN_LT(i)
+#endif
+
 __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const __bf16* __restrict__ Wfr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -54,6 +62,7 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
     const int which = wave >> 2, wn = wave & 3;                      // GEMM role: 32 columns wn of q (0) / k (1) / v (2)
     const int nb_all = 3 * d / 32;
 
+    RGN_LT(0)
     float* bias_s = reinterpret_cast<float*>(smem + QL_BIAS);
     if (tid < 3 * QL_DH) bias_s[tid] = g.bias[(tid >> 7) * d + hd * QL_DH + (tid & 127)];
 
@@ -118,6 +127,7 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    RGN_LT(1)
     // ---- accumulators -> the attention slabs (bf16) ---------------------------------------------------------------------
     __bf16* sQ = reinterpret_cast<__bf16*>(smem + QL_Q);
     __bf16* sK = reinterpret_cast<__bf16*>(smem + QL_K);
@@ -149,6 +159,7 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+    RGN_LT(2)
     // ---- attention: wave w < 5 owns the 32 queries of tile w --------------------------------------------------------------
     constexpr int NS = QL_DH / 16, ND = QL_DH / 32;
     const int w = wave;
@@ -219,6 +230,7 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
         }
         inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
     }
+    RGN_LT(3)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                    // every wave is done with Q / K: reuse them as fp32 output patches
     if (w < QL_TT) {
@@ -245,6 +257,7 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
             }
         }
     }
+    RGN_LT(4)
 }
 
 bool qkv_attn_long_supported(int Tq, int dh, int d) { return Tq > 64 && Tq <= QL_TQP && dh == QL_DH && d == 32 * QL_NK; }

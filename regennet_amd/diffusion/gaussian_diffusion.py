@@ -299,7 +299,7 @@ class GaussianDiffusion:
         try:
             ref = run(S)
             L = max(1, int(getattr(inner, "num_layers", 8)))
-            t = S if S < 40 else min(S, -(-max(8, (S + 99) // 100) * 8 // min(8, L)))
+            t = min(S, -(-max(8, (S + 99) // 100) * 8 // min(8, L)))
             chosen = S
             while t < S:
                 dev = float((run(t) - ref).abs().max())

@@ -31,8 +31,6 @@ LOOPS = ["tiny_ddpm10", "tiny_ddim10_cfg", "tiny_add_ddpm1000", "tiny_text_ddim2
 
 def default_tail(S, layers=8):
     """rgn_api.cpp default_tail(): loop indices below this run split-bf16 under the precision schedule."""
-    if S < 40:
-        return S
     t = max(8, (S + 99) // 100)
     if layers < 8:
         t = -(-t * 8 // layers)

@@ -17,6 +17,9 @@ using namespace rgn;
 #ifdef RGN_QA_PROF
 namespace rgn { void qa_prof_read(long long* out); }
 #endif
+#ifdef RGN_QL_PROF
+namespace rgn { void ql_prof_read(long long* out); }
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
 int main(int argc, char** argv) {
@@ -35,10 +38,13 @@ int main(int argc, char** argv) {
     if (getenv("RS")) g.Wfr = Whi;   // RS=1 (with BF16=1): the register-streamed weight loop (any bytes do for timing)
     g.out.hi = Ohi; g.out.lo = x3 ? Olo : nullptr; g.out.rows = M; g.Bm = Bm; g.Kp = Kp; g.d = d; g.H = H; g.Tq = Tq; g.qscale = 0.0884f;
     CK(configure_qkv_attn());
-    for (int i = 0; i < 3; ++i) CK(launch_qkv_attn(g, x3, nullptr));
+    const bool longk = getenv("LONG") != nullptr;   // LONG=1 BF16=1: k_qkv_attn_long (give Tq = 150)
+    if (longk) { CK(configure_qkv_attn_long()); g.Wfr = Whi; g.out.lo = nullptr; }
+    auto launch = [&] { return longk ? launch_qkv_attn_long(g, nullptr) : launch_qkv_attn(g, x3, nullptr); };
+    for (int i = 0; i < 3; ++i) CK(launch());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < iters; ++i) CK(launch_qkv_attn(g, x3, nullptr));
+    for (int i = 0; i < iters; ++i) CK(launch());
     CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = 1e3 * ms / iters, fl = 2.0 * M * 3 * d * d + 4.0 * Bm * H * Tq * Tq * 128;
@@ -51,6 +57,12 @@ int main(int argc, char** argv) {
                t[1] - t[0], t[2] - t[1], t[4] - t[2], t[5] - t[4], t[6] - t[5], t[3] - t[6]);
     }
     printf("  total cycles %lld\n", pr[8 + 3] - pr[0]);
+#endif
+#ifdef RGN_QL_PROF
+    if (longk) {
+        long long t[16 * 8]; ql_prof_read(t);
+        for (int w : {0, 4, 5, 11}) printf("  wave %2d cycles: gemm %lld | slabs + barrier %lld | attention %lld | barrier + output %lld | total %lld\n", w, t[w * 8 + 1] - t[w * 8], t[w * 8 + 2] - t[w * 8 + 1], t[w * 8 + 3] - t[w * 8 + 2], t[w * 8 + 4] - t[w * 8 + 3], t[w * 8 + 4] - t[w * 8]);
+    }
 #endif
     return 0;
 }
