@@ -1221,6 +1221,7 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
     sp.clip = clip_denoised != 0;
     RGN_HIP(c, hipMemcpyAsync(c->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
     RGN_HIP(c, hipMemcpyAsync(c->d_step, &first_index, sizeof(int), hipMemcpyHostToDevice, s));
+    RGN_HIP(c, hipMemsetAsync(c->d_step + 4, 0, (size_t)(1 + c->cfg.max_batch) * sizeof(int), s));   // k_update's ticket counters (clean even after an aborted call)
     if ((rc = pack_state(c, x, dm, guided != 0, s))) return rc;
 
     // Precision schedule: loop indices >= tail run the plain-bf16 phase, the last `tail` indices the split-bf16 one.

@@ -505,6 +505,24 @@ def test_full_size_batch_is_row_independent(precision, tail):
         assert torch.allclose(full2[b:b + 1], one, atol=2e-5), (b, (full2[b:b + 1] - one).abs().max().item())
 
 
+def test_engine_selection_can_change_between_calls(golden):
+    """rgn_set_small_batch_rows on a live engine: captured graphs belong to the engine they were recorded with, so switching
+    drops them. Small-batch -> throughput -> small-batch on one model: the first and third results are bit-identical, the
+    second agrees within the mode's error, all three meet the reference bound."""
+    g = golden("ntu_ddpm50")
+    cfg, sd, y, tape = fixture_inputs(g, loop=True)
+    model, diffusion = build_hip(cfg, sd, resp="50", precision="bf16_x3tail")
+    kw = dict(clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
+    outs = []
+    for rows in (None, 0, None):
+        model.small_batch_rows = rows
+        outs.append(diffusion.p_sample_loop(model, (2, 56, 6, 60), **kw))
+    assert torch.equal(outs[0], outs[2])
+    assert not torch.equal(outs[0], outs[1]) and (outs[0] - outs[1]).abs().max().item() < 5e-4
+    for o in outs:
+        assert np.abs(o.cpu().numpy() - g["final"]).max() < 1e-3
+
+
 @pytest.mark.parametrize("config,B,T", [("ntu_action", 6, 60), ("chi3d", 2, 150)])
 def test_small_batch_engine_is_bit_exact_under_batch_composition(config, B, T):
     """The small-batch kernels (rgn_sb.hip) accumulate every output element in a fixed order that does not depend on which
