@@ -226,6 +226,30 @@ def test_oracle_parity_sequence_length_edges(frames, etd, engine):
     assert np.abs(out.cpu().numpy() - ref).max() < 1e-3
 
 
+@pytest.mark.parametrize("frames,etd", [(65, False), (100, False), (160, False), (159, True)])
+def test_oracle_parity_long_sequence_fused_attention(frames, etd):
+    """k_qkv_attn_long (plain-bf16 phase, 65 .. 160 tokens: in_proj + flash-style attention per (sample, head) with q / k / v
+    in LDS): the shortest and the longest sequence it takes, a length that is not a multiple of the 32-token tiles, and the
+    emb_trans_dec token as the 160th; odd batch; against the oracle on a 10-step guided DDIM loop whose first 7 steps run the
+    plain-bf16 phase (emb_trans_dec models default to split-bf16 throughout, so the tail is forced)."""
+    from oracle import regennet_oracle as orc
+    from regennet_amd import synth
+    from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    cfg = synth.get_config("chi3d", num_frames=frames, emb_trans_dec=etd)
+    sd = synth.make_state_dict(cfg, seed=11)
+    B = 3
+    model, diffusion = build_hip(cfg, sd, resp="ddim10", precision="bf16_x3tail/throughput", x3_tail=3)
+    y = {"cmotion": synth.make_cmotion(cfg, B, seed=71), "action": synth.make_actions(cfg, B, seed=72), "scale": np.full((B,), 2.5, np.float32)}
+    tape = synth.make_noise_tape(cfg, B, 10, seed=73)
+    ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", "ddim10"), tape, {k: torch.from_numpy(v) for k, v in y.items()},
+                          mode="ddim", guided=True).numpy()
+    out = diffusion.ddim_sample_loop(ClassifierFreeSampleModel(model), (B, 56, 6, frames), clip_denoised=False,
+                                     model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
+    err = float(np.abs(out.cpu().numpy() - ref).max())
+    print(f"\n[long fused attention] T={frames} etd={etd}: {err:.2e}")
+    assert err < 1e-3, (frames, etd, err)
+
+
 @pytest.mark.parametrize("engine", ["throughput", "small-batch"])
 @pytest.mark.parametrize("over", [dict(ff_size=512), dict(ff_size=2048), dict(latent_dim=256, ff_size=1024), dict(num_frames=24, emb_trans_dec=True)])
 def test_oracle_parity_across_kernel_dispatch_paths(over, engine):
