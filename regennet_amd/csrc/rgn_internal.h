@@ -201,6 +201,14 @@ bool sb_supported(int d, int ff, int dh);
 hipError_t configure_sb();
 hipError_t launch_sb_gemm(const SbArgs& g, int pre, int post, bool x3, hipStream_t s);
 
+// XCD-affine workgroup order: the hardware places workgroup id b on XCD b % 8. Remapping the id so that every XCD gets one
+// CONTIGUOUS range of tiles / samples makes the rows a kernel reads the rows the previous kernel of the chain wrote on the
+// same XCD (k_qkv_attn -> k_mlp -> k_qkv_attn ...): they are still in that XCD's L2 instead of behind the fabric.
+__device__ __forceinline__ int xcd_affine(int bid, int nwg) {
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+}
+
 struct Dims {
     int B;        // motions in the bound condition
     int Bm;       // rows of the batched evaluation (B, or 2B under guidance)

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
-    const int m0 = blockIdx.x * ML_BM;
+    const int m0 = xcd_affine(blockIdx.x, gridDim.x) * ML_BM;
     float* red = reinterpret_cast<float*>(smem + ML_RED);
     float* vec = reinterpret_cast<float*>(smem + ML_VEC);
     float* spv = reinterpret_cast<float*>(smem + ML_SPV);

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn(QkvAttnArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;                         // GEMM phase roles: wm = sample of the pair
     const int l31 = lane & 31, kh = lane >> 5;
-    const int b0 = blockIdx.x * QA_NS, Tq = g.Tq, d = g.d;
+    const int b0 = xcd_affine(blockIdx.x, gridDim.x) * QA_NS, Tq = g.Tq, d = g.d;   // (gridDim.x = sample pairs; id = y * gridDim.x + x)
     const int hpb = g.H / (int)gridDim.y, hd0 = blockIdx.y * hpb;    // heads of this workgroup
     const int nsamp = g.Bm - b0 < QA_NS ? g.Bm - b0 : QA_NS;         // an odd batch leaves the last pair half empty
 
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn_rs(QkvAttnArgs g, const _
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int b0 = blockIdx.x * QA_NS, Tq = g.Tq, d = g.d;
+    const int b0 = xcd_affine(blockIdx.x, gridDim.x) * QA_NS, Tq = g.Tq, d = g.d;   // (gridDim.x = sample pairs; id = y * gridDim.x + x)
     const int hpb = g.H / (int)gridDim.y, hd0 = blockIdx.y * hpb;
     const int nsamp = g.Bm - b0 < QA_NS ? g.Bm - b0 : QA_NS;
     const int nb_all = 3 * d / 32;

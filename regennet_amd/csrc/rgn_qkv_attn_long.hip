@@ -57,7 +57,8 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kh = lane >> 5;
-    const int b = blockIdx.x / g.H, hd = blockIdx.x - b * g.H;
+    const int vid = xcd_affine(blockIdx.x, gridDim.x);
+    const int b = vid / g.H, hd = vid - b * g.H;
     const int Tq = g.Tq, d = g.d;
     const int which = wave >> 2, wn = wave & 3;                      // GEMM role: 32 columns wn of q (0) / k (1) / v (2)
     const int nb_all = 3 * d / 32;
