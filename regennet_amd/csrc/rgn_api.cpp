@@ -550,7 +550,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             g.Bm = ns; g.Kp = w.qkv.Kp; g.d = d; g.H = c->H; g.Tq = dm.Tq;
             g.qscale = 1.0f / sqrtf((float)dm.dh);
             RGN_LAUNCH(c, KC_QKV, s, launch_qkv_attn(g, x3, s));   // 93 % of its MFMA work is the in_proj GEMM
-        } else if (fast && c->qkv_long && !x3 && w.qkv.fr && !att_p.lo) {
+        } else if (fast && c->qkv_long && !x3 && w.qkv.fr && !att_p.lo && (size_t)h_p.rows * w.qkv.Kp * 2 < (1ull << 31)) {
             // plain-bf16 phase, long sequence: in_proj + attention of one (sample, head) per workgroup, q / k / v stay in LDS
             QkvAttnArgs g{};
             g.Ahi = h_p.hi; g.a_rows = h_p.rows;

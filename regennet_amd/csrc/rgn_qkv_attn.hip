@@ -489,7 +489,7 @@ hipError_t configure_qkv_attn() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_rs), hipFuncAttributeMaxDynamicSharedMemorySize, qa_lds(true));
 }
 hipError_t launch_qkv_attn(const QkvAttnArgs& g, bool x3, hipStream_t s) {
-    if (!x3 && g.Wfr && g.Kp == 32 * QR_NK && g.d == 512) {   // plain-bf16 phase: weights streamed to registers
+    if (!x3 && g.Wfr && g.Kp == 32 * QR_NK && g.d == 512 && (size_t)g.a_rows * g.Kp * 2 < (1ull << 31)) {   // plain-bf16 phase: weights streamed to registers (32-bit buffer offsets)
         const int pairs = (g.Bm + QA_NS - 1) / QA_NS;
         const int hsplit = (pairs * g.H <= 64) ? g.H : (g.H % 2 == 0 ? 2 : 1);
         hipLaunchKernelGGL(k_qkv_attn_rs, dim3(pairs, hsplit), dim3(QA_NT), qa_lds(true), s, g, g.Wfr);

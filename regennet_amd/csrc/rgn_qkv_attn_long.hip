@@ -266,7 +266,7 @@ hipError_t configure_qkv_attn_long() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_long), hipFuncAttributeMaxDynamicSharedMemorySize, QL_LDS);
 }
 hipError_t launch_qkv_attn_long(const QkvAttnArgs& g, hipStream_t s) {
-    if (!g.Wfr || g.Kp != 32 * QL_NK || g.out.lo) return hipErrorInvalidValue;
+    if (!g.Wfr || g.Kp != 32 * QL_NK || g.out.lo || (size_t)g.a_rows * g.Kp * 2 >= (1ull << 31)) return hipErrorInvalidValue;   // (32-bit buffer offsets)
     hipLaunchKernelGGL(k_qkv_attn_long, dim3(g.Bm * g.H), dim3(QL_NT), QL_LDS, s, g, g.Wfr);
     return hipGetLastError();
 }
