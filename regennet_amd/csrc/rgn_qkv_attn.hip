@@ -369,7 +369,7 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn(QkvAttnArgs g) {
 // ahead as well and written to a 2-stage LDS ring one step ahead) still passes through LDS. No direct-to-LDS DMA in the
 // loop, and the 16 k-steps are fully unrolled: the compiler's own s_waitcnt bookkeeping then stays exact (it drains
 // vmcnt at loop back-edges and before the first LDS read behind a DMA).
-constexpr int QR_NK = 16, QR_D = 2, QR_RING = QR_D + 1;     // weights: issued QR_D k-steps ahead of the MFMAs that consume them
+constexpr int QR_NK = 16, QR_WQ = 18;                          // weight fragment ring (6 fragments per k-step)
 constexpr int QR_DA = 4, QR_ARING = QR_DA + 1;                // activation pieces: QR_DA ahead (they must be in LDS one step early)
 constexpr int QR_ABUF = 96 * 1024;                                   // activation ring [2][128 rows][64 B], behind the exchange buffer
 __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn_rs(QkvAttnArgs g, const __bf16* __restrict__ Wfr) {
@@ -421,24 +421,22 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn_rs(QkvAttnArgs g, const _
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[ta][t][i] = 0.f;
         RGN_QT((hd - hd0) * 8 + 0)
-        bf16x8 wf[QR_RING][3][2];                                    // [slot][q | k | v][ks]
+        // Weight fragments: a ring of QR_WQ = 18 fragments (3 k-steps' worth) recycled ONE AT A TIME: fragment q = 6 kt + 3 ks + t
+        // is consumed by two MFMAs and its registers immediately take fragment q + 18 - the same 72 VGPRs as three whole-step
+        // slots, but every load is issued three k-steps (not two) ahead of its use and the loads are spread between the MFMAs.
+        bf16x8 wq[QR_WQ];
         u32x4 areg[QR_ARING];
         auto issue_a = [&](int kt) { areg[kt % QR_ARING] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_voff * 2, kt * a_kbytes, 0)); };
-        auto issue = [&](int kt) {
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-                    wf[kt % QR_RING][t][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, wofs[t] * 2, (kt * nb_all * 1024 + ks * 512) * 2, 0));
+        auto issue_q = [&](int q) {                                  // q compile-time after unrolling
+            const int kt = q / 6, ks = (q % 6) / 3, t = q % 3;
+            wq[q % QR_WQ] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, wofs[t] * 2, (kt * nb_all * 1024 + ks * 512) * 2, 0));
         };
 #pragma unroll
         for (int kt = 0; kt < QR_DA; ++kt) issue_a(kt);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kt = 0; kt < QR_D; ++kt) {
-            issue(kt);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int q = 0; q < QR_WQ; ++q) issue_q(q);
+        __builtin_amdgcn_sched_barrier(0);
         *reinterpret_cast<u32x4*>(abuf + tid * 16) = areg[0];        // stage 0 <- k-block 0
 #pragma unroll
         for (int kt = 0; kt < QR_NK; ++kt) {
@@ -452,22 +450,23 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn_rs(QkvAttnArgs g, const _
                 for (int ta = 0; ta < 2; ++ta) af[ks][ta] = *reinterpret_cast<const bf16x8*>(sb + a_off[ta][ks]);
             __builtin_amdgcn_sched_barrier(0);
             if (kt + QR_DA < QR_NK) issue_a(kt + QR_DA);
-            if (kt + QR_D < QR_NK) issue(kt + QR_D);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int grp = 0; grp < 6; ++grp) {
-                const int ks = grp / 3, t = grp % 3;
+                const int ks = grp / 3, t = grp % 3, q = kt * 6 + grp;
 #pragma unroll
                 for (int ta = 0; ta < 2; ++ta) {
                     if (t < 2)     // q, k tiles transposed (lane = token, registers = dh)
-                        acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kt % QR_RING][t][ks], af[ks][ta], acc[ta][t], 0, 0, 0);
+                        acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[q % QR_WQ], af[ks][ta], acc[ta][t], 0, 0, 0);
                     else           // v tile: lane = dh, registers = tokens
-                        acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][ta], wf[kt % QR_RING][t][ks], acc[ta][t], 0, 0, 0);
+                        acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][ta], wq[q % QR_WQ], acc[ta][t], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + QR_WQ < 6 * QR_NK) issue_q(q + QR_WQ);
                 if (grp == 2 && kt + 1 < QR_NK)                      // next k-block of the activation tile -> the other stage
                     *reinterpret_cast<u32x4*>(abuf + ((kt + 1) & 1) * 8192 + tid * 16) = areg[(kt + 1) % QR_ARING];
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         RGN_QT((hd - hd0) * 8 + 1)
         qa_attention<false>(acc, g, smem, bias_s + (hd - hd0) * QA_WROWS + wn * 32, hd, hd - hd0, wm, wn, nsamp, b0, lane, tid);
