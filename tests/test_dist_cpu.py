@@ -91,10 +91,10 @@ class FakeEngine:
         return self.blob, self.blob.numel()
 
     def set_small_batch_rows(self, n):
-        pass
+        self.knobs = dict(getattr(self, "knobs", {}), small_batch_rows=int(n))
 
     def set_x3_tail(self, n):
-        pass
+        self.knobs = dict(getattr(self, "knobs", {}), x3_tail=int(n))
 
     def set_schedule(self, tmap, tables, sched_id=None):
         self.schedule_id = sched_id
@@ -158,3 +158,17 @@ def test_cgenerate_entry_point_shards_broadcasts_and_gathers(tmp_path, monkeypat
     assert np.array_equal(one["cmotion"], two["cmotion"])
     assert np.allclose(one["output"], two["output"], atol=1e-6), np.abs(one["output"] - two["output"]).max()
     assert np.abs(one["output"][0] - one["output"][3]).max() > 1e-4      # samples differ (global index, condition)
+
+
+def test_model_knobs_reach_the_engine(monkeypatch):
+    """CMDM(..., x3_tail=, small_batch_rows=) / the attributes of the same name are handed to the engine on every bind
+    (-1 = the engine's default), through the _lib.Engine seam on a CPU-only host."""
+    from regennet_amd import _lib, synth
+    monkeypatch.setattr(_lib, "Engine", FakeEngine)
+    cfg = synth.get_config("tiny")
+    model, _ = synth.build_model(cfg, synth.make_state_dict(cfg, seed=0), precision="bf16_x3tail", device="cpu")
+    eng, _dev = model._get_engine(2)
+    assert eng.knobs == {"x3_tail": -1, "small_batch_rows": -1}
+    model.x3_tail, model.small_batch_rows = 5, 0
+    eng2, _dev = model._get_engine(2)
+    assert eng2 is eng and eng.knobs == {"x3_tail": 5, "small_batch_rows": 0}
