@@ -62,7 +62,7 @@ def flops_per_eval(cfg, B, guided, precision="bf16x3"):
     qkv = M * 3 * d * d * L
     attn = M * 2 * T * d * L
     embed = (B * T * F * d if precision == "f32" else M * F * d) + M * d * F       # input embedding, output projection
-    out = {"gemm_mfma": embed, "qkv_attn": 0, "attention": 0, "rowgemm_ln": 0, "rowgemm_act": 0, "mlp": 0, "sb_gemm": 0}
+    out = {"gemm_mfma": embed, "qkv_attn": 0, "attention": 0, "rowgemm_ln": 0, "rowgemm_act": 0, "mlp": 0, "sb_gemm": 0, "step_fused": 0}
     sb_rows = int(os.environ.get("REGENNET_SB_ROWS", "768"))
     if precision != "f32" and d == 512 and ff % 32 == 0 and T + cfg.get("emb_trans_dec", 0) <= 160 and Bm * (T + cfg.get("emb_trans_dec", 0)) <= sb_rows:
         # small-batch engine (rgn_sb.hip): every GEMM of the evaluation is a column-split k_sb_gemm launch
@@ -77,6 +77,10 @@ def flops_per_eval(cfg, B, guided, precision="bf16x3"):
         out["rowgemm_act"] = M * d * ff * L
     else:
         out["gemm_mfma"] += M * (d * d + 2 * d * ff) * L
+    if (rowgemm_phase(cfg, precision) and not guided and not cfg.get("emb_trans_dec") and F % 4 == 0 and 320 < F <= 352
+            and not os.environ.get("REGENNET_NO_STEP_FUSION") and not os.environ.get("REGENNET_BULK_RESID_LO")):
+        out["step_fused"] = embed                                  # k_step: output projection + sampler update + next input embedding
+        out["gemm_mfma"] -= embed
     if fused_qkv_attention(cfg, precision) or fused_qkv_attention_long(cfg, precision):
         out["qkv_attn"] = qkv + attn
     else:
@@ -235,7 +239,7 @@ def main():
         fl = flops_per_eval(cfg, B, a.guided, a.precision)
         peak = PEAK_TFLOPS[a.precision]
         names = {"gemm_mfma": "k_gemm_x3", "qkv_attn": "k_qkv_attn", "attention": "k_attn_x3", "layernorm": "k_layernorm",
-                 "update": "k_update", "rowgemm_ln": "k_rowgemm<LN>", "rowgemm_act": "k_rowgemm<ACT>", "mlp": "k_mlp", "sb_gemm": "k_sb_gemm"}
+                 "update": "k_update", "rowgemm_ln": "k_rowgemm<LN>", "rowgemm_act": "k_rowgemm<ACT>", "mlp": "k_mlp", "sb_gemm": "k_sb_gemm", "step_fused": "k_step"}
         if a.precision == "f32":
             names.update(gemm_mfma="k_gemm_f32", attention="k_attn_mfma")
         if fused_qkv_attention_long(cfg, a.precision):

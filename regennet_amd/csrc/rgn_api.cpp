@@ -95,6 +95,8 @@ struct rgn_ctx {
     bool fuse_ln = false;              // out_proj / linear2 GEMMs carry their LayerNorms (k_gemm_x3_ln)
     bool rowgemm = false;              // plain-bf16 phase: row-complete GEMMs with fused LayerNorm / GELU (k_rowgemm)
     bool mlp = false;                  // plain-bf16 phase: the whole layer tail in one row-persistent kernel (k_mlp)
+    bool step_fused = false;           // plain-bf16 phase, unguided: output projection + sampler update + next input embedding in one kernel (REGENNET_NO_STEP_FUSION=1: three launches)
+    bool skip_embed_out = false;       // (set by run_eval around run_layers while it enqueues a fused step)
     bool qkv_rs = true;                // plain-bf16 phase: k_qkv_attn with register-streamed weights (REGENNET_NO_QKV_RS=1: the DMA-fed loop)
     bool qkv_long = false;             // plain-bf16 phase, 65 .. 160 tokens: fused in_proj + attention per (sample, head) (REGENNET_NO_QKV_LONG=1: in_proj GEMM + k_attn_x3)
     bool sb = false;                   // small-batch engine: column-split GEMMs with consumer-side LayerNorm (k_sb_gemm)
@@ -152,7 +154,7 @@ struct rgn_ctx {
 
 namespace {
 
-const char* kclass_names[KC_COUNT] = {"gemm_mfma", "attention", "layernorm", "embed", "update", "misc", "qkv_attn", "rowgemm_ln", "rowgemm_act", "mlp", "sb_gemm"};
+const char* kclass_names[KC_COUNT] = {"gemm_mfma", "attention", "layernorm", "embed", "update", "misc", "qkv_attn", "rowgemm_ln", "rowgemm_act", "mlp", "sb_gemm", "step_fused"};
 
 #define RGN_HIP(h, expr)                                                                                    \
     do {                                                                                                    \
@@ -263,10 +265,12 @@ Lin pack_linear(rgn_ctx* c, const float* W, const float* bias, int N, int K, boo
     L.w = blob_put(c, w.data(), w.size() * 4);
     L.hi = blob_put(c, hi.data(), hi.size() * 2);
     L.lo = blob_put(c, lo.data(), lo.size() * 2);
-    if (frag && N % 32 == 0) {
-        // fragment order [Kp/32][N/32][ks 2][lane 64][8]: lane = 32 * ((k % 16) / 8) + n % 32 holds its 8 consecutive k
-        std::vector<uint16_t> fr((size_t)N * L.Kp, 0);
-        const size_t nb_all = (size_t)N / 32;
+    if (frag) {
+        // fragment order [Kp/32][Np/32][ks 2][lane 64][8]: lane = 32 * ((k % 16) / 8) + n % 32 holds its 8 consecutive k
+        // (rows zero-padded to Np = a multiple of 32: only the output projection, N = F, needs it)
+        const size_t Np = align_up((size_t)N, 32);
+        std::vector<uint16_t> fr(Np * L.Kp, 0);
+        const size_t nb_all = Np / 32;
         for (int n = 0; n < N; ++n)
             for (int k = 0; k < K; ++k) {
                 const size_t kt = k / 32, ks = (k % 32) / 16, lane = 32 * ((k % 16) / 8) + n % 32;
@@ -521,7 +525,9 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
     };
     int rc;
     // input embedding + hoisted condition part (InputProcess/fuse/pos-enc, cmdm.py:201-218)
-    if (fast) {   // xin planes and c0 already hold both guidance halves
+    if (c->skip_embed_out) {
+        // fused step boundary (k_step): the residual-stream planes already hold this evaluation's input embedding
+    } else if (fast) {   // xin planes and c0 already hold both guidance halves
         if ((rc = big(c->lin_x, nullptr, 0, xin_p, h32 ? h : nullptr, d, h_p, c->c0 + (size_t)row0 * d, 0, M))) return rc;
     } else {
         if ((rc = big(c->lin_x, c->xin, c->F, none, c->h, d, none, c->c0, 0, Mb))) return rc;
@@ -670,7 +676,28 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
                    launch_layernorm(tmp, h32 ? none : h_p, h32 ? h : nullptr, h_p, M, d, c->dp<float>(w.ln[4]), c->dp<float>(w.ln[5]), nullptr, 0, nullptr, 0,
                                     nullptr, dm.Tq, nullptr, nullptr, s));
     }
+    if (c->skip_embed_out) return RGN_OK;   // (k_step applies the output projection)
     return big(c->lin_out, h, d, h_p, c->x0tok + (size_t)row0 * c->F, c->F, none, nullptr, 0, M);
+}
+
+// Can this evaluation end in the fused step boundary (rgn_step.hip)? Unguided sampling step of the plain-bf16 phase on the
+// throughput kernels with hi-only residual planes.
+bool step_fusable(const rgn_ctx* c, bool guided, bool x3, int rows) {
+    return c->step_fused && !guided && !x3 && c->cfg.precision == RGN_PREC_BF16_X3TAIL && !use_sb(c, rows) && !c->bulk_resid_lo;
+}
+// The input embedding of ALL rows into the residual-stream planes (hi): what every fused step leaves behind for the next
+// one, needed once in front of the first fused step of a sampling call.
+int embed_all(rgn_ctx* c, const Dims& dm, hipStream_t s) {
+    const int M = dm.Bm * dm.Tq;
+    GemmX3Args g{};
+    g.Ahi = c->xin_hi; g.Alo = c->xin_lo; g.a_rows = M;
+    g.Whi = c->dp<__bf16>(c->lin_x.hi); g.Wlo = c->dp<__bf16>(c->lin_x.lo);
+    g.bias = nullptr;
+    g.add = c->c0; g.ldadd = c->d;
+    g.Chi = c->h_hi; g.Clo = nullptr; g.c_rows = M;
+    g.M = M; g.N = c->d; g.Kp = c->lin_x.Kp;
+    RGN_LAUNCH(c, KC_GEMM, s, launch_gemm_x3(g, false, (M >= c->big_tile_rows) ? 1 : 0, s));
+    return RGN_OK;
 }
 
 // One denoiser evaluation on the bound condition, ending in k_update (sampler step or plain output).
@@ -717,20 +744,41 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
     // chain (overlapping the other chains' layers); with guidance the cond / uncond halves of a sample sit in different
     // chains and the update waits for the join.
     const Planes xin_p{fast ? c->xin_hi : nullptr, (fast && has_lo(c)) ? c->xin_lo : nullptr, M};
-    const bool own_update = nch > 1 && !guided;
+    c->skip_embed_out = false;
+    const bool fused = sampling && step_fusable(c, guided, eval_x3(c), M);   // k_step instead of out GEMM + k_update + next in GEMM
+    const bool own_update = (nch > 1 && !guided) || fused;
+    int total_tiles = 0;
+    if (fused) {
+        for (int k2 = 0; k2 < nch; ++k2) total_tiles += ((per + (k2 < extra ? 1 : 0)) * dm.Tq + 63) / 64;
+        c->skip_embed_out = true;
+    }
+    auto step_or_update = [&](int s_first, int n, hipStream_t st) -> int {
+        if (fused) {
+            StepArgs g{};
+            const size_t row0 = (size_t)s_first * dm.Tq;
+            g.h = c->h_hi + row0 * 32; g.hout = c->h_hi + row0 * 32; g.rows = M; g.M = n * dm.Tq;
+            g.Wout = c->dp<__bf16>(c->lin_out.fr); g.bout = c->dp<float>(c->lin_out.b); g.F = c->F; g.nb_out = (c->F + 31) / 32;
+            g.Wx = c->dp<__bf16>(c->lin_x.fr); g.nkx = c->lin_x.Kp / 32;
+            g.c0 = c->c0 + row0 * c->d;
+            g.tab = c->d_tab; g.d_step = c->d_step; g.sp = c->d_sp;
+            g.T = dm.T; g.B = dm.B; g.s0 = s_first; g.total_tiles = total_tiles;
+            RGN_LAUNCH(c, KC_STEP, st, launch_step(g, st));
+        } else {
+            RGN_LAUNCH(c, KC_UPDATE, st, launch_update(c->x0tok, c->scale, c->d_tab, c->d_step, c->d_sp, nullptr, xin_p, dm, s_first, n, st));
+        }
+        return RGN_OK;
+    };
     for (int k = 1; k < nch; ++k) {
         const int n = per + (k < extra ? 1 : 0);
         RGN_HIP(c, hipStreamWaitEvent(c->side[k - 1], c->ev_fork, 0));
         if ((rc = run_layers(c, dm, guided, sampling, cond_rows, ccond_rows, s0, n, c->side[k - 1]))) return rc;
-        if (own_update)
-            RGN_LAUNCH(c, KC_UPDATE, c->side[k - 1],
-                       launch_update(c->x0tok, c->scale, c->d_tab, c->d_step, c->d_sp, nullptr, xin_p, dm, s0, n, c->side[k - 1]));
+        if (own_update && (rc = step_or_update(s0, n, c->side[k - 1]))) return rc;
         RGN_HIP(c, hipEventRecord(c->ev_join[k - 1], c->side[k - 1]));
         s0 += n;
     }
     if ((rc = run_layers(c, dm, guided, sampling, cond_rows, ccond_rows, 0, first_n, s))) return rc;
-    if (own_update)
-        RGN_LAUNCH(c, KC_UPDATE, s, launch_update(c->x0tok, c->scale, c->d_tab, c->d_step, c->d_sp, nullptr, xin_p, dm, 0, first_n, s));
+    if (own_update && (rc = step_or_update(0, first_n, s))) return rc;
+    c->skip_embed_out = false;
     for (int k = 1; k < nch; ++k) RGN_HIP(c, hipStreamWaitEvent(s, c->ev_join[k - 1], 0));
     if (!own_update)
         RGN_LAUNCH(c, KC_UPDATE, s,
@@ -925,7 +973,7 @@ int rgn_finalize_weights(rgn_handle h) {
             memcpy(wcf.data(), wcm, wcf.size() * 4);
             for (int n = 0; n < d; ++n) bconst[n] = (float)((double)bin[n] + (double)bcm[n]);
         }
-        c->lin_x = pack_linear(c, wxf.data(), nullptr, d, F, true);
+        c->lin_x = pack_linear(c, wxf.data(), nullptr, d, F, true, c->cfg.precision == RGN_PREC_BF16_X3TAIL);   // fragment order: k_step
         c->lin_c = pack_linear(c, wcf.data(), bconst.data(), d, F);
     }
     c->lin_t0 = pack_linear(c, W("embed_timestep.time_embed.0.weight"), W("embed_timestep.time_embed.0.bias"), d, d);
@@ -959,7 +1007,8 @@ int rgn_finalize_weights(rgn_handle h) {
         }
     }
     c->lin_g = pack_linear(c, gall.data(), gb.data(), c->L * d, d);
-    c->lin_out = pack_linear(c, W("output_process.poseFinal.weight"), W("output_process.poseFinal.bias"), F, d, true);
+    c->lin_out = pack_linear(c, W("output_process.poseFinal.weight"), W("output_process.poseFinal.bias"), F, d, true,
+                             c->cfg.precision == RGN_PREC_BF16_X3TAIL);   // fragment order: k_step
     if (c->cfg.cond_mode == RGN_COND_TEXT) {
         c->lin_text = pack_linear(c, W("embed_text.weight"), W("embed_text.bias"), d, c->cfg.clip_dim);
         c->off_bt = c->lin_text.b;
@@ -1037,6 +1086,9 @@ int rgn_finalize_weights(rgn_handle h) {
         if (c->mlp) RGN_HIP(c, configure_mlp());
         if (c->fuse_qkv) RGN_HIP(c, configure_qkv_attn());
         c->qkv_rs = getenv("REGENNET_NO_QKV_RS") == nullptr;
+        c->step_fused = c->rowgemm && !c->etd && c->lin_x.fr && c->lin_out.fr && c->lin_out.has_bias && !c->lin_x.has_bias &&
+                        step_fused_supported(d, F, c->lin_x.Kp) && getenv("REGENNET_NO_STEP_FUSION") == nullptr;
+        if (c->step_fused) RGN_HIP(c, configure_step());
         c->qkv_long = c->cfg.precision == RGN_PREC_BF16_X3TAIL && qkv_attn_long_supported(c->Tq, d / c->H, d) && getenv("REGENNET_NO_QKV_LONG") == nullptr;
         if (c->qkv_long) RGN_HIP(c, configure_qkv_attn_long());
         c->sb = c->attn_x3 && sb_supported(d, ff, d / c->H);
@@ -1263,10 +1315,18 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
     const bool graphs = use_graph && !c->prof;
     const int multi = c->graph_steps;
     int k = 0;
+    // Fused step boundaries (k_step) hand the next evaluation's input embedding over in the residual-stream planes and no
+    // longer write the token-major x planes: the first fused step of the call needs the embedding made once up front, and
+    // the first un-fused step behind fused ones (the split-bf16 tail) needs the planes re-made from the sampler state.
+    bool prev_fused = false;
     while (k < count) {
         const int i = first_index - k;                       // loop index of the next step
         const bool x3 = !sched || i < tail;
         const int phase_left = x3 ? (count - k) : ((i - tail + 1) < (count - k) ? (i - tail + 1) : (count - k));   // steps left in this phase
+        const bool fused_now = step_fusable(c, guided != 0, x3, dm.Bm * dm.Tq);
+        if (fused_now && !prev_fused && (rc = embed_all(c, dm, s))) return rc;
+        if (!fused_now && prev_fused && (rc = pack_state(c, x, dm, guided != 0, s))) return rc;
+        prev_fused = fused_now;
         if (graphs) {
             const int steps = (multi > 1 && phase_left >= multi) ? multi : 1;
             hipGraphExec_t ge = nullptr;

@@ -19,6 +19,7 @@ enum KClass : int {
     KC_ROWACT,        // row-complete GEMM + activation (k_rowgemm<1>)
     KC_MLP,           // row-persistent layer tail (k_mlp)
     KC_SB,            // small-batch column-split GEMMs (k_sb_gemm)
+    KC_STEP,          // fused step boundary: output projection + sampler update + next input embedding (k_step)
     KC_COUNT
 };
 
@@ -208,6 +209,25 @@ __device__ __forceinline__ int xcd_affine(int bid, int nwg) {
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
 }
+
+// Step boundary of the plain-bf16 phase as one kernel (rgn_step.hip): output projection + sampler update + the next
+// evaluation's input embedding for 64-row tiles; unguided sampling, d = 512, no emb_trans_dec token.
+struct StepCoef;
+struct SampleParams;
+struct StepArgs {
+    const __bf16* h;            // last layer's output planes (hi) [16][rows][32], advanced to the first row of this launch
+    __bf16* hout;               // residual-stream planes the next evaluation's layer 0 reads (normally the same buffer)
+    int rows, M;                // plane row count; token rows of this launch
+    const __bf16* Wout; const float* bout; int F, nb_out;    // output projection, fragment-ordered [16][nb_out][2][64][8] (rows zero-padded)
+    const __bf16* Wx; int nkx;  // input embedding (folded), fragment-ordered [nkx][16][2][64][8]
+    const float* c0;            // hoisted condition part [M, 512] fp32 (advanced)
+    const StepCoef* tab; int* d_step; const SampleParams* sp;
+    int T, B, s0;               // frames (= tokens) per sample, motions in the bound condition, first sample of this launch
+    int total_tiles;            // 64-row tiles over ALL launches of the step (loop-index ticket)
+};
+bool step_fused_supported(int d, int F, int Kpx);
+hipError_t configure_step();
+hipError_t launch_step(const StepArgs& g, hipStream_t s);
 
 struct Dims {
     int B;        // motions in the bound condition

@@ -1,0 +1,253 @@
+// Step boundary of the plain-bf16 phase as ONE kernel (unguided sampling, d = 512):
+//
+//   x0   = h . Wout^T + bout                       output projection of the evaluation just finished (OutputProcess, cmdm.py:353)
+//   x'   = sampler(x, x0, eps)                     p_sample / ddim_sample update in place (gaussian_diffusion.py:265-276, 508-560,
+//                                                  419-423, 744-794), same device arithmetic and Philox stream as k_update
+//   h'   = x' . Wx'^T + c0                         input embedding of the NEXT evaluation (InputProcess / fuse / positional part
+//                                                  hoisted into c0, cmdm.py:201-218) -> residual-stream planes
+//
+// for one tile of 64 token rows per workgroup. Replaces three launches per chain and step (k_gemm_x3 out, k_update,
+// k_gemm_x3 in) and their round trips: the fp32 x0 rows (20.6 MB written + read at B=256), the token-major x' planes
+// (21.6 MB written, 10.8 MB read), 31 MB of h planes. Both GEMMs use k_mlp's machinery (activation image in LDS, weights
+// streamed from the fragment-ordered planes into a 4-slot register ring).
+//
+// Phases / LDS:  A  h tile -> image (64 KiB, DMA) ; GEMM 1 (K = 512, N = F <= 352: waves 0-5)
+//                B  x0 = acc + bias -> fp32 tile [64][XLD] (over the dead image)
+//                C  lanes = rows (consecutive frames of a sample: coalesced x accesses), waves stride the features:
+//                   sampler update in place, x' as bf16 into the K32-blocked image of GEMM 2's A operand (44 KiB)
+//                D  GEMM 2 (K = 352, N = 512) -> bf16 image (64 KiB, over the dead tile) -> + c0 in the coalesced copy-out
+//                   (the sum is rounded to bf16 twice: plain-bf16 phase only)
+// The last workgroup to finish (over all launches of the step) moves the device-side loop index on, like k_update.
+#include "rgn_internal.h"
+#include "rgn_philox.h"
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+namespace rgn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define RGN_AS1 __attribute__((address_space(1)))
+#define RGN_AS3 __attribute__((address_space(3)))
+
+namespace {
+constexpr int ST_BM = 64, ST_NT = 512, ST_PF = 3;
+constexpr int ST_XLD = 356;                                          // fp32 tile row stride (floats): F <= 352, 16-byte aligned rows
+constexpr int ST_TILE = 0, ST_XIMG = 92160;                          // fp32 tile 64 x 356 x 4 = 91136 B; x' image behind it
+constexpr int ST_LDS = ST_XIMG + 11 * 4096;
+static_assert(ST_BM * ST_XLD * 4 <= ST_XIMG && 16 * 4096 <= ST_XIMG, "tile / images");
+}  // namespace
+
+template <int NKX>
+__global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int m0 = xcd_affine(blockIdx.x, gridDim.x) * ST_BM;
+    const SampleParams sp = *g.sp;
+    const int step = *g.d_step;
+    const StepCoef k = g.tab[step];
+
+    // ---- A: the h tile -> LDS image [16 k-blocks][64 rows][64 B] (16-byte chunk c of row r at c ^ ((r >> 2) & 3))
+    {
+        const int r16 = lane >> 2, c = lane & 3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = wave + 8 * j, kb = p >> 2, r = (p & 3) * 16 + r16;
+            int m = m0 + r;
+            m = m < g.M ? m : g.M - 1;
+            const size_t src = ((size_t)kb * g.rows + m) * 32 + ((c ^ ((r >> 2) & 3)) << 3);
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.h + src), (RGN_AS3 void*)(smem + p * 1024), 16, 0, 0);
+        }
+    }
+    int a_off[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int rr = 32 * mt + l31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a_off[mt][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
+    }
+    bf16x8 wf[ST_PF + 1][2][2];
+    auto load_w = [&](const __bf16* W, int nb_all, int cb0, int kt, int slot) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int cb = cb0 + nt < nb_all ? cb0 + nt : nb_all - 1;
+            const __bf16* base = W + ((size_t)kt * nb_all + cb) * 1024 + lane * 8;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wf[slot][ks][nt] = *reinterpret_cast<const bf16x8*>(base + ks * 512);
+        }
+    };
+    auto prefetch = [&](const __bf16* W, int nb_all, int cb0) {
+#pragma unroll
+        for (int s = 0; s < ST_PF; ++s) load_w(W, nb_all, cb0, s, s);
+    };
+    auto gemm = [&](f32x16 (&acc)[2][2], const char* img, const __bf16* W, int nb_all, int cb0, auto nk_c) {
+        constexpr int NK = decltype(nk_c)::value;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            const char* sb = img + kt * 4096;
+            bf16x8 af[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) af[ks][mt] = *reinterpret_cast<const bf16x8*>(sb + a_off[mt][ks]);
+            asm volatile("" ::: "memory");
+            if (kt + ST_PF < NK) {
+                load_w(W, nb_all, cb0, kt + ST_PF, (kt + ST_PF) & 3);
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // this step's fragments are in; the next three steps' stay in flight
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kt & 3][ks][nt], af[ks][mt], acc[nt][mt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto col4 = [&](int nt, int i4) { return 64 * wave + 32 * nt + 8 * i4 + 4 * kh; };
+
+    // ---- GEMM 1: x0 = h . Wout^T (+ bias below)
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    prefetch(g.Wout, g.nb_out, 2 * wave);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                // in order: the tile landed, the weight prefetch may still fly
+    __builtin_amdgcn_s_barrier();
+    gemm(acc, smem, g.Wout, g.nb_out, 2 * wave, std::integral_constant<int, 16>{});
+    __builtin_amdgcn_s_barrier();                                     // every wave is done reading the image
+
+    // ---- B: x0 -> fp32 tile
+    float* tile = reinterpret_cast<float*>(smem + ST_TILE);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const int n = col4(nt, i4);
+            if (n < 352) {                                            // (waves 6, 7 hold no column of the tile; F % 4 == 0: whole runs)
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (n < g.F) b = *reinterpret_cast<const f32x4*>(g.bout + n);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    *reinterpret_cast<f32x4*>(tile + (32 * mt + l31) * ST_XLD + n) =
+                        f32x4{acc[nt][mt][4 * i4] + b[0], acc[nt][mt][4 * i4 + 1] + b[1], acc[nt][mt][4 * i4 + 2] + b[2], acc[nt][mt][4 * i4 + 3] + b[3]};
+            }
+        }
+    prefetch(g.Wx, 16, 2 * wave);                                    // GEMM 2's first fragments fly under the update phase
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- C: sampler update. lane = row of the tile (consecutive frames of a sample), the waves stride the features
+    {
+        const int m = m0 + lane;
+        const bool valid = m < g.M;
+        const int bl = (valid ? m : g.M - 1) / g.T, t = (valid ? m : g.M - 1) - bl * g.T, b = g.s0 + bl;
+        const size_t FT = (size_t)g.F * g.T;
+        char* ximg = smem + ST_XIMG;
+        for (int f = wave; f < NKX * 32; f += 8) {
+            float nv = 0.f;
+            if (valid && f < g.F) {
+                float x0 = tile[lane * ST_XLD + f];
+                if (sp.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+                const size_t o = (size_t)b * FT + (size_t)f * g.T + t;
+                if (sp.x0_out) sp.x0_out[o] = x0;
+                const float xv = sp.x[o];
+                float eps;
+                if (sp.noise)
+                    eps = sp.noise[(size_t)(sp.first_index - step) * g.B * FT + o];
+                else
+                    eps = philox_normal(sp.seed, sp.sample_offset + b, (uint32_t)step, (uint32_t)(f * 4096 + t));
+                if (sp.sampler == 0) {
+                    const float mean = __fadd_rn(__fmul_rn(k.c1, x0), __fmul_rn(k.c2, xv));
+                    nv = __fadd_rn(mean, __fmul_rn(k.sig_ddpm, eps));
+                } else {
+                    const float e = __fdiv_rn(__fsub_rn(__fmul_rn(k.sr, xv), x0), k.srm1);
+                    const float mean = __fadd_rn(__fmul_rn(x0, k.ca), __fmul_rn(k.cb, e));
+                    nv = __fadd_rn(mean, __fmul_rn(k.sig_ddim, eps));
+                }
+                sp.x[o] = nv;
+            }
+            // x' (0 in the K padding columns and the surplus rows) -> the K32-blocked image of GEMM 2's A operand
+            const int r = lane, chunk = (f & 31) >> 3;
+            *reinterpret_cast<__bf16*>(ximg + (f >> 5) * 4096 + r * 64 + ((chunk ^ ((r >> 2) & 3)) << 4) + (f & 7) * 2) = (__bf16)nv;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- D: h' = x' . Wx'^T (+ c0 in the copy-out)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    gemm(acc, smem + ST_XIMG, g.Wx, 16, 2 * wave, std::integral_constant<int, NKX>{});
+    // (the fp32 tile is dead since the barrier above: the output image goes over it; the x' image is still being read by
+    //  slower waves, but it lies behind the 64 KiB the output image takes)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int r = 32 * mt + l31;
+                bf16x4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = (__bf16)acc[nt][mt][4 * i4 + e];
+                *reinterpret_cast<bf16x4*>(smem + (2 * wave + nt) * 4096 + r * 64 + ((i4 ^ ((r >> 2) & 3)) << 4) + 8 * kh) = hv;
+            }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+        const int r16 = lane >> 2, c = lane & 3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = wave * 8 + j, blk = p >> 2, r = (p & 3) * 16 + r16;
+            const int m = m0 + r;
+            if (m < g.M) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + blk * 4096 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
+                const float* cp = g.c0 + (size_t)m * 512 + blk * 32 + c * 8;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(cp), a1 = *reinterpret_cast<const f32x4*>(cp + 4);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (__bf16)((float)v[e] + a0[e]);
+                    o[4 + e] = (__bf16)((float)v[4 + e] + a1[e]);
+                }
+                *reinterpret_cast<bf16x8*>(g.hout + ((size_t)blk * g.rows + m) * 32 + c * 8) = o;
+            }
+        }
+    }
+    if (tid == 0) {   // ticket: the last tile of the step moves the loop index on (see k_update)
+        int* tick = g.d_step + 4;
+        if (atomicAdd(tick, 1) == g.total_tiles - 1) {
+            tick[0] = 0;
+            g.d_step[0] = step - 1;
+        }
+    }
+}
+
+bool step_fused_supported(int d, int F, int Kpx) { return d == 512 && F % 4 == 0 && F <= 352 && Kpx == 352; }
+hipError_t configure_step() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<11>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+}
+hipError_t launch_step(const StepArgs& g, hipStream_t s) {
+    if (g.nkx != 11 || g.M <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_step<11>, dim3((g.M + ST_BM - 1) / ST_BM), dim3(ST_NT), ST_LDS, s, g);
+    return hipGetLastError();
+}
+
+}  // namespace rgn
