@@ -97,6 +97,7 @@ struct rgn_ctx {
     bool mlp = false;                  // plain-bf16 phase: the whole layer tail in one row-persistent kernel (k_mlp)
     bool step_fused = false;           // plain-bf16 phase, unguided: output projection + sampler update + next input embedding in one kernel (REGENNET_NO_STEP_FUSION=1: three launches)
     bool skip_embed_out = false;       // (set by run_eval around run_layers while it enqueues a fused step)
+    int step_no_quads = 0;             // REGENNET_STEP_NO_QUADS=1 (tests)
     bool qkv_rs = true;                // plain-bf16 phase: k_qkv_attn with register-streamed weights (REGENNET_NO_QKV_RS=1: the DMA-fed loop)
     bool qkv_long = false;             // plain-bf16 phase, 65 .. 160 tokens: fused in_proj + attention per (sample, head) (REGENNET_NO_QKV_LONG=1: in_proj GEMM + k_attn_x3)
     bool sb = false;                   // small-batch engine: column-split GEMMs with consumer-side LayerNorm (k_sb_gemm)
@@ -761,7 +762,7 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
             g.Wx = c->dp<__bf16>(c->lin_x.fr); g.nkx = c->lin_x.Kp / 32;
             g.c0 = c->c0 + row0 * c->d;
             g.tab = c->d_tab; g.d_step = c->d_step; g.sp = c->d_sp;
-            g.T = dm.T; g.B = dm.B; g.s0 = s_first; g.total_tiles = total_tiles;
+            g.T = dm.T; g.B = dm.B; g.s0 = s_first; g.total_tiles = total_tiles; g.no_quads = c->step_no_quads;
             RGN_LAUNCH(c, KC_STEP, st, launch_step(g, st));
         } else {
             RGN_LAUNCH(c, KC_UPDATE, st, launch_update(c->x0tok, c->scale, c->d_tab, c->d_step, c->d_sp, nullptr, xin_p, dm, s_first, n, st));
@@ -1089,6 +1090,7 @@ int rgn_finalize_weights(rgn_handle h) {
         c->step_fused = c->rowgemm && !c->etd && c->lin_x.fr && c->lin_out.fr && c->lin_out.has_bias && !c->lin_x.has_bias &&
                         step_fused_supported(d, F, c->lin_x.Kp) && getenv("REGENNET_NO_STEP_FUSION") == nullptr;
         if (c->step_fused) RGN_HIP(c, configure_step());
+        c->step_no_quads = getenv("REGENNET_STEP_NO_QUADS") != nullptr;
         c->qkv_long = c->cfg.precision == RGN_PREC_BF16_X3TAIL && qkv_attn_long_supported(c->Tq, d / c->H, d) && getenv("REGENNET_NO_QKV_LONG") == nullptr;
         if (c->qkv_long) RGN_HIP(c, configure_qkv_attn_long());
         c->sb = c->attn_x3 && sb_supported(d, ff, d / c->H);

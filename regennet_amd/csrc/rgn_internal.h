@@ -224,6 +224,7 @@ struct StepArgs {
     const StepCoef* tab; int* d_step; const SampleParams* sp;
     int T, B, s0;               // frames (= tokens) per sample, motions in the bound condition, first sample of this launch
     int total_tiles;            // 64-row tiles over ALL launches of the step (loop-index ticket)
+    int no_quads;               // tests: draw the noise per element (philox_normal) instead of per quad of lanes (bit-identical)
 };
 bool step_fused_supported(int d, int F, int Kpx);
 hipError_t configure_step();

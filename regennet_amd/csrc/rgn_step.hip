@@ -149,14 +149,21 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // ---- C: sampler update. lane = row of the tile (consecutive frames of a sample), the waves stride the features
+    // ---- C: sampler update. lane = row of the tile (consecutive frames of a sample), the waves stride the features.
+    //      Noise: one Philox4x32-10 call yields the four normals of frames 4j .. 4j+3 of a (sample, step, feature). When the
+    //      rows of every quad of lanes are exactly such a run (60 frames: always, but for the surplus rows of the last tile),
+    //      lane q of a quad draws feature f + q for the quad's four frames and the quad transposes (DPP): a quarter of the
+    //      Philox rounds, half of the Box-Muller work; the per-element form (bit-identical values) covers everything else.
     {
         const int m = m0 + lane;
         const bool valid = m < g.M;
         const int bl = (valid ? m : g.M - 1) / g.T, t = (valid ? m : g.M - 1) - bl * g.T, b = g.s0 + bl;
         const size_t FT = (size_t)g.F * g.T;
         char* ximg = smem + ST_XIMG;
-        for (int f = wave; f < NKX * 32; f += 8) {
+        const int q = lane & 3, tq = t - q;                            // frame of the quad's first lane, if the quad is a run
+        const bool run4 = valid && (m0 + (lane | 3)) < g.M && tq >= 0 && (tq & 3) == 0 && tq + 3 < g.T;
+        const bool quads = !sp.noise && !g.no_quads && __all(run4);
+        auto update = [&](int f, float eps_in) {
             float nv = 0.f;
             if (valid && f < g.F) {
                 float x0 = tile[lane * ST_XLD + f];
@@ -164,10 +171,10 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
                 const size_t o = (size_t)b * FT + (size_t)f * g.T + t;
                 if (sp.x0_out) sp.x0_out[o] = x0;
                 const float xv = sp.x[o];
-                float eps;
+                float eps = eps_in;
                 if (sp.noise)
                     eps = sp.noise[(size_t)(sp.first_index - step) * g.B * FT + o];
-                else
+                else if (!quads)
                     eps = philox_normal(sp.seed, sp.sample_offset + b, (uint32_t)step, (uint32_t)(f * 4096 + t));
                 if (sp.sampler == 0) {
                     const float mean = __fadd_rn(__fmul_rn(k.c1, x0), __fmul_rn(k.c2, xv));
@@ -182,6 +189,44 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
             // x' (0 in the K padding columns and the surplus rows) -> the K32-blocked image of GEMM 2's A operand
             const int r = lane, chunk = (f & 31) >> 3;
             *reinterpret_cast<__bf16*>(ximg + (f >> 5) * 4096 + r * 64 + ((chunk ^ ((r >> 2) & 3)) << 4) + (f & 7) * 2) = (__bf16)nv;
+        };
+        for (int fg = wave; fg < NKX * 8; fg += 8) {                   // groups of 4 features
+            float eps4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (quads) {                                               // wave-uniform
+                // this lane: the four normals of (feature 4 fg + q, frames tq .. tq + 3), exactly philox_normal's arithmetic
+                const uint32_t elem = (uint32_t)((4 * fg + q) * 4096 + tq);
+                const unsigned long long sample = sp.sample_offset + b;
+                uint32_t r[4];
+                philox4x32_10(elem >> 2, (uint32_t)step, (uint32_t)sample, (uint32_t)(sample >> 32), (uint32_t)sp.seed, (uint32_t)(sp.seed >> 32), r);
+                float n4[4];
+#pragma unroll
+                for (int pair = 0; pair < 2; ++pair) {
+                    const float u1 = ((r[2 * pair] >> 8) + 1u) * 5.9604644775390625e-08f;
+                    const float u2 = (r[2 * pair + 1] >> 8) * 5.9604644775390625e-08f;
+                    const float rad = sqrtf(-2.0f * logf(u1));
+                    float sn, cs;
+                    sincospif(2.0f * u2, &sn, &cs);
+                    n4[2 * pair] = rad * cs;
+                    n4[2 * pair + 1] = rad * sn;
+                }
+                // transpose inside the quad: this lane (frame tq + q) needs, for feature 4 fg + j, element q of lane j's n4
+                auto pick = [&](auto jc) {                              // element q of lane jc's n4, broadcast inside the quad
+                    constexpr int J = decltype(jc)::value;
+                    float v = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float bc = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, n4[e]), J * 0x55, 0xf, 0xf, true));   // quad_perm [J, J, J, J]
+                        v = q == e ? bc : v;
+                    }
+                    return v;
+                };
+                eps4[0] = pick(std::integral_constant<int, 0>{});
+                eps4[1] = pick(std::integral_constant<int, 1>{});
+                eps4[2] = pick(std::integral_constant<int, 2>{});
+                eps4[3] = pick(std::integral_constant<int, 3>{});
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) update(4 * fg + j, eps4[j]);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

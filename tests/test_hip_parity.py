@@ -529,6 +529,34 @@ def test_full_size_batch_is_row_independent(precision, tail):
         assert torch.allclose(full2[b:b + 1], one, atol=2e-5), (b, (full2[b:b + 1] - one).abs().max().item())
 
 
+def test_fused_step_boundary_matches_the_three_kernel_form(monkeypatch):
+    """k_step (plain-bf16 phase, unguided, throughput kernels: output projection + sampler update + next input embedding in
+    one kernel) against the same loop with the three separate launches (REGENNET_NO_STEP_FUSION=1), on-device Philox noise:
+    same noise stream, same sampler arithmetic, so the results differ only by the plain-bf16 phase's rounding (the fused kernel
+    rounds h' to bf16 twice) and end within the parity margin of each other after the split-bf16 tail. And the quad-shared
+    Philox draw of k_step is bit-identical to the per-element one (REGENNET_STEP_NO_QUADS=1)."""
+    from regennet_amd import synth
+    cfg = synth.get_config("ntu")
+    sd = synth.make_state_dict(cfg, seed=0)
+    B = 5                                       # 300 rows: 4 full tiles + a partial one, tiles straddling samples
+    cm = torch.from_numpy(synth.make_cmotion(cfg, B, seed=1)).cuda()
+    outs = {}
+    for tag, env in (("fused", None), ("per_element_noise", "REGENNET_STEP_NO_QUADS"), ("three_kernels", "REGENNET_NO_STEP_FUSION")):
+        if env:
+            monkeypatch.setenv(env, "1")
+        model, diffusion = build_hip(cfg, sd, resp="50", precision="bf16_x3tail/throughput")
+        model._get_engine(B)                    # (the switches are read when the engine is built)
+        if env:
+            monkeypatch.delenv(env)
+        outs[tag] = diffusion.p_sample_loop(model, (B, 56, 6, 60), clip_denoised=False, model_kwargs={"y": {"cmotion": cm}}, seed=3)
+        model._engine.close()
+    assert torch.isfinite(outs["fused"]).all()
+    assert torch.equal(outs["fused"], outs["per_element_noise"])
+    dev = (outs["fused"] - outs["three_kernels"]).abs().max().item()
+    print(f"\n[fused step boundary] vs three kernels: {dev:.2e}")
+    assert 0.0 < dev < 5e-4
+
+
 def test_engine_selection_can_change_between_calls(golden):
     """rgn_set_small_batch_rows on a live engine: captured graphs belong to the engine they were recorded with, so switching
     drops them. Small-batch -> throughput -> small-batch on one model: the first and third results are bit-identical, the
