@@ -246,7 +246,7 @@ def main():
             names.update(qkv_attn="k_qkv_attn_long")
         per_kernel = []
         for cls, (ms, n) in prof.items():
-            if n == 0 or cls not in names:
+            if n < n_eval or cls not in names:        # (classes that ran once per call, e.g. the embedding in front of the first fused step)
                 continue
             # every event bracket carries the dispatch + event latency of an empty bracket (calibrated on a no-op kernel,
             # whose own ~2 us of execution stay in the figure): subtract it, leaving ~ the rocprofv3 kernel duration
