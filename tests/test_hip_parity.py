@@ -529,7 +529,8 @@ def test_full_size_batch_is_row_independent(precision, tail):
         assert torch.allclose(full2[b:b + 1], one, atol=2e-5), (b, (full2[b:b + 1] - one).abs().max().item())
 
 
-def test_fused_step_boundary_matches_the_three_kernel_form(monkeypatch):
+@pytest.mark.parametrize("sampler,clip", [("ddpm", False), ("ddim", True)])
+def test_fused_step_boundary_matches_the_three_kernel_form(monkeypatch, sampler, clip):
     """k_step (plain-bf16 phase, unguided, throughput kernels: output projection + sampler update + next input embedding in
     one kernel) against the same loop with the three separate launches (REGENNET_NO_STEP_FUSION=1), on-device Philox noise:
     same noise stream, same sampler arithmetic, so the results differ only by the plain-bf16 phase's rounding (the fused kernel
@@ -544,16 +545,17 @@ def test_fused_step_boundary_matches_the_three_kernel_form(monkeypatch):
     for tag, env in (("fused", None), ("per_element_noise", "REGENNET_STEP_NO_QUADS"), ("three_kernels", "REGENNET_NO_STEP_FUSION")):
         if env:
             monkeypatch.setenv(env, "1")
-        model, diffusion = build_hip(cfg, sd, resp="50", precision="bf16_x3tail/throughput")
+        model, diffusion = build_hip(cfg, sd, resp="50" if sampler == "ddpm" else "ddim50", precision="bf16_x3tail/throughput")
         model._get_engine(B)                    # (the switches are read when the engine is built)
         if env:
             monkeypatch.delenv(env)
-        outs[tag] = diffusion.p_sample_loop(model, (B, 56, 6, 60), clip_denoised=False, model_kwargs={"y": {"cmotion": cm}}, seed=3)
+        fn = diffusion.p_sample_loop if sampler == "ddpm" else diffusion.ddim_sample_loop
+        outs[tag] = fn(model, (B, 56, 6, 60), clip_denoised=clip, model_kwargs={"y": {"cmotion": cm}}, seed=3)
         model._engine.close()
     assert torch.isfinite(outs["fused"]).all()
     assert torch.equal(outs["fused"], outs["per_element_noise"])
     dev = (outs["fused"] - outs["three_kernels"]).abs().max().item()
-    print(f"\n[fused step boundary] vs three kernels: {dev:.2e}")
+    print(f"\n[fused step boundary] {sampler} clip={clip} vs three kernels: {dev:.2e}")
     assert 0.0 < dev < 5e-4
 
 
