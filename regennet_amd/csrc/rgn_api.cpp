@@ -112,7 +112,8 @@ struct rgn_ctx {
     static constexpr int MAX_SIDE = 15;
     hipStream_t side[MAX_SIDE] = {};   // extra chains of the multi-stream evaluation
     hipEvent_t ev_fork = nullptr, ev_join[MAX_SIDE] = {};
-    int nchains = 4;                   // REGENNET_STREAMS = 1 .. 16 (default 4)
+    int nchains = 4;                   // REGENNET_STREAMS = 1 .. 16 (default 4; 2 for evaluations of 129 .. 256 row tiles, see run_eval)
+    bool nchains_user = false;         // REGENNET_STREAMS was given: no size rule
     // Precision schedule (RGN_PREC_BF16_X3TAIL): the loop indices i >= x3_tail run plain-bf16 GEMMs (one MFMA per
     // product, hi planes only as GEMM operands), the last x3_tail indices and every rgn_denoise call the split-bf16 ones.
     // phase_x3 is the phase of the evaluation being enqueued / captured.
@@ -735,6 +736,10 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
     const bool fast = prec != RGN_PREC_F32;
     int rc;
     int nch = (fast && !c->prof) ? c->nchains : 1;       // per-kernel event timing wants un-overlapped kernels
+    // Two chains instead of four when the whole evaluation is 129 .. 256 row tiles of 64 (B=256 at 60 frames: 240): each of the
+    // two chains' launches then still fills half the chip in one round, with half the launches and joins (measured 314.4 vs
+    // 308.9 motions/s at cfg2; larger evaluations - cfg3 480, cfg4 300 tiles - lose 5-6 % with two chains, smaller ones keep four)
+    if (nch == 4 && !c->nchains_user && (M + 63) / 64 > 128 && (M + 63) / 64 <= 256) nch = 2;
     if (use_sb(c, M)) nch = 1;                            // small-batch engine: one chain of column-split kernels
     if (nch > dm.Bm) nch = dm.Bm;
     if (nch > 1) RGN_HIP(c, hipEventRecord(c->ev_fork, s));
@@ -1111,7 +1116,10 @@ int rgn_finalize_weights(rgn_handle h) {
     RGN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     if (const char* e = getenv("REGENNET_BULK_RESID_LO")) c->bulk_resid_lo = atoi(e) != 0;
     if (const char* e = getenv("REGENNET_GRAPH_STEPS")) c->graph_steps = atoi(e) < 1 ? 1 : (atoi(e) > 100 ? 100 : atoi(e));
-    if (const char* e = getenv("REGENNET_STREAMS")) c->nchains = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
+    if (const char* e = getenv("REGENNET_STREAMS")) {
+        c->nchains = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
+        c->nchains_user = true;
+    }
     RGN_HIP(c, hipMemset(c->xin, 0, Mb * F * sizeof(float)));
     RGN_HIP(c, hipMemset(c->cmo_in, 0, Mb * F * sizeof(float)));
     RGN_HIP(c, hipMemset(c->d_step, 0, (4 + 1 + B) * sizeof(int)));
