@@ -739,7 +739,8 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
     // Two chains instead of four when the whole evaluation is 129 .. 256 row tiles of 64 (B=256 at 60 frames: 240): each of the
     // two chains' launches then still fills half the chip in one round, with half the launches and joins (measured 314.4 vs
     // 308.9 motions/s at cfg2; larger evaluations - cfg3 480, cfg4 300 tiles - lose 5-6 % with two chains, smaller ones keep four)
-    if (nch == 4 && !c->nchains_user && (M + 63) / 64 > 128 && (M + 63) / 64 <= 256) nch = 2;
+    // (plain-bf16 phase only: the split-bf16 kernels - 128-row tiles, separate LayerNorms - measure 107 vs 125 motions/s with two)
+    if (nch == 4 && !c->nchains_user && !eval_x3(c) && (M + 63) / 64 > 128 && (M + 63) / 64 <= 256) nch = 2;
     if (use_sb(c, M)) nch = 1;                            // small-batch engine: one chain of column-split kernels
     if (nch > dm.Bm) nch = dm.Bm;
     if (nch > 1) RGN_HIP(c, hipEventRecord(c->ev_fork, s));
