@@ -77,7 +77,7 @@ def flops_per_eval(cfg, B, guided, precision="bf16x3"):
         out["rowgemm_act"] = M * d * ff * L
     else:
         out["gemm_mfma"] += M * (d * d + 2 * d * ff) * L
-    if (rowgemm_phase(cfg, precision) and not guided and not cfg.get("emb_trans_dec") and F % 4 == 0 and 320 < F <= 352
+    if (rowgemm_phase(cfg, precision) and not cfg.get("emb_trans_dec") and F % 4 == 0 and 320 < F <= 352
             and not os.environ.get("REGENNET_NO_STEP_FUSION") and not os.environ.get("REGENNET_BULK_RESID_LO")):
         out["step_fused"] = embed                                  # k_step: output projection + sampler update + next input embedding
         out["gemm_mfma"] -= embed

@@ -682,10 +682,11 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
     return big(c->lin_out, h, d, h_p, c->x0tok + (size_t)row0 * c->F, c->F, none, nullptr, 0, M);
 }
 
-// Can this evaluation end in the fused step boundary (rgn_step.hip)? Unguided sampling step of the plain-bf16 phase on the
+// Can this evaluation end in the fused step boundary (rgn_step.hip)? Sampling step of the plain-bf16 phase on the
 // throughput kernels with hi-only residual planes.
 bool step_fusable(const rgn_ctx* c, bool guided, bool x3, int rows) {
-    return c->step_fused && !guided && !x3 && c->cfg.precision == RGN_PREC_BF16_X3TAIL && !use_sb(c, rows) && !c->bulk_resid_lo;
+    (void)guided;   // both forms fuse: guided sampling runs one k_step over the conditional rows after the chains have joined
+    return c->step_fused && !x3 && c->cfg.precision == RGN_PREC_BF16_X3TAIL && !use_sb(c, rows) && !c->bulk_resid_lo;
 }
 // The input embedding of ALL rows into the residual-stream planes (hi): what every fused step leaves behind for the next
 // one, needed once in front of the first fused step of a sampling call.
@@ -753,10 +754,11 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
     const Planes xin_p{fast ? c->xin_hi : nullptr, (fast && has_lo(c)) ? c->xin_lo : nullptr, M};
     c->skip_embed_out = false;
     const bool fused = sampling && step_fusable(c, guided, eval_x3(c), M);   // k_step instead of out GEMM + k_update + next in GEMM
-    const bool own_update = (nch > 1 && !guided) || fused;
+    const bool own_update = !guided && (nch > 1 || fused);
     int total_tiles = 0;
     if (fused) {
-        for (int k2 = 0; k2 < nch; ++k2) total_tiles += ((per + (k2 < extra ? 1 : 0)) * dm.Tq + 63) / 64;
+        if (guided) total_tiles = (Mb + 63) / 64;            // one launch over the conditional rows, after the join
+        else for (int k2 = 0; k2 < nch; ++k2) total_tiles += ((per + (k2 < extra ? 1 : 0)) * dm.Tq + 63) / 64;
         c->skip_embed_out = true;
     }
     auto step_or_update = [&](int s_first, int n, hipStream_t st) -> int {
@@ -769,6 +771,7 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
             g.c0 = c->c0 + row0 * c->d;
             g.tab = c->d_tab; g.d_step = c->d_step; g.sp = c->d_sp;
             g.T = dm.T; g.B = dm.B; g.s0 = s_first; g.total_tiles = total_tiles; g.no_quads = c->step_no_quads;
+            if (guided) { g.scale = c->scale; g.half = Mb; }  // x0 = x0_u + scale (x0_c - x0_u); rows [Mb, 2 Mb) are the unconditional half
             RGN_LAUNCH(c, KC_STEP, st, launch_step(g, st));
         } else {
             RGN_LAUNCH(c, KC_UPDATE, st, launch_update(c->x0tok, c->scale, c->d_tab, c->d_step, c->d_sp, nullptr, xin_p, dm, s_first, n, st));
@@ -787,7 +790,9 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
     if (own_update && (rc = step_or_update(0, first_n, s))) return rc;
     c->skip_embed_out = false;
     for (int k = 1; k < nch; ++k) RGN_HIP(c, hipStreamWaitEvent(s, c->ev_join[k - 1], 0));
-    if (!own_update)
+    if (fused && guided) {
+        if ((rc = step_or_update(0, dm.B, s))) return rc;
+    } else if (!own_update)
         RGN_LAUNCH(c, KC_UPDATE, s,
                    launch_update(c->x0tok, c->scale, c->d_tab, c->d_step, c->d_sp, fast ? nullptr : c->xin, xin_p, dm, 0, dm.B, s));
     return RGN_OK;

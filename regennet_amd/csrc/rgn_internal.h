@@ -225,6 +225,8 @@ struct StepArgs {
     int T, B, s0;               // frames (= tokens) per sample, motions in the bound condition, first sample of this launch
     int total_tiles;            // 64-row tiles over ALL launches of the step (loop-index ticket)
     int no_quads;               // tests: draw the noise per element (philox_normal) instead of per quad of lanes (bit-identical)
+    const float* scale; int half;   // guided sampling: scale[B] (nullptr: unguided) and the row distance B * T from a token's conditional
+                                    // to its unconditional row (h / hout / c0 hold both halves; M counts the conditional rows)
 };
 bool step_fused_supported(int d, int F, int Kpx);
 hipError_t configure_step();

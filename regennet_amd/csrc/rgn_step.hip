@@ -40,10 +40,10 @@ constexpr int ST_BM = 64, ST_NT = 512, ST_PF = 3;
 constexpr int ST_XLD = 356;                                          // fp32 tile row stride (floats): F <= 352, 16-byte aligned rows
 constexpr int ST_TILE = 0, ST_XIMG = 92160;                          // fp32 tile 64 x 356 x 4 = 91136 B; x' image behind it
 constexpr int ST_LDS = ST_XIMG + 11 * 4096;
-static_assert(ST_BM * ST_XLD * 4 <= ST_XIMG && 16 * 4096 <= ST_XIMG, "tile / images");
+static_assert(ST_BM * ST_XLD * 4 <= ST_XIMG && 16 * 4096 <= ST_XIMG && 2 * 65536 <= ST_LDS, "tile / images (guided: two 64 KiB input images)");
 }  // namespace
 
-template <int NKX>
+template <int NKX, bool GUIDED>
 __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -64,6 +64,8 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
             m = m < g.M ? m : g.M - 1;
             const size_t src = ((size_t)kb * g.rows + m) * 32 + ((c ^ ((r >> 2) & 3)) << 3);
             __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.h + src), (RGN_AS3 void*)(smem + p * 1024), 16, 0, 0);
+            if constexpr (GUIDED)   // the unconditional evaluation's rows of the same tokens (second half of the planes) -> a second image
+                __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.h + src + (size_t)g.half * 32), (RGN_AS3 void*)(smem + 65536 + p * 1024), 16, 0, 0);
         }
     }
     int a_off[2][2];
@@ -123,14 +125,63 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    f32x16 accu[GUIDED ? 2 : 1][2];                                   // guided: the unconditional evaluation's x0
+    if constexpr (GUIDED) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) accu[a][b][i] = 0.f;
+    }
     prefetch(g.Wout, g.nb_out, 2 * wave);
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                // in order: the tile landed, the weight prefetch may still fly
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                // in order: the tile(s) landed, the weight prefetch may still fly
     __builtin_amdgcn_s_barrier();
-    gemm(acc, smem, g.Wout, g.nb_out, 2 * wave, std::integral_constant<int, 16>{});
-    __builtin_amdgcn_s_barrier();                                     // every wave is done reading the image
+    if constexpr (!GUIDED) {
+        gemm(acc, smem, g.Wout, g.nb_out, 2 * wave, std::integral_constant<int, 16>{});
+    } else {
+        // both evaluations in ONE pass over the weights: every fragment feeds the conditional and the unconditional tile
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kt = 0; kt < 16; ++kt) {
+            const char* sb = smem + kt * 4096;
+            bf16x8 afc[2][2], afu[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    afc[ks][mt] = *reinterpret_cast<const bf16x8*>(sb + a_off[mt][ks]);
+                    afu[ks][mt] = *reinterpret_cast<const bf16x8*>(sb + 65536 + a_off[mt][ks]);
+                }
+            asm volatile("" ::: "memory");
+            if (kt + ST_PF < 16) {
+                load_w(g.Wout, g.nb_out, 2 * wave, kt + ST_PF, (kt + ST_PF) & 3);
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kt & 3][ks][nt], afc[ks][mt], acc[nt][mt], 0, 0, 0);
+                        accu[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kt & 3][ks][nt], afu[ks][mt], accu[nt][mt], 0, 0, 0);
+                    }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_barrier();                                     // every wave is done reading the image(s)
 
     // ---- B: x0 -> fp32 tile
     float* tile = reinterpret_cast<float*>(smem + ST_TILE);
+    float scl[2] = {0.f, 0.f};                                        // guidance scale of the sample of token 32 mt + l31
+    if constexpr (GUIDED) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int mm = m0 + 32 * mt + l31;
+            scl[mt] = g.scale[g.s0 + (mm < g.M ? mm : g.M - 1) / g.T];
+        }
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -140,9 +191,18 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
                 f32x4 b = {0.f, 0.f, 0.f, 0.f};
                 if (n < g.F) b = *reinterpret_cast<const f32x4*>(g.bout + n);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-                    *reinterpret_cast<f32x4*>(tile + (32 * mt + l31) * ST_XLD + n) =
-                        f32x4{acc[nt][mt][4 * i4] + b[0], acc[nt][mt][4 * i4 + 1] + b[1], acc[nt][mt][4 * i4 + 2] + b[2], acc[nt][mt][4 * i4 + 3] + b[3]};
+                for (int mt = 0; mt < 2; ++mt) {
+                    f32x4 v = {acc[nt][mt][4 * i4] + b[0], acc[nt][mt][4 * i4 + 1] + b[1], acc[nt][mt][4 * i4 + 2] + b[2], acc[nt][mt][4 * i4 + 3] + b[3]};
+                    if constexpr (GUIDED) {   // x0 = x0_u + scale_b (x0_c - x0_u), cfg_sampler.py:31, rounded like k_update
+                        const float sc = scl[mt];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float u = accu[nt][mt][4 * i4 + e] + b[e];
+                            v[e] = __fadd_rn(u, __fmul_rn(sc, __fsub_rn(v[e], u)));
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(tile + (32 * mt + l31) * ST_XLD + n) = v;
+                }
             }
         }
     prefetch(g.Wx, 16, 2 * wave);                                    // GEMM 2's first fragments fly under the update phase
@@ -273,6 +333,17 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
                     o[4 + e] = (__bf16)((float)v[4 + e] + a1[e]);
                 }
                 *reinterpret_cast<bf16x8*>(g.hout + ((size_t)blk * g.rows + m) * 32 + c * 8) = o;
+                if constexpr (GUIDED) {   // the unconditional evaluation sees the same x', with its own condition part
+                    const float* cu = cp + (size_t)g.half * 512;
+                    const f32x4 u0 = *reinterpret_cast<const f32x4*>(cu), u1 = *reinterpret_cast<const f32x4*>(cu + 4);
+                    bf16x8 ou;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ou[e] = (__bf16)((float)v[e] + u0[e]);
+                        ou[4 + e] = (__bf16)((float)v[4 + e] + u1[e]);
+                    }
+                    *reinterpret_cast<bf16x8*>(g.hout + ((size_t)blk * g.rows + m + g.half) * 32 + c * 8) = ou;
+                }
             }
         }
     }
@@ -287,11 +358,16 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
 
 bool step_fused_supported(int d, int F, int Kpx) { return d == 512 && F % 4 == 0 && F <= 352 && Kpx == 352; }
 hipError_t configure_step() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<11>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<11, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<11, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
 }
 hipError_t launch_step(const StepArgs& g, hipStream_t s) {
     if (g.nkx != 11 || g.M <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_step<11>, dim3((g.M + ST_BM - 1) / ST_BM), dim3(ST_NT), ST_LDS, s, g);
+    if (g.scale)   // guided: M = token rows of the conditional half; half = row distance to the unconditional half
+        hipLaunchKernelGGL((k_step<11, true>), dim3((g.M + ST_BM - 1) / ST_BM), dim3(ST_NT), ST_LDS, s, g);
+    else
+        hipLaunchKernelGGL((k_step<11, false>), dim3((g.M + ST_BM - 1) / ST_BM), dim3(ST_NT), ST_LDS, s, g);
     return hipGetLastError();
 }
 

@@ -529,18 +529,22 @@ def test_full_size_batch_is_row_independent(precision, tail):
         assert torch.allclose(full2[b:b + 1], one, atol=2e-5), (b, (full2[b:b + 1] - one).abs().max().item())
 
 
-@pytest.mark.parametrize("sampler,clip", [("ddpm", False), ("ddim", True)])
-def test_fused_step_boundary_matches_the_three_kernel_form(monkeypatch, sampler, clip):
-    """k_step (plain-bf16 phase, unguided, throughput kernels: output projection + sampler update + next input embedding in
-    one kernel) against the same loop with the three separate launches (REGENNET_NO_STEP_FUSION=1), on-device Philox noise:
-    same noise stream, same sampler arithmetic, so the results differ only by the plain-bf16 phase's rounding (the fused kernel
-    rounds h' to bf16 twice) and end within the parity margin of each other after the split-bf16 tail. And the quad-shared
-    Philox draw of k_step is bit-identical to the per-element one (REGENNET_STEP_NO_QUADS=1)."""
+@pytest.mark.parametrize("sampler,clip,guided", [("ddpm", False, False), ("ddim", True, False), ("ddim", False, True), ("ddpm", True, True)])
+def test_fused_step_boundary_matches_the_three_kernel_form(monkeypatch, sampler, clip, guided):
+    """k_step (plain-bf16 phase, throughput kernels: output projection + sampler update + next input embedding in one kernel;
+    with guidance both evaluations' output projections and the combination x0_u + scale (x0_c - x0_u)) against the same loop
+    with the three separate launches (REGENNET_NO_STEP_FUSION=1), on-device Philox noise: same noise stream, same sampler
+    arithmetic, so the results differ only by the plain-bf16 phase's rounding (the fused kernel rounds h' to bf16 twice) and
+    end within the parity margin of each other after the split-bf16 tail. And the quad-shared Philox draw of k_step is
+    bit-identical to the per-element one (REGENNET_STEP_NO_QUADS=1)."""
     from regennet_amd import synth
-    cfg = synth.get_config("ntu")
+    cfg = synth.get_config("ntu_action" if guided else "ntu")
     sd = synth.make_state_dict(cfg, seed=0)
     B = 5                                       # 300 rows: 4 full tiles + a partial one, tiles straddling samples
-    cm = torch.from_numpy(synth.make_cmotion(cfg, B, seed=1)).cuda()
+    y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1)).cuda()}
+    if guided:
+        y["action"] = torch.from_numpy(synth.make_actions(cfg, B, seed=2)).cuda()
+        y["scale"] = torch.linspace(1.5, 3.5, B).cuda()          # per-sample scales
     outs = {}
     for tag, env in (("fused", None), ("per_element_noise", "REGENNET_STEP_NO_QUADS"), ("three_kernels", "REGENNET_NO_STEP_FUSION")):
         if env:
@@ -549,13 +553,14 @@ def test_fused_step_boundary_matches_the_three_kernel_form(monkeypatch, sampler,
         model._get_engine(B)                    # (the switches are read when the engine is built)
         if env:
             monkeypatch.delenv(env)
+        fm = _wrap(model, guided)
         fn = diffusion.p_sample_loop if sampler == "ddpm" else diffusion.ddim_sample_loop
-        outs[tag] = fn(model, (B, 56, 6, 60), clip_denoised=clip, model_kwargs={"y": {"cmotion": cm}}, seed=3)
+        outs[tag] = fn(fm, (B, 56, 6, 60), clip_denoised=clip, model_kwargs={"y": y}, seed=3)
         model._engine.close()
     assert torch.isfinite(outs["fused"]).all()
     assert torch.equal(outs["fused"], outs["per_element_noise"])
     dev = (outs["fused"] - outs["three_kernels"]).abs().max().item()
-    print(f"\n[fused step boundary] {sampler} clip={clip} vs three kernels: {dev:.2e}")
+    print(f"\n[fused step boundary] {sampler} clip={clip} guided={guided} vs three kernels: {dev:.2e}")
     assert 0.0 < dev < 5e-4
 
 
