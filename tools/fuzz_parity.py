@@ -4,7 +4,9 @@ Random batch size, sequence length, ff width, guidance, sampler and engine on 2-
 (2) under the precision schedule with the first two loop iterations in the plain-bf16 phase: sample b of the batch against
     the same sample drawn alone (same Philox key) - bit-identical in the small-batch engine, <= 5e-5 in the throughput
     engine. This isolates indexing / tiling mistakes of the plain-bf16 kernels from their (by design larger) rounding, which on
-    such short schedules and shallow guided models is not damped below 1e-3."""
+    such short schedules and shallow guided models is not damped below 1e-3.
+Guidance scales stay <= 2.5 (the reference's setting): on these random 2-layer emb_trans_dec models a scale of 3.5 amplifies ANY
+rounding difference - fp32 op order alone: 1e-4 against 9e-6 at scale 1.5, split-bf16: 2e-3 against 9e-5 - past the 1e-3 bound."""
 import os
 import sys
 
@@ -36,7 +38,7 @@ def main():
         resp = f"ddim{S}" if sampler == "ddim" else str(S)
         y = {"cmotion": synth.make_cmotion(cfg, B, seed=case), "action": synth.make_actions(cfg, B, seed=case + 1)}
         if guided:
-            y["scale"] = np.full((B,), 2.5, np.float32)
+            y["scale"] = np.linspace(1.0, 2.5, B).astype(np.float32)           # per-sample guidance scales (see the docstring)
         yd = {k: torch.from_numpy(v).cuda() for k, v in y.items()}
         tape = synth.make_noise_tape(cfg, B, S, seed=case + 2)
         ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", resp), tape, {k: torch.from_numpy(v) for k, v in y.items()},
