@@ -95,7 +95,7 @@ struct rgn_ctx {
     bool fuse_ln = false;              // out_proj / linear2 GEMMs carry their LayerNorms (k_gemm_x3_ln)
     bool rowgemm = false;              // plain-bf16 phase: row-complete GEMMs with fused LayerNorm / GELU (k_rowgemm)
     bool mlp = false;                  // plain-bf16 phase: the whole layer tail in one row-persistent kernel (k_mlp)
-    bool step_fused = false;           // plain-bf16 phase, unguided: output projection + sampler update + next input embedding in one kernel (REGENNET_NO_STEP_FUSION=1: three launches)
+    bool step_fused = false;           // plain-bf16 phase: output projection (+ guidance) + sampler update + next input embedding in one kernel (REGENNET_NO_STEP_FUSION=1: three launches)
     bool skip_embed_out = false;       // (set by run_eval around run_layers while it enqueues a fused step)
     int step_no_quads = 0;             // REGENNET_STEP_NO_QUADS=1 (tests)
     bool qkv_rs = true;                // plain-bf16 phase: k_qkv_attn with register-streamed weights (REGENNET_NO_QKV_RS=1: the DMA-fed loop)

@@ -211,7 +211,7 @@ __device__ __forceinline__ int xcd_affine(int bid, int nwg) {
 }
 
 // Step boundary of the plain-bf16 phase as one kernel (rgn_step.hip): output projection + sampler update + the next
-// evaluation's input embedding for 64-row tiles; unguided sampling, d = 512, no emb_trans_dec token.
+// evaluation's input embedding for 64-row tiles; d = 512, no emb_trans_dec token; with or without guidance.
 struct StepCoef;
 struct SampleParams;
 struct StepArgs {

@@ -1,4 +1,4 @@
-// Step boundary of the plain-bf16 phase as ONE kernel (unguided sampling, d = 512):
+// Step boundary of the plain-bf16 phase as ONE kernel (d = 512; GUIDED = classifier-free guidance, see below):
 //
 //   x0   = h . Wout^T + bout                       output projection of the evaluation just finished (OutputProcess, cmdm.py:353)
 //   x'   = sampler(x, x0, eps)                     p_sample / ddim_sample update in place (gaussian_diffusion.py:265-276, 508-560,
@@ -17,6 +17,10 @@
 //                   sampler update in place, x' as bf16 into the K32-blocked image of GEMM 2's A operand (44 KiB)
 //                D  GEMM 2 (K = 352, N = 512) -> bf16 image (64 KiB, over the dead tile) -> + c0 in the coalesced copy-out
 //                   (the sum is rounded to bf16 twice: plain-bf16 phase only)
+// GUIDED (cfg_sampler.py:22-31): a token's conditional / unconditional evaluations are rows m / m + half of the planes. One
+// launch over the conditional rows after the chains joined: A stages BOTH tiles (2 x 64 KiB) and runs the two output projections
+// in one pass over Wout (every weight fragment feeds both accumulator sets), B forms x0 = u + scale_b (c - u) with k_update's
+// rounding, C is unchanged, D embeds x' once and writes it to both halves with their own c0 rows.
 // The last workgroup to finish (over all launches of the step) moves the device-side loop index on, like k_update.
 #include "rgn_internal.h"
 #include "rgn_philox.h"
