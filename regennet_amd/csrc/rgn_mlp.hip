@@ -22,6 +22,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace rgn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -49,21 +51,21 @@ __device__ long long g_ml_prof[16];
 #define RGN_MT(i)
 #endif
 
-// GELU (erf form) as in rgn_rowgemm.hip: odd degree-15 polynomial of clamp(x / sqrt 2, +-3.2), max abs error of erf 1.6e-4
+// GELU (erf form): x (0.5 + 0.5 erf(x / sqrt 2)) with 0.5 erf(x / sqrt 2) = t Q(t^2), t = clamp(x, +-3.2 sqrt 2): rgn_rowgemm.hip's
+// odd degree-15 polynomial of erf (max abs error 1.6e-4) with the 1/sqrt 2, the 1/2^k of u^2 = x^2 / 2 and the 0.5 folded into
+// the coefficients: 12 instructions per pair of values instead of 14 (the epilogues are VALU-issue-bound)
 __device__ __forceinline__ f32x2 ml_gelu2(f32x2 x) {
-    f32x2 u = x * 0.70710678118654752440f;
-    u = __builtin_elementwise_min(__builtin_elementwise_max(u, f32x2{-3.2f, -3.2f}), f32x2{3.2f, 3.2f});
-    const f32x2 z = u * u;
-    f32x2 p = f32x2{-2.6911866e-07f, -2.6911866e-07f};
-    p = __builtin_elementwise_fma(p, z, f32x2{1.2661994e-05f, 1.2661994e-05f});
-    p = __builtin_elementwise_fma(p, z, f32x2{-2.5566161e-04f, -2.5566161e-04f});
-    p = __builtin_elementwise_fma(p, z, f32x2{2.9286479e-03f, 2.9286479e-03f});
-    p = __builtin_elementwise_fma(p, z, f32x2{-2.1317327e-02f, -2.1317327e-02f});
-    p = __builtin_elementwise_fma(p, z, f32x2{1.0528564e-01f, 1.0528564e-01f});
-    p = __builtin_elementwise_fma(p, z, f32x2{-3.7135834e-01f, -3.7135834e-01f});
-    p = __builtin_elementwise_fma(p, z, f32x2{1.1274883e+00f, 1.1274883e+00f});
-    const f32x2 hx = x * 0.5f;
-    return __builtin_elementwise_fma(hx, p * u, hx);
+    const f32x2 t = {__builtin_amdgcn_fmed3f(x[0], -4.5254834f, 4.5254834f), __builtin_amdgcn_fmed3f(x[1], -4.5254834f, 4.5254834f)};   // (no canonicalising v_max in front, unlike min(max()))
+    const f32x2 z = t * t;
+    f32x2 p = f32x2{-7.433422766e-10f, -7.433422766e-10f};
+    p = __builtin_elementwise_fma(p, z, f32x2{6.994829249e-08f, 6.994829249e-08f});
+    p = __builtin_elementwise_fma(p, z, f32x2{-2.824688409e-06f, -2.824688409e-06f});
+    p = __builtin_elementwise_fma(p, z, f32x2{6.471458619e-05f, 6.471458619e-05f});
+    p = __builtin_elementwise_fma(p, z, f32x2{-9.421016439e-04f, -9.421016439e-04f});
+    p = __builtin_elementwise_fma(p, z, f32x2{9.306023829e-03f, 9.306023829e-03f});
+    p = __builtin_elementwise_fma(p, z, f32x2{-6.564749777e-02f, -6.564749777e-02f});
+    p = __builtin_elementwise_fma(p, z, f32x2{3.986273110e-01f, 3.986273110e-01f});
+    return x * __builtin_elementwise_fma(t, p, f32x2{0.5f, 0.5f});
 }
 
 __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
@@ -114,16 +116,24 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) a_off[mt][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
     }
+    // the same inside Y: ds_read offsets are 16 bits, so reads of the second 64 KiB want their own base registers (one v_add per
+    // fragment read otherwise: 128 VALU in the linear1 loops)
+    int a_off_y[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a_off_y[mt][ks] = a_off[mt][ks] + ML_Y;
     // One GEMM pass: acc[nt][mt] += A_image(16 k-blocks) . W[column blocks cb0 + {0, 1}, k-blocks kt0 .. kt0 + 15]^T
     // W: fragment-ordered plane [K/32][nb_all][2][64][8]. first = the pass right behind the tile DMA (the compiler drains
     // vmcnt completely at the first ds_read behind a direct-to-LDS DMA, so the weight prefetch of that pass starts after it).
     bf16x8 wf[ML_PF + 1][2][2];
+    const unsigned lane8 = (unsigned)lane * 8u;
     auto load_w = [&](const __bf16* W, int nb_all, int cb0, int kt, int slot) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const __bf16* base = W + ((size_t)kt * nb_all + cb0 + nt) * 1024 + lane * 8;
+            const __bf16* base = W + ((size_t)kt * nb_all + cb0 + nt) * 1024;   // wave-uniform: scalar base + the lane's 32-bit offset
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) wf[slot][ks][nt] = *reinterpret_cast<const bf16x8*>(base + ks * 512);
+            for (int ks = 0; ks < 2; ++ks) wf[slot][ks][nt] = *reinterpret_cast<const bf16x8*>(base + ks * 512 + lane8);
         }
     };
     // the first PF k-steps' fragments of a pass: issued ahead of whatever precedes the pass (tile DMA wait, an epilogue)
@@ -131,16 +141,16 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
 #pragma unroll
         for (int s = 0; s < ML_PF; ++s) load_w(W, nb_all, cb0, kt0 + s, s);
     };
-    auto gemm16 = [&](f32x16 (&acc)[2][2], const char* img, const __bf16* W, int nb_all, int cb0, int kt0) {
+    auto gemm16 = [&](f32x16 (&acc)[2][2], const int (&aoff)[2][2], const __bf16* W, int nb_all, int cb0, int kt0) {
         __builtin_amdgcn_sched_barrier(0);                            // keep epilogue loads out of the k-loop (register pressure -> spills)
 #pragma unroll
         for (int kt = 0; kt < 16; ++kt) {
-            const char* sb = img + kt * 4096;
+            const char* sb = smem + kt * 4096;
             bf16x8 af[2][2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) af[ks][mt] = *reinterpret_cast<const bf16x8*>(sb + a_off[mt][ks]);
+                for (int mt = 0; mt < 2; ++mt) af[ks][mt] = *reinterpret_cast<const bf16x8*>(sb + aoff[mt][ks]);
             asm volatile("" ::: "memory");
             if (kt + ML_PF < 16) {
                 load_w(W, nb_all, cb0, kt0 + kt + ML_PF, (kt + ML_PF) & 3);
@@ -197,26 +207,33 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
         v[1] = s1;
     };
     const float invn = 1.0f / (float)ML_D;
-    auto layernorm = [&](f32x16 (&acc)[2][2], const float* gam, const float* bet) {   // two-pass, in place; gam / bet in LDS
-        float s[2] = {0.f, 0.f};
+    // (has_beta: a compile-time tag - a run-time `bet != nullptr` on an LDS-derived pointer costs two v_cndmask + a wasted add per pair)
+    auto layernorm = [&](f32x16 (&acc)[2][2], const float* gam, const float* bet, auto has_beta) {   // two-pass, in place; gam / bet in LDS
+        // packed fp32 throughout (v_pk_add / v_pk_fma: two columns per instruction): the epilogues are VALU-issue-bound with the
+        // matrix cores idle, so every instruction here is on the kernel's critical path
+        f32x2 s2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s[mt] += acc[nt][mt][i];
+                for (int i = 0; i < 16; i += 2) s2[mt] += f32x2{acc[nt][mt][i], acc[nt][mt][i + 1]};
+        float s[2] = {s2[0][0] + s2[0][1], s2[1][0] + s2[1][1]};
         row_sum(s);
-        const float mean[2] = {s[0] * invn, s[1] * invn};
-        float q[2] = {0.f, 0.f};
+        const f32x2 nmean[2] = {f32x2{-s[0] * invn, -s[0] * invn}, f32x2{-s[1] * invn, -s[1] * invn}};
+        f32x2 q2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    acc[nt][mt][i] -= mean[mt];
-                    q[mt] = fmaf(acc[nt][mt][i], acc[nt][mt][i], q[mt]);
+                for (int i = 0; i < 16; i += 2) {
+                    const f32x2 dlt = f32x2{acc[nt][mt][i], acc[nt][mt][i + 1]} + nmean[mt];
+                    acc[nt][mt][i] = dlt[0];
+                    acc[nt][mt][i + 1] = dlt[1];
+                    q2[mt] = __builtin_elementwise_fma(dlt, dlt, q2[mt]);
                 }
+        float q[2] = {q2[0][0] + q2[0][1], q2[1][0] + q2[1][1]};
         row_sum(q);
         const float rstd[2] = {__builtin_amdgcn_rsqf(q[0] * invn + 1e-5f), __builtin_amdgcn_rsqf(q[1] * invn + 1e-5f)};
         f32x4 ga[2][4], be[2][4];                                     // all the LDS reads first, then the arithmetic
@@ -225,7 +242,7 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
                 ga[nt][i4] = *reinterpret_cast<const f32x4*>(gam + col4(nt, i4));
-                if (bet) be[nt][i4] = *reinterpret_cast<const f32x4*>(bet + col4(nt, i4));
+                if constexpr (decltype(has_beta)::value) be[nt][i4] = *reinterpret_cast<const f32x4*>(bet + col4(nt, i4));
             }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -234,9 +251,14 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float a = acc[nt][mt][4 * i4 + e] * (rstd[mt] * ga[nt][i4][e]);
-                        acc[nt][mt][4 * i4 + e] = bet ? a + be[nt][i4][e] : a;
+                    for (int e = 0; e < 4; e += 2) {
+                        const f32x2 rg = f32x2{ga[nt][i4][e], ga[nt][i4][e + 1]} * f32x2{rstd[mt], rstd[mt]};
+                        const f32x2 v = f32x2{acc[nt][mt][4 * i4 + e], acc[nt][mt][4 * i4 + e + 1]};
+                        f32x2 o;
+                        if constexpr (decltype(has_beta)::value) o = __builtin_elementwise_fma(v, rg, f32x2{be[nt][i4][e], be[nt][i4][e + 1]});
+                        else o = v * rg;
+                        acc[nt][mt][4 * i4 + e] = o[0];
+                        acc[nt][mt][4 * i4 + e + 1] = o[1];
                     }
     };
     // acc += bf16 image value (the residual); all sixteen 8-byte reads first, then the adds
@@ -279,10 +301,10 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
     __builtin_amdgcn_s_barrier();
     init_bias(acc, vec + V_BO);
     RGN_MT(1)
-    gemm16(acc, smem + ML_X, g.Wo, 16, 2 * wave, 0);
+    gemm16(acc, a_off, g.Wo, 16, 2 * wave, 0);
     RGN_MT(2)
     add_resid(acc, smem + ML_Y);
-    layernorm(acc, vec + V_G1, nullptr);                              // beta of norm1 rides in the per-sample vector below
+    layernorm(acc, vec + V_G1, nullptr, std::false_type{});                              // beta of norm1 rides in the per-sample vector below
     {   // + norm1.beta + call_time[step] + call_cond[sample of the token] (pre-summed per sample in LDS)
         const int s0 = m0 / g.Tq;
         int sj[2];
@@ -304,7 +326,7 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
                 }
             }
     }
-    layernorm(acc, vec + V_G2, vec + V_B2);
+    layernorm(acc, vec + V_G2, vec + V_B2, std::true_type{});
     store_img(acc, smem + ML_Y);                                      // h' replaces h element by element (each lane read its own first)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -317,7 +339,7 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
     for (int c = 0; c < 2; ++c) {
         init_bias(acc, vec + V_BF1 + 512 * c);
         gemm_prefetch(g.W1, 32, 16 * c + 2 * wave, 0);
-        gemm16(acc, smem + ML_Y, g.W1, 32, 16 * c + 2 * wave, 0);    // hidden columns [512 c, 512 c + 512)
+        gemm16(acc, a_off_y, g.W1, 32, 16 * c + 2 * wave, 0);    // hidden columns [512 c, 512 c + 512)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -333,13 +355,13 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
         gemm_prefetch(g.W2, 16, 2 * wave, 16 * c);                   // flies while the barrier passes (acc is dead: no extra registers)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        gemm16(acc2, smem + ML_X, g.W2, 16, 2 * wave, 16 * c);       // linear2 over hidden k-blocks [16 c, 16 c + 16)
+        gemm16(acc2, a_off, g.W2, 16, 2 * wave, 16 * c);       // linear2 over hidden k-blocks [16 c, 16 c + 16)
     }
     RGN_MT(4)
 
     // =============== stage 3: + bias + residual h' + norm3 -> output planes ===============================================
     add_resid(acc2, smem + ML_Y);
-    layernorm(acc2, vec + V_G3, vec + V_B3);                                      // (its barriers also fence the last reads of X)
+    layernorm(acc2, vec + V_G3, vec + V_B3, std::true_type{});                                      // (its barriers also fence the last reads of X)
     store_img(acc2, smem + ML_X);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

@@ -149,12 +149,13 @@ __global__ __launch_bounds__(RG_NT, (EPI == 1 && NK <= 16) ? RGN_RG_ACT_WAVES : 
         nbw[nt] = nb < nb_all ? nb : nb_all - 1;
     }
     bf16x8 wf[RG_D + 1][2][2];                                        // [ring slot][ks][nt]
+    const unsigned lane8 = (unsigned)lane * 8u;
     auto load_w = [&](int kt, int slot) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const __bf16* base = g.W + ((size_t)kt * nb_all + nbw[nt]) * 1024 + lane * 8;
+            const __bf16* base = g.W + ((size_t)kt * nb_all + nbw[nt]) * 1024;   // wave-uniform: scalar base + the lane's 32-bit offset
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) wf[slot][ks][nt] = *reinterpret_cast<const bf16x8*>(base + ks * 512);
+            for (int ks = 0; ks < 2; ++ks) wf[slot][ks][nt] = *reinterpret_cast<const bf16x8*>(base + ks * 512 + lane8);
         }
     };
     int a_off[2][2];                                                  // [mt][ks]: B-operand fragment of token 32 mt + l31

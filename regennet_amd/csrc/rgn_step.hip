@@ -80,13 +80,14 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
         for (int ks = 0; ks < 2; ++ks) a_off[mt][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
     }
     bf16x8 wf[ST_PF + 1][2][2];
+    const unsigned lane8 = (unsigned)lane * 8u;
     auto load_w = [&](const __bf16* W, int nb_all, int cb0, int kt, int slot) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int cb = cb0 + nt < nb_all ? cb0 + nt : nb_all - 1;
-            const __bf16* base = W + ((size_t)kt * nb_all + cb) * 1024 + lane * 8;
+            const __bf16* base = W + ((size_t)kt * nb_all + cb) * 1024;   // wave-uniform: scalar base + the lane's 32-bit offset
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) wf[slot][ks][nt] = *reinterpret_cast<const bf16x8*>(base + ks * 512);
+            for (int ks = 0; ks < 2; ++ks) wf[slot][ks][nt] = *reinterpret_cast<const bf16x8*>(base + ks * 512 + lane8);
         }
     };
     auto prefetch = [&](const __bf16* W, int nb_all, int cb0) {
