@@ -381,7 +381,8 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn_rs(QkvAttnArgs g, const _
     const int b0 = xcd_affine(blockIdx.x, gridDim.x) * QA_NS, Tq = g.Tq, d = g.d;   // (gridDim.x = sample pairs; id = y * gridDim.x + x)
     const int hpb = g.H / (int)gridDim.y, hd0 = blockIdx.y * hpb;
     const int nsamp = g.Bm - b0 < QA_NS ? g.Bm - b0 : QA_NS;
-    const int nb_all = 3 * d / 32;
+    constexpr int nb_all = 3 * 512 / 32;                             // d = 512 (launch_qkv_attn): compile-time weight offsets - as run-time
+                                                                     // values the 96 k-step offsets of a head live in SGPRs and spill to VGPR lanes
 
     unsigned a_voff;                                                 // this thread's 16 bytes of every activation k-block (elements)
     {
