@@ -16,8 +16,11 @@ events on the engine's stream in a short profiled pass inside this script) and "
 = CPU port of the reference path, timed on this host's cores on a bounded sample, rank 0 / N=1 only).
 """
 import argparse
+import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -146,7 +149,21 @@ def cpu_baseline(cfg, sd, steps_total, seconds_budget=20.0):
     return out
 
 
-def main():
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks here (one process per GPU over
+    RCCL, rendezvous on 127.0.0.1) — the counterpart of the reference's mpi4py bootstrap (utils/dist_util.py:20-42)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2, help="timed sampling calls")
@@ -162,7 +179,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-evals", type=int, default=3)
-    a = ap.parse_args()
+    ap.add_argument("--engine-stub", default="", help=argparse.SUPPRESS)   # tests only: "module:Class" replaces _lib.Engine (CPU, gloo);
+    a = ap.parse_args(argv)                                                 # the line is then marked "data": "STUB ENGINE ..." and measures nothing
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus, argv))
 
     from regennet_amd import synth
     from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
@@ -170,17 +190,27 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a line for a different rank count")
+    if a.engine_stub:
+        from regennet_amd import _lib
+        mod, cls = a.engine_stub.split(":")
+        _lib.Engine = getattr(importlib.import_module(mod), cls)
+    elif torch.cuda.is_available() and a.gpus > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but this node has {torch.cuda.device_count()} GPU(s)")
     dev = dist_util.setup_dist()
-    assert dev.type == "cuda", "bench.py needs an AMD GPU (no CPU fallback)"
+    assert dev.type == "cuda" or a.engine_stub, "bench.py needs an AMD GPU (no CPU fallback)"
+    if world > 1:
+        assert dist.is_initialized() and dist.get_world_size() == a.gpus, "process group does not span --gpus ranks"
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
 
     cfg = synth.get_config(a.config)
     B = a.batch
     # rank 0 owns the checkpoint; other ranks start from a different seed and receive the packed blob via RCCL
     sd = synth.make_state_dict(cfg, seed=0 if rank == 0 else 1000 + rank)
     model, diffusion = synth.build_model(cfg, sd, resp=a.respacing, precision=a.precision, device=str(dev), x3_tail=a.x3_tail)
+    model.weights_src = 0 if world > 1 else None            # ONE collective over xGMI per engine built (none at N = 1)
     eng, _ = model._get_engine(B)
-    dist_util.broadcast_engine_weights(eng, dev, 0)         # ONE collective over xGMI (no-op at N = 1)
     fm = ClassifierFreeSampleModel(model) if a.guided else model
     lo = rank * B                                           # global sample index of this rank's shard
     y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1 + rank)).to(dev)}
@@ -200,28 +230,31 @@ def main():
 
     for w in range(a.warmup):
         out = one_call(10 + w)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for k in range(a.steps):
         out = one_call(100 + k)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     assert torch.isfinite(out).all()
+    devices = [str(dev)]
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        devices = [None] * world
+        dist.all_gather_object(devices, f"rank{rank}:{dev}" + (f" ({torch.cuda.get_device_name(dev)})" if dev.type == "cuda" else ""))
 
     # ---- roofline: HIP events around every launch of a short eager single-chain pass on the engine's stream -----------
     # (the first loop indices: the plain-bf16 phase under the precision schedule = where >= 97 % of the evaluations run)
     roof = None
-    if rank == 0 and a.profile_evals > 0:   # (--profile-evals 0: tools/collect_pmc.sh wants the sampling call only)
+    if rank == 0 and a.profile_evals > 0 and not a.engine_stub:   # (--profile-evals 0: tools/collect_pmc.sh wants the sampling call only)
         eng.profile_enable(True)
         x = torch.empty(shape, device=dev)
         st = torch.cuda.current_stream().cuda_stream
@@ -291,7 +324,10 @@ def main():
         line = {
             "metric": "sampled motions/sec", "value": round(value, 3), "unit": "motions/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+            "data": "synthetic" if not a.engine_stub else f"STUB ENGINE {a.engine_stub}: launcher test, nothing measured",
+            "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
+            "backend": dist.get_backend() if dist.is_initialized() else None, "devices": devices,
             "config": {"workload": f"{a.config}: [B={B}/GPU,56,6,{cfg['num_frames']}] online/{cfg['cm_mode']}/{cfg['cond_mode']} "
                                    f"L{cfg['layers']} d{cfg['latent_dim']}, {S}-step {a.sampler.upper()}"
                                    f"{' + CFG 2.5' if a.guided else ''}, Philox noise, hipGraph={'off' if a.no_graph else 'on'}",
@@ -303,7 +339,7 @@ def main():
             line["e2e_algorithmic_tflops"] = round(e2e, 2)
             line["e2e_frac_of_peak"] = round(e2e / (PEAK_TFLOPS[a.precision] * world), 4)
         line["roofline"] = roof
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not a.engine_stub:
             line["cpu_baseline"] = cpu_baseline(cfg, synth.make_state_dict(cfg, seed=0), evals)
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)

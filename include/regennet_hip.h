@@ -142,6 +142,11 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
  * (gaussian_diffusion.py:265-276; 0.0016 at t=999, -> 1 at t=0), so early-step rounding is contracted away. */
 int rgn_set_x3_tail(rgn_handle h, int32_t tail_steps);
 
+/* const_noise of p_sample (gaussian_diffusion.py:544-547): every motion of the batch receives the per-step draw of the
+ * batch's motion 0 (tape entry [k, 0] / the Philox stream of sample_offset + 0); x_T is not affected (:706). Holds for the
+ * following rgn_sample_range calls until cleared. */
+int rgn_set_const_noise(rgn_handle h, int32_t on);
+
 /* Evaluations of at most `rows` token rows (motions x tokens, doubled under guidance) run the small-batch engine:
  * column-split GEMMs that spread one row tile over 16-48 workgroups (rgn_sb.hip; d = 512 models, bf16 modes), the
  * latency-bound regime of the reference CLI's own default batch (sample/cgenerate.py:109-135, BASELINE configs[0]).

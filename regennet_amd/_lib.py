@@ -55,6 +55,7 @@ SYMBOLS = {
     "rgn_sample_range": (C.c_int, [_vp, _i32, _i32, _f32, _vp, _vp, _u64, _u64, _i32, _i32, _vp, _i32, _i32, _vp]),
     "rgn_set_x3_tail": (C.c_int, [_vp, _i32]),
     "rgn_set_small_batch_rows": (C.c_int, [_vp, _i32]),
+    "rgn_set_const_noise": (C.c_int, [_vp, _i32]),
     "rgn_randn": (C.c_int, [_vp, _vp, _i32, _u64, _u64, _vp]),
     "rgn_rot6d_to_matrix": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "rgn_gaussian_filter1d": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
@@ -194,6 +195,10 @@ class Engine:
     def set_x3_tail(self, tail_steps):
         """Precision schedule ('bf16_x3tail'): split-bf16 for the last `tail_steps` loop indices (-1: default)."""
         self._ck(self.lib.rgn_set_x3_tail(self.h, int(tail_steps)))
+
+    def set_const_noise(self, on):
+        """p_sample's const_noise (gaussian_diffusion.py:544-547) for the following sample_range calls."""
+        self._ck(self.lib.rgn_set_const_noise(self.h, int(bool(on))))
 
     def set_small_batch_rows(self, rows):
         """Evaluations of at most `rows` token rows run the small-batch (column-split) kernels; -1: default, 0: off."""

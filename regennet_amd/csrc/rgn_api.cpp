@@ -92,7 +92,6 @@ struct rgn_ctx {
     int Tqp = 0;
     bool fuse_qkv = false;             // in_proj GEMM + attention in one per-sample kernel (k_qkv_attn)
     int big_tile_rows = 7000;          // launches of at least this many rows per chain use the 256x256 GEMM tile
-    bool fuse_ln = false;              // out_proj / linear2 GEMMs carry their LayerNorms (k_gemm_x3_ln)
     bool rowgemm = false;              // plain-bf16 phase: row-complete GEMMs with fused LayerNorm / GELU (k_rowgemm)
     bool mlp = false;                  // plain-bf16 phase: the whole layer tail in one row-persistent kernel (k_mlp)
     bool step_fused = false;           // plain-bf16 phase: output projection (+ guidance) + sampler update + next input embedding in one kernel (REGENNET_NO_STEP_FUSION=1: three launches)
@@ -119,6 +118,7 @@ struct rgn_ctx {
     // phase_x3 is the phase of the evaluation being enqueued / captured.
     bool phase_x3 = true;
     int x3_tail = -1;                  // -1: default_tail(S)
+    int const_noise = 0;               // rgn_set_const_noise
     bool bulk_resid_lo = false;        // bulk phase: residual stream as the hi plane only (REGENNET_BULK_RESID_LO=1: hi + lo; the switch-point
                                        // sweeps measure the same final error either way, hi-only is ~6 % faster)
 
@@ -499,7 +499,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
     // The residual stream: fp32 `h` in F32 mode (and for the fused-LN variant, whose kernel reads it), added in the GEMM
     // epilogue. In the bf16 modes only its split planes exist: k_layernorm adds hi + lo to the GEMM output it normalises
     // and writes planes only, so neither kernel touches an fp32 copy (31 MB less HBM traffic per LayerNorm at B=256).
-    const bool h32 = !fast || c->fuse_ln;
+    const bool h32 = !fast;
     auto big = [&](const Lin& L, const float* A32, int lda, const Planes& Ap, float* C, int ldc, const Planes& Cp,
                    const float* add, int act, int rows) -> int {
         if (!fast) {
@@ -644,28 +644,6 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             g.ga = c->dp<float>(w.ln[4]); g.ba = c->dp<float>(w.ln[5]); g.gb = nullptr; g.bb = nullptr;
             g.pervec = nullptr; g.stepvec = nullptr;
             RGN_LAUNCH(c, KC_ROWLN, s, launch_rowgemm(g, true, s));
-            continue;
-        }
-        if (fast && c->fuse_ln) {
-            // out_proj + residual + norm1 + folded cross-attention + norm2 in one kernel; then linear1 (GELU);
-            // then linear2 + residual + norm3 in one kernel. The pre-norm tensors never reach HBM.
-            GemmLnArgs g{};
-            g.Ahi = att_p.hi; g.Alo = att_p.lo; g.a_rows = att_p.rows;
-            g.Whi = c->dp<__bf16>(w.out.hi); g.Wlo = c->dp<__bf16>(w.out.lo);
-            g.bias = c->dp<float>(w.out.b);
-            g.resid = h; g.out = h; g.ohi = h_p.hi; g.olo = h_p.lo; g.o_rows = h_p.rows;
-            g.M = M; g.Kp = w.out.Kp;
-            g.ga = c->dp<float>(w.ln[0]); g.ba = c->dp<float>(w.ln[1]); g.gb = c->dp<float>(w.ln[2]); g.bb = c->dp<float>(w.ln[3]);
-            g.pervec = per_sample; g.ldper = Ld; g.stepvec = step_vec; g.ldstep = Ld; g.d_step = c->d_step; g.Tq = dm.Tq;
-            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm_ln(g, x3, s));
-            if ((rc = big(w.ff1, h, d, h_p, nullptr, c->ff, ffn_p, nullptr, 1, M))) return rc;
-            g.Ahi = ffn_p.hi; g.Alo = ffn_p.lo; g.a_rows = ffn_p.rows;
-            g.Whi = c->dp<__bf16>(w.ff2.hi); g.Wlo = c->dp<__bf16>(w.ff2.lo);
-            g.bias = c->dp<float>(w.ff2.b);
-            g.Kp = w.ff2.Kp;
-            g.ga = c->dp<float>(w.ln[4]); g.ba = c->dp<float>(w.ln[5]); g.gb = nullptr; g.bb = nullptr;
-            g.pervec = nullptr; g.stepvec = nullptr;
-            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm_ln(g, x3, s));
             continue;
         }
         if ((rc = big(w.out, att, d, att_p, tmp, d, none, h32 ? h : nullptr, 0, M))) return rc;
@@ -1075,8 +1053,6 @@ int rgn_finalize_weights(rgn_handle h) {
         RGN_HIP(c, hipMemset(c->ffn_lo, 0, M * ffp * 2));
         RGN_HIP(c, configure_gemm_x3());
         // measured slower than GEMM + k_layernorm at B=256 (heavy epilogue, 64-row tiles): opt-in only
-        c->fuse_ln = gemm_ln_supported(d) && getenv("REGENNET_FUSED_LN") != nullptr;
-        if (c->fuse_ln) RGN_HIP(c, configure_gemm_ln());
         c->attn_x3 = attn_x3_supported(c->Tq, d / c->H);
         if (c->attn_x3) {
             c->Tqp = (c->Tq + 31) / 32 * 32;
@@ -1287,6 +1263,7 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
     sp.mode = 0;
     sp.guided = guided != 0;
     sp.clip = clip_denoised != 0;
+    sp.const_noise = c->const_noise;
     RGN_HIP(c, hipMemcpyAsync(c->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
     RGN_HIP(c, hipMemcpyAsync(c->d_step, &first_index, sizeof(int), hipMemcpyHostToDevice, s));
     RGN_HIP(c, hipMemsetAsync(c->d_step + 4, 0, (size_t)(1 + c->cfg.max_batch) * sizeof(int), s));   // k_update's ticket counters (clean even after an aborted call)
@@ -1364,6 +1341,12 @@ int rgn_set_x3_tail(rgn_handle h, int32_t tail_steps) {
     if (!h) return RGN_ERR_INVALID_ARG;
     if (tail_steps < -1) return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_x3_tail: tail_steps < -1");
     h->x3_tail = tail_steps;
+    return RGN_OK;
+}
+
+int rgn_set_const_noise(rgn_handle h, int32_t on) {
+    if (!h) return RGN_ERR_INVALID_ARG;
+    h->const_noise = on != 0;
     return RGN_OK;
 }
 

@@ -51,7 +51,7 @@ struct SampleParams {
     int32_t mode;             // 0: sampler update, 1: output only (rgn_denoise)
     int32_t guided;
     int32_t clip;             // clamp pred_xstart to [-1,1]
-    int32_t pad;
+    int32_t const_noise;      // p_sample's const_noise: every motion takes motion 0's per-step draw
 };
 
 struct GemmArgs {
@@ -110,25 +110,6 @@ hipError_t launch_qkv_attn(const QkvAttnArgs& g, bool x3, hipStream_t s);
 bool qkv_attn_long_supported(int Tq, int dh, int d);
 hipError_t configure_qkv_attn_long();
 hipError_t launch_qkv_attn_long(const QkvAttnArgs& g, hipStream_t s);
-
-// Row-complete GEMM + fused residual LayerNorm(s) (rgn_gemm_ln.hip); N is fixed to 512.
-struct GemmLnArgs {
-    const __bf16* Ahi; const __bf16* Alo; int a_rows;   // activation planes [Kp/32][a_rows][32]
-    const __bf16* Whi; const __bf16* Wlo;               // weight planes [Kp/32][512][32]
-    const float* bias;
-    const float* resid;                                 // fp32 residual [M,512] (may alias out)
-    float* out;                                         // fp32 result [M,512]
-    __bf16* ohi; __bf16* olo; int o_rows;               // split planes of the result (K32-blocked), optional
-    int M, Kp;
-    const float *ga, *ba;                               // LayerNorm a
-    const float *gb, *bb;                               // LayerNorm b (nullptr: single norm)
-    const float* pervec; int ldper;                     // + pervec[(row / Tq) * ldper + n]   (nullable)
-    const float* stepvec; int ldstep; const int* d_step;   // + stepvec[(*d_step) * ldstep + n] (nullable)
-    int Tq;
-};
-bool gemm_ln_supported(int N);
-hipError_t configure_gemm_ln();
-hipError_t launch_gemm_ln(const GemmLnArgs& g, bool x3, hipStream_t s);
 
 // Row-complete plain-bf16 GEMM with the layer tail fused (rgn_rowgemm.hip): 64 complete rows x 512 columns per workgroup,
 // activation tile resident in LDS, weights streamed into registers.

@@ -902,10 +902,11 @@ __global__ __launch_bounds__(256) void k_update(const float* __restrict__ x0tok,
             if (sp.mode == 0) {
                 const float xv = sp.x[o];
                 float eps;
+                const int bn = sp.const_noise ? 0 : b;              // const_noise: motion 0's draw for every motion (gaussian_diffusion.py:546-547)
                 if (sp.noise)
-                    eps = sp.noise[(size_t)(sp.first_index - step) * dm.B * FT + o];
+                    eps = sp.noise[(size_t)(sp.first_index - step) * dm.B * FT + (size_t)bn * FT + (size_t)f * dm.T + t];
                 else
-                    eps = philox_normal(sp.seed, sp.sample_offset + b, (uint32_t)step, (uint32_t)(f * 4096 + t));   // (feature, frame): independent of T
+                    eps = philox_normal(sp.seed, sp.sample_offset + bn, (uint32_t)step, (uint32_t)(f * 4096 + t));   // (feature, frame): independent of T
                 if (sp.sampler == 0) {
                     const float mean = __fadd_rn(__fmul_rn(k.c1, x0), __fmul_rn(k.c2, xv));
                     nv = __fadd_rn(mean, __fmul_rn(k.sig_ddpm, eps));

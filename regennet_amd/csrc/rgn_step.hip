@@ -224,6 +224,7 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
         const bool valid = m < g.M;
         const int bl = (valid ? m : g.M - 1) / g.T, t = (valid ? m : g.M - 1) - bl * g.T, b = g.s0 + bl;
         const size_t FT = (size_t)g.F * g.T;
+        const int bn = sp.const_noise ? 0 : b;                          // const_noise: motion 0's draw for every motion
         char* ximg = smem + ST_XIMG;
         const int q = lane & 3, tq = t - q;                            // frame of the quad's first lane, if the quad is a run
         const bool run4 = valid && (m0 + (lane | 3)) < g.M && tq >= 0 && (tq & 3) == 0 && tq + 3 < g.T;
@@ -238,9 +239,9 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
                 const float xv = sp.x[o];
                 float eps = eps_in;
                 if (sp.noise)
-                    eps = sp.noise[(size_t)(sp.first_index - step) * g.B * FT + o];
+                    eps = sp.noise[(size_t)(sp.first_index - step) * g.B * FT + (size_t)bn * FT + (size_t)f * g.T + t];
                 else if (!quads)
-                    eps = philox_normal(sp.seed, sp.sample_offset + b, (uint32_t)step, (uint32_t)(f * 4096 + t));
+                    eps = philox_normal(sp.seed, sp.sample_offset + bn, (uint32_t)step, (uint32_t)(f * 4096 + t));
                 if (sp.sampler == 0) {
                     const float mean = __fadd_rn(__fmul_rn(k.c1, x0), __fmul_rn(k.c2, xv));
                     nv = __fadd_rn(mean, __fmul_rn(k.sig_ddpm, eps));
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
             if (quads) {                                               // wave-uniform
                 // this lane: the four normals of (feature 4 fg + q, frames tq .. tq + 3), exactly philox_normal's arithmetic
                 const uint32_t elem = (uint32_t)((4 * fg + q) * 4096 + tq);
-                const unsigned long long sample = sp.sample_offset + b;
+                const unsigned long long sample = sp.sample_offset + bn;
                 uint32_t r[4];
                 philox4x32_10(elem >> 2, (uint32_t)step, (uint32_t)sample, (uint32_t)(sample >> 32), (uint32_t)sp.seed, (uint32_t)(sp.seed >> 32), r);
                 float n4[4];

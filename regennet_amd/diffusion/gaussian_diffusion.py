@@ -9,6 +9,7 @@ ddim_sample_loop :891-909) so sample/cgenerate.py:121-135 and eval/a2m/stgcn_eva
 """
 import enum
 import math
+import sys
 from copy import deepcopy
 
 import numpy as np
@@ -198,11 +199,17 @@ class GaussianDiffusion:
         for name, val in (("denoised_fn", denoised_fn), ("cond_fn", cond_fn)):
             if val is not None:
                 raise NotImplementedError(f"{name} is never set on the sampling path (cgenerate.py:124-135) and is unsupported")
-        if randomize_class or cond_fn_with_grad or const_noise:
-            raise NotImplementedError("randomize_class / cond_fn_with_grad / const_noise are unsupported on the HIP path")
+        if cond_fn_with_grad:
+            raise NotImplementedError("cond_fn_with_grad selects the classifier-guidance sampler (p_sample_with_grad): outside the hot path")
         bind = _engine_of(model)
         assert isinstance(shape, (tuple, list))
         B = int(shape[0])
+        if randomize_class and model_kwargs is not None and "y" in model_kwargs:
+            # gaussian_diffusion.py:726-729 / 990-993 replace model_kwargs['y'] by random class ids before every step: the hook
+            # of the class-conditional image models this sampler came from. With CMDM (y is a dict, the model has no
+            # num_classes) that statement raises AttributeError in the reference, and so does its mirror here.
+            model_kwargs["y"] = th.randint(low=0, high=model.num_classes, size=model_kwargs["y"].shape,
+                                           device=model_kwargs["y"].device)
         y = (model_kwargs or {}).get("y", None)
         if y is None:
             raise KeyError("model_kwargs['y'] with 'cmotion' is required (gaussian_diffusion.py:317, cmdm.py:189)")
@@ -211,7 +218,7 @@ class GaussianDiffusion:
             # denoiser (cmdm.py:181): the fused engine loop does not read them, so these calls take the per-step API
             # (one HIP denoiser evaluation per step + torch elementwise glue) instead of being silently ignored
             yield from self._loop_per_step(sampler, model, shape, noise, clip_denoised, model_kwargs, progress, skip_timesteps,
-                                           init_image, eta, noise_tape)
+                                           init_image, eta, noise_tape, const_noise, seed, sample_offset)
             return
         assert len(shape) == 4, "shape must be (B, njoints, nfeats, T)"
         self._maybe_calibrate_tail(sampler, model, shape, y, eta)
@@ -244,6 +251,10 @@ class GaussianDiffusion:
             assert tape.shape[0] >= first + 1, "noise tape shorter than the number of steps"
         x0 = th.empty_like(img) if progressive else None
         chunk = 1 if progressive else (max(1, (first + 1) // 20) if progress else first + 1)
+        # The precision schedule's contract is the state after the LAST step; callers that look at every
+        # intermediate state (the progressive generators, dump_steps) get uniform split-bf16 arithmetic instead, so that each
+        # yielded state meets the 1e-3 bound like the reference's (gaussian_diffusion.py:731-742).
+        uniform = progressive and getattr(eng, "precision", "") == "bf16_x3tail"
         bar = None
         if progress:
             from tqdm.auto import tqdm
@@ -252,14 +263,21 @@ class GaussianDiffusion:
         while i >= 0:
             n = min(chunk, i + 1)
             tp = tape[first - i: first - i + n] if tape is not None else None
-            eng.sample_range(sampler, guided, eta, img, tp, seed, sample_offset, i, n, x0, use_graph, clip_denoised, stream)
+            if uniform:
+                eng.set_x3_tail(S)                      # (re-asserted per call: another bind may have reset the engine's knob)
+            eng.set_const_noise(bool(const_noise))
+            try:
+                eng.sample_range(sampler, guided, eta, img, tp, seed, sample_offset, i, n, x0, use_graph, clip_denoised, stream)
+            finally:
+                if const_noise:
+                    eng.set_const_noise(False)
             i -= n
             if bar is not None:
                 if dev.type == "cuda":
                     th.cuda.synchronize(dev)
                 bar.update(n)
-            if progressive:
-                yield {"sample": img, "pred_xstart": x0}
+            if progressive:         # fresh tensors per step, like the reference's out dict (a collecting caller keeps every state)
+                yield {"sample": img.clone(), "pred_xstart": x0.clone()}
         if bar is not None:
             bar.close()
         if not progressive:
@@ -273,6 +291,11 @@ class GaussianDiffusion:
         key = (id(self._sched_token), sampler, inner is not model, int(shape[3]), float(eta))
         if key not in inner._auto_tails:
             inner._auto_tails[key] = self.calibrate_x3_tail(model, shape, {"y": y}, sampler=sampler, eta=eta)
+            dev = getattr(self, "_last_calibration_dev", float("nan"))
+            print(f"[regennet_amd] precision schedule calibrated on this checkpoint: split-bf16 for the last {inner._auto_tails[key]} of "
+                  f"{self.num_timesteps} {sampler} steps{' (guided)' if inner is not model else ''}, T={int(shape[3])} "
+                  f"(max |dev| vs uniform split-bf16 on {min(int(shape[0]), 4)} motions: {dev:.1e}; override: x3_tail= / REGENNET_X3_TAIL)",
+                  file=sys.stderr, flush=True)
         inner._auto_tail = inner._auto_tails[key]
 
     def calibrate_x3_tail(self, model, shape, model_kwargs, sampler="ddpm", eta=0.0, tol=2.5e-4, max_batch=4, seed=1234, verbose=False):
@@ -286,7 +309,9 @@ class GaussianDiffusion:
         B, nb, S = int(shape[0]), min(int(shape[0]), max_batch), self.num_timesteps
         ys = {k: (v[:nb].contiguous() if th.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B else (v[:nb] if isinstance(v, (list, tuple)) and len(v) == B else v))
               for k, v in y.items()}
-        saved, self._calibrating = (inner.x3_tail, inner._auto_tail), True
+        saved, self._calibrating, self._last_calibration_dev = (inner.x3_tail, inner._auto_tail, inner.small_batch_rows), True, 0.0
+        if B * int(shape[3]) * (2 if inner is not model else 1) > 768:
+            inner.small_batch_rows = 0      # calibrate on the kernels the caller's batch will run (throughput engine), not the small-batch ones
         fn = self.p_sample_loop if sampler == "ddpm" else self.ddim_sample_loop
         kw = dict(clip_denoised=False, model_kwargs={"y": ys}, seed=seed)
         if sampler == "ddim":
@@ -305,25 +330,41 @@ class GaussianDiffusion:
                 dev = float((run(t) - ref).abs().max())
                 if verbose:
                     print(f"[calibrate_x3_tail] tail {t} of {S}: max |dev| vs uniform split-bf16 = {dev:.2e}")
+                self._last_calibration_dev = dev
                 if dev <= tol:
                     chosen = t
                     break
                 t *= 2
         finally:
-            inner.x3_tail, inner._auto_tail = saved
+            inner.x3_tail, inner._auto_tail, inner.small_batch_rows = saved
             self._calibrating = False
         return chosen
 
+    @staticmethod
+    def _keyed_normal(shape, seed, sample_offset, stream, dev):
+        """N(0,1) [B, ...] in which motion b's values depend on (seed, sample_offset + b, stream) only: the per-step API's
+        counterpart of the engine's Philox keying (results do not depend on how a batch is split over ranks or calls)."""
+        g = th.Generator(device="cpu")
+        rows = []
+        for b in range(int(shape[0])):
+            g.manual_seed(((int(seed) * 1000003 + int(sample_offset) + b) * 8191 + int(stream) + 1) % (2 ** 63 - 1))
+            rows.append(th.randn(tuple(shape[1:]), generator=g))
+        return th.stack(rows).to(dev)
+
     def _loop_per_step(self, sampler, model, shape, noise, clip_denoised, model_kwargs, progress, skip_timesteps, init_image,
-                       eta, noise_tape):
+                       eta, noise_tape, const_noise=False, seed=None, sample_offset=0):
         """The reference's own loop structure (gaussian_diffusion.py:696-742 / 959-1005) around p_sample / ddim_sample:
-        for model_kwargs the fused loop does not cover (inpainting_mask / inpainted_motion, y['uncond'])."""
+        for model_kwargs the fused loop does not cover (inpainting_mask / inpainted_motion, y['uncond']). Noise: the tape,
+        else — when a seed is given — draws keyed by (seed, global sample index, step), else torch's default generator
+        like the reference."""
         dev = next(model.parameters()).device
         B, S = int(shape[0]), self.num_timesteps
         if noise is not None:
             img = noise.to(dev)
         elif noise_tape is not None:
             img = noise_tape[0].to(device=dev, dtype=th.float32)
+        elif seed is not None:
+            img = self._keyed_normal(shape, seed, sample_offset, -1, dev)
         else:
             img = th.randn(*shape, device=dev)
         if skip_timesteps and init_image is None:
@@ -338,9 +379,12 @@ class GaussianDiffusion:
         for k, i in enumerate(indices):
             t = th.tensor([i] * B, device=dev)
             eps = None if noise_tape is None else noise_tape[1 + k].to(device=dev, dtype=th.float32)
+            if eps is None and seed is not None:
+                eps = self._keyed_normal(shape, seed, sample_offset, i, dev)
             with th.no_grad():
                 if sampler == "ddpm":
-                    out = self.p_sample(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs, _noise=eps)
+                    out = self.p_sample(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs, _noise=eps,
+                                        const_noise=const_noise)
                 else:
                     out = self.ddim_sample(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs, eta=eta, _noise=eps)
             yield out
@@ -367,7 +411,8 @@ class GaussianDiffusion:
                                   model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
                                   randomize_class=False, cond_fn_with_grad=False, const_noise=False, *, noise_tape=None,
                                   seed=None, use_graph=False, sample_offset=0):
-        """gaussian_diffusion.py:675-742: yields {'sample','pred_xstart'} after every step (tensors are reused)."""
+        """gaussian_diffusion.py:675-742: yields {'sample','pred_xstart'} after every step (fresh tensors per step; under the
+        default precision schedule the whole loop runs split-bf16 so that every yielded state is inside the 1e-3 bound)."""
         yield from self._loop("ddpm", model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, progress,
                               skip_timesteps, init_image, randomize_class, cond_fn_with_grad, const_noise, 0.0, noise_tape,
                               seed, use_graph, True, sample_offset)

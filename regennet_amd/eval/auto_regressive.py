@@ -12,7 +12,7 @@ index f * B + b, so the result does not depend on how the frames are grouped int
 
 Sequence truncation: the decoder is causal (cmdm.py:168-171,220-227) and only frame f of run f is kept, which depends on
 tokens 0..f alone at every diffusion step. A call that covers the frames [f0, f1) therefore samples sequences of f1 tokens
-instead of T (the model object is length-agnostic, like the reference's): about half the work over a whole evaluation. Noise
+(rounded up to a multiple of 16, which bounds the number of per-length engines) instead of T (the model object is length-agnostic, like the reference's): about half the work over a whole evaluation. Noise
 is keyed by (sample, step, feature, frame), independent of the sequence length, so truncation does not change a bit either.
 """
 import torch as th
@@ -76,7 +76,9 @@ def sample_auto_regressive(sample_fn, model, shape, model_kwargs, setting="cmdm"
     for f0 in range(0, T, frames_per_call):
         f1 = min(T, f0 + frames_per_call)
         n = f1 - f0
-        Tc = f1 if truncate else T
+        # lengths in steps of 16 (extra tokens are harmless under the causal mask): at most ceil(T / 16) distinct engines
+        # however the frames are grouped, below the model's per-length engine cache (CMDM.MAX_ENGINES)
+        Tc = min(T, -(-f1 // 16) * 16) if truncate else T
         yy = _expand_y(y, B, f0, f1, cm_full, Tc)
         kw = dict(sample_kw)
         if noise_tapes is not None:

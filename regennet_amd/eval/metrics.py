@@ -100,3 +100,11 @@ class Evaluation:
                 metrics[f"fid_{key}"] = float(calculate_fid(gtstats, computedfeats[key]["stats"]))
             metrics_all[sets] = metrics
         return {f"{key}_{sets}": metrics_all[sets][key] for sets in ["train", "test"] for key in metrics_all[sets]}
+
+    def evaluate_acc(self, model, loaders, setting):
+        """evaluate.py:127-162 (the `acc_only` runs of stgcn_eval.py:200): recognition accuracy per loader and split only."""
+        out = {}
+        for sets in ["train", "test"]:
+            for key, loader_sets in loaders.items():
+                out[f"accuracy_{key}_{sets}"], _ = calculate_accuracy(model, loader_sets[sets], self.num_classes, self.model, self.device)
+        return out

@@ -136,10 +136,15 @@ class CMDM(nn.Module):
         self.precision = os.environ.get("REGENNET_PRECISION", kargs.get("precision", _lib.DEFAULT_PRECISION))
         # precision schedule: split-bf16 for the last x3_tail loop indices of a sampling loop (None: engine default rule;
         # "auto": measured on this checkpoint at the first sampling call, see diffusion.calibrate_x3_tail)
+        # A model that loads a checkpoint (load_state_dict) without an explicit x3_tail switches to "auto": the default rule was
+        # derived from synthetic weights, so on weights nobody validated the switch point is measured (a few small runs, once).
         self.x3_tail = kargs.get("x3_tail", None)
         # evaluations of at most this many token rows run the small-batch engine (None: engine default, 0: never)
         self.small_batch_rows = kargs.get("small_batch_rows", None)
         self._auto_tail, self._auto_tails = None, {}
+        # multi-GPU runs: rank `weights_src`'s packed blob is broadcast (one RCCL collective) into EVERY engine this model
+        # builds — also the ones built later for another length, a larger batch or after an eviction (None: single process)
+        self.weights_src = None
         self._engine = None
         self._engines = {}
         self._engine_stale = True
@@ -154,6 +159,9 @@ class CMDM(nn.Module):
 
     def load_state_dict(self, state_dict, strict=True):
         self._engine_stale = True
+        self._auto_tail, self._auto_tails = None, {}
+        if self.x3_tail is None and "REGENNET_X3_TAIL" not in os.environ:
+            self.x3_tail = "auto"                   # measured at the first sampling call per (schedule, sampler, guidance, T)
         return super().load_state_dict(state_dict, strict=strict)
 
     def _apply(self, fn, *a, **k):
@@ -212,6 +220,8 @@ class CMDM(nn.Module):
                     continue
                 eng.load_weight(k, v.detach().float().cpu().numpy())
             eng.finalize()
+            if self.weights_src is not None:
+                dist_util.broadcast_engine_weights(eng, dev, int(self.weights_src))
         self._engines[T] = eng                                # (re)inserted last = most recently used
         if eng is not self._engine:
             self._engine, self._cond_key, self._keep = eng, None, None
@@ -248,10 +258,12 @@ class CMDM(nn.Module):
             return eng, guided, dev
         cm_d = cm.to(device=dev, dtype=torch.float32).contiguous()
         if action is not None:
-            action_d = action.to(device=dev).reshape(B, -1)[:, 0].to(torch.int64).contiguous()
-            lo, hi = int(action_d.min()), int(action_d.max())       # EmbedAction indexes a [num_actions, d] table (cmdm.py:363-365)
-            if lo < 0 or hi >= self.num_actions:
-                raise IndexError(f"y['action'] holds ids in [{lo}, {hi}] but the model has {self.num_actions} actions")
+            # EmbedAction indexes a [num_actions, d] table (cmdm.py:363-365): validated on the host copy when there is one,
+            # otherwise with ONE blocking read (the per-step API caches the bind, so not per step)
+            a0 = action.reshape(B, -1)[:, 0]
+            if bool(((a0 < 0) | (a0 >= self.num_actions)).any()):
+                raise IndexError(f"y['action'] holds ids in [{int(a0.min())}, {int(a0.max())}] but the model has {self.num_actions} actions")
+            action_d = a0.to(device=dev, dtype=torch.int64).contiguous()
         else:
             action_d = None
         text_d = scale_d = None
@@ -275,7 +287,7 @@ class CMDM(nn.Module):
         assert (njoints, nfeats) == (self.njoints, self.nfeats)
         eng, _, dev = self._rgn_bind(bs, y, guided=_guided, T=nframes, cache=True)
         assert tuple(timesteps.shape) == (bs,)
-        if timesteps.numel() and (int(timesteps.min()) < 0 or int(timesteps.max()) >= self.sequence_pos_encoder.pe.shape[0]):
+        if timesteps.numel() and bool(((timesteps < 0) | (timesteps >= self.sequence_pos_encoder.pe.shape[0])).any()):
             raise IndexError("timesteps outside the positional table (TimestepEmbedder, cmdm.py:298)")
         xc = x.to(device=dev, dtype=torch.float32).contiguous()
         tc = timesteps.to(device=dev, dtype=torch.int64).contiguous()

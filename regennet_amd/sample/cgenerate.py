@@ -74,8 +74,8 @@ def main(argv=None):
     Bl = hi - lo
     sample_fn = diffusion.p_sample_loop if not args.use_ddim else diffusion.ddim_sample_loop
     inner = model.model if isinstance(model, ClassifierFreeSampleModel) else model
+    inner.weights_src = 0 if world > 1 else None            # rank 0's packed blob -> every engine this model builds (one RCCL broadcast each)
     eng, _ = inner._get_engine(max(Bl, 1), n_frames)
-    dist_util.broadcast_engine_weights(eng, dev, 0)
     all_outputs, all_cmotions, time_all = [], [], 0.0
     for rep_i in range(args.num_repetitions):
         if rank == 0:

@@ -185,7 +185,9 @@ def make_stgcn_state_dict(A, num_class=26, in_channels=12, num_person=2, seed=0)
 
 def build_model(cfg, sd, resp="", precision=None, device="cuda:0", noise_schedule="cosine", sigma_small=True, x3_tail=None):
     """(model, diffusion) from regennet_amd for a synth config + checkpoint dict (reference key names): the same
-    constructor calls the reference factory makes (utils/model_util.py:66-117), for tests, bench.py and tools."""
+    constructor calls the reference factory makes (utils/model_util.py:66-117), for tests, bench.py and tools.
+    x3_tail=None here means the engine's default rule — it was derived on exactly these synthetic checkpoints (DESIGN.md §6);
+    a model that loads a checkpoint through the plain factory path measures its switch point instead ("auto")."""
     import torch
 
     from .diffusion import gaussian_diffusion as gd
@@ -202,6 +204,7 @@ def build_model(cfg, sd, resp="", precision=None, device="cuda:0", noise_schedul
                  emb_trans_dec=cfg.get("emb_trans_dec", False), wo_pos_emb=cfg.get("wo_pos_emb", False),
                  x3_tail=x3_tail, **kw)
     load_model_wo_clip(model, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.x3_tail = x3_tail
     model.to(device)
     model.eval()
     diffusion = SpacedDiffusion(use_timesteps=space_timesteps(1000, resp or [1000]),

@@ -1,0 +1,70 @@
+"""Randomised parity cases at odd shapes (shared by `pytest -m gpu` — tests/test_hip_parity.py runs a fixed set of seeds — and
+by the longer sweep `python tools/fuzz_parity.py [n] [seed]`).
+Random batch size, sequence length, ff width, guidance, sampler and engine on 2-layer d = 512 models. Two checks per case:
+(1) uniform split-bf16 arithmetic against the oracle (<= 1e-3): the split-bf16 kernels of both engines;
+(2) under the precision schedule with the first two loop iterations in the plain-bf16 phase: sample b of the batch against
+    the same sample drawn alone (same Philox key) - bit-identical in the small-batch engine, <= 5e-5 in the throughput
+    engine. This isolates indexing / tiling mistakes of the plain-bf16 kernels from their (by design larger) rounding, which on
+    such short schedules and shallow guided models is not damped below 1e-3.
+Guidance scales stay <= 2.5 (the reference's setting): on these random 2-layer emb_trans_dec models a scale of 3.5 amplifies ANY
+rounding difference - fp32 op order alone: 1e-4 against 9e-6 at scale 1.5, split-bf16: 2e-3 against 9e-5 - past the 1e-3 bound."""
+import numpy as np
+import torch
+
+
+def run_case(case, rng):
+    """One random case drawn from `rng`; returns (ok, description, err_vs_oracle, row_deviation)."""
+    from oracle import regennet_oracle as orc
+    from regennet_amd import synth
+    from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    T = int(rng.choice([8, 17, 32, 33, 59, 60, 64, 65, 96, 127, 150, 160]))
+    etd = bool(rng.integers(0, 2)) and T < 160
+    B = int(rng.integers(1, 14))
+    ff = int(rng.choice([512, 1024]))
+    guided = bool(rng.integers(0, 2))
+    sampler = str(rng.choice(["ddpm", "ddim"]))
+    S = int(rng.integers(5, 9))
+    engine = str(rng.choice(["default", "throughput"]))
+    cfg = synth.get_config("ntu_action", layers=2, num_frames=T, ff_size=ff, emb_trans_dec=etd)
+    sd = synth.make_state_dict(cfg, seed=100 + case)
+    resp = f"ddim{S}" if sampler == "ddim" else str(S)
+    y = {"cmotion": synth.make_cmotion(cfg, B, seed=case), "action": synth.make_actions(cfg, B, seed=case + 1)}
+    if guided:
+        y["scale"] = np.linspace(1.0, 2.5, B).astype(np.float32)           # per-sample guidance scales (see the docstring)
+    yd = {k: torch.from_numpy(v).cuda() for k, v in y.items()}
+    tape = synth.make_noise_tape(cfg, B, S, seed=case + 2)
+    ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", resp), tape, {k: torch.from_numpy(v) for k, v in y.items()},
+                          mode=sampler, guided=guided).numpy()
+    # (1) split-bf16 throughout vs the oracle
+    model, diffusion = synth.build_model(cfg, sd, resp=resp, precision="bf16x3")
+    if engine == "throughput":
+        model.small_batch_rows = 0
+    fm = ClassifierFreeSampleModel(model) if guided else model
+    fn = diffusion.p_sample_loop if sampler == "ddpm" else diffusion.ddim_sample_loop
+    out = fn(fm, (B, 56, 6, T), clip_denoised=False, model_kwargs={"y": yd}, noise_tape=torch.from_numpy(tape))
+    err = float(np.abs(out.cpu().numpy() - ref).max())
+    for e in list(model._engines.values()):
+        e.close()
+    # (2) precision schedule: row consistency of the plain-bf16 kernels
+    model, diffusion = synth.build_model(cfg, sd, resp=resp, precision="bf16_x3tail", x3_tail=S - 2)
+    if engine == "throughput":
+        model.small_batch_rows = 0
+    fm = ClassifierFreeSampleModel(model) if guided else model
+    fn = diffusion.p_sample_loop if sampler == "ddpm" else diffusion.ddim_sample_loop
+    full = fn(fm, (B, 56, 6, T), clip_denoised=False, model_kwargs={"y": yd}, seed=7)
+    dev = 0.0
+    for bsel in sorted({0, B - 1, int(rng.integers(0, B))}):
+        yb = {k: v[bsel:bsel + 1].contiguous() for k, v in yd.items()}
+        one = fn(fm, (1, 56, 6, T), clip_denoised=False, model_kwargs={"y": yb}, seed=7, sample_offset=bsel)
+        dev = max(dev, float((full[bsel:bsel + 1] - one).abs().max()))
+    for e in list(model._engines.values()):
+        e.close()
+    rows = (2 if guided else 1) * B * (T + int(etd))
+    exact = engine == "default" and rows <= 768            # batch AND single run in the small-batch engine
+    mixed = engine == "default" and rows > 768             # batch: throughput kernels, single sample: small-batch engine -
+    #                                                        two different roundings of the plain-bf16 phase: not comparable
+    ok = err < 1e-3 and (mixed or (dev == 0.0 if exact else dev < 5e-5)) and bool(torch.isfinite(full).all())
+    desc = (f"case {case:2d} T={T:3d} etd={int(etd)} B={B} ff={ff} guided={int(guided)} {sampler} S={S} engine={engine}: "
+            f"x3 vs oracle {err:.2e} | row consistency {dev:.1e}"
+            f"{' (exact required)' if exact else (' (mixed engines: not compared)' if mixed else '')}")
+    return ok, desc, err, dev

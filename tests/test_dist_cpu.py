@@ -96,6 +96,9 @@ class FakeEngine:
     def set_x3_tail(self, n):
         self.knobs = dict(getattr(self, "knobs", {}), x3_tail=int(n))
 
+    def set_const_noise(self, on):
+        self.const_noise = bool(on)
+
     def set_schedule(self, tmap, tables, sched_id=None):
         self.schedule_id = sched_id
         self.calls.append("schedule")
@@ -172,3 +175,34 @@ def test_model_knobs_reach_the_engine(monkeypatch):
     model.x3_tail, model.small_batch_rows = 5, 0
     eng2, _dev = model._get_engine(2)
     assert eng2 is eng and eng.knobs == {"x3_tail": 5, "small_batch_rows": 0}
+
+
+# ---- bench.py launches its own ranks (the counterpart of the reference's rank bootstrap, utils/dist_util.py:20-42) ---------------
+def _run_bench(extra_env, *flags):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--engine-stub", "tests.test_dist_cpu:FakeEngine", "--config", "tiny",
+                        "--batch", "2", "--steps", "1", "--warmup", "0", "--respacing", "5", *flags],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=240)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stdout + p.stderr
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no torchrun environment re-launches itself as 2 ranks (gloo here, the engine stubbed at
+    the _lib.Engine seam) and reports the line for 2 ranks; the weight blob of rank 0 reaches rank 1 through the model's
+    per-engine broadcast."""
+    rc, line, log = _run_bench({}, "--gpus", "2")
+    assert rc == 0 and line is not None, log
+    assert line["n_gpus"] == 2 and line["rccl_world_size"] == 2 and line["backend"] == "gloo", line
+    assert line["devices"] == ["rank0:cpu", "rank1:cpu"] and line["config"]["global_batch"] == 4
+    assert line["data"].startswith("STUB ENGINE")                     # never mistaken for a measurement
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    rc, line, log = _run_bench({"WORLD_SIZE": "1", "RANK": "0"}, "--gpus", "2")
+    assert rc != 0 and line is None and "refusing" in log, log

@@ -105,3 +105,6 @@ def test_evaluation_pipeline_end_to_end(golden):
         assert abs(m[f"fid_gt_{sets}"]) < 1e-6 and m[f"fid_gen_{sets}"] > 0
         for key in ("accuracy", "diversity", "multimodality"):
             assert np.isfinite(m[f"{key}_gen_{sets}"])
+    acc = ev.evaluate_acc(type("M", (), {"cond_mode": "action"})(), loaders, "cmdm")       # evaluate.py:127-162 (acc_only runs)
+    assert sorted(acc) == sorted(f"accuracy_{k}_{s}" for k in ("gt", "gen") for s in ("train", "test"))
+    assert all(acc[k] == m[k] for k in acc)

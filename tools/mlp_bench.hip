@@ -1,11 +1,16 @@
-// Stand-alone micro-benchmark of the row-persistent layer-tail kernel (tools only; refcheck lives in the parity tests).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DRGN_ML_PROF=5] -I regennet_amd/csrc tools/mlp_bench.hip regennet_amd/csrc/rgn_mlp.hip -o tools/bin/mlp_bench
+// Stand-alone micro-benchmark + reference check of the row-persistent layer-tail kernel (tools only; the parity tests proper are
+// tests/test_hip_parity.py).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DRGN_ML_PROF=5] -I regennet_amd/csrc tools/mlp_bench.hip regennet_amd/csrc/rgn_mlp.hip -o tools/bin/mlp_bench
+//   mlp_bench [M] [iters] [check]      check = 1: compare the first and the last 64-row tile with an fp64 host evaluation of the
+//                                      same bf16 inputs (the kernel rounds h', the GELU'd hidden tile and its output to bf16)
 #include "rgn_internal.h"
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -15,18 +20,52 @@ namespace rgn { void ml_prof_read(long long* out); }
 #endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
+static float bf2f(uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+
 int main(int argc, char** argv) {
-    const int M = argc > 1 ? atoi(argv[1]) : 15360, iters = argc > 2 ? atoi(argv[2]) : 20, d = 512, ff = 1024, Tq = 60;
+    const int M = argc > 1 ? atoi(argv[1]) : 15360, iters = argc > 2 ? atoi(argv[2]) : 20, check = argc > 3 ? atoi(argv[3]) : 0;
+    const int d = 512, ff = 1024, Tq = 60;
     std::mt19937 rng(1);
-    std::uniform_int_distribution<int> U(0x3c00, 0x3eff);
-    auto bf = [&](size_t n) { std::vector<uint16_t> v(n); for (auto& x : v) x = (uint16_t)(U(rng) | ((rng() & 1) << 15)); void* p; CK(hipMalloc(&p, n * 2)); CK(hipMemcpy(p, v.data(), n * 2, hipMemcpyHostToDevice)); return (__bf16*)p; };
-    auto f32 = [&](size_t n, float s) { std::vector<float> v(n); std::uniform_real_distribution<float> R(-s, s); for (auto& x : v) x = R(rng); void* p; CK(hipMalloc(&p, n * 4)); CK(hipMemcpy(p, v.data(), n * 4, hipMemcpyHostToDevice)); return (float*)p; };
+    std::normal_distribution<float> N01(0.f, 1.f);
+    auto up = [&](const void* h, size_t bytes) { void* p; CK(hipMalloc(&p, bytes)); CK(hipMemcpy(p, h, bytes, hipMemcpyHostToDevice)); return p; };
+    // activations: natural [M][d] values (bf16-rounded), stored K32-blocked [d / 32][M][32]
+    auto act = [&](std::vector<float>& nat, float s) {
+        nat.resize((size_t)M * d);
+        std::vector<uint16_t> pl((size_t)M * d);
+        for (int m = 0; m < M; ++m)
+            for (int k = 0; k < d; ++k) {
+                const uint16_t b = f2bf(s * N01(rng));
+                nat[(size_t)m * d + k] = bf2f(b);
+                pl[((size_t)(k / 32) * M + m) * 32 + k % 32] = b;
+            }
+        return (__bf16*)up(pl.data(), pl.size() * 2);
+    };
+    // weights: natural [N][K] values (bf16-rounded), stored in fragment order [K / 32][N / 32][2][64][8] (rgn_api.cpp pack_linear)
+    auto wgt = [&](std::vector<float>& nat, int N, int K, float gain) {
+        nat.resize((size_t)N * K);
+        std::vector<uint16_t> fr((size_t)N * K);
+        const size_t nb = N / 32;
+        for (int n = 0; n < N; ++n)
+            for (int k = 0; k < K; ++k) {
+                const uint16_t b = f2bf(gain / std::sqrt((float)K) * N01(rng));
+                nat[(size_t)n * K + k] = bf2f(b);
+                const size_t kt = k / 32, ks = (k % 32) / 16, lane = 32 * ((k % 16) / 8) + n % 32;
+                fr[(((kt * nb + n / 32) * 2 + ks) * 64 + lane) * 8 + k % 8] = b;
+            }
+        return (__bf16*)up(fr.data(), fr.size() * 2);
+    };
+    auto vecf = [&](std::vector<float>& v, size_t n, float mean, float s) { v.resize(n); for (auto& x : v) x = mean + s * N01(rng); return (float*)up(v.data(), n * 4); };
+    std::vector<float> att, h, Wo, W1, W2, bo, bf1, bf2, g1, b1, g2, b2, g3, b3, per, stepv;
     MlpArgs g{};
-    g.att = bf((size_t)M * d); g.h = bf((size_t)M * d); g.out = bf((size_t)M * d); g.rows = M; g.M = M;
-    g.Wo = bf((size_t)d * d); g.W1 = bf((size_t)ff * d); g.W2 = bf((size_t)d * ff);
-    g.bo = f32(d, 0.1f); g.bf1 = f32(ff, 0.1f); g.bf2 = f32(d, 0.1f);
-    g.g1 = f32(d, 1.f); g.b1 = f32(d, .1f); g.g2 = f32(d, 1.f); g.b2 = f32(d, .1f); g.g3 = f32(d, 1.f); g.b3 = f32(d, .1f);
-    g.pervec = f32((size_t)(M / Tq + 1) * d, 1.f); g.ldper = d; g.stepvec = f32(d, 1.f); g.ldstep = d; g.Tq = Tq;
+    g.att = act(att, 1.f); g.h = act(h, 1.f); g.rows = M; g.M = M;
+    { void* p; CK(hipMalloc(&p, (size_t)M * d * 2)); CK(hipMemset(p, 0, (size_t)M * d * 2)); g.out = (__bf16*)p; }
+    g.Wo = wgt(Wo, d, d, 1.f); g.W1 = wgt(W1, ff, d, 1.2f); g.W2 = wgt(W2, d, ff, 1.2f);
+    g.bo = vecf(bo, d, 0.f, 0.05f); g.bf1 = vecf(bf1, ff, 0.f, 0.05f); g.bf2 = vecf(bf2, d, 0.f, 0.05f);
+    g.g1 = vecf(g1, d, 1.f, .1f); g.b1 = vecf(b1, d, 0.f, .1f); g.g2 = vecf(g2, d, 1.f, .1f); g.b2 = vecf(b2, d, 0.f, .1f);
+    g.g3 = vecf(g3, d, 1.f, .1f); g.b3 = vecf(b3, d, 0.f, .1f);
+    const int nsamp = (M + Tq - 1) / Tq;
+    g.pervec = vecf(per, (size_t)nsamp * d, 0.f, 0.5f); g.ldper = d; g.stepvec = vecf(stepv, d, 0.f, 0.5f); g.ldstep = d; g.Tq = Tq;
     int* ds; CK(hipMalloc(&ds, 4)); CK(hipMemset(ds, 0, 4)); g.d_step = ds;
     CK(configure_mlp());
     for (int i = 0; i < 3; ++i) CK(launch_mlp(g, nullptr));
@@ -38,9 +77,58 @@ int main(int argc, char** argv) {
     const double us = 1e3 * ms / iters, fl = 2.0 * M * (d * d + 2.0 * d * ff);
     printf("k_mlp M=%d: %.1f us  %.1f TF\n", M, us, fl / us * 1e-6);
 #ifdef RGN_ML_PROF
-    long long t[16]; ml_prof_read(t);
-    printf("  cycles: tile DMA + wait %lld | out_proj k-loop %lld | LN1+vec+LN2+image %lld | ffn (2 x (linear1, gelu, linear2)) %lld | LN3 + store %lld | total %lld\n",
-           t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
+    long long t[32]; ml_prof_read(t);
+    printf("  ticks: tile DMA + wait %lld | out_proj k-loop %lld | LN1+LN2+image %lld | ffn half 0 (linear1, gelu, linear2) %lld | half 1 %lld | LN3 + store %lld | total %lld\n",
+           t[1] - t[0], t[2] - t[1], t[3] - t[2], t[6] - t[3], t[4] - t[6], t[5] - t[4], t[5] - t[0]);
+    printf("  half 0: linear1 loop %lld | gelu %lld | image + barrier %lld | linear2 loop %lld\n", t[7] - t[3], t[8] - t[7], t[9] - t[8], t[6] - t[9]);
 #endif
+    if (check) {
+        std::vector<uint16_t> out((size_t)M * d);
+        CK(hipMemcpy(out.data(), g.out, out.size() * 2, hipMemcpyDeviceToHost));
+        auto ln = [&](std::vector<double>& x, const std::vector<float>& ga, const std::vector<float>* be) {
+            double mu = 0, var = 0;
+            for (double v : x) mu += v;
+            mu /= x.size();
+            for (double v : x) var += (v - mu) * (v - mu);
+            const double r = 1.0 / std::sqrt(var / x.size() + 1e-5);
+            for (size_t i = 0; i < x.size(); ++i) x[i] = (x[i] - mu) * r * ga[i] + (be ? (*be)[i] : 0.0);
+        };
+        double worst = 0, sum = 0; size_t cnt = 0;
+        std::vector<int> rows;
+        for (int m = 0; m < 64 && m < M; ++m) rows.push_back(m);
+        for (int m = (M - 1) / 64 * 64; m < M; ++m) if (m >= 64) rows.push_back(m);
+        if (M > 4096) for (int m = 2048 + 37; m < 2048 + 37 + 64; ++m) rows.push_back(m);
+        for (int m : rows) {
+            std::vector<double> x(d), hp(d), hid(ff), y(d);
+            for (int n = 0; n < d; ++n) {
+                double a = bo[n] + h[(size_t)m * d + n];
+                for (int k = 0; k < d; ++k) a += (double)att[(size_t)m * d + k] * Wo[(size_t)n * d + k];
+                x[n] = a;
+            }
+            ln(x, g1, nullptr);
+            for (int n = 0; n < d; ++n) x[n] += b1[n] + stepv[n] + per[(size_t)(m / Tq) * d + n];
+            ln(x, g2, &b2);
+            for (int n = 0; n < d; ++n) hp[n] = bf2f(f2bf((float)x[n]));
+            for (int j = 0; j < ff; ++j) {
+                double a = bf1[j];
+                for (int k = 0; k < d; ++k) a += hp[k] * W1[(size_t)j * d + k];
+                hid[j] = bf2f(f2bf((float)(0.5 * a * (1.0 + std::erf(a / std::sqrt(2.0))))));
+            }
+            for (int n = 0; n < d; ++n) {
+                double a = bf2[n] + hp[n];
+                for (int j = 0; j < ff; ++j) a += hid[j] * W2[(size_t)n * ff + j];
+                y[n] = a;
+            }
+            ln(y, g3, &b3);
+            for (int n = 0; n < d; ++n) {
+                const double got = bf2f(out[((size_t)(n / 32) * M + m) * 32 + n % 32]);
+                const double e = std::fabs(got - y[n]);
+                worst = e > worst ? e : worst; sum += e; ++cnt;
+            }
+        }
+        printf("  check (%zu rows vs fp64 host): max abs err %.3e, mean abs err %.3e  %s\n", rows.size(), worst, sum / cnt,
+               (worst < 6e-2 && sum / cnt < 6e-3) ? "OK" : "MISMATCH");
+        return (worst < 6e-2 && sum / cnt < 6e-3) ? 0 : 2;
+    }
     return 0;
 }
