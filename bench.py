@@ -306,12 +306,21 @@ def main(argv=None):
                         "matches rocprofv3 --kernel-trace durations, profiles/); the timed region replays 4-chain hipGraphs "
                         "in which kernels of different chains overlap",
                 "per_kernel": per_kernel}
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")   # HBM bytes per launch from the committed PMC passes
-        if os.path.exists(pmc):
-            with open(pmc) as fh:
-                pj = json.load(fh)
-            key = f"{a.config}_B{B}_{a.precision}_{'cfg' if a.guided else 'plain'}"
-            roof["traffic"] = pj.get(key, {}).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
+        # HBM bytes per launch of the dominant kernel: NOT measured by this run (counters need rocprofv3 passes of their own, the
+        # MI355X guide's recipe) - read from the newest committed PMC summary (tools/collect_pmc.sh + tools/summarize_pmc.py) and
+        # labelled as such
+        key = f"{a.config}_B{B}_{a.precision}_{'cfg' if a.guided else 'plain'}"
+        for name in ("r03_pmc_bench.json", "r02_pmc_bench.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc):
+                with open(pmc) as fh:
+                    rec = json.load(fh).get(key, {}).get(dom["kernel"], {})
+                if rec.get("hbm_bytes_per_launch"):
+                    roof["traffic"] = rec["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = (f"profiles/{name} [{key}][{dom['kernel']}]: FETCH_SIZE x 2 (gfx950) + WRITE_SIZE from separate "
+                                              "rocprofv3 --pmc passes of a committed earlier run of this command; not measured in this run")
+                    roof["mfma_util_pmc"] = rec.get("mfma_util")
+                    break
 
     if rank == 0:
         evals = S * (2 if a.guided else 1)
