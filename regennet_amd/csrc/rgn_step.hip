@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
+#include <utility>
 
 namespace rgn {
 
@@ -38,6 +39,13 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define RGN_AS1 __attribute__((address_space(1)))
 #define RGN_AS3 __attribute__((address_space(3)))
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... (the update loop's body is too large for `#pragma unroll` to be honoured,
+// and its prefetched operands must live in registers, i.e. be indexed by constants)
+template <int... Is, class F>
+__device__ __forceinline__ void st_static_for_seq(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void st_static_for(F&& f) { st_static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
 
 namespace {
 constexpr int ST_BM = 64, ST_NT = 512, ST_PF = 3;
@@ -229,14 +237,23 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
         const int q = lane & 3, tq = t - q;                            // frame of the quad's first lane, if the quad is a run
         const bool run4 = valid && (m0 + (lane | 3)) < g.M && tq >= 0 && (tq & 3) == 0 && tq + 3 < g.T;
         const bool quads = !sp.noise && !g.no_quads && __all(run4);
-        auto update = [&](int f, float eps_in) {
+        // the sampler state of this wave's NKX x 4 features, requested in ONE batch: inside the loop below every group of four paid
+        // its own memory round trip (11 dependent latencies per wave; without a noise tape nothing else in the loop reads memory)
+        float xpre[NKX][4];
+#pragma unroll
+        for (int it = 0; it < NKX; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = 4 * (wave + 8 * it) + j;
+                xpre[it][j] = (valid && f < g.F) ? sp.x[(size_t)b * FT + (size_t)f * g.T + t] : 0.f;
+            }
+        auto update = [&](int f, float eps_in, float xv) {
             float nv = 0.f;
             if (valid && f < g.F) {
                 float x0 = tile[lane * ST_XLD + f];
                 if (sp.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
                 const size_t o = (size_t)b * FT + (size_t)f * g.T + t;
                 if (sp.x0_out) sp.x0_out[o] = x0;
-                const float xv = sp.x[o];
                 float eps = eps_in;
                 if (sp.noise)
                     eps = sp.noise[(size_t)(sp.first_index - step) * g.B * FT + (size_t)bn * FT + (size_t)f * g.T + t];
@@ -256,7 +273,9 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
             const int r = lane, chunk = (f & 31) >> 3;
             *reinterpret_cast<__bf16*>(ximg + (f >> 5) * 4096 + r * 64 + ((chunk ^ ((r >> 2) & 3)) << 4) + (f & 7) * 2) = (__bf16)nv;
         };
-        for (int fg = wave; fg < NKX * 8; fg += 8) {                   // groups of 4 features
+        st_static_for<NKX>([&](auto IT) __attribute__((always_inline)) {   // groups of 4 features
+            constexpr int it = decltype(IT)::value;
+            const int fg = wave + 8 * it;
             float eps4[4] = {0.f, 0.f, 0.f, 0.f};
             if (quads) {                                               // wave-uniform
                 // this lane: the four normals of (feature 4 fg + q, frames tq .. tq + 3), exactly philox_normal's arithmetic
@@ -266,15 +285,7 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
                 philox4x32_10(elem >> 2, (uint32_t)step, (uint32_t)sample, (uint32_t)(sample >> 32), (uint32_t)sp.seed, (uint32_t)(sp.seed >> 32), r);
                 float n4[4];
 #pragma unroll
-                for (int pair = 0; pair < 2; ++pair) {
-                    const float u1 = ((r[2 * pair] >> 8) + 1u) * 5.9604644775390625e-08f;
-                    const float u2 = (r[2 * pair + 1] >> 8) * 5.9604644775390625e-08f;
-                    const float rad = sqrtf(-2.0f * logf(u1));
-                    float sn, cs;
-                    sincospif(2.0f * u2, &sn, &cs);
-                    n4[2 * pair] = rad * cs;
-                    n4[2 * pair + 1] = rad * sn;
-                }
+                for (int pair = 0; pair < 2; ++pair) box_muller(r[2 * pair], r[2 * pair + 1], n4[2 * pair], n4[2 * pair + 1]);
                 // transpose inside the quad: this lane (frame tq + q) needs, for feature 4 fg + j, element q of lane j's n4
                 auto pick = [&](auto jc) {                              // element q of lane jc's n4, broadcast inside the quad
                     constexpr int J = decltype(jc)::value;
@@ -292,13 +303,27 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
                 eps4[3] = pick(std::integral_constant<int, 3>{});
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) update(4 * fg + j, eps4[j]);
-        }
+            for (int j = 0; j < 4; ++j) update(4 * fg + j, eps4[j], xpre[it][j]);
+        });
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // ---- D: h' = x' . Wx'^T (+ c0 in the copy-out)
+    // ---- D: h' = x' . Wx'^T (+ c0 in the copy-out). The condition rows of the copy-out are requested NOW, ahead of the GEMM
+    //      (in the copy-out loop each piece waited for its own two loads)
+    f32x4 c0v[8][2];
+    {
+        const int r16 = lane >> 2, c = lane & 3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = wave * 8 + j, blk = p >> 2, r = (p & 3) * 16 + r16;
+            const int m = m0 + r < g.M ? m0 + r : g.M - 1;
+            const float* cp = g.c0 + (size_t)m * 512 + blk * 32 + c * 8;
+            c0v[j][0] = *reinterpret_cast<const f32x4*>(cp);
+            c0v[j][1] = *reinterpret_cast<const f32x4*>(cp + 4);
+        }
+    }
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -331,7 +356,7 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
             if (m < g.M) {
                 const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + blk * 4096 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
                 const float* cp = g.c0 + (size_t)m * 512 + blk * 32 + c * 8;
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(cp), a1 = *reinterpret_cast<const f32x4*>(cp + 4);
+                const f32x4 a0 = c0v[j][0], a1 = c0v[j][1];
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {

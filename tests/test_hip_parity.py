@@ -314,6 +314,11 @@ def test_philox_stream_properties():
     n = a.numel()
     assert abs(a.mean().item()) < 4 / n ** 0.5 and abs(a.var().item() - 1) < 0.02
     assert abs((a ** 3).mean().item()) < 0.05 and abs((a ** 4).mean().item() - 3) < 0.1
+    # Box-Muller on the hardware transcendentals (rgn_philox.h): tails and the independence of the (cos, sin) pair
+    flat = a.reshape(-1, 60)
+    assert abs((flat[:, 0::2] * flat[:, 1::2]).mean().item()) < 5e-3                       # adjacent frames = the two outputs of one pair
+    assert abs((a.abs() > 3).float().mean().item() - 2.6998e-3) < 3e-4 and a.abs().max().item() < 6.5
+    assert torch.isfinite(a).all()
     # sampling with Philox: same seed -> same samples; sharded == unsharded
     y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, 8)).cuda()}
     s1 = diffusion.p_sample_loop(model, (8, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y}, seed=77)
