@@ -301,6 +301,8 @@ def main(argv=None):
                 "avg_launch_us": dom["avg_us"], "launches_per_eval": dom["launches_per_eval"],
                 "algo_gflop_per_launch": dom["algo_gflop_per_launch"],
                 "event_bracket_overhead_us": round(1e3 * ovh_ms, 2),
+                "sustained_peak_note": "a pure v_mfma_f32_32x32x16_bf16 loop on all 1024 SIMDs sustains 1826 TFLOP/s on this pool (1.97 GHz at "
+                                       "1320 W; the sampling loop itself runs at 1.98 GHz / 1230 W): DESIGN.md 10.3. peak/frac use the guide's 2500",
                 "note": "achieved = algorithmic FLOPs of the class's launches / their summed duration; duration = HIP-event "
                         "bracket on the engine stream minus the calibrated empty-bracket latency (single-chain eager pass; "
                         "matches rocprofv3 --kernel-trace durations, profiles/); the timed region replays 4-chain hipGraphs "
