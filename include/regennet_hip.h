@@ -129,7 +129,9 @@ int rgn_denoise(rgn_handle h, const float* x_dev, const int64_t* t_dev, int32_t 
  *               (gaussian_diffusion.py:544,785) in loop order; NULL -> on-device Philox4x32-10
  *               keyed by (seed, global sample index = sample_offset + b, step i, element).
  *   x0_dev    : optional fp32 output, pred_xstart of the LAST executed step (NULL to skip).
- *   use_graph : replay a captured hipGraph of one step instead of launching kernels one by one.
+ *   use_graph : replay captured hipGraphs (10 loop iterations each) instead of launching kernels one by one. Honoured by the
+ *               throughput kernels; the small-batch engine (<= 768 token rows) launches eagerly either way, which is faster
+ *               there (one chain of short kernels; REGENNET_SB_GRAPH=1 forces graphs).
  *   clip_denoised : clamp pred_xstart to [-1,1] (process_xstart, gaussian_diffusion.py:366-372). */
 int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, float* x_dev,
                      const float* noise_dev, uint64_t seed, uint64_t sample_offset,

@@ -1305,7 +1305,12 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
         *out = ge;
         return RGN_OK;
     };
-    const bool graphs = use_graph && !c->prof;
+    // Graph replay is what the throughput engine needs (a step is 2-4 concurrent kernel chains the host could not feed: eager
+    // launches are 2x slower at B = 16). The small-batch engine is one chain of ~43 short kernels per step, and there every graph
+    // node costs ~0.4 us more than the same kernel launched from this loop (B = 1: 278 vs 261 ms per 1000 steps, B = 4: 351 vs 338,
+    // B = 12: 492 vs 487; the host needs ~150 ms per 1000 steps to issue them): it launches eagerly unless REGENNET_SB_GRAPH is set.
+    static const bool sb_graph = getenv("REGENNET_SB_GRAPH") != nullptr;
+    const bool graphs = use_graph && !c->prof && (sb_graph || !use_sb(c, dm.Bm * dm.Tq));
     const int multi = c->graph_steps;
     int k = 0;
     // Fused step boundaries (k_step) hand the next evaluation's input embedding over in the residual-stream planes and no

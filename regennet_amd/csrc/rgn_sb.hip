@@ -143,6 +143,12 @@ __global__ __launch_bounds__(256 * NP) void k_sb_gemm(SbArgs g) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) nrow[c] = min(n0 + c * 32 + l31, g.N - 1);
     const int m = m0 + (tid >> 3), nb = n0 + (tid & 7) * 4;          // this THREAD's outputs after the reduction: row m, columns nb + 32 c .. + 3
+    // the loop index of the sampling step (address of the per-step vector of the second norm): a scalar load, waited for here - as a
+    // vector load inside the staging below it put two dependent memory round trips in front of the LayerNorm phase
+    int step = 0;
+    if constexpr (PRE == 1) {
+        if (g.gb && g.stepvec) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(step) : "s"(g.d_step) : "memory");
+    }
 
     // ---- weight fragments of the first chunk: nothing depends on them until the MFMAs, so their L2 round trip overlaps
     //      the LayerNorm phase / the activation fragment loads
@@ -188,11 +194,23 @@ __global__ __launch_bounds__(256 * NP) void k_sb_gemm(SbArgs g) {
             mr[p] = m0 + w * 8 + p * 4 + rr;
             sb_ldvec(g.src + (unsigned)min(mr[p], g.M - 1) * SB_D, lc, x[p]);
         }
+        // the per-sample vectors of the second norm are requested now, with the rows (behind the first norm they were a third
+        // exposed round trip of this phase)
+        // (only in the smallest build - 32-row tiles, one column block, the B <= 2 regime where this phase is pure latency: the
+        //  64 live registers spill in the larger ones)
+        constexpr bool PV_EARLY = NP == 1 && NC == 1 && !X3;
+        float pv[2][4][8];
+        if constexpr (PV_EARLY) {
+            if (g.gb && g.pervec) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) sb_ldvec(g.pervec + (unsigned)(min(mr[p], g.M - 1) / g.Tq) * g.ldper, lc, pv[p]);
+            }
+        }
         // gamma / beta of both norms and the per-step vector: one LDS copy per workgroup (each lane reads 32 values of each;
         // as per-lane global loads they cost up to 160 VGPRs of live range and four redundant fetches per wave)
         float* vec = reinterpret_cast<float*>(smem + (size_t)(X3 ? 2 : 1) * 16 * ROWS * 32 * 2);   // [5][512]: ga, ba, gb, bb, stepvec
         if (tid < 128) {
-            const float* srcs[5] = {g.ga, g.ba, g.gb, g.bb, (g.gb && g.stepvec) ? g.stepvec + (size_t)(*g.d_step) * g.ldstep : nullptr};
+            const float* srcs[5] = {g.ga, g.ba, g.gb, g.bb, (g.gb && g.stepvec) ? g.stepvec + (size_t)step * g.ldstep : nullptr};
 #pragma unroll
             for (int k = 0; k < 5; ++k)
                 if (srcs[k]) *reinterpret_cast<f32x4*>(vec + k * SB_D + tid * 4) = *reinterpret_cast<const f32x4*>(srcs[k] + tid * 4);
@@ -218,12 +236,11 @@ __global__ __launch_bounds__(256 * NP) void k_sb_gemm(SbArgs g) {
             if (g.pervec) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
-                    float pv[4][8];
-                    sb_ldvec(g.pervec + (unsigned)(min(mr[p], g.M - 1) / g.Tq) * g.ldper, lc, pv);
+                    if constexpr (!PV_EARLY) sb_ldvec(g.pervec + (unsigned)(min(mr[p], g.M - 1) / g.Tq) * g.ldper, lc, pv[p]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) x[p][j][i] += pv[j][i];
+                        for (int i = 0; i < 8; ++i) x[p][j][i] += pv[p][j][i];
                 }
             }
 #pragma unroll
