@@ -77,10 +77,9 @@ int main(int argc, char** argv) {
     const double us = 1e3 * ms / iters, fl = 2.0 * M * (d * d + 2.0 * d * ff);
     printf("k_mlp M=%d: %.1f us  %.1f TF\n", M, us, fl / us * 1e-6);
 #ifdef RGN_ML_PROF
-    long long t[32]; ml_prof_read(t);
-    printf("  ticks: tile DMA + wait %lld | out_proj k-loop %lld | LN1+LN2+image %lld | ffn half 0 (linear1, gelu, linear2) %lld | half 1 %lld | LN3 + store %lld | total %lld\n",
-           t[1] - t[0], t[2] - t[1], t[3] - t[2], t[6] - t[3], t[4] - t[6], t[5] - t[4], t[5] - t[0]);
-    printf("  half 0: linear1 loop %lld | gelu %lld | image + barrier %lld | linear2 loop %lld\n", t[7] - t[3], t[8] - t[7], t[9] - t[8], t[6] - t[9]);
+    long long t[16]; ml_prof_read(t);
+    printf("  cycles of workgroup %d, wave 0 (s_memtime = shader clock): tile DMA + wait %lld | out_proj k-loop %lld | LN1+LN2+image %lld | ffn (2 x (linear1, gelu, linear2)) %lld | LN3 + store %lld | total %lld\n",
+           RGN_ML_PROF, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
 #endif
     if (check) {
         std::vector<uint16_t> out((size_t)M * d);
