@@ -85,6 +85,7 @@ struct rgn_ctx {
     float *xin = nullptr, *cmo_in = nullptr, *c0 = nullptr, *h = nullptr, *tmp = nullptr, *qkv = nullptr, *att = nullptr,
           *ffn = nullptr, *x0tok = nullptr, *pe_rows = nullptr, *emb1 = nullptr, *emb = nullptr, *call = nullptr,
           *condemb = nullptr, *scale = nullptr, *te_all = nullptr, *call_time = nullptr, *call_cond = nullptr, *sched_tmp = nullptr;
+    __bf16* c0h = nullptr;             // bf16 copy of c0 for the fused step boundary (k_step)
     __bf16 *xin_hi = nullptr, *xin_lo = nullptr, *h_hi = nullptr, *h_lo = nullptr, *att_hi = nullptr, *att_lo = nullptr,
            *ffn_hi = nullptr, *ffn_lo = nullptr;   // K32-blocked split planes (bf16 precision modes)
     __bf16 *q_hi = nullptr, *q_lo = nullptr, *k_hi = nullptr, *k_lo = nullptr, *vt_hi = nullptr, *vt_lo = nullptr;   // attention-ready planes
@@ -746,7 +747,7 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
             g.h = c->h_hi + row0 * 32; g.hout = c->h_hi + row0 * 32; g.rows = M; g.M = n * dm.Tq;
             g.Wout = c->dp<__bf16>(c->lin_out.fr); g.bout = c->dp<float>(c->lin_out.b); g.F = c->F; g.nb_out = (c->F + 31) / 32;
             g.Wx = c->dp<__bf16>(c->lin_x.fr); g.nkx = c->lin_x.Kp / 32;
-            g.c0 = c->c0 + row0 * c->d;
+            g.c0 = c->c0h + row0 * c->d;
             g.tab = c->d_tab; g.d_step = c->d_step; g.sp = c->d_sp;
             g.T = dm.T; g.B = dm.B; g.s0 = s_first; g.total_tiles = total_tiles; g.no_quads = c->step_no_quads;
             if (guided) { g.scale = c->scale; g.half = Mb; }  // x0 = x0_u + scale (x0_c - x0_u); rows [Mb, 2 Mb) are the unconditional half
@@ -1041,6 +1042,7 @@ int rgn_finalize_weights(rgn_handle h) {
         const size_t Fp = align_up((size_t)F, 32), ffp = align_up((size_t)ff, 32);
         if ((rc = ws_alloc(c, &c->xin_hi, M * Fp))) return rc;
         if ((rc = ws_alloc(c, &c->xin_lo, M * Fp))) return rc;
+        if ((rc = ws_alloc(c, &c->c0h, M * d))) return rc;
         if ((rc = ws_alloc(c, &c->h_hi, M * d))) return rc;
         if ((rc = ws_alloc(c, &c->h_lo, M * d))) return rc;
         if ((rc = ws_alloc(c, &c->att_hi, M * d))) return rc;
@@ -1182,6 +1184,7 @@ int rgn_set_condition(rgn_handle h, int32_t B, const float* cmotion, const int64
     RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, small_prec(c), s));
     if (!c->cfg.wo_pos_emb) RGN_LAUNCH(c, KC_EMBED, s, launch_add_pe(c->c0, c->dp<float>(c->off_pe), dm, s));
     RGN_HIP(c, hipMemcpyAsync(c->c0 + (size_t)B * dm.Tq * d, c->c0, (size_t)B * dm.Tq * d * sizeof(float), hipMemcpyDeviceToDevice, s));   // uncond half
+    if (c->c0h) RGN_LAUNCH(c, KC_EMBED, s, launch_cvt_bf16(c->c0, c->c0h, (size_t)2 * B * dm.Tq * d, s));   // k_step's copy (plain-bf16 phase only)
     // condition embedding rows: [0,B) conditional, [B,2B) what mask_cond(force_mask=True) leaves
     if (c->cfg.cond_mode == RGN_COND_ACTION) {
         RGN_LAUNCH(c, KC_EMBED, s, launch_cond_rows(c->dp<float>(c->off_action), action, c->condemb, B, d, c->cfg.num_actions, s));

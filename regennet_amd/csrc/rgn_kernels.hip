@@ -973,6 +973,24 @@ __global__ void k_fill_rows(float* __restrict__ out, const float* __restrict__ r
     const int r = blockIdx.x;
     for (int c = threadIdx.x; c < d; c += blockDim.x) out[(size_t)r * d + c] = row ? row[c] : 0.f;
 }
+// fp32 -> bf16 (round to nearest even), 8 values per thread: the bf16 copy of the hoisted condition rows k_step adds (rgn_step.hip)
+__global__ void k_cvt_bf16(const float* __restrict__ in, __bf16* __restrict__ out, long long n8) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    const f32x4 a = reinterpret_cast<const f32x4*>(in)[2 * i], b = reinterpret_cast<const f32x4*>(in)[2 * i + 1];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = (__bf16)a[e]; o[4 + e] = (__bf16)b[e]; }
+    reinterpret_cast<bf16x8*>(out)[i] = o;
+}
+hipError_t launch_cvt_bf16(const float* in, __bf16* out, size_t n, hipStream_t s) {   // n % 8 == 0
+    if (n == 0) return hipSuccess;
+    const long long n8 = (long long)(n / 8);
+    hipLaunchKernelGGL(k_cvt_bf16, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, in, out, n8);
+    return hipGetLastError();
+}
 hipError_t launch_fill_rows(float* out, const float* row, int rows, int d, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_fill_rows, dim3(rows), dim3(256), 0, s, out, row, rows, d);

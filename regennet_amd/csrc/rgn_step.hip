@@ -15,8 +15,9 @@
 //                B  x0 = acc + bias -> fp32 tile [64][XLD] (over the dead image)
 //                C  lanes = rows (consecutive frames of a sample: coalesced x accesses), waves stride the features:
 //                   sampler update in place, x' as bf16 into the K32-blocked image of GEMM 2's A operand (44 KiB)
-//                D  GEMM 2 (K = 352, N = 512) -> bf16 image (64 KiB, over the dead tile) -> + c0 in the coalesced copy-out
-//                   (the sum is rounded to bf16 twice: plain-bf16 phase only)
+//                D  GEMM 2 (K = 352, N = 512) -> bf16 image (64 KiB, over the dead tile) -> + c0 (a bf16 copy of the condition rows:
+//                   half the bytes of the largest operand of the step) in the coalesced copy-out
+//                   (the sum is rounded to bf16 twice, c0 once: plain-bf16 phase only)
 // GUIDED (cfg_sampler.py:22-31): a token's conditional / unconditional evaluations are rows m / m + half of the planes. One
 // launch over the conditional rows after the chains joined: A stages BOTH tiles (2 x 64 KiB) and runs the two output projections
 // in one pass over Wout (every weight fragment feeds both accumulator sets), B forms x0 = u + scale_b (c - u) with k_update's
@@ -311,16 +312,14 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
 
     // ---- D: h' = x' . Wx'^T (+ c0 in the copy-out). The condition rows of the copy-out are requested NOW, ahead of the GEMM
     //      (in the copy-out loop each piece waited for its own two loads)
-    f32x4 c0v[8][2];
+    bf16x8 c0v[8];
     {
         const int r16 = lane >> 2, c = lane & 3;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int p = wave * 8 + j, blk = p >> 2, r = (p & 3) * 16 + r16;
             const int m = m0 + r < g.M ? m0 + r : g.M - 1;
-            const float* cp = g.c0 + (size_t)m * 512 + blk * 32 + c * 8;
-            c0v[j][0] = *reinterpret_cast<const f32x4*>(cp);
-            c0v[j][1] = *reinterpret_cast<const f32x4*>(cp + 4);
+            c0v[j] = *reinterpret_cast<const bf16x8*>(g.c0 + (size_t)m * 512 + blk * 32 + c * 8);
         }
     }
     asm volatile("" ::: "memory");
@@ -355,24 +354,16 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
             const int m = m0 + r;
             if (m < g.M) {
                 const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + blk * 4096 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
-                const float* cp = g.c0 + (size_t)m * 512 + blk * 32 + c * 8;
-                const f32x4 a0 = c0v[j][0], a1 = c0v[j][1];
+                const __bf16* cp = g.c0 + (size_t)m * 512 + blk * 32 + c * 8;
                 bf16x8 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o[e] = (__bf16)((float)v[e] + a0[e]);
-                    o[4 + e] = (__bf16)((float)v[4 + e] + a1[e]);
-                }
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)v[e] + (float)c0v[j][e]);
                 *reinterpret_cast<bf16x8*>(g.hout + ((size_t)blk * g.rows + m) * 32 + c * 8) = o;
                 if constexpr (GUIDED) {   // the unconditional evaluation sees the same x', with its own condition part
-                    const float* cu = cp + (size_t)g.half * 512;
-                    const f32x4 u0 = *reinterpret_cast<const f32x4*>(cu), u1 = *reinterpret_cast<const f32x4*>(cu + 4);
+                    const bf16x8 cu = *reinterpret_cast<const bf16x8*>(cp + (size_t)g.half * 512);
                     bf16x8 ou;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ou[e] = (__bf16)((float)v[e] + u0[e]);
-                        ou[4 + e] = (__bf16)((float)v[4 + e] + u1[e]);
-                    }
+                    for (int e = 0; e < 8; ++e) ou[e] = (__bf16)((float)v[e] + (float)cu[e]);
                     *reinterpret_cast<bf16x8*>(g.hout + ((size_t)blk * g.rows + m + g.half) * 32 + c * 8) = ou;
                 }
             }
