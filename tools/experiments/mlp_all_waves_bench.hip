@@ -1,0 +1,35 @@
+// Needs rgn_mlp.hip instrumented with
+//   #define RGN_WT(i) { sched_barrier(0); if (blockIdx.x == RGN_ML_PROF && (threadIdx.x & 63) == 0) { unsigned id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+//                       g_ml_prof[(i) * 8 + (threadIdx.x >> 6)] = (i) == 7 ? (long long)id : (long long)__builtin_readcyclecounter(); } sched_barrier(0); }
+// (g_ml_prof[64]) with RGN_WT(0) / RGN_WT(1) + RGN_WT(7) around linear2(0) and RGN_WT(2) / RGN_WT(3) around linear1(1).
+#include "rgn_internal.h"
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+using namespace rgn;
+namespace rgn { void ml_prof_read(long long* out); }
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 15360, iters = 20, d = 512, ff = 1024, Tq = 60;
+    std::mt19937 rng(1);
+    std::uniform_int_distribution<int> U(0x3c00, 0x3eff);
+    auto bf = [&](size_t n) { std::vector<uint16_t> v(n); for (auto& x : v) x = (uint16_t)(U(rng) | ((rng() & 1) << 15)); void* p; CK(hipMalloc(&p, n * 2)); CK(hipMemcpy(p, v.data(), n * 2, hipMemcpyHostToDevice)); return (__bf16*)p; };
+    auto f32 = [&](size_t n, float s) { std::vector<float> v(n); std::uniform_real_distribution<float> R(-s, s); for (auto& x : v) x = R(rng); void* p; CK(hipMalloc(&p, n * 4)); CK(hipMemcpy(p, v.data(), n * 4, hipMemcpyHostToDevice)); return (float*)p; };
+    MlpArgs g{};
+    g.att = bf((size_t)M * d); g.h = bf((size_t)M * d); g.out = bf((size_t)M * d); g.rows = M; g.M = M;
+    g.Wo = bf((size_t)d * d); g.W1 = bf((size_t)ff * d); g.W2 = bf((size_t)d * ff);
+    g.bo = f32(d, 0.1f); g.bf1 = f32(ff, 0.1f); g.bf2 = f32(d, 0.1f);
+    g.g1 = f32(d, 1.f); g.b1 = f32(d, .1f); g.g2 = f32(d, 1.f); g.b2 = f32(d, .1f); g.g3 = f32(d, 1.f); g.b3 = f32(d, .1f);
+    g.pervec = f32((size_t)(M / Tq + 1) * d, 1.f); g.ldper = d; g.stepvec = f32(d, 1.f); g.ldstep = d; g.Tq = Tq;
+    int* ds; CK(hipMalloc(&ds, 4)); CK(hipMemset(ds, 0, 4)); g.d_step = ds;
+    CK(configure_mlp());
+    for (int i = 0; i < iters; ++i) CK(launch_mlp(g, nullptr));
+    CK(hipDeviceSynchronize());
+    long long t[64]; ml_prof_read(t);
+    for (int w = 0; w < 8; ++w)
+        printf("wave %d: hw_id %08llx (simd %lld wave_slot %lld cu %lld) | L2(0): start %lld end %lld (%lld) | L1(1): start %lld end %lld (%lld)\n", w, t[56 + w], (t[56 + w] >> 4) & 3, t[56 + w] & 15, (t[56 + w] >> 8) & 15,
+               t[w] - t[0], t[8 + w] - t[0], t[8 + w] - t[w], t[16 + w] - t[0], t[24 + w] - t[0], t[24 + w] - t[16 + w]);
+    return 0;
+}
