@@ -185,6 +185,7 @@ def main(argv=None):
         sys.exit(self_launch(a.gpus, argv))
 
     from regennet_amd import synth
+    from regennet_amd._lib import default_x3_tail
     from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
     from regennet_amd.utils import dist_util
 
@@ -330,7 +331,7 @@ def main(argv=None):
         value = a.steps * B * world / dt
         dtype = a.precision
         if a.precision == "bf16_x3tail":
-            tail = a.x3_tail if a.x3_tail is not None else min(S, -(-max(8, (S + 99) // 100) * 8 // min(8, cfg['layers'])))
+            tail = a.x3_tail if a.x3_tail is not None else default_x3_tail(S, cfg['layers'], bool(cfg.get('emb_trans_dec', False)))
             dtype = f"bf16 MFMA, fp32 accumulate/LayerNorm/softmax; split-bf16 (x3) for the last {min(tail, S)} of {S} steps"
         line = {
             "metric": "sampled motions/sec", "value": round(value, 3), "unit": "motions/s", "n_gpus": world,

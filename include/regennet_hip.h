@@ -139,7 +139,7 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
                      int32_t clip_denoised, void* stream);
 
 /* RGN_PREC_BF16_X3TAIL only: the last `tail_steps` loop indices (i < tail_steps) of every sampling loop run
- * split-bf16, all earlier ones plain bf16. -1 restores the default (max(8, ceil(S/100)), times 8/num_layers for models of fewer than 8 layers, at most S); 0 = plain bf16 throughout;
+ * split-bf16, all earlier ones plain bf16. -1 restores the default (max(5, ceil(S/200)) for models of >= 8 layers, max(8, ceil(S/100)) * 8/num_layers for shallower ones, at most S); 0 = plain bf16 throughout;
  * >= S = split-bf16 throughout. Why it is safe: p_sample scales the denoiser output by posterior_mean_coef1[t]
  * (gaussian_diffusion.py:265-276; 0.0016 at t=999, -> 1 at t=0), so early-step rounding is contracted away. */
 int rgn_set_x3_tail(rgn_handle h, int32_t tail_steps);

@@ -80,6 +80,17 @@ SYMBOLS.update({
 _lib = None
 
 
+def default_x3_tail(S, layers=8, etd=False):
+    """The engine's default precision-schedule switch point (rgn_api.cpp default_tail(), rgn_set_x3_tail(-1)): how many of
+    the last loop indices run split-bf16. Host-side mirror for reporting (bench.py's dtype string) and as the calibration's
+    starting point; the engine applies its own copy."""
+    if etd:
+        return S
+    if layers >= 8:
+        return min(S, max(5, -(-S // 200)))
+    return min(S, -(-max(8, -(-S // 100)) * 8 // max(1, layers)))
+
+
 def load():
     """Load the shared library (once) and type every entry point. Raises if it is not built."""
     global _lib

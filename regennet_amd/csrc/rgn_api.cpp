@@ -344,11 +344,17 @@ inline int default_tail(int S, int layers, bool etd = false) {
     // LayerNorm stack damps - the deeper the model the more. Measured with 10 (of 1000 DDPM) / 8 (of 100 DDIM + CFG) split
     // steps: 8 layers 6.7e-5 / 1.1e-4, 4 layers 1.6e-4, 2 layers 5.2e-4 / 8.3e-4; a 20-step DDIM schedule with 8 of them
     // split measured 3e-3 on a tiny 2-layer model (which the depth scaling now keeps split-bf16 throughout), while the 8-layer
-    // 20-step goldens measure 1.2e-4 with 5 and 1.0e-4 with all 20 steps split. So: max(8, S / 100) split-bf16 steps, scaled by
-    // 8 / layers for models shallower than the shipped 8 layers.
+    // 20-step goldens measure 1.2e-4 with 5 and 1.0e-4 with all 20 steps split. The 8-layer curves are flat from 5 split steps on
+    // (1.2e-4 / 1.2e-4 / 1.0e-4 / 1.2e-4 with 5 on the four sweeps vs 0.7 - 1.2e-4 with 10, 1.4 - 3.7e-4 with 2), the shallow
+    // models' are not (2 layers: 5 -> 1.2e-3 / 1.4e-3). So: max(5, S / 200) split-bf16 steps for models of >= 8 layers,
+    // max(8, S / 100) * 8 / layers for shallower ones.
+    if (layers >= 8) {
+        const int t8 = (S + 199) / 200 < 5 ? 5 : (S + 199) / 200;
+        return t8 < S ? t8 : S;
+    }
     int t = (S + 99) / 100;
     t = t < 8 ? 8 : t;
-    if (layers < 8) t = (t * 8 + layers - 1) / (layers > 0 ? layers : 1);
+    t = (t * 8 + layers - 1) / (layers > 0 ? layers : 1);
     return t < S ? t : S;
 }
 

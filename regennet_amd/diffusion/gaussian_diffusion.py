@@ -324,7 +324,8 @@ class GaussianDiffusion:
         try:
             ref = run(S)
             L = max(1, int(getattr(inner, "num_layers", 8)))
-            t = min(S, -(-max(8, (S + 99) // 100) * 8 // min(8, L)))
+            from .. import _lib
+            t = _lib.default_x3_tail(S, L, bool(getattr(inner, 'emb_trans_dec', False)))
             chosen = S
             while t < S:
                 dev = float((run(t) - ref).abs().max())

@@ -31,10 +31,8 @@ LOOPS = ["tiny_ddpm10", "tiny_ddim10_cfg", "tiny_add_ddpm1000", "tiny_text_ddim2
 
 def default_tail(S, layers=8):
     """rgn_api.cpp default_tail(): loop indices below this run split-bf16 under the precision schedule."""
-    t = max(8, (S + 99) // 100)
-    if layers < 8:
-        t = -(-t * 8 // layers)
-    return min(t, S)
+    from regennet_amd._lib import default_x3_tail
+    return default_x3_tail(S, layers)
 
 
 def _wrap(model, guided):
@@ -116,7 +114,7 @@ def test_precision_schedule_switch_point_sweep(golden, name, engine):
     S = int(g["S"])
     errs = {}
     shape = (int(g["B"]), cfg["njoints"], cfg["nfeats"], cfg["num_frames"])
-    for tail in (0, 2, 5, 10, 25, None, S):
+    for tail in (0, 2, 3, 5, 10, 25, None, S):
         model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision="bf16_x3tail/" + engine, x3_tail=tail)
         fm = _wrap(model, bool(g["guided"]))
         fn = diffusion.p_sample_loop if str(g["mode"]) == "ddpm" else diffusion.ddim_sample_loop
@@ -125,7 +123,7 @@ def test_precision_schedule_switch_point_sweep(golden, name, engine):
         model._engine.close()
     print(f"\n[x3-tail sweep] {name} {engine} (default tail {default_tail(S, cfg['layers'])}): " + ", ".join(f"{k}: {v:.2e}" for k, v in errs.items()))
     for tail, e in errs.items():
-        if tail is None or tail >= 8:
+        if tail is None or tail >= 5:
             assert e < 1e-3, (name, tail, e)
     assert errs[None] < 3.5e-4, errs        # the default keeps a 3x margin on these goldens
     # tail = S is the uniform split-bf16 mode
@@ -644,13 +642,13 @@ def test_bench_shape_against_the_oracle(precision, tail, tol):
 
 def test_bench_shape_bulk_phase_against_the_oracle():
     """The plain-bf16 bulk-phase kernels (k_mlp, k_qkv_attn_rs, k_step: 99 % of the timed region of bench.py) AT THE BENCH SHAPE
-    inside the 1e-3 bound: 16-step schedules at B=256 under the DEFAULT precision schedule = 8 plain-bf16 + 8 split-bf16
+    inside the 1e-3 bound: 16-step schedules at B=256 under the DEFAULT precision schedule = 11 plain-bf16 + 5 split-bf16
     steps, unguided DDPM (k_step) and guided DDIM (k_step<., true>), against the oracle on identical noise."""
     from oracle import regennet_oracle as orc
     from regennet_amd import synth
     from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
     B = 256
-    assert default_tail(16) == 8
+    assert default_tail(16) == 5
     for cfg_name, mode, resp, guided in (("ntu", "ddpm", "16", False), ("ntu_action", "ddim", "ddim16", True)):
         cfg = synth.get_config(cfg_name)
         sd = synth.make_state_dict(cfg, seed=0)
@@ -666,7 +664,7 @@ def test_bench_shape_bulk_phase_against_the_oracle():
         fn = diffusion.p_sample_loop if mode == "ddpm" else diffusion.ddim_sample_loop
         out = fn(fm, (B, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
         err = float(np.abs(out.cpu().numpy() - ref).max())
-        print(f"\n[bench shape, 8 bulk + 8 tail steps vs oracle] {cfg_name} {mode} guided={guided}: {err:.2e}")
+        print(f"\n[bench shape, 11 bulk + 5 tail steps vs oracle] {cfg_name} {mode} guided={guided}: {err:.2e}")
         assert err < 1e-3, (cfg_name, err)
         model._engine.close()
 
