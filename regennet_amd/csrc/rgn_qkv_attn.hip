@@ -23,6 +23,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 namespace rgn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -37,6 +39,12 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int QA_ROWS = 64, QA_NS = 2, QA_DH = 128, QA_WROWS = 3 * QA_DH, QA_NT = 512;
 
+#ifdef RGN_QA_LIFE
+__device__ long long g_qa_life[2048 * 3];   // tools only: wall_clock64() (10 ns) at start / first MFMA operands landed / end of every workgroup
+#define RGN_QL(i) if (tid == 0) g_qa_life[(blockIdx.y * gridDim.x + blockIdx.x) * 3 + i] = wall_clock64();
+#else
+#define RGN_QL(i)
+#endif
 #ifdef RGN_QA_PROF
 __device__ long long g_qa_prof[64];   // tools only: phase cycle stamps of one workgroup (wave 0)
 #define RGN_QT(i) if (blockIdx.x == RGN_QA_PROF && blockIdx.y == 0 && tid == 0) g_qa_prof[i] = clock64();
@@ -371,16 +379,24 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn(QkvAttnArgs g) {
 // vmcnt at loop back-edges and before the first LDS read behind a DMA).
 constexpr int QR_NK = 16, QR_WQ = 18;                          // weight fragment ring (6 fragments per k-step)
 constexpr int QR_DA = 4, QR_ARING = QR_DA + 1;                // activation pieces: QR_DA ahead (they must be in LDS one step early)
-constexpr int QR_ABUF = 96 * 1024;                                   // activation ring [2][128 rows][64 B], behind the exchange buffer
-__global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn_rs(QkvAttnArgs g, const __bf16* __restrict__ Wfr) {
+// NS = samples per workgroup (4 waves each). LDS: [exchange buffer NS x 48 KiB | activation ring [2][NS x 64 rows][64 B] | biases].
+// NS = 1 is the build for full launches: two INDEPENDENT 4-wave workgroups per CU (one wave each per SIMD) instead of one
+// 8-wave workgroup whose two waves per SIMD move through the phases in lockstep - the attention phase and the ring fill of one
+// workgroup (no MFMA work, no weight requests) then run under the other's k-loop.
+template <int NS> constexpr int qr_abuf() { return NS * 48 * 1024; }
+template <int NS> constexpr int qr_lds() { return qr_abuf<NS>() + 2 * NS * QA_ROWS * 64 + 8 * QA_WROWS * 4; }
+template <int NS>
+__global__ __launch_bounds__(NS * 256, 2 / NS) void k_qkv_attn_rs(QkvAttnArgs g, const __bf16* __restrict__ Wfr) {
+    constexpr int NT = NS * 256, STAGE = NS * QA_ROWS * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int b0 = xcd_affine(blockIdx.x, gridDim.x) * QA_NS, Tq = g.Tq, d = g.d;   // (gridDim.x = sample pairs; id = y * gridDim.x + x)
+    const int b0 = xcd_affine(blockIdx.x, gridDim.x) * NS, Tq = g.Tq, d = g.d;   // (gridDim.x = sample groups; id = y * gridDim.x + x)
     const int hpb = g.H / (int)gridDim.y, hd0 = blockIdx.y * hpb;
-    const int nsamp = g.Bm - b0 < QA_NS ? g.Bm - b0 : QA_NS;
+    const int nsamp = g.Bm - b0 < NS ? g.Bm - b0 : NS;
+    RGN_QL(0)
     constexpr int nb_all = 3 * 512 / 32;                             // d = 512 (launch_qkv_attn): compile-time weight offsets - as run-time
                                                                      // values the 96 k-step offsets of a head live in SGPRs and spill to VGPR lanes
 
@@ -403,12 +419,12 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn_rs(QkvAttnArgs g, const _
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) a_off[t][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
     }
-    float* bias_s = reinterpret_cast<float*>(smem + 4 * (QA_NS * QA_ROWS * 64 + QA_WROWS * 64));   // same place as in k_qkv_attn
-    for (int i = tid; i < hpb * QA_WROWS; i += QA_NT) {
+    char* abuf = smem + qr_abuf<NS>();
+    float* bias_s = reinterpret_cast<float*>(abuf + 2 * STAGE);
+    for (int i = tid; i < hpb * QA_WROWS; i += NT) {
         const int hh = i / QA_WROWS, r = i - hh * QA_WROWS;
         bias_s[i] = g.bias[(r >> 7) * d + (hd0 + hh) * QA_DH + (r & 127)];
     }
-    char* abuf = smem + QR_ABUF;
 
     for (int hd = hd0; hd < hd0 + hpb; ++hd) {
         unsigned wofs[3];                                            // fragment block of this wave's 32 columns of q / k / v (elements)
@@ -443,7 +459,7 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn_rs(QkvAttnArgs g, const _
         for (int kt = 0; kt < QR_NK; ++kt) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                            // k-block kt is in its stage; everyone left stage (kt + 1) % 2
-            const char* sb = abuf + (kt & 1) * 8192;
+            const char* sb = abuf + (kt & 1) * STAGE;
             bf16x8 af[2][2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -455,6 +471,9 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn_rs(QkvAttnArgs g, const _
 #pragma unroll
             for (int grp = 0; grp < 6; ++grp) {
                 const int ks = grp / 3, t = grp % 3, q = kt * 6 + grp;
+#ifdef RGN_QA_LIFE
+                if (kt == 0 && grp == 1 && hd == hd0) { RGN_QL(1) }
+#endif
 #pragma unroll
                 for (int ta = 0; ta < 2; ++ta) {
                     if (t < 2)     // q, k tiles transposed (lane = token, registers = dh)
@@ -465,7 +484,7 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn_rs(QkvAttnArgs g, const _
                 __builtin_amdgcn_sched_barrier(0);
                 if (q + QR_WQ < 6 * QR_NK) issue_q(q + QR_WQ);
                 if (grp == 2 && kt + 1 < QR_NK)                      // next k-block of the activation tile -> the other stage
-                    *reinterpret_cast<u32x4*>(abuf + ((kt + 1) & 1) * 8192 + tid * 16) = areg[(kt + 1) % QR_ARING];
+                    *reinterpret_cast<u32x4*>(abuf + ((kt + 1) & 1) * STAGE + tid * 16) = areg[(kt + 1) % QR_ARING];
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -476,6 +495,7 @@ __global__ __launch_bounds__(QA_NT, 1) void k_qkv_attn_rs(QkvAttnArgs g, const _
         __builtin_amdgcn_s_barrier();
         RGN_QT((hd - hd0) * 8 + 3)
     }
+    RGN_QL(2)
 }
 
 bool qkv_attn_supported(int Tq, int dh, int d) { return Tq <= QA_ROWS && dh == QA_DH && d % 32 == 0 && d / dh <= 8 && d >= 128; }
@@ -486,13 +506,23 @@ hipError_t configure_qkv_attn() {
     // (the plain-bf16 build is given the same allocation: its operand buffers, one plane each, alias its 64 KiB of stages)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, qa_lds(true));
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_rs), hipFuncAttributeMaxDynamicSharedMemorySize, qa_lds(true));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_rs<2>), hipFuncAttributeMaxDynamicSharedMemorySize, qr_lds<2>());
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_rs<1>), hipFuncAttributeMaxDynamicSharedMemorySize, qr_lds<1>());
 }
 hipError_t launch_qkv_attn(const QkvAttnArgs& g, bool x3, hipStream_t s) {
     if (!x3 && g.Wfr && g.Kp == 32 * QR_NK && g.d == 512 && (size_t)g.a_rows * g.Kp * 2 < (1ull << 31)) {   // plain-bf16 phase: weights streamed to registers (32-bit buffer offsets)
+        // One sample (4 waves) per workgroup, two workgroups per CU: same results bit for bit as the two-sample workgroup, 36.4 -> 35.4 us
+        // alone at B = 256, 28 -> 21 us at B = 128, and +3 - 4.5 % on the whole step (tools/qkv_attn_bench; REGENNET_QKV_NS=2 keeps the
+        // two-sample build for that comparison).
+        static const bool two = getenv("REGENNET_QKV_NS") && atoi(getenv("REGENNET_QKV_NS")) == 2;
+        static const int hs_env = getenv("REGENNET_QKV_HSPLIT") ? atoi(getenv("REGENNET_QKV_HSPLIT")) : 0;   // tools
         const int pairs = (g.Bm + QA_NS - 1) / QA_NS;
-        const int hsplit = (pairs * g.H <= 64) ? g.H : (g.H % 2 == 0 ? 2 : 1);
-        hipLaunchKernelGGL(k_qkv_attn_rs, dim3(pairs, hsplit), dim3(QA_NT), qa_lds(true), s, g, g.Wfr);
+        const int hsplit = (hs_env > 0 && g.H % hs_env == 0) ? hs_env : (pairs * g.H <= 64) ? g.H : (g.H % 2 == 0 ? 2 : 1);
+        if (!two)
+            hipLaunchKernelGGL(k_qkv_attn_rs<1>, dim3(g.Bm, hsplit), dim3(256), qr_lds<1>(), s, g, g.Wfr);
+        else
+            hipLaunchKernelGGL(k_qkv_attn_rs<2>, dim3(pairs, hsplit), dim3(512), qr_lds<2>(), s, g, g.Wfr);
         return hipGetLastError();
     }
     // heads per workgroup: half of them (the weight stream per sample is what bounds the kernel), but one head each while
@@ -507,6 +537,9 @@ hipError_t launch_qkv_attn(const QkvAttnArgs& g, bool x3, hipStream_t s) {
     return hipGetLastError();
 }
 
+#ifdef RGN_QA_LIFE
+void qa_life_read(long long* out, int n) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qa_life), sizeof(long long) * n); }
+#endif
 #ifdef RGN_QA_PROF
 void qa_prof_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qa_prof), sizeof(long long) * 64); }
 #endif
