@@ -306,7 +306,7 @@ def main(argv=None):
                                        "1320 W; the sampling loop itself runs at 1.98 GHz / 1230 W): DESIGN.md 10.3. peak/frac use the guide's 2500",
                 "note": "achieved = algorithmic FLOPs of the class's launches / their summed duration; duration = HIP-event "
                         "bracket on the engine stream minus the calibrated empty-bracket latency (single-chain eager pass; "
-                        "matches rocprofv3 --kernel-trace durations, profiles/); the timed region replays 4-chain hipGraphs "
+                        "matches rocprofv3 --kernel-trace durations, profiles/); the timed region replays multi-chain hipGraphs "
                         "in which kernels of different chains overlap",
                 "per_kernel": per_kernel}
         # HBM bytes per launch of the dominant kernel: NOT measured by this run (counters need rocprofv3 passes of their own, the
