@@ -933,3 +933,34 @@ def test_auto_regressive_grouping_invariance_with_device_rng():
         assert torch.equal(out, ref), (fpc, trunc)
     other = sample_auto_regressive(diffusion.p_sample_loop, model, shape, {"y": y}, frames_per_call=T, seed=12)
     assert not torch.equal(other, ref)
+
+
+def test_one_and_two_sample_attention_workgroups_agree_bit_for_bit():
+    """k_qkv_attn_rs<1> (one sample, four waves per workgroup, two workgroups per CU: the default) against k_qkv_attn_rs<2>
+    (REGENNET_QKV_NS=2, the round-2 two-sample workgroup): same arithmetic in the same order, so whole sampling runs must be
+    identical - odd batch (the two-sample build pads a dummy), guided, both precision phases. Fresh interpreters: the switch is
+    read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib, torch; sys.path.insert(0, '.')\n"
+        "from regennet_amd import synth\n"
+        "from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel\n"
+        "cfg = synth.get_config('ntu_action')\n"
+        "model, diffusion = synth.build_model(cfg, synth.make_state_dict(cfg, seed=0), resp='ddim6', precision='bf16_x3tail', device='cuda:0', x3_tail=2)\n"
+        "model.small_batch_rows = 0\n"
+        "B = 37\n"
+        "y = {'cmotion': torch.from_numpy(synth.make_cmotion(cfg, B, seed=4)).cuda(), 'action': torch.from_numpy(synth.make_actions(cfg, B, seed=5)).cuda(),\n"
+        "     'scale': torch.full((B,), 2.5, device='cuda')}\n"
+        "out = diffusion.ddim_sample_loop(ClassifierFreeSampleModel(model), (B, 56, 6, 60), clip_denoised=False, model_kwargs={'y': y}, seed=3)\n"
+        "assert torch.isfinite(out).all()\n"
+        "print('HASH', hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for ns in ("1", "2"):
+        env = dict(os.environ, REGENNET_QKV_NS=ns)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
+    assert digests[0] == digests[1], digests
