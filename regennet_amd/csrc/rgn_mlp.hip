@@ -31,6 +31,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#ifndef RGN_ML_ST_AUX
+#define RGN_ML_ST_AUX 16   // cache policy of the output stores: 16 = sc1 (write-through); tools: -DRGN_ML_ST_AUX=0 for plain stores
+#endif
 
 #define RGN_AS1 __attribute__((address_space(1)))
 #define RGN_AS3 __attribute__((address_space(3)))
@@ -366,6 +369,10 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     {
+        // WRITE-THROUGH stores (sc1): nothing of the 15 MB this launch writes is left dirty in the XCD L2s for the end-of-kernel
+        // write-back (the next kernel reads it through the fabric either way: L2 contents do not survive a kernel boundary)
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)((size_t)g.rows * 512 * 2), 0x00020000);
         const int r16 = lane >> 2, c = lane & 3;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -373,7 +380,8 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
             const int m = m0 + r;
             if (m < g.M) {
                 const int off = blk * 4096 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
-                *reinterpret_cast<bf16x8*>(g.out + ((size_t)blk * g.rows + m) * 32 + c * 8) = *reinterpret_cast<const bf16x8*>(smem + ML_X + off);
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(smem + ML_X + off), o_rs,
+                                                       (int)((((size_t)blk * g.rows + m) * 32 + c * 8) * 2), 0, RGN_ML_ST_AUX);
             }
         }
     }

@@ -36,6 +36,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define RGN_AS1 __attribute__((address_space(1)))
 #define RGN_AS3 __attribute__((address_space(3)))
+#ifndef RGN_QA_ST_AUX
+#define RGN_QA_ST_AUX 16   // cache policy of the plain-bf16 build's output stores: 16 = sc1 (write-through)
+#endif
 
 constexpr int QA_ROWS = 64, QA_NS = 2, QA_DH = 128, QA_WROWS = 3 * QA_DH, QA_NT = 512;
 
@@ -203,7 +206,33 @@ __device__ __forceinline__ void qa_attention(f32x16 (&acc)[2][3], const QkvAttnA
         // O^T tile: lane = query (column), registers = 16 dh indices -> 4 runs of 4 consecutive dh = 8-byte plane
         // stores; the 32 x 32 tile is one contiguous 2 KiB run of the K32-blocked plane
         const int q = 32 * qtile + l31;
-        if (live && q < Tq) {
+        if constexpr (!X3) {
+            // plain-bf16 phase (hi plane only): the lane pair (l31, kh = 0 / 1) holds the two 8-byte halves of every 16-byte chunk of the
+            // row - one v_permlane32_swap per register pairs them up, and the row goes out as two 16-byte WRITE-THROUGH stores per lane
+            // (sc1: nothing of the plane stays dirty in L2 for the end-of-kernel write-back; an 8-byte sc1 store costs 2.7x per byte)
+            u32x2 run[4];
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                bf16x4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = (__bf16)(oa[4 * i4 + e] * inv[qtile]);
+                run[i4] = __builtin_bit_cast(u32x2, hv);
+            }
+            const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(g.out.hi, 0, (int)((size_t)g.out.rows * g.d * 2), 0x00020000);
+            const size_t o = ((size_t)(hd * (QA_DH / 32) + wn) * g.out.rows + row0 + q) * 32 + 8 * kh;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {          // runs (2 pr, 2 pr + 1) = elements 16 pr + 4 kh + {0..3} and 16 pr + 8 + 4 kh + {0..3}
+                u32x4 v;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    // after the swap: lanes kh = 0 hold (own even run, partner's even run), lanes kh = 1 (partner's odd run, own odd run)
+                    const auto sw = __builtin_amdgcn_permlane32_swap(run[2 * pr][w], run[2 * pr + 1][w], false, false);
+                    v[w] = sw[0];
+                    v[2 + w] = sw[1];
+                }
+                if (live && q < Tq) __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, (int)((o + 16 * pr) * 2), 0, RGN_QA_ST_AUX);
+            }
+        } else if (live && q < Tq) {
             const size_t o = ((size_t)(hd * (QA_DH / 32) + wn) * g.out.rows + row0 + q) * 32 + 4 * kh;
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {

@@ -242,19 +242,23 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
             for (int i = 0; i < 16; ++i) patch[l31 * QL_OLD + 32 * dt + (i & 3) + 8 * (i >> 2) + 4 * kh] = oa[dt][i] * inv;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        constexpr int C4 = QL_DH / 4;
+        // 16-byte WRITE-THROUGH stores (sc1): the plane is not left dirty in the XCD L2s for the end-of-kernel write-back
+        constexpr int C8 = QL_DH / 8;
         const size_t row0 = (size_t)b * Tq;
-        for (int idx = lane; idx < 32 * C4; idx += 64) {
-            const int r = idx / C4, c = (idx - r * C4) * 4;
+        const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(g.out.hi, 0, (int)((size_t)g.out.rows * g.d * 2), 0x00020000);
+#pragma unroll
+        for (int it = 0; it < 32 * C8 / 64; ++it) {
+            const int idx = lane + 64 * it, r = idx / C8, c = (idx - r * C8) * 8;
             const int q = 32 * w + r;
             if (q < Tq) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(&patch[r * QL_OLD + c]);
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(&patch[r * QL_OLD + c]);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(&patch[r * QL_OLD + c + 4]);
                 const int col = hd * QL_DH + c;
                 const size_t o = ((size_t)(col >> 5) * g.out.rows + row0 + q) * 32 + (col & 31);
-                bf16x4 h;
+                bf16x8 h;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (__bf16)v[e];
-                *reinterpret_cast<bf16x4*>(g.out.hi + o) = h;
+                for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v0[e]; h[4 + e] = (__bf16)v1[e]; }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), o_rs, (int)(o * 2), 0, 16);
             }
         }
     }

@@ -40,6 +40,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define RGN_AS1 __attribute__((address_space(1)))
 #define RGN_AS3 __attribute__((address_space(3)))
+#ifndef RGN_ST_ST_AUX
+#define RGN_ST_ST_AUX 16   // cache policy of the h-plane stores: 16 = sc1 (write-through)
+#endif
 
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... (the update loop's body is too large for `#pragma unroll` to be honoured,
 // and its prefetched operands must live in registers, i.e. be indexed by constants)
@@ -347,6 +350,9 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     {
+        // (write-through stores, as k_mlp's: the 15 / 31 MB of h planes are not left dirty in L2 for the end-of-kernel write-back)
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc(g.hout, 0, (int)((size_t)g.rows * 512 * 2), 0x00020000);
         const int r16 = lane >> 2, c = lane & 3;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -358,13 +364,13 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)v[e] + (float)c0v[j][e]);
-                *reinterpret_cast<bf16x8*>(g.hout + ((size_t)blk * g.rows + m) * 32 + c * 8) = o;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), h_rs, (int)((((size_t)blk * g.rows + m) * 32 + c * 8) * 2), 0, RGN_ST_ST_AUX);
                 if constexpr (GUIDED) {   // the unconditional evaluation sees the same x', with its own condition part
                     const bf16x8 cu = *reinterpret_cast<const bf16x8*>(cp + (size_t)g.half * 512);
                     bf16x8 ou;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) ou[e] = (__bf16)((float)v[e] + (float)cu[e]);
-                    *reinterpret_cast<bf16x8*>(g.hout + ((size_t)blk * g.rows + m + g.half) * 32 + c * 8) = ou;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ou), h_rs, (int)((((size_t)blk * g.rows + m + g.half) * 32 + c * 8) * 2), 0, RGN_ST_ST_AUX);
                 }
             }
         }
