@@ -31,6 +31,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#ifndef RGN_ML_LD_AUX
+#define RGN_ML_LD_AUX 0    // cache policy of the two input-tile DMAs (2 = nt: 55.5 -> 54.2 us in tools/mlp_bench, but -1.5 % in the sampling loop, where the tiles were just written)
+#endif
 #ifndef RGN_ML_ST_AUX
 #define RGN_ML_ST_AUX 16   // cache policy of the output stores: 16 = sc1 (write-through); tools: -DRGN_ML_ST_AUX=0 for plain stores
 #endif
@@ -108,8 +111,8 @@ __global__ __launch_bounds__(ML_NT, 2) void k_mlp(MlpArgs g) {
             int m = m0 + r;
             m = m < g.M ? m : g.M - 1;
             const size_t src = ((size_t)kb * g.rows + m) * 32 + ((c ^ ((r >> 2) & 3)) << 3);
-            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.att + src), (RGN_AS3 void*)(smem + ML_X + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.h + src), (RGN_AS3 void*)(smem + ML_Y + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.att + src), (RGN_AS3 void*)(smem + ML_X + p * 1024), 16, 0, RGN_ML_LD_AUX);
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.h + src), (RGN_AS3 void*)(smem + ML_Y + p * 1024), 16, 0, RGN_ML_LD_AUX);
         }
     }
     int a_off[2][2];                                                  // [mt][ks]: B-operand fragment of token 32 mt + l31 inside a k-block
