@@ -161,13 +161,26 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
     __builtin_amdgcn_s_barrier();
 
     RGN_LT(2)
-    // ---- attention: wave w < 5 owns the 32 queries of tile w --------------------------------------------------------------
+    // ---- attention. Query tile t needs key tiles 0 .. t (causal): one wave per query tile would leave the wave of tile 4 five key
+    //      tiles deep (9.1 k cycles, stamped) with seven waves idle. Nine waves take (query tile, key-tile range) units of at most
+    //      two key tiles instead - primaries 0-4 and secondaries 5-8 -
+    //          wave   0    1      2      3      4    5    6      7      8
+    //          tile   0    1      2      3      4    2    3      4      4
+    //          keys   0   0-1    1-2    2-3     4    0   0-1    0-1    2-3
+    //      each with its own running maximum / sum (flash-style); a secondary dumps its unnormalised O^T accumulators (a register
+    //      image: the primary's lanes hold the same elements) + (max, sum) into the dead V^T slab / activation ring / bias area, and
+    //      the primary of the tile merges: O = sum_u e^(m_u - m) O_u / sum_u e^(m_u - m) l_u.
     constexpr int NS = QL_DH / 16, ND = QL_DH / 32;
+    constexpr int DUMP = ND * 16 * 64 * 4 + 64 * 8;                  // 16 KiB of accumulators + (m, l) per lane
+    static_assert(QL_V + 4 * DUMP <= QL_LDS && QL_TT * 32 * QL_OLD * 4 <= QL_V, "dumps behind the output patches");
     const int w = wave;
-    const int qrow = 32 * w + l31;
+    const int qt = w < 5 ? w : (w == 5 ? 2 : (w == 6 ? 3 : 4));
+    const int k0 = w < 2 ? 0 : (w < 4 ? w - 1 : (w == 4 ? 4 : (w == 8 ? 2 : 0)));
+    const int k1 = w < 5 ? w : (w == 5 ? 0 : (w == 8 ? 3 : 1));
+    const int qrow = 32 * qt + l31;
     f32x16 oa[ND];
-    float inv = 0.f;
-    if (w < QL_TT) {
+    float inv = 0.f, m_run = -INFINITY, l_run = 0.f;
+    if (w < 9) {
         bf16x8 qh[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) qh[s] = *reinterpret_cast<const bf16x8*>(sQ + qrow * QL_KLD + 16 * s + 8 * kh);
@@ -176,10 +189,9 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
         for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) oa[dt][i] = 0.f;
-        float m_run = -INFINITY, l_run = 0.f;
 #pragma unroll
         for (int kj = 0; kj < QL_TT; ++kj) {
-            if (kj <= w) {
+            if (kj >= k0 && kj <= k1) {
                 f32x16 st;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) st[i] = 0.f;
@@ -188,7 +200,8 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
                     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (32 * kj + l31) * QL_KLD + 16 * s + 8 * kh);
                     st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qh[s], st, 0, 0, 0);
                 }
-                // key = 32 kj + (i&3) + 8 (i>>2) + 4 kh, query = qrow (key 0 is valid for every query: the maximum is finite)
+                // key = 32 kj + (i&3) + 8 (i>>2) + 4 kh, query = qrow (a unit's first key tile holds a valid key for every real
+                // query - key 0, or the keys below the query's own tile, or the diagonal - so the maximum is finite)
                 float mt = -INFINITY;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -198,7 +211,7 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
                     mt = fmaxf(mt, st[i]);
                 }
                 mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-                const float m_new = fmaxf(m_run, mt);
+                const float m_new = fmaxf(fmaxf(m_run, mt), -1e30f);   // (a unit with no valid key at all - rows beyond Tq only - stays finite)
                 const float alpha = __expf(m_run - m_new);            // (first tile: exp(-inf) = 0)
                 float ls = 0.f;
 #pragma unroll
@@ -229,12 +242,56 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
                 }
             }
         }
-        inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+        l_run += __shfl_xor(l_run, 32, 64);
     }
     RGN_LT(3)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                    // every wave is done with Q / K: reuse them as fp32 output patches
+    __builtin_amdgcn_s_barrier();                                    // every wave is done with Q / K / V^T: patches over Q and K, dumps behind them
+    if (w >= 5 && w < 9) {
+        char* dump = smem + QL_V + (w - 5) * DUMP;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4)
+                *reinterpret_cast<f32x4*>(dump + ((dt * 4 + i4) * 64 + lane) * 16) = f32x4{oa[dt][4 * i4], oa[dt][4 * i4 + 1], oa[dt][4 * i4 + 2], oa[dt][4 * i4 + 3]};
+        *reinterpret_cast<float2*>(dump + ND * 16 * 64 * 4 + lane * 8) = float2{m_run, l_run};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if (w < QL_TT) {
+        if (w >= 2) {                                                // tiles 2, 3: one secondary (dumps 0, 1); tile 4: two (dumps 2, 3)
+            const int d0 = w == 4 ? 2 : w - 2, nd = w == 4 ? 2 : 1;
+            float ms[2], lsec[2], m = m_run;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float2 st2 = *reinterpret_cast<const float2*>(smem + QL_V + (d0 + (u < nd ? u : 0)) * DUMP + ND * 16 * 64 * 4 + lane * 8);
+                ms[u] = st2.x;
+                lsec[u] = st2.y;
+                if (u < nd) m = fmaxf(m, ms[u]);
+            }
+            const float fp = __expf(m_run - m);
+            l_run *= fp;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oa[dt][i] *= fp;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (u < nd) {                                        // wave-uniform
+                    const float fs = __expf(ms[u] - m);
+                    l_run = __builtin_fmaf(lsec[u], fs, l_run);
+                    const char* dump = smem + QL_V + (d0 + u) * DUMP;
+#pragma unroll
+                    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                        for (int i4 = 0; i4 < 4; ++i4) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(dump + ((dt * 4 + i4) * 64 + lane) * 16);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) oa[dt][4 * i4 + e] = __builtin_fmaf(v[e], fs, oa[dt][4 * i4 + e]);
+                        }
+                }
+        }
+        inv = 1.0f / l_run;
         float* patch = reinterpret_cast<float*>(smem) + w * (32 * QL_OLD);
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt)
