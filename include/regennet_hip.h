@@ -130,7 +130,7 @@ int rgn_denoise(rgn_handle h, const float* x_dev, const int64_t* t_dev, int32_t 
  *               keyed by (seed, global sample index = sample_offset + b, step i, element).
  *   x0_dev    : optional fp32 output, pred_xstart of the LAST executed step (NULL to skip).
  *   use_graph : replay captured hipGraphs (10 loop iterations each) instead of launching kernels one by one. Honoured by the
- *               throughput kernels; the small-batch engine (<= 768 token rows) launches eagerly either way, which is faster
+ *               throughput kernels; the small-batch engine (<= 640 token rows) launches eagerly either way, which is faster
  *               there (one chain of short kernels; REGENNET_SB_GRAPH=1 forces graphs).
  *   clip_denoised : clamp pred_xstart to [-1,1] (process_xstart, gaussian_diffusion.py:366-372). */
 int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, float* x_dev,
@@ -152,7 +152,7 @@ int rgn_set_const_noise(rgn_handle h, int32_t on);
 /* Evaluations of at most `rows` token rows (motions x tokens, doubled under guidance) run the small-batch engine:
  * column-split GEMMs that spread one row tile over 16-48 workgroups (rgn_sb.hip; d = 512 models, bf16 modes), the
  * latency-bound regime of the reference CLI's own default batch (sample/cgenerate.py:109-135, BASELINE configs[0]).
- * Larger evaluations run the row-complete throughput kernels. -1 restores the default (768, or REGENNET_SB_ROWS);
+ * Larger evaluations run the row-complete throughput kernels. -1 restores the default (640, or REGENNET_SB_ROWS);
  * 0 switches the small-batch engine off. Results of the two engines agree within the precision mode's error (both are
  * checked against the same goldens), not bit for bit. */
 int rgn_set_small_batch_rows(rgn_handle h, int32_t rows);

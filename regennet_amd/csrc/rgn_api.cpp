@@ -101,8 +101,9 @@ struct rgn_ctx {
     bool qkv_rs = true;                // plain-bf16 phase: k_qkv_attn with register-streamed weights (REGENNET_NO_QKV_RS=1: the DMA-fed loop)
     bool qkv_long = false;             // plain-bf16 phase, 65 .. 160 tokens: fused in_proj + attention per (sample, head) (REGENNET_NO_QKV_LONG=1: in_proj GEMM + k_attn_x3)
     bool sb = false;                   // small-batch engine: column-split GEMMs with consumer-side LayerNorm (k_sb_gemm)
-    int sb_rows = 768;                 // evaluations of at most this many token rows take it (rgn_set_small_batch_rows; 0 disables)
-    int sb_rows_default = 768;         // (REGENNET_SB_ROWS): measured crossover with the throughput kernels at 60 tokens: B = 12 .. 16
+    int sb_rows = 640;                 // evaluations of at most this many token rows take it (rgn_set_small_batch_rows; 0 disables)
+    int sb_rows_default = 640;         // (REGENNET_SB_ROWS): measured crossover with the throughput kernels at 60 tokens: between B = 10 and 11
+                                       // (round 3, 250-step calls: B = 10 108 vs 116 ms, B = 11 122 vs 117, B = 12 123 vs 117; it was B = 12 .. 16 in round 2)
     StepCoef* d_tab = nullptr;
     int* d_step = nullptr;
     SampleParams* d_sp = nullptr;

@@ -310,7 +310,7 @@ class GaussianDiffusion:
         ys = {k: (v[:nb].contiguous() if th.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B else (v[:nb] if isinstance(v, (list, tuple)) and len(v) == B else v))
               for k, v in y.items()}
         saved, self._calibrating, self._last_calibration_dev = (inner.x3_tail, inner._auto_tail, inner.small_batch_rows), True, 0.0
-        if B * int(shape[3]) * (2 if inner is not model else 1) > 768:
+        if B * int(shape[3]) * (2 if inner is not model else 1) > 640:
             inner.small_batch_rows = 0      # calibrate on the kernels the caller's batch will run (throughput engine), not the small-batch ones
         fn = self.p_sample_loop if sampler == "ddpm" else self.ddim_sample_loop
         kw = dict(clip_denoised=False, model_kwargs={"y": ys}, seed=seed)
