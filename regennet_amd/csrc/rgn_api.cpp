@@ -725,9 +725,13 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
     int nch = (fast && !c->prof) ? c->nchains : 1;       // per-kernel event timing wants un-overlapped kernels
     // Two chains instead of four when the whole evaluation is 129 .. 256 row tiles of 64 (B=256 at 60 frames: 240): each of the
     // two chains' launches then still fills half the chip in one round, with half the launches and joins (measured 314.4 vs
-    // 308.9 motions/s at cfg2; larger evaluations - cfg3 480, cfg4 300 tiles - lose 5-6 % with two chains, smaller ones keep four)
+    // 308.9 motions/s at cfg2 in round 2, when larger evaluations - cfg3 480, cfg4 300 tiles - lost 5-6 % with two chains; smaller ones keep four)
     // (plain-bf16 phase only: the split-bf16 kernels - 128-row tiles, separate LayerNorms - measure 107 vs 125 motions/s with two)
-    if (nch == 4 && !c->nchains_user && !eval_x3(c) && (M + 63) / 64 > 128 && (M + 63) / 64 <= 256) nch = 2;
+    // Round 3 (one-sample attention workgroups, write-through stores): 385 .. 512 tiles (cfg3: 480 = two chains of one full round each)
+    // now also prefer two - 1899 vs 1869 motions/s, three 1842, six 1581; cfg4's 300 tiles keep four (969 / 928 / 913 with 2 / 3 / 4),
+    // cfg5's 1200 measure the same with two, three and four.
+    const int tiles64 = (M + 63) / 64;
+    if (nch == 4 && !c->nchains_user && !eval_x3(c) && ((tiles64 > 128 && tiles64 <= 256) || (tiles64 > 384 && tiles64 <= 512))) nch = 2;
     if (use_sb(c, M)) nch = 1;                            // small-batch engine: one chain of column-split kernels
     if (nch > dm.Bm) nch = dm.Bm;
     if (nch > 1) RGN_HIP(c, hipEventRecord(c->ev_fork, s));
