@@ -565,6 +565,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             g.out = att_p;
             g.Bm = ns; g.Kp = w.qkv.Kp; g.d = d; g.H = c->H; g.Tq = dm.Tq;
             g.qscale = 1.0f / sqrtf((float)dm.dh);
+            g.Bm_eval = dm.Bm;
             RGN_LAUNCH(c, KC_QKV, s, launch_qkv_attn(g, x3, s));   // 93 % of its MFMA work is the in_proj GEMM
         } else if (fast && c->qkv_long && !x3 && w.qkv.fr && !att_p.lo && (size_t)h_p.rows * w.qkv.Kp * 2 < (1ull << 31)) {
             // plain-bf16 phase, long sequence: in_proj + attention of one (sample, head) per workgroup, q / k / v stay in LDS
@@ -732,6 +733,10 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
     // cfg5's 1200 measure the same with two, three and four.
     const int tiles64 = (M + 63) / 64;
     if (nch == 4 && !c->nchains_user && !eval_x3(c) && ((tiles64 > 128 && tiles64 <= 256) || (tiles64 > 384 && tiles64 <= 512))) nch = 2;
+    // up to 48 tiles: ONE chain, in both phases (B = 32 at 60 frames, 250-step calls: plain-bf16 phase 108.3 vs 114.1 ms with four chains,
+    // split-bf16 phase 246 vs 277; one chain in the bulk phase and four in the tail measured 120 - 137 ms against 111 with one throughout)
+    // (B = 40 / 48: 114.3 / 113.8 vs 120.0 / 118.8 with four; B = 64, 60 tiles: the same with one, two and four)
+    if (nch == 4 && !c->nchains_user && tiles64 <= 48) nch = 1;
     if (use_sb(c, M)) nch = 1;                            // small-batch engine: one chain of column-split kernels
     if (nch > dm.Bm) nch = dm.Bm;
     if (nch > 1) RGN_HIP(c, hipEventRecord(c->ev_fork, s));

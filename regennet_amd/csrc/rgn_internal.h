@@ -102,6 +102,7 @@ struct QkvAttnArgs {
     Planes out;                                         // attention output planes (advanced to the first sample's row)
     int Bm, Kp, d, H, Tq;
     float qscale;
+    int Bm_eval;                                        // samples of the WHOLE evaluation (all kernel chains; 0: = Bm): what else runs beside this launch
 };
 bool qkv_attn_supported(int Tq, int dh, int d);
 hipError_t configure_qkv_attn();

@@ -547,7 +547,11 @@ hipError_t launch_qkv_attn(const QkvAttnArgs& g, bool x3, hipStream_t s) {
         static const bool two = getenv("REGENNET_QKV_NS") && atoi(getenv("REGENNET_QKV_NS")) == 2;
         static const int hs_env = getenv("REGENNET_QKV_HSPLIT") ? atoi(getenv("REGENNET_QKV_HSPLIT")) : 0;   // tools
         const int pairs = (g.Bm + QA_NS - 1) / QA_NS;
-        const int hsplit = (hs_env > 0 && g.H % hs_env == 0) ? hs_env : (pairs * g.H <= 64) ? g.H : (g.H % 2 == 0 ? 2 : 1);
+        // Heads per workgroup: two (half the in_proj weight requests per sample) once the evaluation alone fills the chip with 4-wave
+        // workgroups - >= 256 samples over all chains: 512 workgroups, two per CU - and ONE head per workgroup below that (B = 64 / 128 /
+        // 192 at 60 frames: 116.9 / 131.0 / 154.1 vs 135.6 / 139.7 / 158.0 ms per 250-step call; B = 256: 360 vs 369 motions/s the other way)
+        const int beval = g.Bm_eval > 0 ? g.Bm_eval : g.Bm;
+        const int hsplit = (hs_env > 0 && g.H % hs_env == 0) ? hs_env : (beval < 256 || g.H % 2) ? g.H : 2;
         if (!two)
             hipLaunchKernelGGL(k_qkv_attn_rs<1>, dim3(g.Bm, hsplit), dim3(256), qr_lds<1>(), s, g, g.Wfr);
         else
