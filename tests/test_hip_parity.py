@@ -964,3 +964,39 @@ def test_one_and_two_sample_attention_workgroups_agree_bit_for_bit():
         assert r.returncode == 0, r.stderr[-2000:]
         digests.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASH")][0])
     assert digests[0] == digests[1], digests
+
+
+@pytest.mark.parametrize("T", [65, 96, 97, 128, 129, 160])
+def test_long_sequence_attention_units_against_the_unfused_path(T):
+    """k_qkv_attn_long splits the causal attention of a (sample, head) into nine (query tile, key-tile range) units whose partial
+    results are merged flash-style; which units see valid keys depends on the length (at <= 128 tokens the unit of query tile 4 has
+    none at all). Check every tile-count / remainder combination against the unfused plain-bf16 path (in_proj GEMM + k_attn_x3,
+    REGENNET_NO_QKV_LONG=1: same operands, one wave per query tile) on whole sampling runs - a key tile dropped or double-counted
+    would show as O(0.1), the two roundings agree to ~1e-3 - and against the oracle within the plain-bf16 phase's own error."""
+    import os
+    from oracle import regennet_oracle as orc
+    from regennet_amd import synth
+    cfg = synth.get_config("ntu_action", layers=1, num_frames=T)   # one layer, two steps: rounding differences stay small, a wrong key set does not
+    sd = synth.make_state_dict(cfg, seed=3)
+    B, S = 3, 2
+    y = {"cmotion": synth.make_cmotion(cfg, B, seed=6), "action": synth.make_actions(cfg, B, seed=7)}
+    tape = synth.make_noise_tape(cfg, B, S, seed=8)
+    outs = []
+    for unfused in (False, True):
+        if unfused:
+            os.environ["REGENNET_NO_QKV_LONG"] = "1"
+        try:
+            model, diffusion = build_hip(cfg, sd, resp=f"ddim{S}", precision="bf16_x3tail/throughput", x3_tail=0)
+            outs.append(diffusion.ddim_sample_loop(model, (B, 56, 6, T), clip_denoised=False, model_kwargs={"y": y_to_device(y)},
+                                                   noise_tape=torch.from_numpy(tape)).cpu().numpy())
+            model._engine.close()
+        finally:
+            os.environ.pop("REGENNET_NO_QKV_LONG", None)
+    ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", f"ddim{S}"), tape, {k: torch.from_numpy(v) for k, v in y.items()},
+                          mode="ddim", guided=False).numpy()
+    d_paths = float(np.abs(outs[0] - outs[1]).max())
+    d_ref, d_ref_unfused = float(np.abs(outs[0] - ref).max()), float(np.abs(outs[1] - ref).max())
+    print(f"\n[long attention units] T={T}: fused vs unfused {d_paths:.2e}, vs oracle (plain bf16 throughout): fused {d_ref:.2e}, unfused {d_ref_unfused:.2e}")
+    assert np.isfinite(outs[0]).all()
+    assert d_ref < 2.0 * d_ref_unfused + 2e-3, (T, d_ref, d_ref_unfused)
+    assert d_paths < 2.0 * d_ref_unfused + 2e-3, (T, d_paths, d_ref_unfused)
