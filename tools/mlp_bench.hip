@@ -18,6 +18,11 @@ using namespace rgn;
 #ifdef RGN_ML_PROF
 namespace rgn { void ml_prof_read(long long* out); }
 #endif
+#ifdef RGN_M3_STAMPS
+namespace rgn { void m3_stamps_read(long long* out); }
+#include <algorithm>
+#include <map>
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
 static float bf2f(uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; }
@@ -80,6 +85,47 @@ int main(int argc, char** argv) {
     long long t[16]; ml_prof_read(t);
     printf("  cycles of workgroup %d, wave 0 (s_memtime = shader clock): tile DMA + wait %lld | out_proj k-loop %lld | LN1+LN2+image %lld | ffn (2 x (linear1, gelu, linear2)) %lld | LN3 + store %lld | total %lld\n",
            RGN_ML_PROF, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
+#endif
+#ifdef RGN_M3_STAMPS
+    {   // REGENNET_MLP_ROWS=32: phase stamps of wave 0 of every workgroup, grouped by the CU it ran on (the last launch)
+        std::vector<long long> st(1024 * 8);
+        m3_stamps_read(st.data());
+        const int nwg = std::min(1024, (M + 31) / 32);
+        std::map<long long, std::vector<int>> by_cu;
+        for (int b = 0; b < nwg; ++b) {
+            const unsigned hw = (unsigned)st[b * 8 + 6];
+            by_cu[(st[b * 8 + 7] << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)].push_back(b);
+        }
+        long long t00 = st[0];
+        for (int b = 0; b < nwg; ++b) t00 = std::min(t00, st[b * 8]);
+        int shown = 0, pairs = 0, singles = 0, more = 0;
+        double ph[5] = {0, 0, 0, 0, 0}, life = 0, ovl = 0;
+        for (auto& kv : by_cu) {
+            auto& v = kv.second;
+            if (v.size() == 1) ++singles; else if (v.size() == 2) ++pairs; else ++more;
+            for (int b : v) {
+                for (int i = 0; i < 5; ++i) ph[i] += (double)(st[b * 8 + i + 1] - st[b * 8 + i]);
+                life += (double)(st[b * 8 + 5] - st[b * 8]);
+            }
+            if (v.size() == 2) {   // cycles during which both are inside an MFMA loop phase (stamps 1-2 and 3-4) at once
+                auto inter = [&](int a0, int a1, int b0, int b1) { return (double)std::max(0LL, std::min(st[v[0] * 8 + a1], st[v[1] * 8 + b1]) - std::max(st[v[0] * 8 + a0], st[v[1] * 8 + b0])); };
+                ovl += inter(1, 2, 1, 2) + inter(1, 2, 3, 4) + inter(3, 4, 1, 2) + inter(3, 4, 3, 4);
+            }
+            if (v.size() == 2 && shown < 6) {
+                ++shown;
+                printf("  CU %05llx:", kv.first);
+                for (int b : v) {
+                    printf("  wg %3d [", b);
+                    for (int i = 0; i < 6; ++i) printf("%s%lld", i ? " " : "", st[b * 8 + i] - t00);
+                    printf("]");
+                }
+                printf("\n");
+            }
+        }
+        printf("  %d workgroups on %zu CUs: %d CUs with two, %d with one, %d with more\n", nwg, by_cu.size(), pairs, singles, more);
+        printf("  mean cycles per workgroup (wave 0): tile wait %.0f | out_proj %.0f | res+LN1+LN2+image %.0f | ffn %.0f | res+LN3+store %.0f | lifetime %.0f; both-in-a-loop overlap per pair %.0f\n",
+               ph[0] / nwg, ph[1] / nwg, ph[2] / nwg, ph[3] / nwg, ph[4] / nwg, life / nwg, pairs ? ovl / pairs : 0.0);
+    }
 #endif
     if (check) {
         std::vector<uint16_t> out((size_t)M * d);
