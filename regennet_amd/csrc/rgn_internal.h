@@ -156,10 +156,10 @@ struct MlpArgs {
 bool mlp_supported(int d, int ff, int Tq);
 hipError_t configure_mlp();
 hipError_t launch_mlp(const MlpArgs& g, hipStream_t s);
-// the same layer tail as 32-row tiles, four waves per workgroup, two workgroups per CU (rgn_mlp32.hip); Tq >= 32
-bool mlp32_supported(int d, int ff, int Tq);
-hipError_t configure_mlp32();
-hipError_t launch_mlp32(const MlpArgs& g, hipStream_t s);
+// second build of the layer tail (rgn_mlp2.hip): rows = 64 (8 waves, one workgroup per CU) or 32 (4 waves, two per CU)
+bool mlp2_supported(int rows, int d, int ff, int Tq);
+hipError_t configure_mlp2();
+hipError_t launch_mlp2(int rows, const MlpArgs& g, hipStream_t s);
 
 // Small-batch column-split GEMM (rgn_sb.hip): 64 rows x 32 output columns per workgroup; LayerNorm applied by the consumer.
 struct SbArgs {

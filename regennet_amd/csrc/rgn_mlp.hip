@@ -397,20 +397,22 @@ void ml_prof_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_
 #endif
 
 bool mlp_supported(int d, int ff, int Tq) { return d == ML_D && ff == 2 * ML_D && 63 / Tq + 2 <= ML_NSAMP; }   // samples a 64-row tile can touch
-// tile rows of the layer tail: 64 (this file) or 32 (rgn_mlp32.hip, two workgroups per CU); REGENNET_MLP_ROWS overrides
-static int mlp_rows() {
+// REGENNET_MLP_KERNEL: 1 = this file's kernel, 2 = rgn_mlp2.hip with 64-row tiles, 3 = rgn_mlp2.hip with 32-row tiles
+static int mlp_kernel() {
     static const int r = [] {
-        const char* e = getenv("REGENNET_MLP_ROWS");
-        return e ? atoi(e) : 64;
+        const char* e = getenv("REGENNET_MLP_KERNEL");
+        return e ? atoi(e) : 1;
     }();
     return r;
 }
 hipError_t configure_mlp() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp), hipFuncAttributeMaxDynamicSharedMemorySize, ML_LDS);
-    return e != hipSuccess ? e : configure_mlp32();
+    return e != hipSuccess ? e : configure_mlp2();
 }
 hipError_t launch_mlp(const MlpArgs& g, hipStream_t s) {
-    if (mlp_rows() == 32 && mlp32_supported(ML_D, 2 * ML_D, g.Tq)) return launch_mlp32(g, s);
+    const int k = mlp_kernel();
+    if (k == 3 && mlp2_supported(32, ML_D, 2 * ML_D, g.Tq)) return launch_mlp2(32, g, s);
+    if (k == 2 && mlp2_supported(64, ML_D, 2 * ML_D, g.Tq)) return launch_mlp2(64, g, s);
     hipLaunchKernelGGL(k_mlp, dim3((g.M + ML_BM - 1) / ML_BM), dim3(ML_NT), ML_LDS, s, g);
     return hipGetLastError();
 }

@@ -18,8 +18,8 @@ using namespace rgn;
 #ifdef RGN_ML_PROF
 namespace rgn { void ml_prof_read(long long* out); }
 #endif
-#ifdef RGN_M3_STAMPS
-namespace rgn { void m3_stamps_read(long long* out); }
+#ifdef RGN_M2_STAMPS
+namespace rgn { void m2_stamps_read(long long* out); }
 #include <algorithm>
 #include <map>
 #endif
@@ -86,11 +86,12 @@ int main(int argc, char** argv) {
     printf("  cycles of workgroup %d, wave 0 (s_memtime = shader clock): tile DMA + wait %lld | out_proj k-loop %lld | LN1+LN2+image %lld | ffn (2 x (linear1, gelu, linear2)) %lld | LN3 + store %lld | total %lld\n",
            RGN_ML_PROF, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
 #endif
-#ifdef RGN_M3_STAMPS
-    {   // REGENNET_MLP_ROWS=32: phase stamps of wave 0 of every workgroup, grouped by the CU it ran on (the last launch)
+#ifdef RGN_M2_STAMPS
+    {   // REGENNET_MLP_KERNEL=2|3: phase stamps of wave 0 of every workgroup, grouped by the CU it ran on (the last launch)
         std::vector<long long> st(1024 * 8);
-        m3_stamps_read(st.data());
-        const int nwg = std::min(1024, (M + 31) / 32);
+        m2_stamps_read(st.data());
+        const int trows = (getenv("REGENNET_MLP_KERNEL") && atoi(getenv("REGENNET_MLP_KERNEL")) == 3) ? 32 : 64;
+        const int nwg = std::min(1024, (M + trows - 1) / trows);
         std::map<long long, std::vector<int>> by_cu;
         for (int b = 0; b < nwg; ++b) {
             const unsigned hw = (unsigned)st[b * 8 + 6];
