@@ -96,6 +96,7 @@ struct rgn_ctx {
     bool rowgemm = false;              // plain-bf16 phase: row-complete GEMMs with fused LayerNorm / GELU (k_rowgemm)
     bool mlp = false;                  // plain-bf16 phase: the whole layer tail in one row-persistent kernel (k_mlp)
     bool step_fused = false;           // plain-bf16 phase: output projection (+ guidance) + sampler update + next input embedding in one kernel (REGENNET_NO_STEP_FUSION=1: three launches)
+    bool layers_fused = false;         // plain-bf16 phase, <= 64 tokens: the whole decoder stack of an evaluation as one kernel, one sample per workgroup (k_layers; REGENNET_LAYERS=0: kernel per stage)
     bool skip_embed_out = false;       // (set by run_eval around run_layers while it enqueues a fused step)
     int step_no_quads = 0;             // REGENNET_STEP_NO_QUADS=1 (tests)
     bool qkv_rs = true;                // plain-bf16 phase: k_qkv_attn with register-streamed weights (REGENNET_NO_QKV_RS=1: the DMA-fed loop)
@@ -158,7 +159,7 @@ struct rgn_ctx {
 
 namespace {
 
-const char* kclass_names[KC_COUNT] = {"gemm_mfma", "attention", "layernorm", "embed", "update", "misc", "qkv_attn", "rowgemm_ln", "rowgemm_act", "mlp", "sb_gemm", "step_fused"};
+const char* kclass_names[KC_COUNT] = {"gemm_mfma", "attention", "layernorm", "embed", "update", "misc", "qkv_attn", "rowgemm_ln", "rowgemm_act", "mlp", "sb_gemm", "step_fused", "layers"};
 
 #define RGN_HIP(h, expr)                                                                                    \
     do {                                                                                                    \
@@ -553,6 +554,31 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
                                                       c->cfg.wo_pos_emb, s));
     }
     const size_t slab0 = (size_t)s0 * c->H * c->Tqp * dm.dh;      // attention-ready planes: first slab of this range
+    if (fast && !x3 && c->layers_fused && !h_p.lo) {
+        // plain-bf16 phase, <= 64 tokens, d = 512 / ff = 1024 / 4 heads: ALL layers in one kernel, one sample per workgroup - the residual
+        // stream stays in LDS from the input embedding to the last norm3, only the weights stream (rgn_layers.hip)
+        bool ok = true;
+        for (int l = 0; l < c->L; ++l) ok = ok && c->layers[l].qkv.fr && c->layers[l].out.fr && c->layers[l].ff1.fr && c->layers[l].ff2.fr;
+        if (ok) {
+            LayersArgs g{};
+            g.h = h_p.hi; g.out = h_p.hi; g.rows = h_p.rows; g.Bm = ns; g.Tq = dm.Tq; g.L = c->L;
+            for (int l = 0; l < c->L; ++l) {
+                const LayerW& w = c->layers[l];
+                LayerWts& t = g.lw[l];
+                t.Wqkv = c->dp<__bf16>(w.qkv.fr); t.Wo = c->dp<__bf16>(w.out.fr); t.W1 = c->dp<__bf16>(w.ff1.fr); t.W2 = c->dp<__bf16>(w.ff2.fr);
+                t.bqkv = c->dp<float>(w.qkv.b); t.bo = c->dp<float>(w.out.b); t.bf1 = c->dp<float>(w.ff1.b); t.bf2 = c->dp<float>(w.ff2.b);
+                t.g1 = c->dp<float>(w.ln[0]); t.b1 = c->dp<float>(w.ln[1]); t.g2 = c->dp<float>(w.ln[2]); t.b2 = c->dp<float>(w.ln[3]);
+                t.g3 = c->dp<float>(w.ln[4]); t.b3 = c->dp<float>(w.ln[5]);
+            }
+            g.pervec = sampling ? (ccond_rows ? ccond_rows + (size_t)s0 * Ld : nullptr) : c->call + (size_t)s0 * Ld;
+            g.ldper = Ld;
+            g.stepvec = sampling ? c->call_time : nullptr;
+            g.ldstep = Ld; g.d_step = c->d_step;
+            g.qscale = 1.0f / sqrtf((float)dm.dh);
+            RGN_LAUNCH(c, KC_LAYERS, s, launch_layers(g, s));
+            return RGN_OK;
+        }
+    }
     for (int l = 0; l < c->L; ++l) {
         const LayerW& w = c->layers[l];
         if (fast && c->fuse_qkv) {
@@ -1095,6 +1121,9 @@ int rgn_finalize_weights(rgn_handle h) {
         c->step_fused = c->rowgemm && !c->etd && c->lin_x.fr && c->lin_out.fr && c->lin_out.has_bias && !c->lin_x.has_bias &&
                         step_fused_supported(d, F, c->lin_x.Kp) && getenv("REGENNET_NO_STEP_FUSION") == nullptr;
         if (c->step_fused) RGN_HIP(c, configure_step());
+        c->layers_fused = c->mlp && c->fuse_qkv && c->qkv_rs && layers_supported(d, ff, c->H, c->Tq, c->L) && getenv("REGENNET_LAYERS") != nullptr &&
+                          atoi(getenv("REGENNET_LAYERS")) != 0;
+        if (c->layers_fused) RGN_HIP(c, configure_layers());
         c->step_no_quads = getenv("REGENNET_STEP_NO_QUADS") != nullptr;
         c->qkv_long = c->cfg.precision == RGN_PREC_BF16_X3TAIL && qkv_attn_long_supported(c->Tq, d / c->H, d) && getenv("REGENNET_NO_QKV_LONG") == nullptr;
         if (c->qkv_long) RGN_HIP(c, configure_qkv_attn_long());

@@ -20,6 +20,7 @@ enum KClass : int {
     KC_MLP,           // row-persistent layer tail (k_mlp)
     KC_SB,            // small-batch column-split GEMMs (k_sb_gemm)
     KC_STEP,          // fused step boundary: output projection + sampler update + next input embedding (k_step)
+    KC_LAYERS,        // the whole decoder stack of an evaluation, one sample per workgroup (k_layers)
     KC_COUNT
 };
 
@@ -160,6 +161,28 @@ hipError_t launch_mlp(const MlpArgs& g, hipStream_t s);
 bool mlp2_supported(int rows, int d, int ff, int Tq);
 hipError_t configure_mlp2();
 hipError_t launch_mlp2(int rows, const MlpArgs& g, hipStream_t s);
+
+// The whole decoder stack of one evaluation as one kernel, one sample (Tq <= 64 tokens) per workgroup (rgn_layers.hip): plain-bf16 phase,
+// d = 512, ff = 1024, 4 heads of 128. Weight planes fragment-ordered as for k_mlp / k_qkv_attn_rs.
+constexpr int LY_MAXL = 8;
+struct LayerWts {                          // one entry per decoder layer; the table travels in the kernel arguments (scalar loads)
+    const __bf16 *Wqkv, *Wo, *W1, *W2;
+    const float *bqkv, *bo, *bf1, *bf2;
+    const float *g1, *b1, *g2, *b2, *g3, *b3;
+};
+struct LayersArgs {
+    const __bf16* h;                      // residual-stream planes (hi) [16][rows][32], advanced to the first sample's row
+    __bf16* out;                          // (may alias h)
+    int rows;                             // plane row count (stride)
+    int Bm, Tq, L;                        // samples of this launch, tokens per sample, layers
+    LayerWts lw[LY_MAXL];                 // [L], L <= LY_MAXL
+    const float* pervec; int ldper;       // + pervec[sample * ldper + layer * 512 + n]   (nullable; advanced to the first sample)
+    const float* stepvec; int ldstep; const int* d_step;   // + stepvec[(*d_step) * ldstep + layer * 512 + n] (nullable)
+    float qscale;
+};
+bool layers_supported(int d, int ff, int H, int Tq, int L);
+hipError_t configure_layers();
+hipError_t launch_layers(const LayersArgs& g, hipStream_t s);
 
 // Small-batch column-split GEMM (rgn_sb.hip): 64 rows x 32 output columns per workgroup; LayerNorm applied by the consumer.
 struct SbArgs {

@@ -1,0 +1,587 @@
+// The whole decoder stack of one denoiser evaluation as ONE kernel: a workgroup owns ONE sample (Tq <= 64 tokens, padded to a
+// 64-row tile) and carries its residual stream through all L layers without leaving the CU
+//
+//   for every layer:  a   = SelfAttention(h)            in_proj (q | k | v), causal softmax, p . v        (model/cmdm.py:227 ->
+//                     h'  = LN2( LN1( a . Wo^T + bo + h ) + call_time[step] + call_cond[sample] )          TransformerDecoderLayer,
+//                     h   = LN3( gelu( h' . W1^T + b1 ) . W2^T + b2 + h' )                                  built at :75-81)
+//
+// Causal attention never looks across samples and everything else is row-local, so a sample's tokens close on themselves: no
+// workgroup ever needs another one's data. What that buys over the kernel-per-stage form (k_qkv_attn_rs + k_mlp per layer: 16
+// launches per evaluation): no kernel boundaries, no chip-wide tile burst at the head of every kernel (the XCD L2s are
+// invalidated at boundaries, so every hand-over went through the memory-side cache: ~13 % of the step), no attention-output /
+// residual planes in HBM at all - only the weights stream (L2-resident per layer, every CU of an XCD reads the same bytes at about
+// the same time) and B workgroups of 8 waves for B samples (256 samples = 256 CUs).
+//
+// 8 waves. LDS (160 KiB):
+//   X (64 KiB)   the residual stream as a bf16 MFMA-operand image [16 k-blocks][64 rows][64 B] (16-byte chunks swizzled by the
+//                row): h -> h' -> next h, updated IN PLACE by the wave that owns the columns; A operand of in_proj and linear1
+//   Y (64 KiB)   attention output image (A operand of out_proj) -> GELU(hidden half) images (A operand of linear2)
+//   Y + 32 KiB   while the attention runs: the 96 KiB fp32 exchange of the S^T partials (two heads at a time x 4 dh tiles)
+//   last 32 KiB  layer tail: LayerNorm statistics exchange (8 KiB) + wave-private per-column vectors (20 KiB)
+// Attention: heads two at a time, waves 0-3 / 4-7 one head each, wave = 32 dh columns of q, k, v for all 64 tokens (96 x 64
+// accumulators); q, k, v, the scores and p never leave the register file (rgn_qkv_attn.hip: the C/D layouts of q^T, k^T, v and
+// of the softmaxed S^T agree as MFMA operands by construction); the activation operand comes from the RESIDENT image X, so the
+// k-loop has no barrier and no staging at all. Layer tail: the structure of rgn_mlp2.hip (MT = 2) on the resident images.
+// Weights: fragment-ordered planes streamed into register rings through buffer loads (scalar resource, compile-time offsets).
+#include "rgn_internal.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <type_traits>
+
+namespace rgn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define RGN_AS1 __attribute__((address_space(1)))
+#define RGN_AS3 __attribute__((address_space(3)))
+#ifndef RGN_LY_ST_AUX
+#define RGN_LY_ST_AUX 16   // output stores write-through (sc1)
+#endif
+
+constexpr int LY_NTH = 512, LY_KB = 4096;
+constexpr int LY_X = 0, LY_Y = 64 * 1024, LY_EXCH = LY_Y, LY_RED = 128 * 1024, LY_REDF = 2 * 8 * 64, LY_VEC = LY_RED + 2 * LY_REDF * 4, LY_VECW = 640,
+              LY_LDS = 160 * 1024;
+static_assert(LY_VEC + 8 * LY_VECW * 4 <= LY_LDS, "LDS map");
+// wave-private vector region (floats, 64 columns each)
+enum { V_BO = 0, V_G1 = 64, V_G2 = 128, V_B2 = 192, V_SPV = 256, V_BF1 = 320 /* 2 x 64: hidden halves */, V_BF2 = 448, V_G3 = 512, V_B3 = 576 };
+constexpr int LY_RDA = 6;   // in_proj weight ring: granules (half k-steps) of 3 fragments (q | k | v): 72 registers
+constexpr int LY_RDM = 8;   // layer-tail weight ring: granules of 2 fragments: 64 registers
+
+#ifdef RGN_LY_STAMPS
+__device__ long long g_ly_st[1024][16];
+#define RGN_LYT(i)                                                                                   \
+    {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        if (threadIdx.x == 0 && blockIdx.x < 1024 && l == RGN_LY_STAMPS) g_ly_st[blockIdx.x][i] = __builtin_readcyclecounter(); \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+    }
+#else
+#define RGN_LYT(i)
+#endif
+
+// GELU (erf form), see rgn_mlp2.hip
+__device__ __forceinline__ f32x2 ly_gelu2(f32x2 x) {
+    const f32x2 t = {__builtin_amdgcn_fmed3f(x[0], -4.5254834f, 4.5254834f), __builtin_amdgcn_fmed3f(x[1], -4.5254834f, 4.5254834f)};
+    const f32x2 z = t * t;
+    f32x2 p = f32x2{-7.433422766e-10f, -7.433422766e-10f};
+    p = __builtin_elementwise_fma(p, z, f32x2{6.994829249e-08f, 6.994829249e-08f});
+    p = __builtin_elementwise_fma(p, z, f32x2{-2.824688409e-06f, -2.824688409e-06f});
+    p = __builtin_elementwise_fma(p, z, f32x2{6.471458619e-05f, 6.471458619e-05f});
+    p = __builtin_elementwise_fma(p, z, f32x2{-9.421016439e-04f, -9.421016439e-04f});
+    p = __builtin_elementwise_fma(p, z, f32x2{9.306023829e-03f, 9.306023829e-03f});
+    p = __builtin_elementwise_fma(p, z, f32x2{-6.564749777e-02f, -6.564749777e-02f});
+    p = __builtin_elementwise_fma(p, z, f32x2{3.986273110e-01f, 3.986273110e-01f});
+    return x * __builtin_elementwise_fma(t, p, f32x2{0.5f, 0.5f});
+}
+
+__global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3, hg = wave >> 2;                     // attention roles: dh tile, head of the pair
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int b = xcd_affine(blockIdx.x, gridDim.x), Tq = g.Tq;
+    const size_t row0 = (size_t)b * Tq;
+    float* vec = reinterpret_cast<float*>(smem + LY_VEC) + wave * LY_VECW;   // this wave's private region
+    const int lane16 = lane * 16;
+    const int swz = (l31 >> 2) & 3;
+    // ---- the sample's residual rows -> X by DMA: 16 k-blocks x 4 pieces of 1 KiB (16 rows x 64 B); padding rows replicate the
+    //      last token (row-local everywhere, masked as keys)
+    {
+        const int r16 = lane >> 2, c = lane & 3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = wave + 8 * j, kb = p >> 2, r = (p & 3) * 16 + r16;
+            const int rr = r < Tq ? r : Tq - 1;
+            const size_t src = ((size_t)kb * g.rows + row0 + rr) * 32 + ((c ^ ((r >> 2) & 3)) << 3);
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.h + src), (RGN_AS3 void*)(smem + LY_X + p * 1024), 16, 0, 0);
+        }
+    }
+    const int step = g.stepvec ? *g.d_step : 0;
+    // B-operand fragment of token l31 (+ 32 ta: an immediate offset of 2 KiB) inside a k-block image, per 16-wide k-half; reads of
+    // the second image want their own base registers (16-bit ds_read offsets)
+    int a_off[2], a_offy[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a_off[ks] = l31 * 64 + (((2 * ks + kh) ^ swz) << 4);
+        a_offy[ks] = a_off[ks] + LY_Y;
+    }
+    // element (token 32 mt + l31, column 64 wave + 32 nt + 8 i4 + 4 kh + e) <-> register acc[nt][mt][4 i4 + e] of the layer tail;
+    // its 8-byte run inside an image
+    auto col4 = [&](int nt, int i4) { return 32 * nt + 8 * i4 + 4 * kh; };
+    int img_base = (2 * wave) * LY_KB + l31 * 64 + 8 * kh;
+    asm volatile("" : "+v"(img_base));
+    auto img_off = [&](int nt, int i4, int mt) { return img_base + nt * LY_KB + mt * 2048 + ((i4 ^ swz) << 4); };
+    int red_base = LY_RED + 4 * l31;
+    asm volatile("" : "+v"(red_base));
+    const float invn = 1.0f / 512.f;
+    const float qs2 = g.qscale * 1.44269504088896340736f;        // scores in log2 units: softmax = exp2(s - max)
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int l = 0; l < g.L; ++l) {
+        const LayerWts& w = g.lw[l];
+        RGN_LYT(0)
+        // ========================= self-attention: in_proj + causal softmax + p . v, two heads at a time ===================
+        bf16x4 attk[2][2][4];                                    // [round][query tile][run of 4 dh]: this wave's O^T tiles as bf16
+        {
+            struct PassA { __amdgpu_buffer_rsrc_t rs; };
+            auto qrs = [&](int r) {
+                const int blk = (2 * r + hg) * 4 + wn;           // first column block (32 columns) of this wave's q slice
+                return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(w.Wqkv) + (size_t)blk * 1024, 0, 3 * 512 * 512 * 2 - blk * 2048, 0x00020000);
+            };
+            const PassA pa[2] = {{qrs(0)}, {qrs(1)}};
+            bf16x8 wq[LY_RDA][3];
+            // granule hs = 2 kt + ks of the plane [16 k-blocks][48 column blocks][2][64][8]: the q, k, v fragments sit 16 column blocks apart
+            auto load_ga = [&](const PassA& ps, int hs, int slot) {
+                // (the granule offset is materialised by a volatile s_mov right here: as plain literals the ~300 offsets of a layer are hoisted
+                // out of the layer loop as loop invariants and live in spilled SGPRs)
+                int soff;
+                asm volatile("s_mov_b32 %0, %1" : "=s"(soff) : "i"((hs >> 1) * (48 * 2048) + (hs & 1) * 1024));
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    wq[slot][t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ps.rs, lane16, soff + t * (16 * 2048), 0));
+            };
+            constexpr int AH = LY_RDA - 1;
+#pragma unroll
+            for (int s = 0; s < AH; ++s) load_ga(pa[0], s, s);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int head = 2 * r + hg;
+                // accumulators start from the in_proj bias: q^T, k^T (lane = token, register i <-> dh 8 (i >> 2) + 4 kh + (i & 3)),
+                // v (lane = dh, registers = tokens)
+                f32x16 acc[2][3];
+                {
+                    const float* bq = w.bqkv + head * 128 + wn * 32;
+                    f32x4 q4[4], k4[4];
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        q4[i4] = *reinterpret_cast<const f32x4*>(bq + 8 * i4 + 4 * kh);
+                        k4[i4] = *reinterpret_cast<const f32x4*>(bq + 512 + 8 * i4 + 4 * kh);
+                    }
+                    const float bv = bq[1024 + l31];
+#pragma unroll
+                    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                        for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                acc[ta][0][4 * i4 + e] = q4[i4][e];
+                                acc[ta][1][4 * i4 + e] = k4[i4][e];
+                                acc[ta][2][4 * i4 + e] = bv;
+                            }
+                }
+                // ---- in_proj: [64 tokens] x [q | k | v of this wave's 32 dh columns] over K = 512, from the resident image X
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    bf16x8 af[2];
+#pragma unroll
+                    for (int ta = 0; ta < 2; ++ta) af[ta] = *reinterpret_cast<const bf16x8*>(smem + a_off[0] + ta * 2048);
+#pragma unroll
+                    for (int hs = 0; hs < 32; ++hs) {
+                        bf16x8 afn[2];
+#pragma unroll
+                        for (int ta = 0; ta < 2; ++ta) {
+                            afn[ta] = af[ta];
+                            if (hs + 1 < 32) afn[ta] = *reinterpret_cast<const bf16x8*>(smem + ((hs + 1) >> 1) * LY_KB + a_off[(hs + 1) & 1] + ta * 2048);
+                        }
+                        if (hs + AH < 32) load_ga(pa[r], hs + AH, (32 * r + hs + AH) % LY_RDA);
+                        else if (r == 0) load_ga(pa[1], hs + AH - 32, (32 * r + hs + AH) % LY_RDA);
+                        if (hs + AH < 32 || r == 0) {
+                            if (hs < AH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * AH + 9) : "memory");   // (+ the 9 bias loads)
+                            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * AH) : "memory");
+                        }
+                        const int slot = (32 * r + hs) % LY_RDA;
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+#pragma unroll
+                            for (int ta = 0; ta < 2; ++ta) {
+                                if (t < 2) acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[slot][t], af[ta], acc[ta][t], 0, 0, 0);
+                                else acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ta], wq[slot][t], acc[ta][t], 0, 0, 0);
+                            }
+#pragma unroll
+                        for (int ta = 0; ta < 2; ++ta) af[ta] = afn[ta];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                RGN_LYT(1 + 3 * r)
+                // ---- attention straight from the accumulators (rgn_qkv_attn.hip qa_attention, plain-bf16 form)
+                bf16x8 qh[2][2], kf[2][2], vh[2][2];             // [token tile][16-slice of the register index]
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int i = 8 * sl + j;
+                            qh[ta][sl][j] = (__bf16)(acc[ta][0][i] * qs2);
+                            kf[ta][sl][j] = (__bf16)acc[ta][1][i];
+                            vh[ta][sl][j] = (__bf16)acc[ta][2][i];
+                        }
+                // causal tiles of S^T: 0 = (keys 0-31, queries 0-31), 1 = (keys 0-31, queries 32-63), 2 = (keys 32-63, queries 32-63)
+                f32x16 st[3];
+#pragma unroll
+                for (int tl = 0; tl < 3; ++tl) {
+                    const int kj = tl >> 1, qtile = tl ? 1 : 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) st[tl][i] = 0.f;
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) st[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kj][sl], qh[qtile][sl], st[tl], 0, 0, 0);
+                }
+                // sum the partials of the four dh tiles: [head of the pair][tile][wave wn][i / 4][lane] float4
+                f32x4* sred = reinterpret_cast<f32x4*>(smem + LY_EXCH);
+#pragma unroll
+                for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        const f32x4 v = {st[tl][4 * i4], st[tl][4 * i4 + 1], st[tl][4 * i4 + 2], st[tl][4 * i4 + 3]};
+                        sred[(((hg * 3 + tl) * 4 + wn) * 4 + i4) * 64 + lane] = v;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        f32x4 v = sred[(((hg * 3 + tl) * 4 + 0) * 4 + i4) * 64 + lane];
+#pragma unroll
+                        for (int ww = 1; ww < 4; ++ww) {
+                            const f32x4 u = sred[(((hg * 3 + tl) * 4 + ww) * 4 + i4) * 64 + lane];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += u[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) st[tl][4 * i4 + e] = v[e];
+                    }
+                // softmax over keys for the lane's two queries (l31 and 32 + l31); every wave of the head does the same work
+                float inv[2];
+#pragma unroll
+                for (int qtile = 0; qtile < 2; ++qtile) {
+                    const int q = 32 * qtile + l31;
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int tl = qtile; tl <= 2 * qtile; ++tl) {   // tiles {0} for query tile 0, {1, 2} for query tile 1
+                        const int kj = tl >> 1;
+                        // key of register i = 32 kj + 4 kh + c_i, c_i = (i & 3) + 8 (i >> 2); visible iff key <= min(q, Tq - 1) (tile 1 lies below
+                        // the diagonal: only key < Tq). One per-lane limit, made opaque HERE: as loop invariants the 96 compares of a layer are
+                        // hoisted out of the layer loop and their lane masks live in spilled SGPR pairs
+                        int lim = (tl == 1 ? Tq - 1 : (q < Tq - 1 ? q : Tq - 1)) - 32 * kj - 4 * kh;
+                        asm volatile("" : "+v"(lim));
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            st[tl][i] = ((i & 3) + 8 * (i >> 2) <= lim) ? st[tl][i] : -INFINITY;
+                            mx = fmaxf(mx, st[tl][i]);
+                        }
+                    }
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    float sum = 0.f;
+#pragma unroll
+                    for (int tl = qtile; tl <= 2 * qtile; ++tl)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float e = __builtin_amdgcn_exp2f(st[tl][i] - mx);
+                            st[tl][i] = e;
+                            sum += e;
+                        }
+                    sum += __shfl_xor(sum, 32, 64);
+                    inv[qtile] = 1.0f / sum;
+                }
+                // O^T[dh tile wn, queries] = V (A operand, registers = keys) x P^T (B operand, registers = keys)
+#pragma unroll
+                for (int qtile = 0; qtile < 2; ++qtile) {
+                    f32x16 oa;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) oa[i] = 0.f;
+#pragma unroll
+                    for (int tl = qtile; tl <= 2 * qtile; ++tl) {
+                        const int kj = tl >> 1;
+#pragma unroll
+                        for (int sl = 0; sl < 2; ++sl) {
+                            bf16x8 ph;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) ph[j] = (__bf16)st[tl][8 * sl + j];
+                            oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[kj][sl], ph, oa, 0, 0, 0);
+                        }
+                    }
+                    // O^T tile: lane = query, registers = 16 dh indices -> 4 runs of 4 consecutive dh
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) attk[r][qtile][i4][e] = (__bf16)(oa[4 * i4 + e] * inv[qtile]);
+                }
+                RGN_LYT(2 + 3 * r)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                    // every wave has read this round's sums: the exchange may be overwritten
+                RGN_LYT(3 + 3 * r)
+            }
+        }
+        // ========================= layer tail on the resident images (rgn_mlp2.hip, MT = 2) ==================================
+        struct Pass { __amdgpu_buffer_rsrc_t rs; int kstride, hs0; };
+        auto wrs = [&](const __bf16* W, int cb0, int bytes) {
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(W) + (size_t)cb0 * 1024, 0, bytes - cb0 * 2048, 0x00020000);
+        };
+        const Pass p_wo{wrs(w.Wo, 2 * wave, 512 * 512 * 2), 16 * 2048, 0}, p_w1a{wrs(w.W1, 2 * wave, 1024 * 512 * 2), 32 * 2048, 0},
+            p_w1b{wrs(w.W1, 16 + 2 * wave, 1024 * 512 * 2), 32 * 2048, 0}, p_w2a{wrs(w.W2, 2 * wave, 512 * 1024 * 2), 16 * 2048, 0},
+            p_w2b{p_w2a.rs, 16 * 2048, 32};
+        bf16x8 wf[LY_RDM][2];
+        auto load_g = [&](const Pass& ps, int hs_rel, int slot) {
+            const int hs = ps.hs0 + hs_rel;
+            int soff;
+            asm volatile("s_mov_b32 %0, %1" : "=s"(soff) : "i"((hs >> 1) * ps.kstride + (hs & 1) * 1024));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                wf[slot][nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ps.rs, lane16, soff + nt * 2048, 0));
+        };
+        // one GEMM pass over K = 512 from the image at byte offsets aoff (see rgn_mlp2.hip): the ring never drains between passes
+        auto gemm32 = [&](f32x16 (&acc)[2][2], const int (&aoff)[2], const Pass& cur, const Pass& nxt, auto chain, auto extra) {
+            constexpr int EX = decltype(extra)::value, AH = LY_RDM - 1;
+            constexpr bool CH = decltype(chain)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 af[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(smem + aoff[0] + mt * 2048);
+#pragma unroll
+            for (int hs = 0; hs < 32; ++hs) {
+                bf16x8 afn[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    afn[mt] = af[mt];
+                    if (hs + 1 < 32) afn[mt] = *reinterpret_cast<const bf16x8*>(smem + ((hs + 1) >> 1) * LY_KB + aoff[(hs + 1) & 1] + mt * 2048);
+                }
+                if (hs + AH < 32) load_g(cur, hs + AH, (hs + AH) % LY_RDM);
+                else if (CH) load_g(nxt, hs + AH - 32, (hs + AH) % LY_RDM);
+                if (hs + AH < 32 || CH) {
+                    if (hs < AH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * AH + EX) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * AH) : "memory");
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[hs % LY_RDM][nt], af[mt], acc[nt][mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) af[mt] = afn[mt];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto init_bias = [&](f32x16 (&acc)[2][2], const float* bias) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + col4(nt, i4));
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[nt][mt][4 * i4 + e] = bb[e];
+                }
+        };
+        // LayerNorm over the 512 columns of every token, in place: one exchange of (sum, sum of squares) - rgn_mlp2.hip
+        auto layernorm = [&](f32x16 (&acc)[2][2], const float* gam, auto slot, auto shift /* (nt, i4) -> f32x4 */) {
+            const char* buf = smem + red_base + decltype(slot)::value * LY_REDF * 4;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x2 s2 = f32x2{0.f, 0.f}, q2 = f32x2{0.f, 0.f};
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; i += 2) {
+                        const f32x2 v = f32x2{acc[nt][mt][i], acc[nt][mt][i + 1]};
+                        s2 += v;
+                        q2 = __builtin_elementwise_fma(v, v, q2);
+                    }
+                float s = s2[0] + s2[1], q = q2[0] + q2[1];
+                s += __shfl_xor(s, 32, 64);
+                q += __shfl_xor(q, 32, 64);
+                *reinterpret_cast<float*>(const_cast<char*>(buf) + (kh * 512 + wave * 64 + 32 * mt) * 4) = kh ? q : s;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            f32x2 rs[2], nm[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float p[2][8];
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int ww = 0; ww < 8; ++ww) p[st][ww] = *reinterpret_cast<const float*>(buf + (st * 512 + ww * 64 + 32 * mt) * 4);
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int dd = 1; dd < 8; dd *= 2)
+#pragma unroll
+                        for (int ww = 0; ww < 8; ww += 2 * dd) p[st][ww] += p[st][ww + dd];
+                const float mean = p[0][0] * invn;
+                const float var = __builtin_fmaxf(p[1][0] * invn - mean * mean, 0.f);
+                const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+                rs[mt] = f32x2{rstd, rstd};
+                nm[mt] = f32x2{-mean, -mean};
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x4 ga[4], sh[4];
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    ga[i4] = *reinterpret_cast<const f32x4*>(gam + col4(nt, i4));
+                    sh[i4] = shift(nt, i4);
+                }
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int e = 0; e < 4; e += 2) {
+                            const f32x2 rg = f32x2{ga[i4][e], ga[i4][e + 1]} * rs[mt];
+                            const f32x2 bb = __builtin_elementwise_fma(nm[mt], rg, f32x2{sh[i4][e], sh[i4][e + 1]});
+                            const f32x2 o = __builtin_elementwise_fma(f32x2{acc[nt][mt][4 * i4 + e], acc[nt][mt][4 * i4 + e + 1]}, rg, bb);
+                            acc[nt][mt][4 * i4 + e] = o[0];
+                            acc[nt][mt][4 * i4 + e + 1] = o[1];
+                        }
+            }
+        };
+        auto store_img = [&](const f32x16 (&acc)[2][2], int img) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        bf16x4 hh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hh[e] = (__bf16)acc[nt][mt][4 * i4 + e];
+                        *reinterpret_cast<bf16x4*>(smem + img + img_off(nt, i4, mt)) = hh;
+                    }
+        };
+        // acc += bf16 residual from the image X (this wave's own columns)
+        auto add_resid = [&](f32x16 (&acc)[2][2], const float* bias) {
+            bf16x4 rr[2][2][4];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4) rr[nt][mt][i4] = *reinterpret_cast<const bf16x4*>(smem + LY_X + img_off(nt, i4, mt));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+                    if (bias) bb = *reinterpret_cast<const f32x4*>(bias + col4(nt, i4));
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[nt][mt][4 * i4 + e] += (float)rr[nt][mt][i4][e] + bb[e];
+                }
+        };
+
+        // ---- out_proj's first fragments and this layer's per-column vectors (this wave's 64 columns: lane = column)
+#pragma unroll
+        for (int s = 0; s < LY_RDM - 1; ++s) load_g(p_wo, s, s);
+        const int cw = 64 * wave + lane;
+        float vv[12];
+        {
+            const float* src[9] = {w.bo, w.g1, w.g2, w.b2, w.bf1, w.bf1 + 512, w.bf2, w.g3, w.b3};
+            vv[0] = src[0][cw]; vv[1] = src[1][cw]; vv[2] = src[2][cw]; vv[3] = src[3][cw];
+            vv[4] = w.b1[cw] + (g.stepvec ? g.stepvec[(size_t)step * g.ldstep + (size_t)l * 512 + cw] : 0.f) +
+                    (g.pervec ? g.pervec[(size_t)b * g.ldper + (size_t)l * 512 + cw] : 0.f);   // norm1's beta + call_time[step] + call_cond[sample]
+            vv[5] = src[4][cw]; vv[6] = src[5][cw]; vv[7] = src[6][cw]; vv[8] = src[7][cw]; vv[9] = src[8][cw];
+        }
+        asm volatile("" ::: "memory");
+        // ---- the attention output -> image Y (the exchange is dead: every wave passed the barrier behind the last round)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int qtile = 0; qtile < 2; ++qtile)
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4)
+                    *reinterpret_cast<bf16x4*>(smem + LY_Y + ((2 * r + hg) * 4 + wn) * LY_KB + (32 * qtile + l31) * 64 + ((i4 ^ swz) << 4) + 8 * kh) = attk[r][qtile][i4];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
+        RGN_LYT(7)
+        gemm32(acc, a_offy, p_wo, p_w1a, std::true_type{}, std::integral_constant<int, 12>{});
+        RGN_LYT(8)
+        // vectors -> the wave's LDS region (wave-private: program order suffices)
+        vec[V_BO + lane] = vv[0]; vec[V_G1 + lane] = vv[1]; vec[V_G2 + lane] = vv[2]; vec[V_B2 + lane] = vv[3]; vec[V_SPV + lane] = vv[4];
+        vec[V_BF1 + lane] = vv[5]; vec[V_BF1 + 64 + lane] = vv[6]; vec[V_BF2 + lane] = vv[7]; vec[V_G3 + lane] = vv[8]; vec[V_B3 + lane] = vv[9];
+        add_resid(acc, vec + V_BO);
+        layernorm(acc, vec + V_G1, std::integral_constant<int, 0>{}, [&](int nt, int i4) { return *reinterpret_cast<const f32x4*>(vec + V_SPV + col4(nt, i4)); });
+        layernorm(acc, vec + V_G2, std::integral_constant<int, 1>{}, [&](int nt, int i4) { return *reinterpret_cast<const f32x4*>(vec + V_B2 + col4(nt, i4)); });
+        store_img(acc, LY_X);                                    // h' replaces h in place (this wave's columns: it read them above)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        RGN_LYT(9)
+        f32x16 acc2[2][2];
+        init_bias(acc2, vec + V_BF2);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            init_bias(acc, vec + V_BF1 + 64 * c);
+            gemm32(acc, a_off, c ? p_w1b : p_w1a, c ? p_w2b : p_w2a, std::true_type{}, std::integral_constant<int, 0>{});   // hidden columns [512 c, 512 c + 512)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 16; i += 2) {
+                        const f32x2 gl = ly_gelu2(f32x2{acc[nt][mt][i], acc[nt][mt][i + 1]});
+                        acc[nt][mt][i] = gl[0];
+                        acc[nt][mt][i + 1] = gl[1];
+                    }
+            if (c == 1) __builtin_amdgcn_s_barrier();             // every wave is done reading the first half's image
+            store_img(acc, LY_Y);                                 // (c == 0: Y holds the attention output, dead since out_proj)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (c == 0) gemm32(acc2, a_offy, p_w2a, p_w1b, std::true_type{}, std::integral_constant<int, 0>{});
+            else gemm32(acc2, a_offy, p_w2b, p_w2b, std::false_type{}, std::integral_constant<int, 0>{});
+        }
+        RGN_LYT(10)
+        add_resid(acc2, nullptr);
+        layernorm(acc2, vec + V_G3, std::integral_constant<int, 0>{}, [&](int nt, int i4) { return *reinterpret_cast<const f32x4*>(vec + V_B3 + col4(nt, i4)); });
+        store_img(acc2, LY_X);                                   // the next layer's input, in place
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        RGN_LYT(11)
+    }
+    // ---- the sample's rows -> output planes (write-through)
+    {
+        const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)((size_t)g.rows * 512 * 2), 0x00020000);
+        const int r16 = lane >> 2, c = lane & 3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = wave * 8 + j, blk = p >> 2, r = (p & 3) * 16 + r16;
+            if (r < Tq) {
+                const int off = blk * LY_KB + r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(smem + LY_X + off), o_rs,
+                                                       (int)((((size_t)blk * g.rows + row0 + r) * 32 + c * 8) * 2), 0, RGN_LY_ST_AUX);
+            }
+        }
+    }
+}
+
+#ifdef RGN_LY_STAMPS
+void ly_stamps_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ly_st), sizeof(long long) * 1024 * 16); }
+#endif
+
+bool layers_supported(int d, int ff, int H, int Tq, int L) { return d == 512 && ff == 1024 && H == 4 && Tq >= 1 && Tq <= 64 && L >= 1 && L <= LY_MAXL; }
+hipError_t configure_layers() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_layers), hipFuncAttributeMaxDynamicSharedMemorySize, LY_LDS);
+}
+hipError_t launch_layers(const LayersArgs& g, hipStream_t s) {
+    hipLaunchKernelGGL(k_layers, dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
+    return hipGetLastError();
+}
+
+}  // namespace rgn

@@ -401,7 +401,7 @@ bool mlp_supported(int d, int ff, int Tq) { return d == ML_D && ff == 2 * ML_D &
 static int mlp_kernel() {
     static const int r = [] {
         const char* e = getenv("REGENNET_MLP_KERNEL");
-        return e ? atoi(e) : 1;
+        return e ? atoi(e) : 2;
     }();
     return r;
 }

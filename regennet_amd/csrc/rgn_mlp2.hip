@@ -37,6 +37,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#ifndef RGN_M2_HRES
+#define RGN_M2_HRES 0      // where the residual tile is requested: 0 = in the prologue behind the att DMA, 1 = behind the att barrier
+#endif
 #ifndef RGN_M2_ST_AUX
 #define RGN_M2_ST_AUX 16   // output stores write-through (sc1): nothing left dirty in the XCD L2s for the end-of-kernel write-back
 #endif
@@ -63,7 +66,7 @@ static_assert(M2<1>::LDS == 78 * 1024 && M2<2>::LDS == 152 * 1024, "LDS map");
 #ifdef RGN_M2_STAMPS
 // tools/mlp_bench -DRGN_M2_STAMPS: wave 0 of EVERY workgroup stamps s_memtime at the phase boundaries, plus where it runs
 // (HW_ID: SIMD / CU / SE, XCC_ID), so that the host can put the workgroups of one CU next to each other
-__device__ long long g_m2_st[1024][8];
+__device__ long long g_m2_st[1024][12];
 #define RGN_M2T(i)                                                                                                  \
     {                                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
@@ -73,8 +76,8 @@ __device__ long long g_m2_st[1024][8];
                 unsigned hw, xcc;                                                                                   \
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                    \
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                                  \
-                g_m2_st[blockIdx.x][6] = hw;                                                                        \
-                g_m2_st[blockIdx.x][7] = xcc;                                                                       \
+                g_m2_st[blockIdx.x][10] = hw;                                                                       \
+                g_m2_st[blockIdx.x][11] = xcc;                                                                       \
             }                                                                                                       \
         }                                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
@@ -287,20 +290,23 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
     f32x16 acc[NT][MT];
 #pragma unroll
     for (int s = 0; s < RD - 1; ++s) load_g(p_wo, s, s);           // right behind the att DMA: the first MFMA needs both, and nothing else
+    RGN_M2T(6)
     const int cw = CW * wave + lane;                                 // this lane's column(s) of every vector slice: cw (+ 64)
-    // phase A vectors of the wave's columns (staged to LDS below)
+    // phase A vectors of the wave's columns: requested now, staged to the wave's LDS region after the out_proj loop - nothing
+    // before the first MFMA depends on them (the accumulators start from zero; out_proj's bias is added with the residual)
     float va[4][VK], sv[VK], pv[NSAMP][VK];
+    int step = 0;
     {
         const float* srcA[4] = {g.bo, g.g1, g.g2, g.b2};
 #pragma unroll
         for (int v = 0; v < 4; ++v)
 #pragma unroll
             for (int k = 0; k < VK; ++k) va[v][k] = srcA[v][cw + 64 * k];
-        const int step = g.stepvec ? *g.d_step : 0;
+        if (g.stepvec) step = *g.d_step;
         const int s0 = m0 / g.Tq, slast = (g.M - 1) / g.Tq;
 #pragma unroll
         for (int k = 0; k < VK; ++k) {
-            sv[k] = (g.stepvec ? g.stepvec[(size_t)step * g.ldstep + cw + 64 * k] : 0.f) + g.b1[cw + 64 * k];   // norm1's beta folded in
+            sv[k] = g.b1[cw + 64 * k];                               // norm1's beta, folded into the per-sample vector
 #pragma unroll
             for (int j = 0; j < NSAMP; ++j) {
                 const int sidx = s0 + j < slast ? s0 + j : slast;
@@ -311,16 +317,21 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
     asm volatile("" ::: "memory");
     // the residual tile straight into registers (needed after the loop: NOT waited for before the first MFMA), then phase B
     bf16x4 hres[NT][MT][4];
+    auto load_hres = [&]() {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int m = m0 + 32 * mt + l31;
-        m = m < g.M ? m : g.M - 1;
+        for (int mt = 0; mt < MT; ++mt) {
+            int m = m0 + 32 * mt + l31;
+            m = m < g.M ? m : g.M - 1;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4)
-                hres[nt][mt][i4] = *reinterpret_cast<const bf16x4*>(g.h + ((size_t)(NT * wave + nt) * g.rows + m) * 32 + 8 * i4 + 4 * kh);
-    }
+                for (int i4 = 0; i4 < 4; ++i4)
+                    hres[nt][mt][i4] = *reinterpret_cast<const bf16x4*>(g.h + ((size_t)(NT * wave + nt) * g.rows + m) * 32 + 8 * i4 + 4 * kh);
+        }
+    };
+#if RGN_M2_HRES == 0
+    load_hres();
+#endif
     float vb[5][VK];                                                 // phase B, held in registers until the wave is past norm2
 #pragma unroll
     for (int k = 0; k < VK; ++k) {
@@ -331,7 +342,29 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
         vb[4][k] = g.b3[cw + 64 * k];
     }
     asm volatile("" ::: "memory");
-    constexpr int EXTRA = 16 + 5 * VK;                               // residual + phase B loads
+    constexpr int EXTRA = 16 + 6 * VK;                               // residual + phase B + step vector loads
+    // the att image is complete once EVERY wave's DMA pieces have landed: they are the oldest vector-memory operations of this
+    // wave, so the count below leaves everything younger than the first weight fragments in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RGN_M2_HRES == 0 ? 16 : 0) + 5 * VK) : "memory");
+    RGN_M2T(7)
+    __builtin_amdgcn_s_barrier();
+#if RGN_M2_HRES == 1
+    load_hres();
+#endif
+    float tv[VK];
+#pragma unroll
+    for (int k = 0; k < VK; ++k) tv[k] = g.stepvec ? g.stepvec[(size_t)step * g.ldstep + cw + 64 * k] : 0.f;   // (the loop index landed long ago)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
+    RGN_M2T(1)
+    gemm32(acc, smem + C::X, p_wo, p_w1a, std::true_type{}, std::integral_constant<int, EXTRA>{});
+    RGN_M2T(2)
+    // phase A vectors -> the wave's LDS region (wave-private: no barrier, the exchange barrier of norm1 is far behind the writes)
 #pragma unroll
     for (int v = 0; v < 4; ++v)
 #pragma unroll
@@ -339,24 +372,17 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
 #pragma unroll
     for (int j = 0; j < NSAMP; ++j)
 #pragma unroll
-        for (int k = 0; k < VK; ++k) vec[C::A_SPV + CW * j + 64 * k + lane] = sv[k] + pv[j][k];
-    // the att image is complete once EVERY wave's DMA pieces have landed: they are the oldest vector-memory operations of this
-    // wave, so the count below leaves the residual and the phase-B vectors in flight
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EXTRA) : "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    init_bias(acc, vec + C::A_BO);
-    RGN_M2T(1)
-    gemm32(acc, smem + C::X, p_wo, p_w1a, std::true_type{}, std::integral_constant<int, EXTRA>{});
-    RGN_M2T(2)
+        for (int k = 0; k < VK; ++k) vec[C::A_SPV + CW * j + 64 * k + lane] = (tv[k] + sv[k]) + pv[j][k];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(vec + C::A_BO + col4(nt, i4));
 #pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[nt][mt][4 * i4 + e] += (float)hres[nt][mt][i4][e];
+                for (int e = 0; e < 4; ++e) acc[nt][mt][4 * i4 + e] += (float)hres[nt][mt][i4][e] + b[e];
+        }
     {   // norm1 (gamma only) + norm1.beta + call_time[step] + call_cond[sample of the token] (pre-summed per sample in LDS)
         const float* spv[MT];
 #pragma unroll
@@ -444,7 +470,7 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
 }
 
 #ifdef RGN_M2_STAMPS
-void m2_stamps_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_m2_st), sizeof(long long) * 1024 * 8); }
+void m2_stamps_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_m2_st), sizeof(long long) * 1024 * 12); }
 #endif
 
 // samples a tile of `rows` rows can touch

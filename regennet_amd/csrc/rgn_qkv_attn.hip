@@ -156,11 +156,14 @@ __device__ __forceinline__ void qa_attention(f32x16 (&acc)[2][3], const QkvAttnA
 #pragma unroll
         for (int tl = qtile; tl <= 2 * qtile; ++tl) {             // tiles {0} for query tile 0, {1, 2} for query tile 1
             const int kj = tl >> 1;
+            // key of register i = 32 kj + 4 kh + c_i, c_i = (i & 3) + 8 (i >> 2); visible iff key <= min(q, Tq - 1) (tile 1 - keys 0-31,
+            // queries 32-63 - lies below the diagonal: only key < Tq). ONE per-lane limit, made opaque here: written as 48 compares of
+            // loop-invariant values they are hoisted out of the head loop and their lane masks live in ~70 SGPRs spilled to VGPR lanes
+            int lim = (tl == 1 ? Tq - 1 : (q < Tq - 1 ? q : Tq - 1)) - 32 * kj - 4 * kh;
+            asm volatile("" : "+v"(lim));
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int key = 32 * kj + (i & 3) + 8 * (i >> 2) + 4 * kh;
-                const bool ok = (tl == 1 || key <= q) && (key < Tq);   // tile 1 (keys 0-31, queries 32-63) lies below the diagonal
-                st[tl][i] = ok ? st[tl][i] : -INFINITY;
+                st[tl][i] = ((i & 3) + 8 * (i >> 2) <= lim) ? st[tl][i] : -INFINITY;
                 mx = fmaxf(mx, st[tl][i]);
             }
         }

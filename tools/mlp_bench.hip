@@ -88,28 +88,28 @@ int main(int argc, char** argv) {
 #endif
 #ifdef RGN_M2_STAMPS
     {   // REGENNET_MLP_KERNEL=2|3: phase stamps of wave 0 of every workgroup, grouped by the CU it ran on (the last launch)
-        std::vector<long long> st(1024 * 8);
+        std::vector<long long> st(1024 * 12);
         m2_stamps_read(st.data());
         const int trows = (getenv("REGENNET_MLP_KERNEL") && atoi(getenv("REGENNET_MLP_KERNEL")) == 3) ? 32 : 64;
         const int nwg = std::min(1024, (M + trows - 1) / trows);
         std::map<long long, std::vector<int>> by_cu;
         for (int b = 0; b < nwg; ++b) {
-            const unsigned hw = (unsigned)st[b * 8 + 6];
-            by_cu[(st[b * 8 + 7] << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)].push_back(b);
+            const unsigned hw = (unsigned)st[b * 12 + 10];
+            by_cu[(st[b * 12 + 11] << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)].push_back(b);
         }
         long long t00 = st[0];
-        for (int b = 0; b < nwg; ++b) t00 = std::min(t00, st[b * 8]);
+        for (int b = 0; b < nwg; ++b) t00 = std::min(t00, st[b * 12]);
         int shown = 0, pairs = 0, singles = 0, more = 0;
         double ph[5] = {0, 0, 0, 0, 0}, life = 0, ovl = 0;
         for (auto& kv : by_cu) {
             auto& v = kv.second;
             if (v.size() == 1) ++singles; else if (v.size() == 2) ++pairs; else ++more;
             for (int b : v) {
-                for (int i = 0; i < 5; ++i) ph[i] += (double)(st[b * 8 + i + 1] - st[b * 8 + i]);
-                life += (double)(st[b * 8 + 5] - st[b * 8]);
+                for (int i = 0; i < 5; ++i) ph[i] += (double)(st[b * 12 + i + 1] - st[b * 12 + i]);
+                life += (double)(st[b * 12 + 5] - st[b * 12]);
             }
             if (v.size() == 2) {   // cycles during which both are inside an MFMA loop phase (stamps 1-2 and 3-4) at once
-                auto inter = [&](int a0, int a1, int b0, int b1) { return (double)std::max(0LL, std::min(st[v[0] * 8 + a1], st[v[1] * 8 + b1]) - std::max(st[v[0] * 8 + a0], st[v[1] * 8 + b0])); };
+                auto inter = [&](int a0, int a1, int b0, int b1) { return (double)std::max(0LL, std::min(st[v[0] * 12 + a1], st[v[1] * 12 + b1]) - std::max(st[v[0] * 12 + a0], st[v[1] * 12 + b0])); };
                 ovl += inter(1, 2, 1, 2) + inter(1, 2, 3, 4) + inter(3, 4, 1, 2) + inter(3, 4, 3, 4);
             }
             if (v.size() == 2 && shown < 6) {
@@ -117,13 +117,16 @@ int main(int argc, char** argv) {
                 printf("  CU %05llx:", kv.first);
                 for (int b : v) {
                     printf("  wg %3d [", b);
-                    for (int i = 0; i < 6; ++i) printf("%s%lld", i ? " " : "", st[b * 8 + i] - t00);
+                    for (int i = 0; i < 6; ++i) printf("%s%lld", i ? " " : "", st[b * 12 + i] - st[v[0] * 12]);
                     printf("]");
                 }
                 printf("\n");
             }
         }
         printf("  %d workgroups on %zu CUs: %d CUs with two, %d with one, %d with more\n", nwg, by_cu.size(), pairs, singles, more);
+        double pro[2] = {0, 0};
+        for (int b = 0; b < nwg; ++b) { pro[0] += (double)(st[b * 12 + 6] - st[b * 12]); pro[1] += (double)(st[b * 12 + 7] - st[b * 12]); }
+        printf("  prologue (mean cycles from the start): DMA + first fragments issued %.0f | att tile landed (this wave) %.0f\n", pro[0] / nwg, pro[1] / nwg);
         printf("  mean cycles per workgroup (wave 0): tile wait %.0f | out_proj %.0f | res+LN1+LN2+image %.0f | ffn %.0f | res+LN3+store %.0f | lifetime %.0f; both-in-a-loop overlap per pair %.0f\n",
                ph[0] / nwg, ph[1] / nwg, ph[2] / nwg, ph[3] / nwg, ph[4] / nwg, life / nwg, pairs ? ovl / pairs : 0.0);
     }
