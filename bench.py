@@ -49,6 +49,15 @@ def fused_qkv_attention_long(cfg, precision):
             and not os.environ.get("REGENNET_NO_QKV_LONG"))
 
 
+def layers_fused(cfg, precision):
+    """Mirrors rgn_api.cpp (layers_fused): the whole decoder stack of an evaluation runs as ONE kernel, one sample per workgroup."""
+    Tq = cfg["num_frames"] + int(bool(cfg.get("emb_trans_dec")))
+    return (precision == "bf16_x3tail" and int(os.environ.get("REGENNET_LAYERS_MIN_TQ", "52")) <= Tq <= 64 and cfg["latent_dim"] == 512
+            and cfg["ff_size"] == 1024 and cfg["num_heads"] == 4 and cfg["layers"] <= 8 and os.environ.get("REGENNET_LAYERS", "1") != "0"
+            and not os.environ.get("REGENNET_NO_MLP") and not os.environ.get("REGENNET_NO_FUSED_QKV") and not os.environ.get("REGENNET_NO_QKV_RS")
+            and not os.environ.get("REGENNET_NO_ROWGEMM") and not os.environ.get("REGENNET_BULK_RESID_LO"))
+
+
 def rowgemm_phase(cfg, precision):
     """Mirrors rgn_api.cpp: the plain-bf16 phase runs out_proj+LN / linear1+GELU / linear2+LN as row-complete kernels."""
     return (precision == "bf16_x3tail" and cfg["latent_dim"] == 512 and cfg["ff_size"] in (384, 512, 1024)
@@ -65,8 +74,8 @@ def flops_per_eval(cfg, B, guided, precision="bf16x3"):
     qkv = M * 3 * d * d * L
     attn = M * 2 * T * d * L
     embed = (B * T * F * d if precision == "f32" else M * F * d) + M * d * F       # input embedding, output projection
-    out = {"gemm_mfma": embed, "qkv_attn": 0, "attention": 0, "rowgemm_ln": 0, "rowgemm_act": 0, "mlp": 0, "sb_gemm": 0, "step_fused": 0}
-    sb_rows = int(os.environ.get("REGENNET_SB_ROWS", "768"))
+    out = {"gemm_mfma": embed, "qkv_attn": 0, "attention": 0, "rowgemm_ln": 0, "rowgemm_act": 0, "mlp": 0, "sb_gemm": 0, "step_fused": 0, "layers": 0}
+    sb_rows = int(os.environ.get("REGENNET_SB_ROWS", "640"))
     if precision != "f32" and d == 512 and ff % 32 == 0 and T + cfg.get("emb_trans_dec", 0) <= 160 and Bm * (T + cfg.get("emb_trans_dec", 0)) <= sb_rows:
         # small-batch engine (rgn_sb.hip): every GEMM of the evaluation is a column-split k_sb_gemm launch
         out["gemm_mfma"] = 0
@@ -84,7 +93,10 @@ def flops_per_eval(cfg, B, guided, precision="bf16x3"):
             and not os.environ.get("REGENNET_NO_STEP_FUSION") and not os.environ.get("REGENNET_BULK_RESID_LO")):
         out["step_fused"] = embed                                  # k_step: output projection + sampler update + next input embedding
         out["gemm_mfma"] -= embed
-    if fused_qkv_attention(cfg, precision) or fused_qkv_attention_long(cfg, precision):
+    if layers_fused(cfg, precision):
+        out["layers"] = qkv + attn + out["mlp"]                    # k_layers: in_proj + attention + layer tail of all L layers, one launch per chain
+        out["mlp"] = 0
+    elif fused_qkv_attention(cfg, precision) or fused_qkv_attention_long(cfg, precision):
         out["qkv_attn"] = qkv + attn
     else:
         out["rowgemm_act" if rowgemm_phase(cfg, precision) else "gemm_mfma"] += qkv   # long sequences: in_proj GEMM + k_attn_x3
@@ -273,7 +285,7 @@ def main(argv=None):
         fl = flops_per_eval(cfg, B, a.guided, a.precision)
         peak = PEAK_TFLOPS[a.precision]
         names = {"gemm_mfma": "k_gemm_x3", "qkv_attn": "k_qkv_attn", "attention": "k_attn_x3", "layernorm": "k_layernorm",
-                 "update": "k_update", "rowgemm_ln": "k_rowgemm<LN>", "rowgemm_act": "k_rowgemm<ACT>", "mlp": "k_mlp", "sb_gemm": "k_sb_gemm", "step_fused": "k_step"}
+                 "update": "k_update", "rowgemm_ln": "k_rowgemm<LN>", "rowgemm_act": "k_rowgemm<ACT>", "mlp": "k_mlp", "sb_gemm": "k_sb_gemm", "step_fused": "k_step", "layers": "k_layers"}
         if a.precision == "f32":
             names.update(gemm_mfma="k_gemm_f32", attention="k_attn_mfma")
         if fused_qkv_attention_long(cfg, a.precision):

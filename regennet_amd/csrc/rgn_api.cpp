@@ -97,6 +97,8 @@ struct rgn_ctx {
     bool mlp = false;                  // plain-bf16 phase: the whole layer tail in one row-persistent kernel (k_mlp)
     bool step_fused = false;           // plain-bf16 phase: output projection (+ guidance) + sampler update + next input embedding in one kernel (REGENNET_NO_STEP_FUSION=1: three launches)
     bool layers_fused = false;         // plain-bf16 phase, <= 64 tokens: the whole decoder stack of an evaluation as one kernel, one sample per workgroup (k_layers; REGENNET_LAYERS=0: kernel per stage)
+    int layers_min_b = 64;             // ... for evaluations of at least this many samples (REGENNET_LAYERS_MIN_B): one workgroup per sample is a latency chain of 8 layers (250-step calls: 114 ms at any B <= 256), the kernel-per-stage form spreads a sample over more CUs (B = 16 / 32 / 48: 110-111 ms; B = 64: 114.4 vs 113.6)
+    bool layers_steps = false;         // ... and, unguided, whole runs of sampler steps in ONE launch (k_layers<true>: stack + step boundary per sample; REGENNET_LAYERS_STEPS=0: one k_layers + one k_step per step)
     bool skip_embed_out = false;       // (set by run_eval around run_layers while it enqueues a fused step)
     int step_no_quads = 0;             // REGENNET_STEP_NO_QUADS=1 (tests)
     bool qkv_rs = true;                // plain-bf16 phase: k_qkv_attn with register-streamed weights (REGENNET_NO_QKV_RS=1: the DMA-fed loop)
@@ -479,6 +481,25 @@ int run_layers_sb(rgn_ctx* c, const Dims& dm, bool sampling, const float* cond_r
 
 // Embedding GEMM + the L decoder layers + output projection for samples [s0, s0+ns) of the evaluation's sample list
 // (row range [s0*Tq, (s0+ns)*Tq)), enqueued on stream s. F32 mode is always called with the full range.
+// Arguments of k_layers that do not depend on the launch's sample range but for the per-sample vector base (rgn_layers.hip)
+void fill_layers_args(rgn_ctx* c, LayersArgs& g, const Dims& dm, bool sampling, const float* ccond_rows, int s0) {
+    const int Ld = c->L * c->d;
+    g.Tq = dm.Tq; g.L = c->L;
+    for (int l = 0; l < c->L; ++l) {
+        const LayerW& w = c->layers[l];
+        LayerWts& t = g.lw[l];
+        t.Wqkv = c->dp<__bf16>(w.qkv.fr); t.Wo = c->dp<__bf16>(w.out.fr); t.W1 = c->dp<__bf16>(w.ff1.fr); t.W2 = c->dp<__bf16>(w.ff2.fr);
+        t.bqkv = c->dp<float>(w.qkv.b); t.bo = c->dp<float>(w.out.b); t.bf1 = c->dp<float>(w.ff1.b); t.bf2 = c->dp<float>(w.ff2.b);
+        t.g1 = c->dp<float>(w.ln[0]); t.b1 = c->dp<float>(w.ln[1]); t.g2 = c->dp<float>(w.ln[2]); t.b2 = c->dp<float>(w.ln[3]);
+        t.g3 = c->dp<float>(w.ln[4]); t.b3 = c->dp<float>(w.ln[5]);
+    }
+    g.pervec = sampling ? (ccond_rows ? ccond_rows + (size_t)s0 * Ld : nullptr) : c->call + (size_t)s0 * Ld;
+    g.ldper = Ld;
+    g.stepvec = sampling ? c->call_time : nullptr;
+    g.ldstep = Ld; g.d_step = c->d_step;
+    g.qscale = 1.0f / sqrtf((float)dm.dh);
+}
+
 int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const float* cond_rows, const float* ccond_rows,
                int s0, int ns, hipStream_t s) {
     const int prec = c->cfg.precision;
@@ -554,32 +575,21 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
                                                       c->cfg.wo_pos_emb, s));
     }
     const size_t slab0 = (size_t)s0 * c->H * c->Tqp * dm.dh;      // attention-ready planes: first slab of this range
-    if (fast && !x3 && c->layers_fused && !h_p.lo) {
+    bool layers_done = false;
+    if (fast && !x3 && c->layers_fused && dmf.Bm >= c->layers_min_b && !h_p.lo) {
         // plain-bf16 phase, <= 64 tokens, d = 512 / ff = 1024 / 4 heads: ALL layers in one kernel, one sample per workgroup - the residual
         // stream stays in LDS from the input embedding to the last norm3, only the weights stream (rgn_layers.hip)
         bool ok = true;
         for (int l = 0; l < c->L; ++l) ok = ok && c->layers[l].qkv.fr && c->layers[l].out.fr && c->layers[l].ff1.fr && c->layers[l].ff2.fr;
         if (ok) {
             LayersArgs g{};
-            g.h = h_p.hi; g.out = h_p.hi; g.rows = h_p.rows; g.Bm = ns; g.Tq = dm.Tq; g.L = c->L;
-            for (int l = 0; l < c->L; ++l) {
-                const LayerW& w = c->layers[l];
-                LayerWts& t = g.lw[l];
-                t.Wqkv = c->dp<__bf16>(w.qkv.fr); t.Wo = c->dp<__bf16>(w.out.fr); t.W1 = c->dp<__bf16>(w.ff1.fr); t.W2 = c->dp<__bf16>(w.ff2.fr);
-                t.bqkv = c->dp<float>(w.qkv.b); t.bo = c->dp<float>(w.out.b); t.bf1 = c->dp<float>(w.ff1.b); t.bf2 = c->dp<float>(w.ff2.b);
-                t.g1 = c->dp<float>(w.ln[0]); t.b1 = c->dp<float>(w.ln[1]); t.g2 = c->dp<float>(w.ln[2]); t.b2 = c->dp<float>(w.ln[3]);
-                t.g3 = c->dp<float>(w.ln[4]); t.b3 = c->dp<float>(w.ln[5]);
-            }
-            g.pervec = sampling ? (ccond_rows ? ccond_rows + (size_t)s0 * Ld : nullptr) : c->call + (size_t)s0 * Ld;
-            g.ldper = Ld;
-            g.stepvec = sampling ? c->call_time : nullptr;
-            g.ldstep = Ld; g.d_step = c->d_step;
-            g.qscale = 1.0f / sqrtf((float)dm.dh);
+            g.h = h_p.hi; g.out = h_p.hi; g.rows = h_p.rows; g.Bm = ns;
+            fill_layers_args(c, g, dm, sampling, ccond_rows, s0);
             RGN_LAUNCH(c, KC_LAYERS, s, launch_layers(g, s));
-            return RGN_OK;
+            layers_done = true;
         }
     }
-    for (int l = 0; l < c->L; ++l) {
+    for (int l = layers_done ? c->L : 0; l < c->L; ++l) {
         const LayerW& w = c->layers[l];
         if (fast && c->fuse_qkv) {
             // in_proj + attention in one kernel (two samples x half the heads per workgroup): q, k, v only ever exist in LDS
@@ -1121,9 +1131,15 @@ int rgn_finalize_weights(rgn_handle h) {
         c->step_fused = c->rowgemm && !c->etd && c->lin_x.fr && c->lin_out.fr && c->lin_out.has_bias && !c->lin_x.has_bias &&
                         step_fused_supported(d, F, c->lin_x.Kp) && getenv("REGENNET_NO_STEP_FUSION") == nullptr;
         if (c->step_fused) RGN_HIP(c, configure_step());
-        c->layers_fused = c->mlp && c->fuse_qkv && c->qkv_rs && layers_supported(d, ff, c->H, c->Tq, c->L) && getenv("REGENNET_LAYERS") != nullptr &&
-                          atoi(getenv("REGENNET_LAYERS")) != 0;
+        // one workgroup per sample costs a full 64-row tile whatever the length, the kernel-per-stage chain costs the rows there are, and the
+        // fused form is worth ~20 % of a layer: it takes evaluations of at least 52 tokens per sample (REGENNET_LAYERS_MIN_TQ overrides: tests)
+        const int ly_min_tq = getenv("REGENNET_LAYERS_MIN_TQ") ? atoi(getenv("REGENNET_LAYERS_MIN_TQ")) : 52;
+        c->layers_fused = c->mlp && c->fuse_qkv && c->qkv_rs && layers_supported(d, ff, c->H, c->Tq, c->L) && c->Tq >= ly_min_tq &&
+                          !(getenv("REGENNET_LAYERS") != nullptr && atoi(getenv("REGENNET_LAYERS")) == 0);
         if (c->layers_fused) RGN_HIP(c, configure_layers());
+        if (const char* e = getenv("REGENNET_LAYERS_MIN_B")) c->layers_min_b = atoi(e);
+        c->layers_steps = c->layers_fused && c->step_fused && layers_steps_supported(d, F, c->lin_x.Kp) &&
+                          !(getenv("REGENNET_LAYERS_STEPS") != nullptr && atoi(getenv("REGENNET_LAYERS_STEPS")) == 0);
         c->step_no_quads = getenv("REGENNET_STEP_NO_QUADS") != nullptr;
         c->qkv_long = c->cfg.precision == RGN_PREC_BF16_X3TAIL && qkv_attn_long_supported(c->Tq, d / c->H, d) && getenv("REGENNET_NO_QKV_LONG") == nullptr;
         if (c->qkv_long) RGN_HIP(c, configure_qkv_attn_long());
@@ -1373,6 +1389,28 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
         if (fused_now && !prev_fused && (rc = embed_all(c, dm, s))) return rc;
         if (!fused_now && prev_fused && (rc = pack_state(c, x, dm, guided != 0, s))) return rc;
         prev_fused = fused_now;
+        if (fused_now && !guided && !x3 && c->layers_steps && dm.Bm >= c->layers_min_b && !c->prof) {
+            // unguided plain-bf16 phase, <= 64 tokens: ALL remaining steps of the phase in one launch - a workgroup carries its sample
+            // through decoder stack and step boundary step after step; nothing but x, the condition rows and the weights is read
+            bool ok = true;
+            for (int l = 0; l < c->L; ++l) ok = ok && c->layers[l].qkv.fr && c->layers[l].out.fr && c->layers[l].ff1.fr && c->layers[l].ff2.fr;
+            if (ok) {
+                const int M = dm.Bm * dm.Tq;
+                const bool has_cond = c->cfg.cond_mode != RGN_COND_NONE;
+                LayersArgs g{};
+                g.h = c->h_hi; g.out = c->h_hi; g.rows = M; g.Bm = dm.Bm;
+                fill_layers_args(c, g, dm, true, has_cond ? c->call_cond : nullptr, 0);
+                g.steps = phase_left;
+                g.Wout = c->dp<__bf16>(c->lin_out.fr); g.bout = c->dp<float>(c->lin_out.b); g.F = c->F; g.nb_out = (c->F + 31) / 32;
+                g.Wx = c->dp<__bf16>(c->lin_x.fr);
+                g.c0 = c->c0h;
+                g.tab = c->d_tab; g.d_stepw = c->d_step; g.sp = c->d_sp;
+                g.B = dm.B; g.s0 = 0; g.no_quads = c->step_no_quads;
+                RGN_LAUNCH(c, KC_LAYERS, s, launch_layers(g, s));
+                k += phase_left;
+                continue;
+            }
+        }
         if (graphs) {
             const int steps = (multi > 1 && phase_left >= multi) ? multi : 1;
             hipGraphExec_t ge = nullptr;

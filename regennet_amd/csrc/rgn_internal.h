@@ -165,6 +165,8 @@ hipError_t launch_mlp2(int rows, const MlpArgs& g, hipStream_t s);
 // The whole decoder stack of one evaluation as one kernel, one sample (Tq <= 64 tokens) per workgroup (rgn_layers.hip): plain-bf16 phase,
 // d = 512, ff = 1024, 4 heads of 128. Weight planes fragment-ordered as for k_mlp / k_qkv_attn_rs.
 constexpr int LY_MAXL = 8;
+struct StepCoef;
+struct SampleParams;
 struct LayerWts {                          // one entry per decoder layer; the table travels in the kernel arguments (scalar loads)
     const __bf16 *Wqkv, *Wo, *W1, *W2;
     const float *bqkv, *bo, *bf1, *bf2;
@@ -179,8 +181,19 @@ struct LayersArgs {
     const float* pervec; int ldper;       // + pervec[sample * ldper + layer * 512 + n]   (nullable; advanced to the first sample)
     const float* stepvec; int ldstep; const int* d_step;   // + stepvec[(*d_step) * ldstep + layer * 512 + n] (nullable)
     float qscale;
+    // ---- steps > 0: the kernel runs `steps` complete sampler steps per sample (unguided): after the stack the step boundary of
+    //      rgn_step.hip in per-sample form - output projection, sampler update of x in place, the next evaluation's input embedding
+    //      into the resident image - and the loop index *d_step moves on by `steps` when the last workgroup finishes
+    int steps;
+    const __bf16* Wout; const float* bout; int F, nb_out;    // output projection, fragment-ordered [16][nb_out][2][64][8]
+    const __bf16* Wx;                                         // input embedding (folded), fragment-ordered [11][16][2][64][8]
+    const __bf16* c0;                                         // hoisted condition part [rows, 512] as bf16, advanced like h
+    const StepCoef* tab; int* d_stepw; const SampleParams* sp;
+    int B, s0;                                                // motions in the bound condition, first sample of this launch
+    int no_quads;
 };
 bool layers_supported(int d, int ff, int H, int Tq, int L);
+bool layers_steps_supported(int d, int F, int Kpx);
 hipError_t configure_layers();
 hipError_t launch_layers(const LayersArgs& g, hipStream_t s);
 

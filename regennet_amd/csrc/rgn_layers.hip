@@ -24,11 +24,13 @@
 // k-loop has no barrier and no staging at all. Layer tail: the structure of rgn_mlp2.hip (MT = 2) on the resident images.
 // Weights: fragment-ordered planes streamed into register rings through buffer loads (scalar resource, compile-time offsets).
 #include "rgn_internal.h"
+#include "rgn_philox.h"
 
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <type_traits>
+#include <utility>
 
 namespace rgn {
 
@@ -81,6 +83,15 @@ __device__ __forceinline__ f32x2 ly_gelu2(f32x2 x) {
     return x * __builtin_elementwise_fma(t, p, f32x2{0.5f, 0.5f});
 }
 
+// step boundary (STEPS build): fp32 x0 tile [64][356] over the dead images, x' image (A operand of the input embedding) behind it
+constexpr int LY_XLD = 356, LY_TILE = 0, LY_XIMG = 92160, LY_NKX = 11;
+static_assert(64 * LY_XLD * 4 <= LY_XIMG && LY_XIMG + LY_NKX * 4096 <= LY_LDS, "step boundary LDS map");
+template <int... Is, class F>
+__device__ __forceinline__ void ly_static_for_seq(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void ly_static_for(F&& f) { ly_static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
+
+template <bool STEPS>
 __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
             __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.h + src), (RGN_AS3 void*)(smem + LY_X + p * 1024), 16, 0, 0);
         }
     }
-    const int step = g.stepvec ? *g.d_step : 0;
+    const int first_step = (g.stepvec || STEPS) ? *g.d_step : 0;
     // B-operand fragment of token l31 (+ 32 ta: an immediate offset of 2 KiB) inside a k-block image, per 16-wide k-half; reads of
     // the second image want their own base registers (16-bit ds_read offsets)
     int a_off[2], a_offy[2];
@@ -124,9 +135,167 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
     const float invn = 1.0f / 512.f;
     const float qs2 = g.qscale * 1.44269504088896340736f;        // scores in log2 units: softmax = exp2(s - max)
 
+    struct Pass { __amdgpu_buffer_rsrc_t rs; int kstride, hs0; };
+    bf16x8 wf[LY_RDM][2];
+    auto load_g = [&](const Pass& ps, int hs_rel, int slot) {
+        const int hs = ps.hs0 + hs_rel;
+        int soff;
+        asm volatile("s_mov_b32 %0, %1" : "=s"(soff) : "i"((hs >> 1) * ps.kstride + (hs & 1) * 1024));
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            wf[slot][nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ps.rs, lane16, soff + nt * 2048, 0));
+    };
+    // one GEMM pass over K = 512 from the image at byte offsets aoff (see rgn_mlp2.hip): the ring never drains between passes
+    auto gemm_n = [&](f32x16 (&acc)[2][2], const int (&aoff)[2], const Pass& cur, const Pass& nxt, auto chain, auto extra, auto ngran) {
+        constexpr int EX = decltype(extra)::value, AH = LY_RDM - 1, NG = decltype(ngran)::value;   // NG granules = NG / 2 k-blocks
+        constexpr bool CH = decltype(chain)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 af[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(smem + aoff[0] + mt * 2048);
+#pragma unroll
+        for (int hs = 0; hs < NG; ++hs) {
+            bf16x8 afn[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                afn[mt] = af[mt];
+                if (hs + 1 < NG) afn[mt] = *reinterpret_cast<const bf16x8*>(smem + ((hs + 1) >> 1) * LY_KB + aoff[(hs + 1) & 1] + mt * 2048);
+            }
+            if (hs + AH < NG) load_g(cur, hs + AH, (hs + AH) % LY_RDM);
+            else if (CH) load_g(nxt, hs + AH - NG, (hs + AH) % LY_RDM);
+            if (hs + AH < NG || CH) {
+                if (hs < AH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * AH + EX) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * AH) : "memory");
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[hs % LY_RDM][nt], af[mt], acc[nt][mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) af[mt] = afn[mt];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto init_bias = [&](f32x16 (&acc)[2][2], const float* bias) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + col4(nt, i4));
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[nt][mt][4 * i4 + e] = bb[e];
+            }
+    };
+    // LayerNorm over the 512 columns of every token, in place: one exchange of (sum, sum of squares) - rgn_mlp2.hip
+    auto layernorm = [&](f32x16 (&acc)[2][2], const float* gam, auto slot, auto shift /* (nt, i4) -> f32x4 */) {
+        const char* buf = smem + red_base + decltype(slot)::value * LY_REDF * 4;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x2 s2 = f32x2{0.f, 0.f}, q2 = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const f32x2 v = f32x2{acc[nt][mt][i], acc[nt][mt][i + 1]};
+                    s2 += v;
+                    q2 = __builtin_elementwise_fma(v, v, q2);
+                }
+            float s = s2[0] + s2[1], q = q2[0] + q2[1];
+            s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 32, 64);
+            *reinterpret_cast<float*>(const_cast<char*>(buf) + (kh * 512 + wave * 64 + 32 * mt) * 4) = kh ? q : s;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        f32x2 rs[2], nm[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float p[2][8];
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) p[st][ww] = *reinterpret_cast<const float*>(buf + (st * 512 + ww * 64 + 32 * mt) * 4);
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int dd = 1; dd < 8; dd *= 2)
+#pragma unroll
+                    for (int ww = 0; ww < 8; ww += 2 * dd) p[st][ww] += p[st][ww + dd];
+            const float mean = p[0][0] * invn;
+            const float var = __builtin_fmaxf(p[1][0] * invn - mean * mean, 0.f);
+            const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+            rs[mt] = f32x2{rstd, rstd};
+            nm[mt] = f32x2{-mean, -mean};
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x4 ga[4], sh[4];
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                ga[i4] = *reinterpret_cast<const f32x4*>(gam + col4(nt, i4));
+                sh[i4] = shift(nt, i4);
+            }
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const f32x2 rg = f32x2{ga[i4][e], ga[i4][e + 1]} * rs[mt];
+                        const f32x2 bb = __builtin_elementwise_fma(nm[mt], rg, f32x2{sh[i4][e], sh[i4][e + 1]});
+                        const f32x2 o = __builtin_elementwise_fma(f32x2{acc[nt][mt][4 * i4 + e], acc[nt][mt][4 * i4 + e + 1]}, rg, bb);
+                        acc[nt][mt][4 * i4 + e] = o[0];
+                        acc[nt][mt][4 * i4 + e + 1] = o[1];
+                    }
+        }
+    };
+    auto store_img = [&](const f32x16 (&acc)[2][2], int img) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    bf16x4 hh;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hh[e] = (__bf16)acc[nt][mt][4 * i4 + e];
+                    *reinterpret_cast<bf16x4*>(smem + img + img_off(nt, i4, mt)) = hh;
+                }
+    };
+    // acc += bf16 residual from the image X (this wave's own columns)
+    auto add_resid = [&](f32x16 (&acc)[2][2], const float* bias) {
+        bf16x4 rr[2][2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) rr[nt][mt][i4] = *reinterpret_cast<const bf16x4*>(smem + LY_X + img_off(nt, i4, mt));
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+                if (bias) bb = *reinterpret_cast<const f32x4*>(bias + col4(nt, i4));
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[nt][mt][4 * i4 + e] += (float)rr[nt][mt][i4][e] + bb[e];
+            }
+    };
+
+    auto gemm32 = [&](f32x16 (&acc)[2][2], const int (&aoff)[2], const Pass& cur, const Pass& nxt, auto chain, auto extra) {
+        gemm_n(acc, aoff, cur, nxt, chain, extra, std::integral_constant<int, 32>{});
+    };
+
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+    const int nit = STEPS ? g.steps : 1;
+    for (int it = 0; it < nit; ++it) {
+    const int step = first_step - it;
     for (int l = 0; l < g.L; ++l) {
         const LayerWts& w = g.lw[l];
         RGN_LYT(0)
@@ -324,163 +493,12 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
             }
         }
         // ========================= layer tail on the resident images (rgn_mlp2.hip, MT = 2) ==================================
-        struct Pass { __amdgpu_buffer_rsrc_t rs; int kstride, hs0; };
         auto wrs = [&](const __bf16* W, int cb0, int bytes) {
             return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(W) + (size_t)cb0 * 1024, 0, bytes - cb0 * 2048, 0x00020000);
         };
         const Pass p_wo{wrs(w.Wo, 2 * wave, 512 * 512 * 2), 16 * 2048, 0}, p_w1a{wrs(w.W1, 2 * wave, 1024 * 512 * 2), 32 * 2048, 0},
             p_w1b{wrs(w.W1, 16 + 2 * wave, 1024 * 512 * 2), 32 * 2048, 0}, p_w2a{wrs(w.W2, 2 * wave, 512 * 1024 * 2), 16 * 2048, 0},
             p_w2b{p_w2a.rs, 16 * 2048, 32};
-        bf16x8 wf[LY_RDM][2];
-        auto load_g = [&](const Pass& ps, int hs_rel, int slot) {
-            const int hs = ps.hs0 + hs_rel;
-            int soff;
-            asm volatile("s_mov_b32 %0, %1" : "=s"(soff) : "i"((hs >> 1) * ps.kstride + (hs & 1) * 1024));
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                wf[slot][nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ps.rs, lane16, soff + nt * 2048, 0));
-        };
-        // one GEMM pass over K = 512 from the image at byte offsets aoff (see rgn_mlp2.hip): the ring never drains between passes
-        auto gemm32 = [&](f32x16 (&acc)[2][2], const int (&aoff)[2], const Pass& cur, const Pass& nxt, auto chain, auto extra) {
-            constexpr int EX = decltype(extra)::value, AH = LY_RDM - 1;
-            constexpr bool CH = decltype(chain)::value;
-            __builtin_amdgcn_sched_barrier(0);
-            bf16x8 af[2];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(smem + aoff[0] + mt * 2048);
-#pragma unroll
-            for (int hs = 0; hs < 32; ++hs) {
-                bf16x8 afn[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    afn[mt] = af[mt];
-                    if (hs + 1 < 32) afn[mt] = *reinterpret_cast<const bf16x8*>(smem + ((hs + 1) >> 1) * LY_KB + aoff[(hs + 1) & 1] + mt * 2048);
-                }
-                if (hs + AH < 32) load_g(cur, hs + AH, (hs + AH) % LY_RDM);
-                else if (CH) load_g(nxt, hs + AH - 32, (hs + AH) % LY_RDM);
-                if (hs + AH < 32 || CH) {
-                    if (hs < AH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * AH + EX) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * AH) : "memory");
-                }
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[hs % LY_RDM][nt], af[mt], acc[nt][mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) af[mt] = afn[mt];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto init_bias = [&](f32x16 (&acc)[2][2], const float* bias) {
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int i4 = 0; i4 < 4; ++i4) {
-                    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + col4(nt, i4));
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[nt][mt][4 * i4 + e] = bb[e];
-                }
-        };
-        // LayerNorm over the 512 columns of every token, in place: one exchange of (sum, sum of squares) - rgn_mlp2.hip
-        auto layernorm = [&](f32x16 (&acc)[2][2], const float* gam, auto slot, auto shift /* (nt, i4) -> f32x4 */) {
-            const char* buf = smem + red_base + decltype(slot)::value * LY_REDF * 4;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                f32x2 s2 = f32x2{0.f, 0.f}, q2 = f32x2{0.f, 0.f};
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int i = 0; i < 16; i += 2) {
-                        const f32x2 v = f32x2{acc[nt][mt][i], acc[nt][mt][i + 1]};
-                        s2 += v;
-                        q2 = __builtin_elementwise_fma(v, v, q2);
-                    }
-                float s = s2[0] + s2[1], q = q2[0] + q2[1];
-                s += __shfl_xor(s, 32, 64);
-                q += __shfl_xor(q, 32, 64);
-                *reinterpret_cast<float*>(const_cast<char*>(buf) + (kh * 512 + wave * 64 + 32 * mt) * 4) = kh ? q : s;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            f32x2 rs[2], nm[2];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                float p[2][8];
-#pragma unroll
-                for (int st = 0; st < 2; ++st)
-#pragma unroll
-                    for (int ww = 0; ww < 8; ++ww) p[st][ww] = *reinterpret_cast<const float*>(buf + (st * 512 + ww * 64 + 32 * mt) * 4);
-#pragma unroll
-                for (int st = 0; st < 2; ++st)
-#pragma unroll
-                    for (int dd = 1; dd < 8; dd *= 2)
-#pragma unroll
-                        for (int ww = 0; ww < 8; ww += 2 * dd) p[st][ww] += p[st][ww + dd];
-                const float mean = p[0][0] * invn;
-                const float var = __builtin_fmaxf(p[1][0] * invn - mean * mean, 0.f);
-                const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
-                rs[mt] = f32x2{rstd, rstd};
-                nm[mt] = f32x2{-mean, -mean};
-            }
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                f32x4 ga[4], sh[4];
-#pragma unroll
-                for (int i4 = 0; i4 < 4; ++i4) {
-                    ga[i4] = *reinterpret_cast<const f32x4*>(gam + col4(nt, i4));
-                    sh[i4] = shift(nt, i4);
-                }
-#pragma unroll
-                for (int i4 = 0; i4 < 4; ++i4)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int e = 0; e < 4; e += 2) {
-                            const f32x2 rg = f32x2{ga[i4][e], ga[i4][e + 1]} * rs[mt];
-                            const f32x2 bb = __builtin_elementwise_fma(nm[mt], rg, f32x2{sh[i4][e], sh[i4][e + 1]});
-                            const f32x2 o = __builtin_elementwise_fma(f32x2{acc[nt][mt][4 * i4 + e], acc[nt][mt][4 * i4 + e + 1]}, rg, bb);
-                            acc[nt][mt][4 * i4 + e] = o[0];
-                            acc[nt][mt][4 * i4 + e + 1] = o[1];
-                        }
-            }
-        };
-        auto store_img = [&](const f32x16 (&acc)[2][2], int img) {
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int i4 = 0; i4 < 4; ++i4)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        bf16x4 hh;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) hh[e] = (__bf16)acc[nt][mt][4 * i4 + e];
-                        *reinterpret_cast<bf16x4*>(smem + img + img_off(nt, i4, mt)) = hh;
-                    }
-        };
-        // acc += bf16 residual from the image X (this wave's own columns)
-        auto add_resid = [&](f32x16 (&acc)[2][2], const float* bias) {
-            bf16x4 rr[2][2][4];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int i4 = 0; i4 < 4; ++i4) rr[nt][mt][i4] = *reinterpret_cast<const bf16x4*>(smem + LY_X + img_off(nt, i4, mt));
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int i4 = 0; i4 < 4; ++i4) {
-                    f32x4 bb = {0.f, 0.f, 0.f, 0.f};
-                    if (bias) bb = *reinterpret_cast<const f32x4*>(bias + col4(nt, i4));
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[nt][mt][4 * i4 + e] += (float)rr[nt][mt][i4][e] + bb[e];
-                }
-        };
-
         // ---- out_proj's first fragments and this layer's per-column vectors (this wave's 64 columns: lane = column)
 #pragma unroll
         for (int s = 0; s < LY_RDM - 1; ++s) load_g(p_wo, s, s);
@@ -555,6 +573,174 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         __builtin_amdgcn_s_barrier();
         RGN_LYT(11)
     }
+    if constexpr (STEPS) {
+        // ========================= step boundary, per sample (rgn_step.hip k_step<11, false>) =====================================
+        //   x0 = h . Wout^T + bout (OutputProcess, cmdm.py:353); x' = sampler(x, x0, eps) in place (gaussian_diffusion.py:508-560,
+        //   744-794; same arithmetic and Philox stream as k_update); h' = x' . Wx'^T + c0 (InputProcess / fuse / positional part hoisted
+        //   into c0, cmdm.py:201-218) -> the resident image X: the next step's layer 0 reads it without leaving the CU
+        // (lane / wave / sample ids made opaque PER ITERATION: everything below is invariant across the step loop, and hoisted out of it
+        //  the ~90 addresses of the update phase alone spill hundreds of registers)
+        int lane_s = lane, wave_s = wave, b_s = b;
+        asm volatile("" : "+v"(lane_s));
+        asm volatile("" : "+s"(wave_s), "+s"(b_s));
+        const int l31_s = lane_s & 31, kh_s = lane_s >> 5;
+        const size_t row0_s = (size_t)b_s * Tq;
+        auto col4s = [&](int nt, int i4) { return 32 * nt + 8 * i4 + 4 * kh_s; };
+        const SampleParams sp = *g.sp;
+        const StepCoef k = g.tab[step];
+        const int T = Tq, gb = g.s0 + b_s;                                  // frames = tokens (no emb_trans_dec token on this path); motion index
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a2][b2][i] = 0.f;
+        // ---- A: x0 = h . Wout^T from the image X (N = F <= 352: waves 0-5; a column block past the plane reads in-bounds garbage or
+        //      zeros and is never stored)
+        if (wave_s < 6) {
+            const int cb0 = 2 * wave_s;
+            const Pass p_out{__builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(g.Wout) + (size_t)cb0 * 1024, 0, (16 * g.nb_out - cb0) * 2048, 0x00020000), LY_NKX * 2048, 0};
+#pragma unroll
+            for (int s2 = 0; s2 < LY_RDM - 1; ++s2) load_g(p_out, s2, s2);
+            gemm_n(acc, a_off, p_out, p_out, std::false_type{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 32>{});
+        }
+        __builtin_amdgcn_s_barrier();                                     // every wave is done reading the image
+        // ---- B: x0 + bias -> fp32 tile [64][356]
+        float* tile = reinterpret_cast<float*>(smem + LY_TILE);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const int n = 64 * wave_s + col4s(nt, i4);
+                if (n < 352) {
+                    f32x4 bb = {0.f, 0.f, 0.f, 0.f};
+                    if (n < g.F) bb = *reinterpret_cast<const f32x4*>(g.bout + n);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const f32x4 v = {acc[nt][mt][4 * i4] + bb[0], acc[nt][mt][4 * i4 + 1] + bb[1], acc[nt][mt][4 * i4 + 2] + bb[2], acc[nt][mt][4 * i4 + 3] + bb[3]};
+                        *reinterpret_cast<f32x4*>(tile + (32 * mt + l31_s) * LY_XLD + n) = v;
+                    }
+                }
+            }
+        const Pass p_wx{__builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(g.Wx) + (size_t)(2 * wave_s) * 1024, 0, (LY_NKX * 16 - 2 * wave_s) * 2048, 0x00020000), 16 * 2048, 0};
+#pragma unroll
+        for (int s2 = 0; s2 < LY_RDM - 1; ++s2) load_g(p_wx, s2, s2);   // the embedding's first fragments fly under the update phase
+        // the condition rows the embedding adds, in the accumulator layout (requested now, used behind the GEMM)
+        bf16x4 c0v[2][2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int r = 32 * mt + l31_s, rr = r < T ? r : T - 1;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4)
+                    c0v[nt][mt][i4] = *reinterpret_cast<const bf16x4*>(g.c0 + (row0_s + rr) * 512 + 64 * wave_s + col4s(nt, i4));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- C: sampler update. lane = frame, the waves stride the features; Philox per quad of lanes where the quad is a run of four
+        //      frames (see rgn_step.hip), per element otherwise (bit-identical values)
+        {
+            const int t = lane_s;
+            const bool valid = t < T;
+            const size_t FT = (size_t)g.F * T;
+            const int bn = sp.const_noise ? 0 : gb;
+            char* ximg = smem + LY_XIMG;
+            const int q = lane_s & 3, tq = t - q;
+            const bool run4 = valid && (tq & 3) == 0 && tq + 3 < T;
+            const bool quads = !sp.noise && !g.no_quads && __all(run4 || tq >= T);   // (a quad past the last frame does nothing)
+            float xpre[LY_NKX][4];
+#pragma unroll
+            for (int i2 = 0; i2 < LY_NKX; ++i2)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = 4 * (wave_s + 8 * i2) + j;
+                    xpre[i2][j] = (valid && f < g.F) ? sp.x[(size_t)gb * FT + (size_t)f * T + t] : 0.f;
+                }
+            auto update = [&](int f, float eps_in, float xv) {
+                float nv = 0.f;
+                if (valid && f < g.F) {
+                    float x0 = tile[lane_s * LY_XLD + f];
+                    if (sp.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+                    const size_t o = (size_t)gb * FT + (size_t)f * T + t;
+                    if (sp.x0_out) sp.x0_out[o] = x0;
+                    float eps = eps_in;
+                    if (sp.noise)
+                        eps = sp.noise[(size_t)(sp.first_index - step) * g.B * FT + (size_t)bn * FT + (size_t)f * T + t];
+                    else if (!quads)
+                        eps = philox_normal(sp.seed, sp.sample_offset + bn, (uint32_t)step, (uint32_t)(f * 4096 + t));
+                    if (sp.sampler == 0) {
+                        const float mean = __fadd_rn(__fmul_rn(k.c1, x0), __fmul_rn(k.c2, xv));
+                        nv = __fadd_rn(mean, __fmul_rn(k.sig_ddpm, eps));
+                    } else {
+                        const float e = __fdiv_rn(__fsub_rn(__fmul_rn(k.sr, xv), x0), k.srm1);
+                        const float mean = __fadd_rn(__fmul_rn(x0, k.ca), __fmul_rn(k.cb, e));
+                        nv = __fadd_rn(mean, __fmul_rn(k.sig_ddim, eps));
+                    }
+                    sp.x[o] = nv;
+                }
+                // x' (0 in the K padding columns and the surplus rows) -> the K32-blocked image of the embedding's A operand
+                const int r = lane_s, chunk = (f & 31) >> 3;
+                *reinterpret_cast<__bf16*>(ximg + (f >> 5) * 4096 + r * 64 + ((chunk ^ ((r >> 2) & 3)) << 4) + (f & 7) * 2) = (__bf16)nv;
+            };
+            ly_static_for<LY_NKX>([&](auto IT) __attribute__((always_inline)) {   // groups of 4 features
+                constexpr int i2 = decltype(IT)::value;
+                const int fg = wave_s + 8 * i2;
+                float eps4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (quads) {                                               // wave-uniform
+                    const uint32_t elem = (uint32_t)((4 * fg + q) * 4096 + tq);
+                    const unsigned long long sample = sp.sample_offset + bn;
+                    uint32_t rr4[4];
+                    philox4x32_10(elem >> 2, (uint32_t)step, (uint32_t)sample, (uint32_t)(sample >> 32), (uint32_t)sp.seed, (uint32_t)(sp.seed >> 32), rr4);
+                    float n4[4];
+#pragma unroll
+                    for (int pair = 0; pair < 2; ++pair) box_muller(rr4[2 * pair], rr4[2 * pair + 1], n4[2 * pair], n4[2 * pair + 1]);
+                    auto pick = [&](auto jc) {                              // element q of lane jc's n4, broadcast inside the quad
+                        constexpr int J = decltype(jc)::value;
+                        float v = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float bc = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, n4[e]), J * 0x55, 0xf, 0xf, true));   // quad_perm [J, J, J, J]
+                            v = q == e ? bc : v;
+                        }
+                        return v;
+                    };
+                    eps4[0] = pick(std::integral_constant<int, 0>{});
+                    eps4[1] = pick(std::integral_constant<int, 1>{});
+                    eps4[2] = pick(std::integral_constant<int, 2>{});
+                    eps4[3] = pick(std::integral_constant<int, 3>{});
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) update(4 * fg + j, eps4[j], xpre[i2][j]);
+            });
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- D: h' = x' . Wx'^T + c0 -> image X (the fp32 tile is dead since the barrier above; the x' image lies behind X)
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a2][b2][i] = 0.f;
+        {
+            int a_offx[2] = {a_off[0] + LY_XIMG, a_off[1] + LY_XIMG};
+            gemm_n(acc, a_offx, p_wx, p_wx, std::false_type{}, std::integral_constant<int, 8 + 16>{}, std::integral_constant<int, 2 * LY_NKX>{});
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[nt][mt][4 * i4 + e] += (float)c0v[nt][mt][i4][e];
+        store_img(acc, LY_X);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    }
     // ---- the sample's rows -> output planes (write-through)
     {
         const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)((size_t)g.rows * 512 * 2), 0x00020000);
@@ -569,6 +755,15 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
             }
         }
     }
+    if constexpr (STEPS) {
+        if (tid == 0) {   // ticket: the last workgroup of the launch moves the device-side loop index on by the steps it ran
+            int* tick = g.d_stepw + 4;
+            if (atomicAdd(tick, 1) == (int)gridDim.x - 1) {
+                tick[0] = 0;
+                g.d_stepw[0] = first_step - g.steps;
+            }
+        }
+    }
 }
 
 #ifdef RGN_LY_STAMPS
@@ -576,11 +771,14 @@ void ly_stamps_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(
 #endif
 
 bool layers_supported(int d, int ff, int H, int Tq, int L) { return d == 512 && ff == 1024 && H == 4 && Tq >= 1 && Tq <= 64 && L >= 1 && L <= LY_MAXL; }
+bool layers_steps_supported(int d, int F, int Kpx) { return d == 512 && F % 4 == 0 && F <= 352 && Kpx == 32 * LY_NKX; }
 hipError_t configure_layers() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_layers), hipFuncAttributeMaxDynamicSharedMemorySize, LY_LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_layers<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LY_LDS);
+    return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(k_layers<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LY_LDS);
 }
 hipError_t launch_layers(const LayersArgs& g, hipStream_t s) {
-    hipLaunchKernelGGL(k_layers, dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
+    if (g.steps > 0) hipLaunchKernelGGL(k_layers<true>, dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
+    else hipLaunchKernelGGL(k_layers<false>, dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
     return hipGetLastError();
 }
 
