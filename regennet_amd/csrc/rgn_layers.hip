@@ -416,54 +416,72 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                     }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+                // ---- softmax, each score ONCE: wave wn takes the queries {8 wn .. 8 wn + 7} of both query tiles, lane = (query qi, key group
+                //      kg of 16 keys), so a row lives in 4 adjacent lanes x 16 registers. Every exchange entry [..][lane'] is read by exactly
+                //      one wave - the one that owns query lane' & 31 - which is what lets the normalised probabilities go back INTO the
+                //      exchange (slots [tile][wave 0][run = 16-key slice][lane'], 8 bf16 = one PV operand each) without another buffer.
+                {
+                    const int kg = lane & 3, qi = lane >> 2, qt = qi >> 3, ql = 8 * wn + (qi & 7), Q = 32 * qt + ql;
+                    const int kj = kg >> 1, sl = kg & 1;
+                    const bool live = !(qt == 0 && kj == 1);               // keys 32-63 never reach queries 0-31
+                    const int tl = live ? qt + kj : 0;
+                    const char* ex = smem + LY_EXCH + ((hg * 3 + tl) * 4 * 4 + 2 * sl) * 1024 + ql * 16;   // [hg][tl][w][i4][lane'] x 16 B
+                    f32x4 sv[4];                                            // keys 16 sl + {0-3 | 4-7 | 8-11 | 12-15} of key tile kj
 #pragma unroll
-                for (int tl = 0; tl < 3; ++tl)
+                    for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-                    for (int i4 = 0; i4 < 4; ++i4) {
-                        f32x4 v = sred[(((hg * 3 + tl) * 4 + 0) * 4 + i4) * 64 + lane];
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            f32x4 v = *reinterpret_cast<const f32x4*>(ex + a2 * 1024 + h2 * 512);
 #pragma unroll
-                        for (int ww = 1; ww < 4; ++ww) {
-                            const f32x4 u = sred[(((hg * 3 + tl) * 4 + ww) * 4 + i4) * 64 + lane];
+                            for (int ww = 1; ww < 4; ++ww) {
+                                const f32x4 u = *reinterpret_cast<const f32x4*>(ex + ww * 4096 + a2 * 1024 + h2 * 512);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += u[e];
+                                for (int e = 0; e < 4; ++e) v[e] += u[e];
+                            }
+                            sv[2 * a2 + h2] = v;
                         }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) st[tl][4 * i4 + e] = v[e];
-                    }
-                // softmax over keys for the lane's two queries (l31 and 32 + l31); every wave of the head does the same work
-                float inv[2];
-#pragma unroll
-                for (int qtile = 0; qtile < 2; ++qtile) {
-                    const int q = 32 * qtile + l31;
+                    // visible iff key <= min(Q, Tq - 1); key = 32 kj + 16 sl + x. One per-lane limit, opaque: see the note at the mask of
+                    // rgn_qkv_attn.hip (hoisted compares -> spilled lane masks)
+                    int xlim = live ? (Q < Tq - 1 ? Q : Tq - 1) - 32 * kj - 16 * sl : -1;
+                    asm volatile("" : "+v"(xlim));
                     float mx = -INFINITY;
 #pragma unroll
-                    for (int tl = qtile; tl <= 2 * qtile; ++tl) {   // tiles {0} for query tile 0, {1, 2} for query tile 1
-                        const int kj = tl >> 1;
-                        // key of register i = 32 kj + 4 kh + c_i, c_i = (i & 3) + 8 (i >> 2); visible iff key <= min(q, Tq - 1) (tile 1 lies below
-                        // the diagonal: only key < Tq). One per-lane limit, made opaque HERE: as loop invariants the 96 compares of a layer are
-                        // hoisted out of the layer loop and their lane masks live in spilled SGPR pairs
-                        int lim = (tl == 1 ? Tq - 1 : (q < Tq - 1 ? q : Tq - 1)) - 32 * kj - 4 * kh;
-                        asm volatile("" : "+v"(lim));
+                    for (int c4 = 0; c4 < 4; ++c4)
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            st[tl][i] = ((i & 3) + 8 * (i >> 2) <= lim) ? st[tl][i] : -INFINITY;
-                            mx = fmaxf(mx, st[tl][i]);
+                        for (int e = 0; e < 4; ++e) {
+                            sv[c4][e] = (4 * c4 + e <= xlim) ? sv[c4][e] : -INFINITY;
+                            mx = fmaxf(mx, sv[c4][e]);
                         }
-                    }
-                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mx), 0xB1, 0xf, 0xf, true)));   // quad_perm [1,0,3,2]
+                    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mx), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]
                     float sum = 0.f;
 #pragma unroll
-                    for (int tl = qtile; tl <= 2 * qtile; ++tl)
+                    for (int c4 = 0; c4 < 4; ++c4)
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const float e = __builtin_amdgcn_exp2f(st[tl][i] - mx);
-                            st[tl][i] = e;
-                            sum += e;
+                        for (int e = 0; e < 4; ++e) {
+                            sv[c4][e] = __builtin_amdgcn_exp2f(sv[c4][e] - mx);
+                            sum += sv[c4][e];
                         }
-                    sum += __shfl_xor(sum, 32, 64);
-                    inv[qtile] = 1.0f / sum;
+                    sum += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sum), 0xB1, 0xf, 0xf, true));
+                    sum += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sum), 0x4E, 0xf, 0xf, true));
+                    const float inv = 1.0f / sum;
+                    // PV operand of (tile, slice sl), lane half h2: keys 16 sl + 4 h2 + {0-3} and 16 sl + 8 + 4 h2 + {0-3}
+                    if (live) {
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            bf16x8 pp;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                pp[e] = (__bf16)(sv[h2][e] * inv);
+                                pp[4 + e] = (__bf16)(sv[2 + h2][e] * inv);
+                            }
+                            *reinterpret_cast<bf16x8*>(smem + LY_EXCH + (((hg * 3 + tl) * 4 + 0) * 4 + sl) * 1024 + (h2 * 32 + ql) * 16) = pp;
+                        }
+                    }
                 }
-                // O^T[dh tile wn, queries] = V (A operand, registers = keys) x P^T (B operand, registers = keys)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                // O^T[dh tile wn, queries] = V (A operand, registers = keys) x P^T (B operand: this lane's slot of the probabilities)
 #pragma unroll
                 for (int qtile = 0; qtile < 2; ++qtile) {
                     f32x16 oa;
@@ -474,9 +492,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                         const int kj = tl >> 1;
 #pragma unroll
                         for (int sl = 0; sl < 2; ++sl) {
-                            bf16x8 ph;
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) ph[j] = (__bf16)st[tl][8 * sl + j];
+                            const bf16x8 ph = *reinterpret_cast<const bf16x8*>(smem + LY_EXCH + (((hg * 3 + tl) * 4 + 0) * 4 + sl) * 1024 + lane * 16);
                             oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[kj][sl], ph, oa, 0, 0, 0);
                         }
                     }
@@ -484,7 +500,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
 #pragma unroll
                     for (int i4 = 0; i4 < 4; ++i4)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) attk[r][qtile][i4][e] = (__bf16)(oa[4 * i4 + e] * inv[qtile]);
+                        for (int e = 0; e < 4; ++e) attk[r][qtile][i4][e] = (__bf16)oa[4 * i4 + e];
                 }
                 RGN_LYT(2 + 3 * r)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
