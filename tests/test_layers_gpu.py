@@ -1,0 +1,131 @@
+"""GPU: the one-kernel decoder stack (rgn_layers.hip: one workgroup per sample carries the residual stream through all layers -
+and, unguided, through whole runs of sampler steps) against the reference's goldens, the oracle and the kernel-per-stage chain it
+replaces. The engine takes it for evaluations of >= 64 samples of 52 .. 64 tokens; REGENNET_LAYERS_MIN_B=1 lets test-sized batches
+reach it. Tolerance: BASELINE.json north_star, 1e-3 abs on rot6d."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import build_hip, fixture_inputs, y_to_device
+
+pytestmark = pytest.mark.gpu
+
+# per evaluation: k_layers<false> + k_step / k_update per step; whole runs: k_layers<true> (unguided, no emb_trans_dec token)
+FORMS = {"per-step": {"REGENNET_LAYERS_MIN_B": "1", "REGENNET_LAYERS_STEPS": "0"}, "multi-step": {"REGENNET_LAYERS_MIN_B": "1"},
+         "kernel-per-stage": {"REGENNET_LAYERS": "0"}}
+
+
+def _engine_with(monkeypatch, env, model, B):
+    """The switches are read when the engine is built."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    model._get_engine(B)
+    for k in env:
+        monkeypatch.delenv(k)
+
+
+def _wrap(model, guided):
+    if not guided:
+        return model
+    from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    return ClassifierFreeSampleModel(model)
+
+
+@pytest.mark.parametrize("form", ["per-step", "multi-step"])
+@pytest.mark.parametrize("name", ["ntu_ddpm50", "ntu_action_ddim100_cfg", "ntu_add_etd_ddpm20", "ntu_ddpm1000"])
+def test_decoder_stack_kernel_against_the_reference(golden, monkeypatch, name, form):
+    """The reference's own sampling-loop outputs on identical noise: 50 / 1000-step DDPM (unguided: whole runs of steps in one
+    launch in the multi-step form), guided 100-step DDIM (k_layers per evaluation over the 2B rows + the guided k_step), 61 tokens
+    with the emb_trans_dec token (k_layers + the three-kernel step boundary)."""
+    g = golden(name)
+    cfg, sd, y, tape = fixture_inputs(g, loop=True)
+    model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision="bf16_x3tail/throughput")
+    B = int(g["B"])
+    _engine_with(monkeypatch, FORMS[form], model, B)
+    fm = _wrap(model, bool(g["guided"]))
+    shape = (B, cfg["njoints"], cfg["nfeats"], cfg["num_frames"])
+    fn = diffusion.p_sample_loop if str(g["mode"]) == "ddpm" else diffusion.ddim_sample_loop
+    out = fn(fm, shape, clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
+    err = np.abs(out.cpu().numpy() - g["final"]).max()
+    print(f"\n[k_layers {form}] {name}: {err:.2e}")
+    assert err < 1e-3, (name, form, err)
+    model._engine.close()
+
+
+@pytest.mark.parametrize("sampler,clip", [("ddpm", False), ("ddim", True)])
+def test_decoder_stack_kernel_against_the_kernel_per_stage_chain(monkeypatch, sampler, clip):
+    """Same noise stream (on-device Philox), same sampler arithmetic: the three forms differ only by where bf16 roundings fall in
+    the plain-bf16 phase and end within half the parity margin of each other behind the split-bf16 tail; the multi-step form also
+    writes pred_xstart and honours clip_denoised like the per-step one."""
+    from regennet_amd import synth
+    cfg = synth.get_config("ntu")
+    sd = synth.make_state_dict(cfg, seed=0)
+    B = 9
+    y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1)).cuda()}
+    outs = {}
+    for form, env in FORMS.items():
+        model, diffusion = build_hip(cfg, sd, resp="40" if sampler == "ddpm" else "ddim40", precision="bf16_x3tail/throughput")
+        _engine_with(monkeypatch, env, model, B)
+        fn = diffusion.p_sample_loop if sampler == "ddpm" else diffusion.ddim_sample_loop
+        outs[form] = fn(model, (B, 56, 6, 60), clip_denoised=clip, model_kwargs={"y": y}, seed=5)
+        model._engine.close()
+    for form in ("per-step", "multi-step"):
+        assert torch.isfinite(outs[form]).all()
+        dev = (outs[form] - outs["kernel-per-stage"]).abs().max().item()
+        print(f"\n[k_layers {form} vs kernel per stage] {sampler} clip={clip}: {dev:.2e}")
+        assert 0.0 < dev < 5e-4
+    dev = (outs["per-step"] - outs["multi-step"]).abs().max().item()
+    print(f"\n[k_layers per-step vs multi-step] {sampler} clip={clip}: {dev:.2e}")
+    assert dev < 5e-4
+
+
+def test_decoder_stack_kernel_is_independent_of_the_batch_composition(monkeypatch):
+    """One workgroup per sample, nothing shared but the weights: a motion drawn alone with its global sample index (same Philox key)
+    equals its row of the batch BIT FOR BIT in the plain-bf16 phase - what sharding over GPUs relies on."""
+    from regennet_amd import synth
+    cfg = synth.get_config("ntu")
+    sd = synth.make_state_dict(cfg, seed=0)
+    B = 70                                                    # >= 64: the default engine takes the one-kernel form
+    y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1)).cuda()}
+    model, diffusion = build_hip(cfg, sd, resp="12", precision="bf16_x3tail/throughput", x3_tail=0)
+    full = diffusion.p_sample_loop(model, (B, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y}, seed=11)
+    model._engine.close()
+    model1, diffusion1 = build_hip(cfg, sd, resp="12", precision="bf16_x3tail/throughput", x3_tail=0)
+    _engine_with(monkeypatch, FORMS["multi-step"], model1, 1)
+    for b in (0, 33, 69):
+        yb = {k: v[b:b + 1].contiguous() for k, v in y.items()}
+        one = diffusion1.p_sample_loop(model1, (1, 56, 6, 60), clip_denoised=False, model_kwargs={"y": yb}, seed=11, sample_offset=b)
+        assert torch.equal(full[b:b + 1], one), (b, (full[b:b + 1] - one).abs().max().item())
+    model1._engine.close()
+
+
+def test_decoder_stack_kernel_lengths_and_partial_ranges(monkeypatch):
+    """52 .. 64 tokens per sample (padding rows replicate the last token and are masked as keys) against the oracle, and a sampling
+    call cut into ranges through the C-ABI (rgn_sample_range with a count below the schedule: the loop index lives on the device and
+    a multi-step launch moves it by the steps it ran) against the same call in one piece: equal up to the first embedding of each
+    range, which adds the fp32 condition rows where a step boundary inside a run adds their bf16 copy."""
+    from oracle import regennet_oracle as orc
+    from regennet_amd import synth
+    for T in (52, 57, 64):
+        cfg = synth.get_config("ntu", num_frames=T)
+        sd = synth.make_state_dict(cfg, seed=0)
+        B = 3
+        y = {"cmotion": synth.make_cmotion(cfg, B, seed=7)}
+        tape = synth.make_noise_tape(cfg, B, 12, seed=8)
+        ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", "12"), tape, {k: torch.from_numpy(v) for k, v in y.items()}, mode="ddpm").numpy()
+        model, diffusion = build_hip(cfg, sd, resp="12", precision="bf16_x3tail/throughput")
+        _engine_with(monkeypatch, FORMS["multi-step"], model, B)
+        out = diffusion.p_sample_loop(model, (B, 56, 6, T), clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
+        err = float(np.abs(out.cpu().numpy() - ref).max())
+        print(f"\n[k_layers multi-step vs oracle] {T} frames: {err:.2e}")
+        assert err < 1e-3, (T, err)
+        if T == 57:   # the same 12 steps as ranges of 4 + 5 + 3 (the last two straddle the switch to the split-bf16 tail at index 4)
+            eng = model._engine
+            st = torch.cuda.current_stream().cuda_stream
+            td = torch.from_numpy(tape).cuda()
+            x = td[0].clone()
+            for first, count in ((11, 4), (7, 5), (2, 3)):
+                eng.sample_range("ddpm", False, 0.0, x, td[1 + (11 - first):], 0, 0, first, count, None, True, False, st)
+            torch.cuda.synchronize()
+            assert (x - out).abs().max().item() < 2e-4, (x - out).abs().max().item()
+        model._engine.close()
