@@ -58,6 +58,13 @@ def layers_fused(cfg, precision):
             and not os.environ.get("REGENNET_NO_ROWGEMM") and not os.environ.get("REGENNET_BULK_RESID_LO"))
 
 
+def layers_steps(cfg, precision, guided):
+    """Mirrors rgn_api.cpp (layers_steps): unguided, whole runs of sampler steps (stack + step boundary) are ONE launch."""
+    F = cfg["njoints"] * cfg["nfeats"]
+    return (layers_fused(cfg, precision) and not guided and not cfg.get("emb_trans_dec") and F % 4 == 0 and 320 < F <= 352
+            and os.environ.get("REGENNET_LAYERS_STEPS", "1") != "0" and not os.environ.get("REGENNET_NO_STEP_FUSION"))
+
+
 def rowgemm_phase(cfg, precision):
     """Mirrors rgn_api.cpp: the plain-bf16 phase runs out_proj+LN / linear1+GELU / linear2+LN as row-complete kernels."""
     return (precision == "bf16_x3tail" and cfg["latent_dim"] == 512 and cfg["ff_size"] in (384, 512, 1024)
@@ -74,7 +81,7 @@ def flops_per_eval(cfg, B, guided, precision="bf16x3"):
     qkv = M * 3 * d * d * L
     attn = M * 2 * T * d * L
     embed = (B * T * F * d if precision == "f32" else M * F * d) + M * d * F       # input embedding, output projection
-    out = {"gemm_mfma": embed, "qkv_attn": 0, "attention": 0, "rowgemm_ln": 0, "rowgemm_act": 0, "mlp": 0, "sb_gemm": 0, "step_fused": 0, "layers": 0}
+    out = {"gemm_mfma": embed, "qkv_attn": 0, "attention": 0, "rowgemm_ln": 0, "rowgemm_act": 0, "mlp": 0, "sb_gemm": 0, "step_fused": 0, "layers": 0, "steps_fused": 0}
     sb_rows = int(os.environ.get("REGENNET_SB_ROWS", "640"))
     if precision != "f32" and d == 512 and ff % 32 == 0 and T + cfg.get("emb_trans_dec", 0) <= 160 and Bm * (T + cfg.get("emb_trans_dec", 0)) <= sb_rows:
         # small-batch engine (rgn_sb.hip): every GEMM of the evaluation is a column-split k_sb_gemm launch
@@ -93,9 +100,12 @@ def flops_per_eval(cfg, B, guided, precision="bf16x3"):
             and not os.environ.get("REGENNET_NO_STEP_FUSION") and not os.environ.get("REGENNET_BULK_RESID_LO")):
         out["step_fused"] = embed                                  # k_step: output projection + sampler update + next input embedding
         out["gemm_mfma"] -= embed
-    if layers_fused(cfg, precision):
+    if layers_fused(cfg, precision) and Bm >= int(os.environ.get("REGENNET_LAYERS_MIN_B", "64")):
         out["layers"] = qkv + attn + out["mlp"]                    # k_layers: in_proj + attention + layer tail of all L layers, one launch per chain
         out["mlp"] = 0
+        if layers_steps(cfg, precision, guided):                   # ... and the step boundary: one launch per RUN of steps
+            out["steps_fused"] = out["layers"] + out["step_fused"]
+            out["layers"] = out["step_fused"] = 0
     elif fused_qkv_attention(cfg, precision) or fused_qkv_attention_long(cfg, precision):
         out["qkv_attn"] = qkv + attn
     else:
@@ -170,6 +180,8 @@ def self_launch(n, argv):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC - without it RCCL's intra-node transport fails with
+    # `hipIpcGetMemHandle: invalid argument` (the image exports it already; kept explicit for environments that were scrubbed)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.call(cmd, env=env)
 
@@ -222,8 +234,24 @@ def main(argv=None):
     # rank 0 owns the checkpoint; other ranks start from a different seed and receive the packed blob via RCCL
     sd = synth.make_state_dict(cfg, seed=0 if rank == 0 else 1000 + rank)
     model, diffusion = synth.build_model(cfg, sd, resp=a.respacing, precision=a.precision, device=str(dev), x3_tail=a.x3_tail)
-    model.weights_src = 0 if world > 1 else None            # ONE collective over xGMI per engine built (none at N = 1)
-    eng, _ = model._get_engine(B)
+    # Engine build = host-side repack of the checkpoint into the device blob (fp32 -> bf16 planes in three layouts) + upload; timed and
+    # reported ("engine_build_s": ~2 s of one host core at N = 1). N ranks repack concurrently by default; REGENNET_SERIAL_ENGINE_BUILD=1
+    # makes them take turns (a host whose memory bandwidth 8 concurrent repacks would saturate), the broadcast follows either way.
+    t_build = time.perf_counter()
+    if world > 1 and os.environ.get("REGENNET_SERIAL_ENGINE_BUILD"):
+        eng = None
+        for r in range(world):
+            if r == rank:
+                eng, _ = model._get_engine(B)
+            dist.barrier()
+        dist_util.broadcast_engine_weights(eng, dev, 0)     # ONE collective over xGMI: rank 0's packed blob
+        eng._blob_synced = True
+        model.weights_src = 0
+    else:
+        model.weights_src = 0 if world > 1 else None        # ONE collective over xGMI for the engine every rank builds here (none at N = 1)
+        eng, _ = model._get_engine(B)
+    sync()
+    build_s = time.perf_counter() - t_build
     fm = ClassifierFreeSampleModel(model) if a.guided else model
     lo = rank * B                                           # global sample index of this rank's shard
     y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1 + rank)).to(dev)}
@@ -277,21 +305,38 @@ def main(argv=None):
         eng.sample_range(a.sampler, a.guided, 0.0, x, None, 5, lo, first, 1, None, False, False, st)   # warm (untimed)
         torch.cuda.synchronize()
         eng.profile_enable(True)                            # reset
-        eng.sample_range(a.sampler, a.guided, 0.0, x, None, 5, lo, first - 1, n_eval, None, False, False, st)
+        fl = flops_per_eval(cfg, B, a.guided, a.precision)
+        run_steps = 0
+        if fl.get("steps_fused", 0.0) > 0:
+            # the timed region's dominant launch covers the WHOLE plain-bf16 phase of a call: profile exactly that launch (every
+            # k_layers<steps> launch of this command then has the same step count, and rocprofv3's average duration is comparable)
+            tail = a.x3_tail if a.x3_tail is not None else default_x3_tail(S, cfg['layers'], bool(cfg.get('emb_trans_dec', False)))
+            run_steps = n_eval = max(S - min(tail, S), 1)
+            eng.randn(x, B, 5, lo, st)
+            eng.sample_range(a.sampler, a.guided, 0.0, x, None, 5, lo, first, run_steps, None, False, False, st)
+        else:
+            eng.sample_range(a.sampler, a.guided, 0.0, x, None, 5, lo, first - 1, n_eval, None, False, False, st)
         torch.cuda.synchronize()
         prof = eng.profile_query()
         ovh_ms = eng.profile_bracket_overhead_ms()
         eng.profile_enable(False)
-        fl = flops_per_eval(cfg, B, a.guided, a.precision)
         peak = PEAK_TFLOPS[a.precision]
         names = {"gemm_mfma": "k_gemm_x3", "qkv_attn": "k_qkv_attn", "attention": "k_attn_x3", "layernorm": "k_layernorm",
-                 "update": "k_update", "rowgemm_ln": "k_rowgemm<LN>", "rowgemm_act": "k_rowgemm<ACT>", "mlp": "k_mlp", "sb_gemm": "k_sb_gemm", "step_fused": "k_step", "layers": "k_layers"}
+                 "update": "k_update", "rowgemm_ln": "k_rowgemm<LN>", "rowgemm_act": "k_rowgemm<ACT>", "mlp": "k_mlp", "sb_gemm": "k_sb_gemm", "step_fused": "k_step", "layers": "k_layers", "steps_fused": "k_layers<steps>"}
         if a.precision == "f32":
             names.update(gemm_mfma="k_gemm_f32", attention="k_attn_mfma")
         if fused_qkv_attention_long(cfg, a.precision):
             names.update(qkv_attn="k_qkv_attn_long")
         per_kernel = []
         for cls, (ms, n) in prof.items():
+            if cls == "steps_fused" and run_steps and n >= 1:
+                us = max(1e3 * (ms - n * ovh_ms) / n, 0.1)
+                tf = fl[cls] * run_steps / (us * 1e-6) / 1e12
+                per_kernel.append({"kernel": names[cls], "launches_per_eval": round(n / run_steps, 6), "steps_per_launch": run_steps, "avg_us": round(us, 2),
+                                   "us_per_step": round(us / run_steps, 2), "ms_per_eval": round(us / run_steps * 1e-3, 4), "bound": "mfma",
+                                   "algo_gflop_per_launch": round(fl[cls] * run_steps / 1e9, 3), "achieved": round(tf, 1), "peak": peak,
+                                   "unit": "TFLOP/s", "frac": round(tf / peak, 4)})
+                continue
             if n < n_eval or cls not in names:        # (classes that ran once per call, e.g. the embedding in front of the first fused step)
                 continue
             # every event bracket carries the dispatch + event latency of an empty bracket (calibrated on a no-op kernel,
@@ -311,21 +356,22 @@ def main(argv=None):
             phase = " (plain-bf16 phase of the precision schedule: single-plane operands, one MFMA per product)"
         roof = {"bound": "mfma", "kernel": dom["kernel"] + phase, "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s",
                 "frac": dom["frac"], "traffic": None,
-                "avg_launch_us": dom["avg_us"], "launches_per_eval": dom["launches_per_eval"],
+                "avg_launch_us": dom["avg_us"], "launches_per_eval": dom["launches_per_eval"], "steps_per_launch": dom.get("steps_per_launch"),
                 "algo_gflop_per_launch": dom["algo_gflop_per_launch"],
                 "event_bracket_overhead_us": round(1e3 * ovh_ms, 2),
                 "sustained_peak_note": "a pure v_mfma_f32_32x32x16_bf16 loop on all 1024 SIMDs sustains 1826 TFLOP/s on this pool (1.97 GHz at "
                                        "1320 W; the sampling loop itself runs at 1.98 GHz / 1230 W): DESIGN.md 10.3. peak/frac use the guide's 2500",
                 "note": "achieved = algorithmic FLOPs of the class's launches / their summed duration; duration = HIP-event "
                         "bracket on the engine stream minus the calibrated empty-bracket latency (single-chain eager pass; "
-                        "matches rocprofv3 --kernel-trace durations, profiles/); the timed region replays multi-chain hipGraphs "
-                        "in which kernels of different chains overlap",
+                        "matches rocprofv3 --kernel-trace durations, profiles/). k_layers<steps>: ONE launch carries every sample through "
+                        "steps_per_launch complete sampler steps (decoder stack + step boundary), exactly the launch the timed region issues "
+                        "once per call; other forms: the timed region replays multi-chain hipGraphs in which kernels of different chains overlap",
                 "per_kernel": per_kernel}
         # HBM bytes per launch of the dominant kernel: NOT measured by this run (counters need rocprofv3 passes of their own, the
         # MI355X guide's recipe) - read from the newest committed PMC summary (tools/collect_pmc.sh + tools/summarize_pmc.py) and
         # labelled as such
         key = f"{a.config}_B{B}_{a.precision}_{'cfg' if a.guided else 'plain'}"
-        for name in ("r03_pmc_bench.json", "r02_pmc_bench.json"):
+        for name in ("r04_pmc_bench.json", "r03_pmc_bench.json", "r02_pmc_bench.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 with open(pmc) as fh:
@@ -350,6 +396,7 @@ def main(argv=None):
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic" if not a.engine_stub else f"STUB ENGINE {a.engine_stub}: launcher test, nothing measured",
+            "engine_build_s": round(build_s, 2),
             "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
             "backend": dist.get_backend() if dist.is_initialized() else None, "devices": devices,
             "config": {"workload": f"{a.config}: [B={B}/GPU,56,6,{cfg['num_frames']}] online/{cfg['cm_mode']}/{cfg['cond_mode']} "

@@ -87,6 +87,8 @@ def default_x3_tail(S, layers=8, etd=False):
     if etd:
         return S
     if layers >= 8:
+        if S <= 10:
+            return min(S, 3)
         return min(S, max(5, -(-S // 200)))
     return min(S, -(-max(8, -(-S // 100)) * 8 // max(1, layers)))
 

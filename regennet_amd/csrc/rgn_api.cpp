@@ -161,7 +161,7 @@ struct rgn_ctx {
 
 namespace {
 
-const char* kclass_names[KC_COUNT] = {"gemm_mfma", "attention", "layernorm", "embed", "update", "misc", "qkv_attn", "rowgemm_ln", "rowgemm_act", "mlp", "sb_gemm", "step_fused", "layers"};
+const char* kclass_names[KC_COUNT] = {"gemm_mfma", "attention", "layernorm", "embed", "update", "misc", "qkv_attn", "rowgemm_ln", "rowgemm_act", "mlp", "sb_gemm", "step_fused", "layers", "steps_fused"};
 
 #define RGN_HIP(h, expr)                                                                                    \
     do {                                                                                                    \
@@ -352,7 +352,13 @@ inline int default_tail(int S, int layers, bool etd = false) {
     // (1.2e-4 / 1.2e-4 / 1.0e-4 / 1.2e-4 with 5 on the four sweeps vs 0.7 - 1.2e-4 with 10, 1.4 - 3.7e-4 with 2), the shallow
     // models' are not (2 layers: 5 -> 1.2e-3 / 1.4e-3). So: max(5, S / 200) split-bf16 steps for models of >= 8 layers,
     // max(8, S / 100) * 8 / layers for shallower ones.
+    // Short schedules - the reference's shipped evaluation setting is 5 steps (`--timestep_respacing ddim5` through p_sample_loop,
+    // README.md:134-137) - measured on the reference's own 5-step outputs (tests: test_reference_evaluation_setting_switch_point_sweep,
+    // three 8-layer goldens, both kernel forms): 4.3 - 5.0e-5 with all 5 steps split, 4.6 - 5.6e-5 with 3, 6.6 - 7.9e-5 with 2, ~1e-3
+    // with 1, 2e-2 with none. Up to 10 steps: 3 split-bf16 steps (the other steps then reach the plain-bf16 kernels: 10.7 -> 7.7 ms per
+    // 5-step call at B = 256).
     if (layers >= 8) {
+        if (S <= 10) return S < 3 ? S : 3;
         const int t8 = (S + 199) / 200 < 5 ? 5 : (S + 199) / 200;
         return t8 < S ? t8 : S;
     }
@@ -601,7 +607,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             g.out = att_p;
             g.Bm = ns; g.Kp = w.qkv.Kp; g.d = d; g.H = c->H; g.Tq = dm.Tq;
             g.qscale = 1.0f / sqrtf((float)dm.dh);
-            g.Bm_eval = dm.Bm;
+            g.Bm_eval = dmf.Bm;   // samples of the WHOLE evaluation (all kernel chains), not of this chain
             RGN_LAUNCH(c, KC_QKV, s, launch_qkv_attn(g, x3, s));   // 93 % of its MFMA work is the in_proj GEMM
         } else if (fast && c->qkv_long && !x3 && w.qkv.fr && !att_p.lo && (size_t)h_p.rows * w.qkv.Kp * 2 < (1ull << 31)) {
             // plain-bf16 phase, long sequence: in_proj + attention of one (sample, head) per workgroup, q / k / v stay in LDS
@@ -1389,7 +1395,7 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
         if (fused_now && !prev_fused && (rc = embed_all(c, dm, s))) return rc;
         if (!fused_now && prev_fused && (rc = pack_state(c, x, dm, guided != 0, s))) return rc;
         prev_fused = fused_now;
-        if (fused_now && !guided && !x3 && c->layers_steps && dm.Bm >= c->layers_min_b && !c->prof) {
+        if (fused_now && !guided && !x3 && c->layers_steps && dm.Bm >= c->layers_min_b) {
             // unguided plain-bf16 phase, <= 64 tokens: ALL remaining steps of the phase in one launch - a workgroup carries its sample
             // through decoder stack and step boundary step after step; nothing but x, the condition rows and the weights is read
             bool ok = true;
@@ -1406,7 +1412,7 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
                 g.c0 = c->c0h;
                 g.tab = c->d_tab; g.d_stepw = c->d_step; g.sp = c->d_sp;
                 g.B = dm.B; g.s0 = 0; g.no_quads = c->step_no_quads;
-                RGN_LAUNCH(c, KC_LAYERS, s, launch_layers(g, s));
+                RGN_LAUNCH(c, KC_STEPS, s, launch_layers(g, s));
                 k += phase_left;
                 continue;
             }

@@ -21,6 +21,7 @@ enum KClass : int {
     KC_SB,            // small-batch column-split GEMMs (k_sb_gemm)
     KC_STEP,          // fused step boundary: output projection + sampler update + next input embedding (k_step)
     KC_LAYERS,        // the whole decoder stack of an evaluation, one sample per workgroup (k_layers)
+    KC_STEPS,         // a run of complete sampler steps (stack + step boundary per sample) in one launch (k_layers<true>)
     KC_COUNT
 };
 

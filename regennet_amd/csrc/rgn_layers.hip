@@ -64,8 +64,15 @@ __device__ long long g_ly_st[1024][16];
         if (threadIdx.x == 0 && blockIdx.x < 1024 && l == RGN_LY_STAMPS) g_ly_st[blockIdx.x][i] = __builtin_readcyclecounter(); \
         __builtin_amdgcn_sched_barrier(0);                                                           \
     }
+#define RGN_LYS(i)                                                                                   \
+    {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        if (threadIdx.x == 0 && blockIdx.x < 1024 && it == 1) g_ly_st[blockIdx.x][i] = __builtin_readcyclecounter(); \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+    }
 #else
 #define RGN_LYT(i)
+#define RGN_LYS(i)
 #endif
 
 // GELU (erf form), see rgn_mlp2.hip
@@ -602,6 +609,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         const int l31_s = lane_s & 31, kh_s = lane_s >> 5;
         const size_t row0_s = (size_t)b_s * Tq;
         auto col4s = [&](int nt, int i4) { return 32 * nt + 8 * i4 + 4 * kh_s; };
+        RGN_LYS(12)
         const SampleParams sp = *g.sp;
         const StepCoef k = g.tab[step];
         const int T = Tq, gb = g.s0 + b_s;                                  // frames = tokens (no emb_trans_dec token on this path); motion index
@@ -655,6 +663,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        RGN_LYS(13)
         // ---- C: sampler update. lane = frame, the waves stride the features; Philox per quad of lanes where the quad is a run of four
         //      frames (see rgn_step.hip), per element otherwise (bit-identical values)
         {
@@ -733,6 +742,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        RGN_LYS(14)
         // ---- D: h' = x' . Wx'^T + c0 -> image X (the fp32 tile is dead since the barrier above; the x' image lies behind X)
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2)
@@ -755,6 +765,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         store_img(acc, LY_X);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        RGN_LYS(15)
     }
     }
     // ---- the sample's rows -> output planes (write-through)

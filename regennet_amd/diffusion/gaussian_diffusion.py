@@ -288,15 +288,30 @@ class GaussianDiffusion:
         inner = getattr(model, "model", model)
         if getattr(inner, "x3_tail", None) != "auto" or getattr(inner, "precision", "") != "bf16_x3tail" or getattr(self, "_calibrating", False):
             return
-        key = (id(self._sched_token), sampler, inner is not model, int(shape[3]), float(eta))
-        if key not in inner._auto_tails:
-            inner._auto_tails[key] = self.calibrate_x3_tail(model, shape, {"y": y}, sampler=sampler, eta=eta)
+        # one calibration per (schedule, sampler, guidance, eta): measured at the longest sequence seen so far and reused for every shorter
+        # one (auto_regressive evaluation samples a ladder of lengths: the first, longest-needed calibration serves them all)
+        key = (id(self._sched_token), sampler, inner is not model, float(eta))
+        T = int(shape[3])
+        if key not in inner._auto_tails or inner._auto_tails[key][0] < T:
+            tail = self.calibrate_x3_tail(model, shape, {"y": y}, sampler=sampler, eta=eta)
+            if key in inner._auto_tails:
+                tail = max(tail, inner._auto_tails[key][1])
+            # every rank of a sharded run must use ONE switch point (a sample's result may not depend on the rank it landed on): the
+            # ranks calibrate on their own first motions and agree on the longest tail any of them needs
+            if th.distributed.is_available() and th.distributed.is_initialized() and th.distributed.get_world_size() > 1:
+                t_all = th.tensor([tail], device=y["cmotion"].device if th.is_tensor(y.get("cmotion")) else "cpu", dtype=th.int64)
+                if th.distributed.get_backend() == "gloo":
+                    t_all = t_all.cpu()
+                th.distributed.all_reduce(t_all, op=th.distributed.ReduceOp.MAX)
+                tail = int(t_all.item())
+            inner._auto_tails[key] = (T, tail)
             dev = getattr(self, "_last_calibration_dev", float("nan"))
-            print(f"[regennet_amd] precision schedule calibrated on this checkpoint: split-bf16 for the last {inner._auto_tails[key]} of "
-                  f"{self.num_timesteps} {sampler} steps{' (guided)' if inner is not model else ''}, T={int(shape[3])} "
-                  f"(max |dev| vs uniform split-bf16 on {min(int(shape[0]), 4)} motions: {dev:.1e}; override: x3_tail= / REGENNET_X3_TAIL)",
+            print(f"[regennet_amd] precision schedule calibrated on this checkpoint: split-bf16 for the last {tail} of "
+                  f"{self.num_timesteps} {sampler} steps{' (guided)' if inner is not model else ''}, T={T} "
+                  f"(max |dev| vs uniform split-bf16 on {min(int(shape[0]), 4)} motions: {dev:.1e}; one full {self.num_timesteps}-step run plus the candidates, "
+                  f"once per schedule; override: x3_tail= / REGENNET_X3_TAIL)",
                   file=sys.stderr, flush=True)
-        inner._auto_tail = inner._auto_tails[key]
+        inner._auto_tail = inner._auto_tails[key][1]
 
     def calibrate_x3_tail(self, model, shape, model_kwargs, sampler="ddpm", eta=0.0, tol=2.5e-4, max_batch=4, seed=1234, verbose=False):
         """How many split-bf16 steps THIS checkpoint needs at the end of THIS schedule: the precision schedule's validity
@@ -336,6 +351,8 @@ class GaussianDiffusion:
                     chosen = t
                     break
                 t *= 2
+            if chosen == S:
+                self._last_calibration_dev = 0.0      # (no shorter tail passed: the schedule stays uniform split-bf16)
         finally:
             inner.x3_tail, inner._auto_tail, inner.small_batch_rows = saved
             self._calibrating = False

@@ -221,7 +221,15 @@ class CMDM(nn.Module):
                 eng.load_weight(k, v.detach().float().cpu().numpy())
             eng.finalize()
             if self.weights_src is not None:
-                dist_util.broadcast_engine_weights(eng, dev, int(self.weights_src))
+                # The RCCL broadcast is a collective: it may only run where EVERY rank builds an engine - the first one (the callers
+                # build it at start-up, whatever their shard size). Engines built later by one rank alone (a new sequence length, a
+                # larger batch, an evicted length) take the already-synchronised blob of a live engine of this model instead.
+                donor = next((e for e in self._engines.values() if getattr(e, "_blob_synced", False)), None)
+                if donor is not None and not dist_util.copy_engine_weights(donor, eng, dev):
+                    donor = None
+                if donor is None:
+                    dist_util.broadcast_engine_weights(eng, dev, int(self.weights_src))
+                eng._blob_synced = True
         self._engines[T] = eng                                # (re)inserted last = most recently used
         if eng is not self._engine:
             self._engine, self._cond_key, self._keep = eng, None, None

@@ -97,6 +97,22 @@ def broadcast_engine_weights(engine, device, src=0):
     engine.schedule_id = None
 
 
+def copy_engine_weights(src_engine, dst_engine, device):
+    """Device-to-device copy of one engine's packed weight blob into another engine of the SAME model (same blob layout): what a
+    rank does for engines it builds alone after the start-up broadcast (no collective). False if the layouts differ."""
+    sp, sn = src_engine.weight_blob()
+    dp, dn = dst_engine.weight_blob()
+    if int(sn) != int(dn):
+        return False
+    sv = sp if torch.is_tensor(sp) else device_view(sp, sn, device)
+    dv = dp if torch.is_tensor(dp) else device_view(dp, dn, device)
+    synchronize(device)
+    dv.copy_(sv)
+    synchronize(device)
+    dst_engine.schedule_id = None
+    return True
+
+
 def sync_params(params):
     """dist_util.py:77-83, but as a single flattened broadcast instead of one per tensor."""
     params = list(params)

@@ -331,6 +331,11 @@ JOBS = {
     "chi3d_ddpm20": lambda: gen_loop("chi3d_ddpm20", "chi3d", 2, "20", "ddpm"),
     "chi3d_ddim20_cfg": lambda: gen_loop("chi3d_ddim20_cfg", "chi3d", 2, "ddim20", "ddim", guided=True),
     "text150_ddim50_cfg": lambda: gen_loop("text150_ddim50_cfg", "text150", 2, "ddim50", "ddim", guided=True),
+    # the reference's shipped evaluation setting (README.md:134-137: `--timestep_respacing ddim5` through p_sample_loop,
+    # eval/a2m/stgcn_eval.py:61,69) and the plain 5-step spacing, 8-layer NTU model, per-step trace kept
+    "ntu_eval_ddim5": lambda: gen_loop("ntu_eval_ddim5", "ntu", 2, "ddim5", "ddpm", keep_trace=True),
+    "ntu_eval_5": lambda: gen_loop("ntu_eval_5", "ntu", 2, "5", "ddpm", keep_trace=True),
+    "ntu_action_eval_ddim5": lambda: gen_loop("ntu_action_eval_ddim5", "ntu_action", 2, "ddim5", "ddpm"),
     # long: the headline configuration (1000-step DDPM), B=2
     "ntu_ddpm1000": lambda: gen_loop("ntu_ddpm1000", "ntu", 2, "", "ddpm"),
 }

@@ -203,6 +203,46 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
     assert line["data"].startswith("STUB ENGINE")                     # never mistaken for a measurement
 
 
+def test_bench_gpus_2_chi3d_shard_and_serial_engine_build():
+    """The per-GPU shard of BASELINE configs[3] (Chi3D, 150 frames, 1024 / 8 = 128 motions per rank) through the same self-launch,
+    once with the ranks building their engines in turn (REGENNET_SERIAL_ENGINE_BUILD=1): global batch, world size, per-rank devices."""
+    for env in ({}, {"REGENNET_SERIAL_ENGINE_BUILD": "1"}):
+        rc, line, log = _run_bench(env, "--gpus", "2", "--config", "chi3d", "--batch", "128")
+        assert rc == 0 and line is not None, log
+        assert line["n_gpus"] == 2 and line["rccl_world_size"] == 2 and line["config"]["global_batch"] == 256, line
+        assert line["config"]["batch_per_gpu"] == 128 and line["devices"] == ["rank0:cpu", "rank1:cpu"], line
+        assert "chi3d" in line["config"]["workload"] and line["scaling"] == "weak" and line["engine_build_s"] >= 0, line
+
+
+class FailingEngine:
+    """Engine stub whose construction fails on rank 0 (test_bench_rank_failure_is_a_nonzero_exit)."""
+    requires_gpu = False
+
+    def __init__(self, *a, **k):
+        if os.environ.get("RANK", "0") == "0":
+            raise RuntimeError("rank 0 cannot build its engine (test)")
+        FakeEngine.__init__(self, *a, **k)
+
+    def __getattr__(self, name):
+        return getattr(FakeEngine, name).__get__(self)
+
+
+def test_bench_rank_failure_is_a_nonzero_exit():
+    """A rank that dies (here: rank 0 while building its engine) must make `bench.py --gpus 2` exit non-zero with no JSON line: the
+    driver launches the scaling bench unattended and reads the exit code."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--engine-stub", "tests.test_dist_cpu:FailingEngine", "--config", "tiny",
+                        "--batch", "2", "--steps", "1", "--warmup", "0", "--respacing", "5", "--gpus", "2"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode != 0, p.stdout + p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    del json
+
+
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():
     rc, line, log = _run_bench({"WORLD_SIZE": "1", "RANK": "0"}, "--gpus", "2")
     assert rc != 0 and line is None and "refusing" in log, log

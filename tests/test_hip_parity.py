@@ -517,6 +517,36 @@ def test_full_size_batch_is_row_independent(precision, tail):
         assert torch.allclose(full2[b:b + 1], one, atol=2e-5), (b, (full2[b:b + 1] - one).abs().max().item())
 
 
+@pytest.mark.parametrize("name", ["ntu_eval_ddim5", "ntu_eval_5", "ntu_action_eval_ddim5"])
+def test_reference_evaluation_setting_switch_point_sweep(golden, monkeypatch, name):
+    """The reference's shipped evaluation setting (README.md:134-137, eval/a2m/stgcn_eval.py:61,69): `--timestep_respacing ddim5`
+    (and the plain 5-step spacing) through p_sample_loop, 8-layer NTU model, against the reference's own outputs - for every
+    precision-schedule switch point 0 .. 5, on the throughput kernels and with the one-kernel decoder stack forced on (a
+    test-sized batch). The default (3 split-bf16 steps for schedules of up to 10) and every longer tail must stay at the level
+    of the all-split run (< 1.5e-4, bound 1e-3); what fewer split-bf16 steps cost is printed."""
+    g = golden(name)
+    cfg, sd, y, tape = fixture_inputs(g, loop=True)
+    S = int(g["S"])
+    assert S == 5 and default_tail(S) == 3
+    shape = (int(g["B"]), cfg["njoints"], cfg["nfeats"], cfg["num_frames"])
+    errs = {}
+    for layers_on in (False, True):
+        for tail in (0, 1, 2, 3, 4, 5, None):
+            monkeypatch.setenv("REGENNET_LAYERS_MIN_B", "1" if layers_on else "100000")
+            model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision="bf16_x3tail/throughput", x3_tail=tail)
+            model._get_engine(shape[0])
+            monkeypatch.delenv("REGENNET_LAYERS_MIN_B")
+            out = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
+            errs[(layers_on, tail)] = float(np.abs(out.cpu().numpy() - g["final"]).max())
+            model._engine.close()
+    for layers_on in (False, True):
+        print(f"\n[5-step evaluation schedule] {name} {'k_layers' if layers_on else 'kernel per stage'}: " +
+              ", ".join(f"tail {t}: {errs[(layers_on, t)]:.2e}" for t in (0, 1, 2, 3, 4, 5, None)))
+        for t in (None, 3, 4, 5):
+            assert errs[(layers_on, t)] < 1.5e-4, (layers_on, t, errs[(layers_on, t)])
+        assert errs[(layers_on, 2)] < 3.5e-4
+
+
 @pytest.mark.parametrize("sampler,clip,guided", [("ddpm", False, False), ("ddim", True, False), ("ddim", False, True), ("ddpm", True, True)])
 def test_fused_step_boundary_matches_the_three_kernel_form(monkeypatch, sampler, clip, guided):
     """k_step (plain-bf16 phase, throughput kernels: output projection + sampler update + next input embedding in one kernel;

@@ -10,7 +10,8 @@ from tests.helpers import autoreg_inputs, fixture_inputs, fixture_opts
 FWD = ["tiny_fwd", "tiny_fwd_cfg", "tiny_add_fwd", "tiny_etd_fwd", "tiny_wope_fwd", "tiny_text_fwd_cfg", "ntu_fwd",
        "ntu_action_fwd_cfg", "chi3d_fwd"]
 LOOPS = ["tiny_ddpm10", "tiny_ddim10_cfg", "tiny_add_ddpm1000", "tiny_text_ddim20_cfg", "tiny_etd_ddim10_cfg",
-         "tiny_wope_ddpm10", "ntu_ddpm50", "ntu_add_etd_ddpm20", "chi3d_ddpm20", "chi3d_ddim20_cfg"]
+         "tiny_wope_ddpm10", "ntu_ddpm50", "ntu_add_etd_ddpm20", "chi3d_ddpm20", "chi3d_ddim20_cfg",
+         "ntu_eval_ddim5", "ntu_eval_5", "ntu_action_eval_ddim5"]   # (the last three: the reference's shipped evaluation setting, README.md:134-137)
 
 
 def _ty(y):

@@ -2,7 +2,7 @@
 // (k_qkv_attn_rs + k_mlp per layer) on the same random bf16 inputs (tools only; the parity tests proper are tests/test_hip_parity.py).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I regennet_amd/csrc tools/layers_bench.hip regennet_amd/csrc/rgn_layers.hip \
 //         regennet_amd/csrc/rgn_qkv_attn.hip regennet_amd/csrc/rgn_qkv_attn_long.hip regennet_amd/csrc/rgn_mlp.hip regennet_amd/csrc/rgn_mlp2.hip -o tools/bin/layers_bench
-//   layers_bench [Bm] [Tq] [L] [iters]
+//   layers_bench [Bm] [Tq] [L] [iters] [steps]     steps > 0: also time k_layers<true> over that many complete sampler steps (synthetic schedule)
 #include "rgn_internal.h"
 
 #include <hip/hip_runtime.h>
@@ -55,6 +55,7 @@ int main(int argc, char** argv) {
         t.bqkv = vecf(3 * d, 0.f, 0.05f); t.bo = vecf(d, 0.f, 0.05f); t.bf1 = vecf(ff, 0.f, 0.05f); t.bf2 = vecf(d, 0.f, 0.05f);
         t.g1 = vecf(d, 1.f, .1f); t.b1 = vecf(d, 0.f, .1f); t.g2 = vecf(d, 1.f, .1f); t.b2 = vecf(d, 0.f, .1f); t.g3 = vecf(d, 1.f, .1f); t.b3 = vecf(d, 0.f, .1f);
     }
+    if (getenv("SAMEW")) for (int l = 1; l < L; ++l) ga.lw[l] = ga.lw[0];   // every layer streams the SAME 4 MB: what the L2-cold first touch of a layer's weights costs
     const int Ld = L * d;
     ga.pervec = vecf((size_t)Bm * Ld, 0.f, 0.5f); ga.ldper = Ld; ga.stepvec = vecf((size_t)4 * Ld, 0.f, 0.5f); ga.ldstep = Ld;
     int* ds; CK(hipMalloc(&ds, 4)); { int one = 1; CK(hipMemcpy(ds, &one, 4, hipMemcpyHostToDevice)); } ga.d_step = ds;
@@ -103,6 +104,37 @@ int main(int argc, char** argv) {
         const double fl = (2.0 * M * (4.0 * d * d + 2.0 * d * ff) + 4.0 * Bm * H * Tq * Tq * 128.0) * L;
         printf("  %d layers: chain %.1f us (%.1f per layer, %.0f TF)   fused %.1f us (%.1f per layer, %.0f TF)\n", L, us_c, us_c / L, fl / us_c * 1e-6, us_f, us_f / L, fl / us_f * 1e-6);
     }
+    const int nsteps = argc > 5 ? atoi(argv[5]) : 0;
+    if (nsteps > 0) {   // whole sampler steps in one launch: stack + step boundary per sample (synthetic DDPM coefficients, Philox noise)
+        const int F = 336, nb_out = 11;
+        auto frag = [&](int NB, int KB, float gain) {   // a fragment-ordered plane [KB][NB][2][64][8] of random bf16
+            std::vector<uint16_t> fr((size_t)KB * NB * 1024);
+            for (auto& x : fr) x = f2bf(gain * N01(rng));
+            return (__bf16*)up(fr.data(), fr.size() * 2);
+        };
+        ga.steps = nsteps;
+        ga.Wout = frag(nb_out, 16, 1.f / std::sqrt(512.f)); ga.bout = vecf(F, 0.f, 0.05f); ga.F = F; ga.nb_out = nb_out;
+        ga.Wx = frag(16, 11, 1.f / std::sqrt(336.f));
+        { std::vector<uint16_t> c0((size_t)M * 512); for (auto& x : c0) x = f2bf(0.5f * N01(rng)); ga.c0 = (__bf16*)up(c0.data(), c0.size() * 2); }
+        std::vector<StepCoef> tab(1024);
+        for (auto& k : tab) { k.c1 = 0.05f; k.c2 = 0.94f; k.sig_ddpm = 0.05f; k.sr = 1.1f; k.srm1 = 0.45f; k.ca = 0.9f; k.cb = 0.4f; k.sig_ddim = 0.f; k.t_model = 0; }
+        ga.tab = (StepCoef*)up(tab.data(), tab.size() * sizeof(StepCoef));
+        float* x; CK(hipMalloc(&x, (size_t)Bm * F * Tq * 4));
+        { std::vector<float> xh((size_t)Bm * F * Tq); for (auto& v : xh) v = N01(rng); CK(hipMemcpy(x, xh.data(), xh.size() * 4, hipMemcpyHostToDevice)); }
+        SampleParams sp{}; sp.x = x; sp.seed = 7; sp.first_index = 999; sp.sampler = 0;
+        ga.sp = (SampleParams*)up(&sp, sizeof(sp));
+        int* dsw; CK(hipMalloc(&dsw, 64)); ga.d_stepw = dsw; ga.d_step = dsw;
+        ga.B = Bm; ga.s0 = 0; ga.h = hB; ga.out = hB;
+        for (int rep = 0; rep < 3; ++rep) {
+            int z[16] = {0}; z[0] = 999; CK(hipMemcpy(dsw, z, 64, hipMemcpyHostToDevice));
+            CK(hipEventRecord(e0, nullptr));
+            CK(launch_layers(ga, nullptr));
+            CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+            int after; CK(hipMemcpy(&after, dsw, 4, hipMemcpyDeviceToHost));
+            printf("  %d steps in one launch: %.1f us per step (loop index 999 -> %d)\n", nsteps, 1e3 * ms / nsteps, after);
+        }
+        ga.steps = 0;
+    }
 #ifdef RGN_LY_STAMPS
     {
         std::vector<long long> st(1024 * 16); ly_stamps_read(st.data());
@@ -112,6 +144,12 @@ int main(int argc, char** argv) {
         printf("  layer %d, mean cycles (wave 0): in_proj(0) %.0f | attention(0) %.0f | barrier %.0f | in_proj(1) %.0f | attention(1) %.0f | barrier %.0f | att image + barrier %.0f | out_proj %.0f | res+LN1+LN2+image %.0f | ffn %.0f | res+LN3+image %.0f | total %.0f\n",
                RGN_LY_STAMPS, ph[1] / nwg, ph[2] / nwg, ph[3] / nwg, ph[4] / nwg, ph[5] / nwg, ph[6] / nwg, ph[7] / nwg, ph[8] / nwg, ph[9] / nwg, ph[10] / nwg, ph[11] / nwg,
                [&] { double t = 0; for (int b = 0; b < nwg; ++b) t += (double)(st[b * 16 + 11] - st[b * 16]); return t / nwg; }());
+        if (nsteps > 1) {
+            double sp4[4] = {0, 0, 0, 0};
+            for (int b = 0; b < nwg; ++b) for (int i = 0; i < 3; ++i) sp4[i] += (double)(st[b * 16 + 13 + i] - st[b * 16 + 12 + i]);
+            printf("  step boundary of step 1, mean cycles (wave 0): output projection + x0 tile %.0f | sampler update (Philox, x) %.0f | input embedding + image %.0f | total %.0f\n",
+                   sp4[0] / nwg, sp4[1] / nwg, sp4[2] / nwg, (sp4[0] + sp4[1] + sp4[2]) / nwg);
+        }
     }
 #endif
     return 0;
