@@ -63,7 +63,10 @@ def run_case(case, rng):
     exact = engine == "default" and rows <= 640            # batch AND single run in the small-batch engine
     mixed = engine == "default" and rows > 640             # batch: throughput kernels, single sample: small-batch engine -
     #                                                        two different roundings of the plain-bf16 phase: not comparable
-    ok = err < 1e-3 and (mixed or (dev == 0.0 if exact else dev < 5e-5)) and bool(torch.isfinite(full).all())
+    # (a batch of >= 64 samples of 52 .. 64 tokens runs the one-kernel decoder stack, the single sample the kernel-per-stage chain:
+    #  two roundings of the plain-bf16 phase, compared at the level the forms agree to)
+    forms = rows > 640 and (2 if guided else 1) * B >= 64 and 52 <= T + int(etd) <= 64 and ff == 1024
+    ok = err < 1e-3 and (mixed or (dev == 0.0 if exact else dev < (5e-4 if forms else 5e-5))) and bool(torch.isfinite(full).all())
     desc = (f"case {case:2d} T={T:3d} etd={int(etd)} B={B} ff={ff} guided={int(guided)} {sampler} S={S} engine={engine}: "
             f"x3 vs oracle {err:.2e} | row consistency {dev:.1e}"
             f"{' (exact required)' if exact else (' (mixed engines: not compared)' if mixed else '')}")

@@ -485,12 +485,15 @@ def test_big_gemm_tiles_meet_the_same_bound(golden, monkeypatch):
 
 
 @pytest.mark.parametrize("precision,tail", [("bf16x3", None), ("bf16_x3tail", 2)])
-def test_full_size_batch_is_row_independent(precision, tail):
+def test_full_size_batch_is_row_independent(monkeypatch, precision, tail):
     """BASELINE configs[1] size (B=256, NTU): every sample's chain is independent, so sample b of a 256-batch must equal
     the same sample drawn alone with the same Philox key (sample_offset=b) — a size-independent property that checks
     tiling, chain splitting and row mapping at the full bench size without needing a 256-sample reference run.
-    ("bf16_x3tail", 2): 3 of the 5 steps run the plain-bf16 phase kernels, 2 the split-bf16 ones.)"""
+    ("bf16_x3tail", 2): 3 of the 5 steps run the plain-bf16 phase kernels, 2 the split-bf16 ones. The engine picks the kernel form
+    by the size of the evaluation - one workgroup per sample from 64 samples on, kernel per stage below - and the forms differ by
+    bf16 roundings: REGENNET_LAYERS_MIN_B=1 gives the single-sample runs the form of the batch.)"""
     from regennet_amd import synth
+    monkeypatch.setenv("REGENNET_LAYERS_MIN_B", "1")
     cfg = synth.get_config("ntu")
     sd = synth.make_state_dict(cfg, seed=0)
     model, diffusion = build_hip(cfg, sd, resp="ddim5", precision=precision + "/throughput", x3_tail=tail)   # (the B = 1 runs too)
