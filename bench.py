@@ -378,6 +378,9 @@ def main(argv=None):
                     rec = json.load(fh).get(key, {}).get(dom["kernel"], {})
                 if rec.get("hbm_bytes_per_launch"):
                     roof["traffic"] = rec["hbm_bytes_per_launch"]
+                    if rec.get("steps_per_launch") and dom.get("steps_per_launch"):   # counted on a short run: scale to the timed launch's step count
+                        roof["traffic"] = round(rec["hbm_bytes_per_launch"] / rec["steps_per_launch"] * dom["steps_per_launch"])
+                        roof["traffic_per_step"] = round(rec["hbm_bytes_per_launch"] / rec["steps_per_launch"])
                     roof["traffic_source"] = (f"profiles/{name} [{key}][{dom['kernel']}]: FETCH_SIZE x 2 (gfx950) + WRITE_SIZE from separate "
                                               "rocprofv3 --pmc passes of a committed earlier run of this command; not measured in this run")
                     roof["mfma_util_pmc"] = rec.get("mfma_util")

@@ -23,4 +23,4 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" 
         > "$R/gpurun_out/pmc/pass$i.log" 2>&1 < /dev/null
     echo "pass $i ($grp): rc=$?"
 done
-python "$R/tools/summarize_pmc.py" "$R/gpurun_out/pmc" "$OUT" $KEY
+python "$R/tools/summarize_pmc.py" "$R/gpurun_out/pmc" "$OUT" $KEY 3   # (3-step schedules above: a k_layers<steps> dispatch covers 3 steps)

@@ -1,0 +1,32 @@
+# Round-4 measurement set (run on the GPU box): bench lines of the BASELINE configs, rocprofv3 kernel stats of the default bench command and of
+# the other configs, PMC passes of four workloads. Outputs under gpurun_out/final/; what should be judged is copied into profiles/r04_*.
+set -u
+R=$PWD; O=$R/gpurun_out/final
+rm -rf $O; mkdir -p $O
+python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err < /dev/null; echo bench rc=$?
+head -c 300 $O/bench_cfg2.json; echo
+python bench.py --config ntu_action --sampler ddim --respacing ddim100 --guided --no-cpu-baseline --steps 5 --warmup 1 > $O/bench_cfg3.json 2>/dev/null; head -c 160 $O/bench_cfg3.json; echo
+python bench.py --config chi3d --batch 128 --no-cpu-baseline --steps 2 --warmup 1 > $O/bench_cfg4.json 2>/dev/null; head -c 160 $O/bench_cfg4.json; echo
+python bench.py --config text150 --batch 256 --sampler ddim --respacing ddim50 --guided --no-cpu-baseline --steps 5 --warmup 1 > $O/bench_cfg5.json 2>/dev/null; head -c 160 $O/bench_cfg5.json; echo
+python bench.py --batch 1 --no-cpu-baseline --steps 3 --warmup 1 > $O/bench_cfg1_B1.json 2>/dev/null; head -c 160 $O/bench_cfg1_B1.json; echo
+python bench.py --respacing ddim5 --no-cpu-baseline --steps 20 --warmup 3 --profile-evals 0 > $O/bench_eval_ddim5.json 2>/dev/null; head -c 160 $O/bench_eval_ddim5.json; echo
+REGENNET_LAYERS=0 python bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/bench_cfg2_kernel_per_stage.json 2>/dev/null; head -c 160 $O/bench_cfg2_kernel_per_stage.json; echo
+cd /tmp && export TMPDIR=/tmp
+prof() {  # name, bench flags...
+  n=$1; shift
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o $n -- python $R/bench.py --no-cpu-baseline "$@" > $O/$n.log 2>&1 < /dev/null; echo "$n rc=$?"
+}
+prof cfg2_default
+prof cfg2_kernel_per_stage_s1 --steps 1 --warmup 1 --respacing 50 --x3-tail 0 --profile-evals 0
+prof cfg3 --steps 1 --warmup 1 --profile-evals 0 --config ntu_action --sampler ddim --respacing ddim100 --guided
+prof cfg4 --steps 1 --warmup 1 --profile-evals 0 --config chi3d --batch 128 --respacing 50
+prof cfg5 --steps 1 --warmup 1 --profile-evals 0 --config text150 --batch 256 --sampler ddim --respacing ddim50 --guided
+prof cfg2_tail --steps 1 --warmup 1 --profile-evals 0 --respacing 50 --x3-tail 50
+rm -f $O/*kernel_trace.csv $O/*agent_info.csv $O/*domain_stats.csv
+cd $R
+bash tools/collect_pmc.sh gpurun_out/final/pmc_bench.json ntu_B256_bf16_x3tail_plain 2>&1 | grep "rc="
+mkdir -p $O/pmc_raw && cp gpurun_out/pmc/*counter_collection.csv $O/pmc_raw/ 2>/dev/null
+bash tools/collect_pmc.sh gpurun_out/final/pmc_bench.json ntu_action_B256_bf16_x3tail_cfg --config ntu_action --sampler ddim --guided 2>&1 | grep "rc="
+bash tools/collect_pmc.sh gpurun_out/final/pmc_bench.json chi3d_B128_bf16_x3tail_plain --config chi3d --batch 128 2>&1 | grep "rc="
+bash tools/collect_pmc.sh gpurun_out/final/pmc_bench.json text150_B256_bf16_x3tail_cfg --config text150 --batch 256 --sampler ddim --guided 2>&1 | grep "rc="
+ls $O

@@ -1,6 +1,9 @@
 """Summarise rocprofv3 --pmc CSVs (tools/collect_pmc.sh) into per-kernel means per launch.
 
-    python tools/summarize_pmc.py <dir with *counter_collection.csv> <out.json> [workload-key]
+    python tools/summarize_pmc.py <dir with *counter_collection.csv> <out.json> [workload-key] [steps-per-launch]
+
+(steps-per-launch: how many sampler steps ONE k_layers<steps> dispatch of the counted run covered - tools/collect_pmc.sh runs 3-step
+schedules - so that bench.py can scale the per-launch bytes to the launch it times.)
 
 Units (MI355X_MICROARCH.md, counter rows): FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies 64 B per 128-B
 request, so fetched bytes = FETCH_SIZE * 1024 * 2. SQ_VALU_MFMA_BUSY_CYCLES counts CYCLES, summed over every SIMD of the
@@ -21,14 +24,14 @@ import os
 import sys
 
 # substring of the kernel name -> the name bench.py uses (first match wins)
-CLASSES = [("k_step", "k_step"), ("k_mlp", "k_mlp"), ("k_rowgemm<0", "k_rowgemm<LN>"), ("k_rowgemm<1", "k_rowgemm<ACT>"), ("k_gemm_x3", "k_gemm_x3"),
+CLASSES = [("k_layers<true", "k_layers<steps>"), ("k_layers", "k_layers"), ("k_step", "k_step"), ("k_mlp", "k_mlp"), ("k_rowgemm<0", "k_rowgemm<LN>"), ("k_rowgemm<1", "k_rowgemm<ACT>"), ("k_gemm_x3", "k_gemm_x3"),
            ("k_qkv_attn_long", "k_qkv_attn_long"), ("k_qkv_attn", "k_qkv_attn"), ("k_attn_x3", "k_attn_x3"), ("k_sb_gemm", "k_sb_gemm"), ("k_layernorm", "k_layernorm"), ("k_update", "k_update"),
            ("k_gemm_bf16", "k_gemm_bf16"), ("k_gemm_f32", "k_gemm_f32"), ("k_attn_mfma", "k_attn_mfma")]
 N_SIMD = 1024          # 256 CUs x 4
 PEAK_CLOCK_HZ = 2.4e9
 
 
-def main(src, out, key=None):
+def main(src, out, key=None, steps_per_launch=None):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for path in sorted(glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)):
         tot, dur = collections.defaultdict(float), {}
@@ -58,6 +61,8 @@ def main(src, out, key=None):
             cs["mfma_util"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (N_SIMD * PEAK_CLOCK_HZ * m["_mfma_pass_duration_ns"] * 1e-9), 4)
         if "SQ_WAIT_INST_ANY" in m and m.get("SQ_WAVE_CYCLES", 0) > 0:
             cs["issue_stall_frac"] = round(m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"], 3)
+    if steps_per_launch and "k_layers<steps>" in summary:
+        summary["k_layers<steps>"]["steps_per_launch"] = int(steps_per_launch)
     result = {key: summary} if key else summary
     if key and os.path.exists(out):          # one file holds several workloads
         with open(out) as f:
@@ -71,4 +76,4 @@ def main(src, out, key=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None, sys.argv[4] if len(sys.argv) > 4 else None)
