@@ -302,10 +302,11 @@ def main(argv=None):
         eng.randn(x, B, 5, lo, st)
         first = S - 1
         n_eval = min(a.profile_evals, S)
-        eng.sample_range(a.sampler, a.guided, 0.0, x, None, 5, lo, first, 1, None, False, False, st)   # warm (untimed)
+        fl = flops_per_eval(cfg, B, a.guided, a.precision)
+        if not fl.get("steps_fused", 0.0) > 0:              # (the multi-step launch was warmed by the timed region; a 1-step launch of it would only
+            eng.sample_range(a.sampler, a.guided, 0.0, x, None, 5, lo, first, 1, None, False, False, st)   # skew rocprofv3's average) warm (untimed)
         torch.cuda.synchronize()
         eng.profile_enable(True)                            # reset
-        fl = flops_per_eval(cfg, B, a.guided, a.precision)
         run_steps = 0
         if fl.get("steps_fused", 0.0) > 0:
             # the timed region's dominant launch covers the WHOLE plain-bf16 phase of a call: profile exactly that launch (every

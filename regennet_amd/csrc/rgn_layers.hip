@@ -421,8 +421,10 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                         const f32x4 v = {st[tl][4 * i4], st[tl][4 * i4 + 1], st[tl][4 * i4 + 2], st[tl][4 * i4 + 3]};
                         sred[(((hg * 3 + tl) * 4 + wn) * 4 + i4) * 64 + lane] = v;
                     }
+                if (r == 0) { RGN_LYT(12) }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+                if (r == 0) { RGN_LYT(13) }
                 // ---- softmax, each score ONCE: wave wn takes the queries {8 wn .. 8 wn + 7} of both query tiles, lane = (query qi, key group
                 //      kg of 16 keys), so a row lives in 4 adjacent lanes x 16 registers. Every exchange entry [..][lane'] is read by exactly
                 //      one wave - the one that owns query lane' & 31 - which is what lets the normalised probabilities go back INTO the
@@ -486,8 +488,10 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                         }
                     }
                 }
+                if (r == 0) { RGN_LYT(14) }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+                if (r == 0) { RGN_LYT(15) }
                 // O^T[dh tile wn, queries] = V (A operand, registers = keys) x P^T (B operand: this lane's slot of the probabilities)
 #pragma unroll
                 for (int qtile = 0; qtile < 2; ++qtile) {
@@ -683,31 +687,42 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                     const int f = 4 * (wave_s + 8 * i2) + j;
                     xpre[i2][j] = (valid && f < g.F) ? sp.x[(size_t)gb * FT + (size_t)f * T + t] : 0.f;
                 }
-            auto update = [&](int f, float eps_in, float xv) {
-                float nv = 0.f;
-                if (valid && f < g.F) {
-                    float x0 = tile[lane_s * LY_XLD + f];
-                    if (sp.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-                    const size_t o = (size_t)gb * FT + (size_t)f * T + t;
-                    if (sp.x0_out) sp.x0_out[o] = x0;
-                    float eps = eps_in;
-                    if (sp.noise)
-                        eps = sp.noise[(size_t)(sp.first_index - step) * g.B * FT + (size_t)bn * FT + (size_t)f * T + t];
-                    else if (!quads)
-                        eps = philox_normal(sp.seed, sp.sample_offset + bn, (uint32_t)step, (uint32_t)(f * 4096 + t));
-                    if (sp.sampler == 0) {
-                        const float mean = __fadd_rn(__fmul_rn(k.c1, x0), __fmul_rn(k.c2, xv));
-                        nv = __fadd_rn(mean, __fmul_rn(k.sig_ddpm, eps));
-                    } else {
-                        const float e = __fdiv_rn(__fsub_rn(__fmul_rn(k.sr, xv), x0), k.srm1);
-                        const float mean = __fadd_rn(__fmul_rn(x0, k.ca), __fmul_rn(k.cb, e));
-                        nv = __fadd_rn(mean, __fmul_rn(k.sig_ddim, eps));
+            // the four features 4 fg + {0 .. 3} of this lane's frame: one 16-byte read of the x0 tile, four x updates, ONE 8-byte store of
+            // the bf16 x' run (feature 32 i2 + 4 wave + j sits in k-block i2, 16-byte chunk wave >> 1, bytes 8 (wave & 1) + 2 j of its row)
+            const int ximg_lane = lane_s * 64 + ((((wave_s >> 1) ^ ((lane_s >> 2) & 3)) << 4) + 8 * (wave_s & 1));
+            auto update4 = [&](int i2, int fg, const float (&eps_in)[4], const float (&xv)[4]) {
+                bf16x4 nvb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nvb[j] = (__bf16)0.f;
+                if (valid && 4 * fg < g.F) {                              // (F % 4 == 0: whole groups)
+                    const f32x4 x04 = *reinterpret_cast<const f32x4*>(tile + lane_s * LY_XLD + 4 * fg);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = 4 * fg + j;
+                        float x0 = x04[j];
+                        if (sp.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+                        const size_t o = (size_t)gb * FT + (size_t)f * T + t;
+                        if (sp.x0_out) sp.x0_out[o] = x0;
+                        float eps = eps_in[j];
+                        if (sp.noise)
+                            eps = sp.noise[(size_t)(sp.first_index - step) * g.B * FT + (size_t)bn * FT + (size_t)f * T + t];
+                        else if (!quads)
+                            eps = philox_normal(sp.seed, sp.sample_offset + bn, (uint32_t)step, (uint32_t)(f * 4096 + t));
+                        float nv;
+                        if (sp.sampler == 0) {
+                            const float mean = __fadd_rn(__fmul_rn(k.c1, x0), __fmul_rn(k.c2, xv[j]));
+                            nv = __fadd_rn(mean, __fmul_rn(k.sig_ddpm, eps));
+                        } else {
+                            const float e = __fdiv_rn(__fsub_rn(__fmul_rn(k.sr, xv[j]), x0), k.srm1);
+                            const float mean = __fadd_rn(__fmul_rn(x0, k.ca), __fmul_rn(k.cb, e));
+                            nv = __fadd_rn(mean, __fmul_rn(k.sig_ddim, eps));
+                        }
+                        sp.x[o] = nv;
+                        nvb[j] = (__bf16)nv;
                     }
-                    sp.x[o] = nv;
                 }
                 // x' (0 in the K padding columns and the surplus rows) -> the K32-blocked image of the embedding's A operand
-                const int r = lane_s, chunk = (f & 31) >> 3;
-                *reinterpret_cast<__bf16*>(ximg + (f >> 5) * 4096 + r * 64 + ((chunk ^ ((r >> 2) & 3)) << 4) + (f & 7) * 2) = (__bf16)nv;
+                *reinterpret_cast<bf16x4*>(ximg + i2 * 4096 + ximg_lane) = nvb;
             };
             ly_static_for<LY_NKX>([&](auto IT) __attribute__((always_inline)) {   // groups of 4 features
                 constexpr int i2 = decltype(IT)::value;
@@ -721,23 +736,23 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                     float n4[4];
 #pragma unroll
                     for (int pair = 0; pair < 2; ++pair) box_muller(rr4[2 * pair], rr4[2 * pair + 1], n4[2 * pair], n4[2 * pair + 1]);
-                    auto pick = [&](auto jc) {                              // element q of lane jc's n4, broadcast inside the quad
-                        constexpr int J = decltype(jc)::value;
-                        float v = 0.f;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float bc = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, n4[e]), J * 0x55, 0xf, 0xf, true));   // quad_perm [J, J, J, J]
-                            v = q == e ? bc : v;
-                        }
-                        return v;
+                    // 4 x 4 transpose inside the quad (this lane - frame tq + q - needs, for feature 4 fg + j, element q of lane j's n4): two
+                    // butterfly stages of a conditional swap with the lane q ^ 1, then q ^ 2 (DPP quad_perm): 16 operations instead of 32
+                    auto stage = [&](float& lo_r, float& hi_r, bool bit, auto ctrl) {
+                        const float send = bit ? lo_r : hi_r;
+                        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), decltype(ctrl)::value, 0xf, 0xf, true));
+                        lo_r = bit ? recv : lo_r;
+                        hi_r = bit ? hi_r : recv;
                     };
-                    eps4[0] = pick(std::integral_constant<int, 0>{});
-                    eps4[1] = pick(std::integral_constant<int, 1>{});
-                    eps4[2] = pick(std::integral_constant<int, 2>{});
-                    eps4[3] = pick(std::integral_constant<int, 3>{});
-                }
+                    const bool b0 = (q & 1) != 0, b1 = (q & 2) != 0;
+                    stage(n4[0], n4[1], b0, std::integral_constant<int, 0xB1>{});   // quad_perm [1, 0, 3, 2]
+                    stage(n4[2], n4[3], b0, std::integral_constant<int, 0xB1>{});
+                    stage(n4[0], n4[2], b1, std::integral_constant<int, 0x4E>{});   // quad_perm [2, 3, 0, 1]
+                    stage(n4[1], n4[3], b1, std::integral_constant<int, 0x4E>{});
 #pragma unroll
-                for (int j = 0; j < 4; ++j) update(4 * fg + j, eps4[j], xpre[i2][j]);
+                    for (int j = 0; j < 4; ++j) eps4[j] = n4[j];
+                }
+                update4(i2, fg, eps4, xpre[i2]);
             });
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

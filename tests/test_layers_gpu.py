@@ -99,6 +99,26 @@ def test_decoder_stack_kernel_is_independent_of_the_batch_composition(monkeypatc
     model1._engine.close()
 
 
+def test_decoder_stack_kernel_quad_shared_noise_is_the_per_element_stream(monkeypatch):
+    """The multi-step launch draws its Philox normals per quad of lanes (four frames of one feature per call, transposed inside the
+    quad by two butterfly stages): bit-identical to the per-element draw (REGENNET_STEP_NO_QUADS=1), for DDPM and DDIM."""
+    from regennet_amd import synth
+    cfg = synth.get_config("ntu")
+    sd = synth.make_state_dict(cfg, seed=0)
+    B = 3
+    y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1)).cuda()}
+    for sampler, resp in (("ddpm", "8"), ("ddim", "ddim8")):
+        outs = []
+        for extra in ({}, {"REGENNET_STEP_NO_QUADS": "1"}):
+            model, diffusion = build_hip(cfg, sd, resp=resp, precision="bf16_x3tail/throughput", x3_tail=0)
+            _engine_with(monkeypatch, dict(FORMS["multi-step"], **extra), model, B)
+            fn = diffusion.p_sample_loop if sampler == "ddpm" else diffusion.ddim_sample_loop
+            kw = {"eta": 1.0} if sampler == "ddim" else {}
+            outs.append(fn(model, (B, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y}, seed=21, **kw))
+            model._engine.close()
+        assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
+
+
 def test_decoder_stack_kernel_lengths_and_partial_ranges(monkeypatch):
     """52 .. 64 tokens per sample (padding rows replicate the last token and are masked as keys) against the oracle, and a sampling
     call cut into ranges through the C-ABI (rgn_sample_range with a count below the schedule: the loop index lives on the device and

@@ -144,6 +144,15 @@ int main(int argc, char** argv) {
         printf("  layer %d, mean cycles (wave 0): in_proj(0) %.0f | attention(0) %.0f | barrier %.0f | in_proj(1) %.0f | attention(1) %.0f | barrier %.0f | att image + barrier %.0f | out_proj %.0f | res+LN1+LN2+image %.0f | ffn %.0f | res+LN3+image %.0f | total %.0f\n",
                RGN_LY_STAMPS, ph[1] / nwg, ph[2] / nwg, ph[3] / nwg, ph[4] / nwg, ph[5] / nwg, ph[6] / nwg, ph[7] / nwg, ph[8] / nwg, ph[9] / nwg, ph[10] / nwg, ph[11] / nwg,
                [&] { double t = 0; for (int b = 0; b < nwg; ++b) t += (double)(st[b * 16 + 11] - st[b * 16]); return t / nwg; }());
+        if (nsteps == 0) {   // round 0's S phase in detail (stamps 12-15 sit between stamps 1 and 2)
+            double d[5] = {0, 0, 0, 0, 0};
+            for (int b = 0; b < nwg; ++b) {
+                const long long* t = &st[b * 16];
+                d[0] += (double)(t[12] - t[1]); d[1] += (double)(t[13] - t[12]); d[2] += (double)(t[14] - t[13]); d[3] += (double)(t[15] - t[14]); d[4] += (double)(t[2] - t[15]);
+            }
+            printf("  attention(0) in detail (wave 0): operands + S^T partials + writes %.0f | wait for every wave's partials %.0f | sums + softmax + p writes %.0f | wait %.0f | p reads + PV + pack %.0f\n",
+                   d[0] / nwg, d[1] / nwg, d[2] / nwg, d[3] / nwg, d[4] / nwg);
+        }
         if (nsteps > 1) {
             double sp4[4] = {0, 0, 0, 0};
             for (int b = 0; b < nwg; ++b) for (int i = 0; i < 3; ++i) sp4[i] += (double)(st[b * 16 + 13 + i] - st[b * 16 + 12 + i]);
