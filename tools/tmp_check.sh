@@ -1,8 +1,8 @@
 mkdir -p gpurun_out
 v() { python -c "import sys, json; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'])"; }
 {
-python -m pytest tests/test_hip_parity.py -m gpu -x -q -s -k "reference_evaluation_setting" 2>&1 | grep -E "5-step|passed|failed|Error|assert" | head -20
-echo "== bench NTU B=256, ddim5 schedule through p_sample_loop: tail 5 (default) | 3 | 2 | 0"
-for t in 5 3 2 0; do echo "tail $t: $(python bench.py --respacing ddim5 --x3-tail $t --no-cpu-baseline --steps 20 --warmup 3 --profile-evals 0 2>/dev/null | v)"; done
+timeout 200 tools/bin/layers_bench_stamps 256 60 8 5 | tail -3
+python -m pytest tests/test_layers_gpu.py -m gpu -x -q -k "quad_shared or kernel_per_stage_chain" 2>&1 | tail -3
+for r in 1 2; do echo "cfg2: $(python bench.py --no-cpu-baseline --steps 3 --warmup 1 --profile-evals 0 2>/dev/null | v)"; done
 } > gpurun_out/tmp_check.txt 2>&1
 cat gpurun_out/tmp_check.txt
