@@ -140,7 +140,7 @@ bool rowgemm_supported(int N, int Kp, bool ln);
 hipError_t configure_rowgemm();
 hipError_t launch_rowgemm(const RowGemmArgs& g, bool ln, hipStream_t s);
 
-// Row-persistent decoder-layer tail (rgn_mlp.hip): out_proj + norm1 + folded cross-attention + norm2 + linear1 + GELU + linear2 + norm3
+// Row-persistent decoder-layer tail (rgn_mlp2.hip): out_proj + norm1 + folded cross-attention + norm2 + linear1 + GELU + linear2 + norm3
 // for 64-row tiles, plain-bf16 phase, d = 512, ff = 1024. All planes are hi-only K32-blocked [16][rows][32]; weights fragment-ordered.
 struct MlpArgs {
     const __bf16* att;                    // attention output planes (A operand of out_proj), advanced to the first row

@@ -1,4 +1,4 @@
-// Row-persistent decoder-layer tail for the plain-bf16 phase, second build (replaces the kernel of rgn_mlp.hip): for a tile of R
+// Row-persistent decoder-layer tail for the plain-bf16 phase (second build: round 2's k_mlp is gone, its measurements are DESIGN.md 4.0b): for a tile of R
 // complete token rows ONE workgroup runs
 //
 //   h' = LN2( LN1( att . Wo^T + bo + h ) + call_time[step] + call_cond[sample] )        out_proj, norm1, folded cross-attn, norm2
@@ -11,7 +11,7 @@
 //   MT = 1: R = 32 rows, 4 waves, wave w = columns [128 w, 128 w + 128) (4 x 1 tiles), TWO independently scheduled workgroups
 //           per CU - a weight fragment feeds one MFMA, i.e. twice the L2 -> register weight stream per row: measured slower
 //           whenever the 64-row tiles fill the chip (the stream is what bounds the loops), faster for launches of few tiles
-// What changed against rgn_mlp.hip (all measured in the sampling loop):
+// What changed against round 2's k_mlp (all measured in the sampling loop):
 //   * the layer input tile h (residual of norm1) never touches LDS: every lane loads the 64 values it will add straight into
 //     registers BEHIND the att DMA and the first weight fragments, and the first MFMA waits for the att tile only
 //   * ONE continuous weight stream: buffer loads (scalar resource + compile-time offsets, the lane contributes lane * 16), a ring of
@@ -486,6 +486,18 @@ hipError_t launch_mlp2(int rows, const MlpArgs& g, hipStream_t s) {
     if (rows == 32) hipLaunchKernelGGL(k_mlp2<1>, dim3((g.M + 31) / 32), dim3(M2<1>::NTH), M2<1>::LDS, s, g);
     else hipLaunchKernelGGL(k_mlp2<2>, dim3((g.M + 63) / 64), dim3(M2<2>::NTH), M2<2>::LDS, s, g);
     return hipGetLastError();
+}
+
+// ---- the layer tail as the engine sees it: 64-row tiles by default; REGENNET_MLP_ROWS=32 selects the two-workgroups-per-CU form where the
+//      sequence allows it (tools, A/B: it loses wherever the 64-row tiles fill the chip)
+bool mlp_supported(int d, int ff, int Tq) { return mlp2_supported(64, d, ff, Tq); }
+hipError_t configure_mlp() { return configure_mlp2(); }
+hipError_t launch_mlp(const MlpArgs& g, hipStream_t s) {
+    static const int rows = [] {
+        const char* e = getenv("REGENNET_MLP_ROWS");
+        return e && atoi(e) == 32 ? 32 : 64;
+    }();
+    return launch_mlp2(rows == 32 && mlp2_supported(32, 512, 1024, g.Tq) ? 32 : 64, g, s);
 }
 
 }  // namespace rgn

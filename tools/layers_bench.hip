@@ -1,7 +1,7 @@
 // Stand-alone check + micro-benchmark of the one-kernel decoder stack (rgn_layers.hip) against the kernel-per-stage chain it replaces
 // (k_qkv_attn_rs + k_mlp per layer) on the same random bf16 inputs (tools only; the parity tests proper are tests/test_hip_parity.py).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I regennet_amd/csrc tools/layers_bench.hip regennet_amd/csrc/rgn_layers.hip \
-//         regennet_amd/csrc/rgn_qkv_attn.hip regennet_amd/csrc/rgn_qkv_attn_long.hip regennet_amd/csrc/rgn_mlp.hip regennet_amd/csrc/rgn_mlp2.hip -o tools/bin/layers_bench
+//         regennet_amd/csrc/rgn_qkv_attn.hip regennet_amd/csrc/rgn_qkv_attn_long.hip regennet_amd/csrc/rgn_mlp2.hip -o tools/bin/layers_bench
 //   layers_bench [Bm] [Tq] [L] [iters] [steps]     steps > 0: also time k_layers<true> over that many complete sampler steps (synthetic schedule)
 #include "rgn_internal.h"
 

@@ -1,6 +1,6 @@
 // Stand-alone micro-benchmark + reference check of the row-persistent layer-tail kernel (tools only; the parity tests proper are
 // tests/test_hip_parity.py).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DRGN_ML_PROF=5] -I regennet_amd/csrc tools/mlp_bench.hip regennet_amd/csrc/rgn_mlp.hip -o tools/bin/mlp_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DRGN_M2_STAMPS] -I regennet_amd/csrc tools/mlp_bench.hip regennet_amd/csrc/rgn_mlp2.hip -o tools/bin/mlp_bench      (REGENNET_MLP_ROWS=32: the two-workgroups-per-CU form)
 //   mlp_bench [M] [iters] [check]      check = 1: compare the first and the last 64-row tile with an fp64 host evaluation of the
 //                                      same bf16 inputs (the kernel rounds h', the GELU'd hidden tile and its output to bf16)
 #include "rgn_internal.h"
@@ -15,9 +15,6 @@
 #include <vector>
 
 using namespace rgn;
-#ifdef RGN_ML_PROF
-namespace rgn { void ml_prof_read(long long* out); }
-#endif
 #ifdef RGN_M2_STAMPS
 namespace rgn { void m2_stamps_read(long long* out); }
 #include <algorithm>
@@ -81,16 +78,11 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = 1e3 * ms / iters, fl = 2.0 * M * (d * d + 2.0 * d * ff);
     printf("k_mlp M=%d: %.1f us  %.1f TF\n", M, us, fl / us * 1e-6);
-#ifdef RGN_ML_PROF
-    long long t[16]; ml_prof_read(t);
-    printf("  cycles of workgroup %d, wave 0 (s_memtime = shader clock): tile DMA + wait %lld | out_proj k-loop %lld | LN1+LN2+image %lld | ffn (2 x (linear1, gelu, linear2)) %lld | LN3 + store %lld | total %lld\n",
-           RGN_ML_PROF, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[5] - t[0]);
-#endif
 #ifdef RGN_M2_STAMPS
-    {   // REGENNET_MLP_KERNEL=2|3: phase stamps of wave 0 of every workgroup, grouped by the CU it ran on (the last launch)
+    {   // phase stamps of wave 0 of every workgroup, grouped by the CU it ran on (the last launch)
         std::vector<long long> st(1024 * 12);
         m2_stamps_read(st.data());
-        const int trows = (getenv("REGENNET_MLP_KERNEL") && atoi(getenv("REGENNET_MLP_KERNEL")) == 3) ? 32 : 64;
+        const int trows = (getenv("REGENNET_MLP_ROWS") && atoi(getenv("REGENNET_MLP_ROWS")) == 32) ? 32 : 64;
         const int nwg = std::min(1024, (M + trows - 1) / trows);
         std::map<long long, std::vector<int>> by_cu;
         for (int b = 0; b < nwg; ++b) {
