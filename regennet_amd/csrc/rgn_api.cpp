@@ -99,6 +99,7 @@ struct rgn_ctx {
     bool layers_fused = false;         // plain-bf16 phase, <= 64 tokens: the whole decoder stack of an evaluation as one kernel, one sample per workgroup (k_layers; REGENNET_LAYERS=0: kernel per stage)
     int layers_min_b = 64;             // ... for evaluations of at least this many samples (REGENNET_LAYERS_MIN_B): one workgroup per sample is a latency chain of 8 layers (250-step calls: 114 ms at any B <= 256), the kernel-per-stage form spreads a sample over more CUs (B = 16 / 32 / 48: 110-111 ms; B = 64: 114.4 vs 113.6)
     bool layers_steps = false;         // ... and, unguided, whole runs of sampler steps in ONE launch (k_layers<true>: stack + step boundary per sample; REGENNET_LAYERS_STEPS=0: one k_layers + one k_step per step)
+    bool layers_guided = true;         // ... and guided runs too (a motion's two evaluations in one workgroup; REGENNET_LAYERS_GUIDED=0: k_layers per evaluation + the guided k_step)
     bool skip_embed_out = false;       // (set by run_eval around run_layers while it enqueues a fused step)
     int step_no_quads = 0;             // REGENNET_STEP_NO_QUADS=1 (tests)
     bool qkv_rs = true;                // plain-bf16 phase: k_qkv_attn with register-streamed weights (REGENNET_NO_QKV_RS=1: the DMA-fed loop)
@@ -1144,6 +1145,7 @@ int rgn_finalize_weights(rgn_handle h) {
                           !(getenv("REGENNET_LAYERS") != nullptr && atoi(getenv("REGENNET_LAYERS")) == 0);
         if (c->layers_fused) RGN_HIP(c, configure_layers());
         if (const char* e = getenv("REGENNET_LAYERS_MIN_B")) c->layers_min_b = atoi(e);
+        if (const char* e = getenv("REGENNET_LAYERS_GUIDED")) c->layers_guided = atoi(e) != 0;
         c->layers_steps = c->layers_fused && c->step_fused && layers_steps_supported(d, F, c->lin_x.Kp) &&
                           !(getenv("REGENNET_LAYERS_STEPS") != nullptr && atoi(getenv("REGENNET_LAYERS_STEPS")) == 0);
         c->step_no_quads = getenv("REGENNET_STEP_NO_QUADS") != nullptr;
@@ -1395,7 +1397,7 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
         if (fused_now && !prev_fused && (rc = embed_all(c, dm, s))) return rc;
         if (!fused_now && prev_fused && (rc = pack_state(c, x, dm, guided != 0, s))) return rc;
         prev_fused = fused_now;
-        if (fused_now && !guided && !x3 && c->layers_steps && dm.Bm >= c->layers_min_b) {
+        if (fused_now && !x3 && c->layers_steps && dm.Bm >= c->layers_min_b && (!guided || (c->layers_guided && c->ffn_hi))) {
             // unguided plain-bf16 phase, <= 64 tokens: ALL remaining steps of the phase in one launch - a workgroup carries its sample
             // through decoder stack and step boundary step after step; nothing but x, the condition rows and the weights is read
             bool ok = true;
@@ -1404,9 +1406,13 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
                 const int M = dm.Bm * dm.Tq;
                 const bool has_cond = c->cfg.cond_mode != RGN_COND_NONE;
                 LayersArgs g{};
-                g.h = c->h_hi; g.out = c->h_hi; g.rows = M; g.Bm = dm.Bm;
+                g.h = c->h_hi; g.out = c->h_hi; g.rows = M; g.Bm = dm.B;   // one workgroup per MOTION (guided: its two evaluations back to back)
                 fill_layers_args(c, g, dm, true, has_cond ? c->call_cond : nullptr, 0);
                 g.steps = phase_left;
+                if (guided) {
+                    g.scale = c->scale; g.half = dm.B * dm.Tq;
+                    g.park = reinterpret_cast<float*>(c->ffn_hi);           // (the hidden-tensor planes are idle on this path: 2B * T * ff * 2 bytes >= B * 96 KiB)
+                }
                 g.Wout = c->dp<__bf16>(c->lin_out.fr); g.bout = c->dp<float>(c->lin_out.b); g.F = c->F; g.nb_out = (c->F + 31) / 32;
                 g.Wx = c->dp<__bf16>(c->lin_x.fr);
                 g.c0 = c->c0h;

@@ -192,6 +192,10 @@ struct LayersArgs {
     const StepCoef* tab; int* d_stepw; const SampleParams* sp;
     int B, s0;                                                // motions in the bound condition, first sample of this launch
     int no_quads;
+    // ---- scale != nullptr: classifier-free guidance inside the launch (cfg_sampler.py:22-31). A workgroup owns a MOTION: its conditional
+    //      evaluation (planes rows of sample b) and its unconditional one (rows of sample B + b) run back to back in the same workgroup, the
+    //      conditional x0 parked in `park` meanwhile; Bm = B motions; pervec / c0 / h hold both halves, `half` = row distance B * T
+    const float* scale; int half; float* park;                // scale[B]; park: >= B * 6 * 4096 floats of scratch
 };
 bool layers_supported(int d, int ff, int H, int Tq, int L);
 bool layers_steps_supported(int d, int F, int Kpx);

@@ -98,8 +98,9 @@ __device__ __forceinline__ void ly_static_for_seq(std::integer_sequence<int, Is.
 template <int N, class F>
 __device__ __forceinline__ void ly_static_for(F&& f) { ly_static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
 
-template <bool STEPS>
+template <bool STEPS, bool GUIDED = false>
 __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
+    static_assert(STEPS || !GUIDED, "guidance inside the launch needs the step boundary");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -301,8 +302,58 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
     __builtin_amdgcn_s_barrier();
 
     const int nit = STEPS ? g.steps : 1;
+    // the output projection of the step boundary: acc = h . Wout^T from the image X (N = F <= 352: waves 0-5; a column block past the plane
+    // reads in-bounds garbage or zeros and is never stored)
+    auto out_proj = [&](f32x16 (&acc)[2][2], int wv) {
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a2][b2][i] = 0.f;
+        if (wv < 6) {
+            const int cb0 = 2 * wv;
+            const Pass p_out{__builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(g.Wout) + (size_t)cb0 * 1024, 0, (16 * g.nb_out - cb0) * 2048, 0x00020000), LY_NKX * 2048, 0};
+#pragma unroll
+            for (int s2 = 0; s2 < LY_RDM - 1; ++s2) load_g(p_out, s2, s2);
+            gemm_n(acc, a_off, p_out, p_out, std::false_type{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 32>{});
+        }
+    };
     for (int it = 0; it < nit; ++it) {
     const int step = first_step - it;
+    for (int pass = 0; pass < (GUIDED ? 2 : 1); ++pass) {
+    if (GUIDED && pass == 1) {
+        // ---- guidance: the conditional evaluation is done - its x0 goes to the parking buffer (accumulator layout: every lane reads back
+        //      what it wrote), the unconditional evaluation's input (written to the planes by the previous step boundary / the up-front
+        //      embedding; sc1: past this CU's L1, which may still hold last step's lines) takes its place in X
+        f32x16 accp[2][2];
+        int wave_p = wave;
+        asm volatile("" : "+s"(wave_p));
+        out_proj(accp, wave_p);
+        if (wave_p < 6) {
+            float* pk = g.park + ((size_t)b * 6 + wave_p) * 4096 + lane * 4;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4)
+                        *reinterpret_cast<f32x4*>(pk + ((nt * 2 + mt) * 4 + i4) * 256) = f32x4{accp[nt][mt][4 * i4], accp[nt][mt][4 * i4 + 1], accp[nt][mt][4 * i4 + 2], accp[nt][mt][4 * i4 + 3]};
+        }
+        __builtin_amdgcn_s_barrier();                                     // every wave is done reading the image
+        {
+            const int r16 = lane >> 2, c = lane & 3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = wave + 8 * j, kb = p >> 2, r = (p & 3) * 16 + r16;
+                const int rr = r < Tq ? r : Tq - 1;
+                const size_t src = ((size_t)kb * g.rows + g.half + row0 + rr) * 32 + ((c ^ ((r >> 2) & 3)) << 3);
+                __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.h + src), (RGN_AS3 void*)(smem + LY_X + p * 1024), 16, 0, 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
     for (int l = 0; l < g.L; ++l) {
         const LayerWts& w = g.lw[l];
         RGN_LYT(0)
@@ -535,7 +586,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
             const float* src[9] = {w.bo, w.g1, w.g2, w.b2, w.bf1, w.bf1 + 512, w.bf2, w.g3, w.b3};
             vv[0] = src[0][cw]; vv[1] = src[1][cw]; vv[2] = src[2][cw]; vv[3] = src[3][cw];
             vv[4] = w.b1[cw] + (g.stepvec ? g.stepvec[(size_t)step * g.ldstep + (size_t)l * 512 + cw] : 0.f) +
-                    (g.pervec ? g.pervec[(size_t)b * g.ldper + (size_t)l * 512 + cw] : 0.f);   // norm1's beta + call_time[step] + call_cond[sample]
+                    (g.pervec ? g.pervec[((size_t)b + (size_t)pass * g.B) * g.ldper + (size_t)l * 512 + cw] : 0.f);   // norm1's beta + call_time[step] + call_cond[sample]
             vv[5] = src[4][cw]; vv[6] = src[5][cw]; vv[7] = src[6][cw]; vv[8] = src[7][cw]; vv[9] = src[8][cw];
         }
         asm volatile("" ::: "memory");
@@ -600,6 +651,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         __builtin_amdgcn_s_barrier();
         RGN_LYT(11)
     }
+    }
     if constexpr (STEPS) {
         // ========================= step boundary, per sample (rgn_step.hip k_step<11, false>) =====================================
         //   x0 = h . Wout^T + bout (OutputProcess, cmdm.py:353); x' = sampler(x, x0, eps) in place (gaussian_diffusion.py:508-560,
@@ -617,22 +669,10 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         const SampleParams sp = *g.sp;
         const StepCoef k = g.tab[step];
         const int T = Tq, gb = g.s0 + b_s;                                  // frames = tokens (no emb_trans_dec token on this path); motion index
+        const float gscale = GUIDED ? g.scale[gb] : 0.f;
         f32x16 acc[2][2];
-#pragma unroll
-        for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[a2][b2][i] = 0.f;
-        // ---- A: x0 = h . Wout^T from the image X (N = F <= 352: waves 0-5; a column block past the plane reads in-bounds garbage or
-        //      zeros and is never stored)
-        if (wave_s < 6) {
-            const int cb0 = 2 * wave_s;
-            const Pass p_out{__builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(g.Wout) + (size_t)cb0 * 1024, 0, (16 * g.nb_out - cb0) * 2048, 0x00020000), LY_NKX * 2048, 0};
-#pragma unroll
-            for (int s2 = 0; s2 < LY_RDM - 1; ++s2) load_g(p_out, s2, s2);
-            gemm_n(acc, a_off, p_out, p_out, std::false_type{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 32>{});
-        }
+        // ---- A: x0 = h . Wout^T from the image X (guided: of the unconditional evaluation)
+        out_proj(acc, wave_s);
         __builtin_amdgcn_s_barrier();                                     // every wave is done reading the image
         // ---- B: x0 + bias -> fp32 tile [64][356]
         float* tile = reinterpret_cast<float*>(smem + LY_TILE);
@@ -646,7 +686,12 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                     if (n < g.F) bb = *reinterpret_cast<const f32x4*>(g.bout + n);
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        const f32x4 v = {acc[nt][mt][4 * i4] + bb[0], acc[nt][mt][4 * i4 + 1] + bb[1], acc[nt][mt][4 * i4 + 2] + bb[2], acc[nt][mt][4 * i4 + 3] + bb[3]};
+                        f32x4 v = {acc[nt][mt][4 * i4] + bb[0], acc[nt][mt][4 * i4 + 1] + bb[1], acc[nt][mt][4 * i4 + 2] + bb[2], acc[nt][mt][4 * i4 + 3] + bb[3]};
+                        if constexpr (GUIDED) {   // x0 = x0_u + scale_b (x0_c - x0_u), cfg_sampler.py:31, rounded like k_update / k_step
+                            const f32x4 cc = *reinterpret_cast<const f32x4*>(g.park + ((size_t)b_s * 6 + wave_s) * 4096 + lane_s * 4 + ((nt * 2 + mt) * 4 + i4) * 256);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(v[e], __fmul_rn(gscale, __fsub_rn(cc[e] + bb[e], v[e])));
+                        }
                         *reinterpret_cast<f32x4*>(tile + (32 * mt + l31_s) * LY_XLD + n) = v;
                     }
                 }
@@ -664,6 +709,18 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
 #pragma unroll
                 for (int i4 = 0; i4 < 4; ++i4)
                     c0v[nt][mt][i4] = *reinterpret_cast<const bf16x4*>(g.c0 + (row0_s + rr) * 512 + 64 * wave_s + col4s(nt, i4));
+        }
+        bf16x4 c0u[GUIDED ? 2 : 1][2][4];                                 // guided: the unconditional evaluation's condition rows
+        if constexpr (GUIDED) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int r = 32 * mt + l31_s, rr = r < T ? r : T - 1;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4)
+                        c0u[nt][mt][i4] = *reinterpret_cast<const bf16x4*>(g.c0 + ((size_t)g.half + row0_s + rr) * 512 + 64 * wave_s + col4s(nt, i4));
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -769,6 +826,19 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
             int a_offx[2] = {a_off[0] + LY_XIMG, a_off[1] + LY_XIMG};
             gemm_n(acc, a_offx, p_wx, p_wx, std::false_type{}, std::integral_constant<int, 8 + 16>{}, std::integral_constant<int, 2 * LY_NKX>{});
         }
+        if constexpr (GUIDED) {   // the same embedding with the unconditional condition rows -> image Y -> the planes (read back at the next step's pass 1)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        bf16x4 hh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hh[e] = (__bf16)(acc[nt][mt][4 * i4 + e] + (float)c0u[nt][mt][i4][e]);
+                        *reinterpret_cast<bf16x4*>(smem + LY_Y + img_off(nt, i4, mt)) = hh;
+                    }
+        }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -780,6 +850,19 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         store_img(acc, LY_X);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if constexpr (GUIDED) {
+            const __amdgpu_buffer_rsrc_t u_rs = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)((size_t)g.rows * 512 * 2), 0x00020000);
+            const int r16 = lane_s >> 2, c = lane_s & 3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = wave_s * 8 + j, blk = p >> 2, r = (p & 3) * 16 + r16;
+                if (r < T) {
+                    const int off = blk * LY_KB + r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(smem + LY_Y + off), u_rs,
+                                                           (int)((((size_t)blk * g.rows + g.half + row0_s + r) * 32 + c * 8) * 2), 0, RGN_LY_ST_AUX);
+                }
+            }
+        }
         RGN_LYS(15)
     }
     }
@@ -816,10 +899,13 @@ bool layers_supported(int d, int ff, int H, int Tq, int L) { return d == 512 && 
 bool layers_steps_supported(int d, int F, int Kpx) { return d == 512 && F % 4 == 0 && F <= 352 && Kpx == 32 * LY_NKX; }
 hipError_t configure_layers() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_layers<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LY_LDS);
-    return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(k_layers<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LY_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_layers<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LY_LDS);
+    return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(k_layers<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LY_LDS);
 }
 hipError_t launch_layers(const LayersArgs& g, hipStream_t s) {
-    if (g.steps > 0) hipLaunchKernelGGL(k_layers<true>, dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
+    if (g.steps > 0 && g.scale) hipLaunchKernelGGL((k_layers<true, true>), dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
+    else if (g.steps > 0) hipLaunchKernelGGL(k_layers<true>, dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
     else hipLaunchKernelGGL(k_layers<false>, dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
     return hipGetLastError();
 }

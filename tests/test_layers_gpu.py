@@ -11,7 +11,7 @@ from tests.helpers import build_hip, fixture_inputs, y_to_device
 pytestmark = pytest.mark.gpu
 
 # per evaluation: k_layers<false> + k_step / k_update per step; whole runs: k_layers<true> (unguided, no emb_trans_dec token)
-FORMS = {"per-step": {"REGENNET_LAYERS_MIN_B": "1", "REGENNET_LAYERS_STEPS": "0"}, "multi-step": {"REGENNET_LAYERS_MIN_B": "1"},
+FORMS = {"per-step": {"REGENNET_LAYERS_MIN_B": "1", "REGENNET_LAYERS_STEPS": "0"}, "multi-step": {"REGENNET_LAYERS_MIN_B": "1"},   # (guided: a motion per workgroup)
          "kernel-per-stage": {"REGENNET_LAYERS": "0"}}
 
 
@@ -52,30 +52,34 @@ def test_decoder_stack_kernel_against_the_reference(golden, monkeypatch, name, f
     model._engine.close()
 
 
-@pytest.mark.parametrize("sampler,clip", [("ddpm", False), ("ddim", True)])
-def test_decoder_stack_kernel_against_the_kernel_per_stage_chain(monkeypatch, sampler, clip):
+@pytest.mark.parametrize("sampler,clip,guided", [("ddpm", False, False), ("ddim", True, False), ("ddim", False, True), ("ddpm", True, True)])
+def test_decoder_stack_kernel_against_the_kernel_per_stage_chain(monkeypatch, sampler, clip, guided):
     """Same noise stream (on-device Philox), same sampler arithmetic: the three forms differ only by where bf16 roundings fall in
     the plain-bf16 phase and end within half the parity margin of each other behind the split-bf16 tail; the multi-step form also
-    writes pred_xstart and honours clip_denoised like the per-step one."""
+    honours clip_denoised like the per-step one. Guided (per-sample scales): in the multi-step form a workgroup owns a MOTION and runs
+    its conditional and unconditional evaluations back to back, the conditional x0 parked in global scratch meanwhile."""
     from regennet_amd import synth
-    cfg = synth.get_config("ntu")
+    cfg = synth.get_config("ntu_action" if guided else "ntu")
     sd = synth.make_state_dict(cfg, seed=0)
     B = 9
     y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1)).cuda()}
+    if guided:
+        y["action"] = torch.from_numpy(synth.make_actions(cfg, B, seed=2)).cuda()
+        y["scale"] = torch.linspace(1.5, 3.5, B).cuda()
     outs = {}
     for form, env in FORMS.items():
         model, diffusion = build_hip(cfg, sd, resp="40" if sampler == "ddpm" else "ddim40", precision="bf16_x3tail/throughput")
         _engine_with(monkeypatch, env, model, B)
         fn = diffusion.p_sample_loop if sampler == "ddpm" else diffusion.ddim_sample_loop
-        outs[form] = fn(model, (B, 56, 6, 60), clip_denoised=clip, model_kwargs={"y": y}, seed=5)
+        outs[form] = fn(_wrap(model, guided), (B, 56, 6, 60), clip_denoised=clip, model_kwargs={"y": y}, seed=5)
         model._engine.close()
     for form in ("per-step", "multi-step"):
         assert torch.isfinite(outs[form]).all()
         dev = (outs[form] - outs["kernel-per-stage"]).abs().max().item()
-        print(f"\n[k_layers {form} vs kernel per stage] {sampler} clip={clip}: {dev:.2e}")
+        print(f"\n[k_layers {form} vs kernel per stage] {sampler} clip={clip} guided={guided}: {dev:.2e}")
         assert 0.0 < dev < 5e-4
     dev = (outs["per-step"] - outs["multi-step"]).abs().max().item()
-    print(f"\n[k_layers per-step vs multi-step] {sampler} clip={clip}: {dev:.2e}")
+    print(f"\n[k_layers per-step vs multi-step] {sampler} clip={clip} guided={guided}: {dev:.2e}")
     assert dev < 5e-4
 
 
