@@ -9,7 +9,8 @@ in fp64 (plain torch linear algebra - this row is glue around the sampler, not a
 
 C1 C2 is similar to the symmetric PSD matrix C1^(1/2) C2 C1^(1/2), so Tr((C1 C2)^(1/2)) is the sum of the square roots
 of that matrix's eigenvalues: two `eigh` calls, no general (complex) matrix square root, no imaginary residue to discard.
-The ST-GCN feature extractor and the diversity/multimodality metrics of the same harness are not built.
+The ST-GCN feature extractor (`regennet_amd/eval/stgcn.py` over the HIP kernels of `rgn_stgcn.hip`) and the diversity / multimodality /
+accuracy metrics (`regennet_amd/eval/metrics.py`) of the same harness are their own modules.
 """
 import torch as th
 

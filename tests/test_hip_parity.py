@@ -520,6 +520,45 @@ def test_full_size_batch_is_row_independent(monkeypatch, precision, tail):
         assert torch.allclose(full2[b:b + 1], one, atol=2e-5), (b, (full2[b:b + 1] - one).abs().max().item())
 
 
+@pytest.mark.parametrize("case", range(6))
+def test_default_precision_schedule_on_random_8_layer_cases(monkeypatch, case):
+    """The DEFAULT precision schedule (plain-bf16 bulk + split-bf16 tail: what every caller gets) against the oracle on random 8-layer
+    models at S >= 20 - random batch, length (52 .. 64 tokens, with and without the emb_trans_dec token), guidance with per-sample scales,
+    sampler, and both kernel forms of the bulk phase (one workgroup per sample forced on for these test-sized batches in the odd cases,
+    kernel per stage in the even ones). The fixed goldens pin the shipped shapes; this pins the schedule away from them."""
+    from oracle import regennet_oracle as orc
+    from regennet_amd import synth
+    rng = np.random.default_rng(4200 + case)
+    T = int(rng.choice([52, 57, 60, 63, 64]))
+    etd = bool(rng.integers(0, 2)) and T < 64
+    B = int(rng.integers(1, 5))
+    guided = bool(rng.integers(0, 2))
+    sampler = str(rng.choice(["ddpm", "ddim"]))
+    S = int(rng.integers(20, 27))
+    cfg = synth.get_config("ntu_action", num_frames=T, emb_trans_dec=etd)
+    assert cfg["layers"] == 8
+    sd = synth.make_state_dict(cfg, seed=300 + case)
+    resp = f"ddim{S}" if sampler == "ddim" else str(S)
+    y = {"cmotion": synth.make_cmotion(cfg, B, seed=case), "action": synth.make_actions(cfg, B, seed=case + 1)}
+    if guided:
+        y["scale"] = np.linspace(1.0, 2.5, B).astype(np.float32)
+    tape = synth.make_noise_tape(cfg, B, S, seed=case + 2)
+    ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", resp), tape, {k: torch.from_numpy(v) for k, v in y.items()},
+                          mode=sampler, guided=guided).numpy()
+    monkeypatch.setenv("REGENNET_LAYERS_MIN_B", "1" if case % 2 else "100000")
+    model, diffusion = build_hip(cfg, sd, resp=resp, precision="bf16_x3tail/throughput")
+    model._get_engine(B)
+    monkeypatch.delenv("REGENNET_LAYERS_MIN_B")
+    fm = _wrap(model, guided)
+    fn = diffusion.p_sample_loop if sampler == "ddpm" else diffusion.ddim_sample_loop
+    out = fn(fm, (B, 56, 6, T), clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
+    err = float(np.abs(out.cpu().numpy() - ref).max())
+    print(f"\n[default schedule, random 8-layer case {case}] T={T} etd={int(etd)} B={B} guided={int(guided)} {sampler} S={S} "
+          f"{'k_layers' if case % 2 else 'kernel per stage'}: {err:.2e}")
+    assert err < 1e-3, err
+    model._engine.close()
+
+
 @pytest.mark.parametrize("name", ["ntu_eval_ddim5", "ntu_eval_5", "ntu_action_eval_ddim5"])
 def test_reference_evaluation_setting_switch_point_sweep(golden, monkeypatch, name):
     """The reference's shipped evaluation setting (README.md:134-137, eval/a2m/stgcn_eval.py:61,69): `--timestep_respacing ddim5`

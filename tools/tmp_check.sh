@@ -1,12 +1,8 @@
 mkdir -p gpurun_out
-v() { python -c "import sys, json; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'])"; }
 {
-python -m pytest tests/test_layers_gpu.py -m gpu -x -q -s 2>&1 | grep -E "k_layers|passed|failed|Error|error" | head -40
-python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "bench_shape or fused_step or row_independent" 2>&1 | tail -3
-for r in 1 2; do
-echo "cfg3 guided in-launch: $(python bench.py --config ntu_action --sampler ddim --respacing ddim100 --guided --no-cpu-baseline --steps 3 --warmup 1 --profile-evals 0 2>/dev/null | v)"
-echo "cfg3 per-step:         $(REGENNET_LAYERS_GUIDED=0 python bench.py --config ntu_action --sampler ddim --respacing ddim100 --guided --no-cpu-baseline --steps 3 --warmup 1 --profile-evals 0 2>/dev/null | v)"
-done
-echo "cfg2: $(python bench.py --no-cpu-baseline --steps 3 --warmup 1 --profile-evals 0 2>/dev/null | v)"
+echo "== k_qkv_attn_rs output hash (round 3 recorded c0ab23edee7c619b at 256, be02817a69a0f51b at 128)"
+RS=1 BF16=1 timeout 100 tools/bin/qkv_attn_bench 256 60 50
+RS=1 BF16=1 timeout 100 tools/bin/qkv_attn_bench 128 60 50
+python -m pytest tests/test_hip_parity.py -m gpu -x -q -s -k "random_8_layer" 2>&1 | grep -E "default schedule|passed|failed|rror" | head
 } > gpurun_out/tmp_check.txt 2>&1
 cat gpurun_out/tmp_check.txt
