@@ -1,8 +1,8 @@
 mkdir -p gpurun_out
 {
-echo "== k_qkv_attn_rs output hash (round 3 recorded c0ab23edee7c619b at 256, be02817a69a0f51b at 128)"
-RS=1 BF16=1 timeout 100 tools/bin/qkv_attn_bench 256 60 50
-RS=1 BF16=1 timeout 100 tools/bin/qkv_attn_bench 128 60 50
-python -m pytest tests/test_hip_parity.py -m gpu -x -q -s -k "random_8_layer" 2>&1 | grep -E "default schedule|passed|failed|rror" | head
+for r in 1 2 3; do for M in 15360 19200; do
+echo "M=$M base: $(timeout 100 tools/bin/mlp_bench $M 50 | head -1)   dma-first: $(timeout 100 tools/bin/mlp_bench_df $M 50 | head -1)"
+done; done
+timeout 100 tools/bin/mlp_bench_df_stamps 15360 20 | tail -3
 } > gpurun_out/tmp_check.txt 2>&1
 cat gpurun_out/tmp_check.txt
