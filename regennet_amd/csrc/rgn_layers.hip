@@ -298,8 +298,22 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         gemm_n(acc, aoff, cur, nxt, chain, extra, std::integral_constant<int, 32>{});
     };
 
+    // ---- in_proj bias of the NEXT round, requested a phase ahead (before the previous layer's norm3 / during the previous round's softmax), so the
+    //      round's first MFMA does not wait an L2 round trip for its accumulators' start value. q: register i <-> dh 8 (i >> 2) + 4 kh + (i & 3);
+    //      v: lane = dh. The k bias is not applied at all: q . (k + b_k) = q . k + q . b_k adds the same number to every score of a query's row,
+    //      which the softmax removes (exact in real arithmetic; the reference's output does not depend on it either)
+    f32x4 qb[4];
+    float vb1;
+    auto load_qbias = [&](const float* bqkv, int r) {
+        const float* bq = bqkv + (2 * r + hg) * 128 + wn * 32;
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) qb[i4] = *reinterpret_cast<const f32x4*>(bq + 8 * i4 + 4 * kh);
+        vb1 = bq[1024 + l31];
+    };
+
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    load_qbias(g.lw[0].bqkv, 0);
 
     const int nit = STEPS ? g.steps : 1;
     // the output projection of the step boundary: acc = h . Wout^T from the image X (N = F <= 352: waves 0-5; a column block past the plane
@@ -383,29 +397,18 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int head = 2 * r + hg;
-                // accumulators start from the in_proj bias: q^T, k^T (lane = token, register i <-> dh 8 (i >> 2) + 4 kh + (i & 3)),
-                // v (lane = dh, registers = tokens)
+                // accumulators start from the in_proj bias (requested a phase ago: load_qbias): q^T, k^T (lane = token, registers = dh), v (lane = dh)
                 f32x16 acc[2][3];
-                {
-                    const float* bq = w.bqkv + head * 128 + wn * 32;
-                    f32x4 q4[4], k4[4];
 #pragma unroll
-                    for (int i4 = 0; i4 < 4; ++i4) {
-                        q4[i4] = *reinterpret_cast<const f32x4*>(bq + 8 * i4 + 4 * kh);
-                        k4[i4] = *reinterpret_cast<const f32x4*>(bq + 512 + 8 * i4 + 4 * kh);
-                    }
-                    const float bv = bq[1024 + l31];
+                for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-                    for (int ta = 0; ta < 2; ++ta)
+                    for (int i4 = 0; i4 < 4; ++i4)
 #pragma unroll
-                        for (int i4 = 0; i4 < 4; ++i4)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                acc[ta][0][4 * i4 + e] = q4[i4][e];
-                                acc[ta][1][4 * i4 + e] = k4[i4][e];
-                                acc[ta][2][4 * i4 + e] = bv;
-                            }
-                }
+                        for (int e = 0; e < 4; ++e) {
+                            acc[ta][0][4 * i4 + e] = qb[i4][e];
+                            acc[ta][1][4 * i4 + e] = 0.f;
+                            acc[ta][2][4 * i4 + e] = vb1;
+                        }
                 // ---- in_proj: [64 tokens] x [q | k | v of this wave's 32 dh columns] over K = 512, from the resident image X
                 __builtin_amdgcn_sched_barrier(0);
                 {
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                         if (hs + AH < 32) load_ga(pa[r], hs + AH, (32 * r + hs + AH) % LY_RDA);
                         else if (r == 0) load_ga(pa[1], hs + AH - 32, (32 * r + hs + AH) % LY_RDA);
                         if (hs + AH < 32 || r == 0) {
-                            if (hs < AH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * AH + 9) : "memory");   // (+ the 9 bias loads)
+                            if (hs < AH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * AH + 5) : "memory");   // (+ the 5 bias loads: behind round 1's chained granules)
                             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * AH) : "memory");
                         }
                         const int slot = (32 * r + hs) % LY_RDA;
@@ -453,6 +456,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                             kf[ta][sl][j] = (__bf16)acc[ta][1][i];
                             vh[ta][sl][j] = (__bf16)acc[ta][2][i];
                         }
+                if (r == 0) load_qbias(w.bqkv, 1);                // (the accumulators are dead: round 1's start value lands under this round's softmax)
                 // causal tiles of S^T: 0 = (keys 0-31, queries 0-31), 1 = (keys 0-31, queries 32-63), 2 = (keys 32-63, queries 32-63)
                 f32x16 st[3];
 #pragma unroll
@@ -643,6 +647,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
             if (c == 0) gemm32(acc2, a_offy, p_w2a, p_w1b, std::true_type{}, std::integral_constant<int, 0>{});
             else gemm32(acc2, a_offy, p_w2b, p_w2b, std::false_type{}, std::integral_constant<int, 0>{});
         }
+        load_qbias(g.lw[l + 1 < g.L ? l + 1 : 0].bqkv, 0);      // the next layer's (next step's first layer's) round 0: lands under norm3
         RGN_LYT(10)
         add_resid(acc2, nullptr);
         layernorm(acc2, vec + V_G3, std::integral_constant<int, 0>{}, [&](int nt, int i4) { return *reinterpret_cast<const f32x4*>(vec + V_B3 + col4(nt, i4)); });
