@@ -59,10 +59,10 @@ def layers_fused(cfg, precision):
 
 
 def layers_steps(cfg, precision, guided):
-    """Mirrors rgn_api.cpp (layers_steps): unguided, whole runs of sampler steps (stack + step boundary) are ONE launch."""
+    """Mirrors rgn_api.cpp (layers_steps): whole runs of sampler steps (stack + step boundary; guided: both evaluations of a motion) are ONE launch."""
     F = cfg["njoints"] * cfg["nfeats"]
-    return (layers_fused(cfg, precision) and not guided and not cfg.get("emb_trans_dec") and F % 4 == 0 and 320 < F <= 352
-            and os.environ.get("REGENNET_LAYERS_STEPS", "1") != "0" and not os.environ.get("REGENNET_NO_STEP_FUSION"))
+    return (layers_fused(cfg, precision) and (not guided or os.environ.get("REGENNET_LAYERS_GUIDED", "1") != "0") and not cfg.get("emb_trans_dec")
+            and F % 4 == 0 and 320 < F <= 352 and os.environ.get("REGENNET_LAYERS_STEPS", "1") != "0" and not os.environ.get("REGENNET_NO_STEP_FUSION"))
 
 
 def rowgemm_phase(cfg, precision):

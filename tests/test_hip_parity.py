@@ -520,7 +520,7 @@ def test_full_size_batch_is_row_independent(monkeypatch, precision, tail):
         assert torch.allclose(full2[b:b + 1], one, atol=2e-5), (b, (full2[b:b + 1] - one).abs().max().item())
 
 
-@pytest.mark.parametrize("case", range(6))
+@pytest.mark.parametrize("case", range(4))
 def test_default_precision_schedule_on_random_8_layer_cases(monkeypatch, case):
     """The DEFAULT precision schedule (plain-bf16 bulk + split-bf16 tail: what every caller gets) against the oracle on random 8-layer
     models at S >= 20 - random batch, length (52 .. 64 tokens, with and without the emb_trans_dec token), guidance with per-sample scales,
@@ -573,7 +573,7 @@ def test_reference_evaluation_setting_switch_point_sweep(golden, monkeypatch, na
     shape = (int(g["B"]), cfg["njoints"], cfg["nfeats"], cfg["num_frames"])
     errs = {}
     for layers_on in (False, True):
-        for tail in (0, 1, 2, 3, 4, 5, None):
+        for tail in (0, 1, 2, None, 5):                       # (None = the default = 3)
             monkeypatch.setenv("REGENNET_LAYERS_MIN_B", "1" if layers_on else "100000")
             model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision="bf16_x3tail/throughput", x3_tail=tail)
             model._get_engine(shape[0])
@@ -583,8 +583,8 @@ def test_reference_evaluation_setting_switch_point_sweep(golden, monkeypatch, na
             model._engine.close()
     for layers_on in (False, True):
         print(f"\n[5-step evaluation schedule] {name} {'k_layers' if layers_on else 'kernel per stage'}: " +
-              ", ".join(f"tail {t}: {errs[(layers_on, t)]:.2e}" for t in (0, 1, 2, 3, 4, 5, None)))
-        for t in (None, 3, 4, 5):
+              ", ".join(f"tail {t}: {errs[(layers_on, t)]:.2e}" for t in (0, 1, 2, None, 5)))
+        for t in (None, 5):
             assert errs[(layers_on, t)] < 1.5e-4, (layers_on, t, errs[(layers_on, t)])
         assert errs[(layers_on, 2)] < 3.5e-4
 
