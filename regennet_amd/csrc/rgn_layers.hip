@@ -832,6 +832,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
             gemm_n(acc, a_offx, p_wx, p_wx, std::false_type{}, std::integral_constant<int, 8 + 16>{}, std::integral_constant<int, 2 * LY_NKX>{});
         }
         if constexpr (GUIDED) {   // the same embedding with the unconditional condition rows -> image Y -> the planes (read back at the next step's pass 1)
+            __builtin_amdgcn_s_barrier();                                 // Y overlaps the x' image: every wave must be out of the embedding's k-loop first
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
