@@ -675,6 +675,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         const StepCoef k = g.tab[step];
         const int T = Tq, gb = g.s0 + b_s;                                  // frames = tokens (no emb_trans_dec token on this path); motion index
         const float gscale = GUIDED ? g.scale[gb] : 0.f;
+        const __amdgpu_buffer_rsrc_t park_rs = __builtin_amdgcn_make_buffer_rsrc(GUIDED ? g.park + ((size_t)b_s * 6 + (wave_s < 6 ? wave_s : 0)) * 4096 : nullptr, 0, 4096 * 4, 0x00020000);
         f32x16 acc[2][2];
         // ---- A: x0 = h . Wout^T from the image X (guided: of the unconditional evaluation)
         out_proj(acc, wave_s);
@@ -693,7 +694,8 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                     for (int mt = 0; mt < 2; ++mt) {
                         f32x4 v = {acc[nt][mt][4 * i4] + bb[0], acc[nt][mt][4 * i4 + 1] + bb[1], acc[nt][mt][4 * i4 + 2] + bb[2], acc[nt][mt][4 * i4 + 3] + bb[3]};
                         if constexpr (GUIDED) {   // x0 = x0_u + scale_b (x0_c - x0_u), cfg_sampler.py:31, rounded like k_update / k_step
-                            const f32x4 cc = *reinterpret_cast<const f32x4*>(g.park + ((size_t)b_s * 6 + wave_s) * 4096 + lane_s * 4 + ((nt * 2 + mt) * 4 + i4) * 256);
+                            // (sc1: served by L2, past this CU's L1 - the same addresses were read a step ago and rewritten since)
+                            const f32x4 cc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(park_rs, (lane_s * 4 + ((nt * 2 + mt) * 4 + i4) * 256) * 4, 0, 16));
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(v[e], __fmul_rn(gscale, __fsub_rn(cc[e] + bb[e], v[e])));
                         }
