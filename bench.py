@@ -215,6 +215,9 @@ def main(argv=None):
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    # REGENNET_FORCE_DIST=1 (tools): a ONE-rank process group takes every multi-rank code path below - RCCL init, the blob broadcast, the
+    # barriers, the MAX all-reduce of the time, the gather of the device names - which is how they are exercised on a 1-GPU box
+    multi = world > 1 or bool(os.environ.get("REGENNET_FORCE_DIST"))
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a line for a different rank count")
     if a.engine_stub:
@@ -225,7 +228,7 @@ def main(argv=None):
         raise SystemExit(f"bench.py: --gpus {a.gpus} but this node has {torch.cuda.device_count()} GPU(s)")
     dev = dist_util.setup_dist()
     assert dev.type == "cuda" or a.engine_stub, "bench.py needs an AMD GPU (no CPU fallback)"
-    if world > 1:
+    if multi:
         assert dist.is_initialized() and dist.get_world_size() == a.gpus, "process group does not span --gpus ranks"
     sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
 
@@ -238,7 +241,7 @@ def main(argv=None):
     # reported ("engine_build_s": ~2 s of one host core at N = 1). N ranks repack concurrently by default; REGENNET_SERIAL_ENGINE_BUILD=1
     # makes them take turns (a host whose memory bandwidth 8 concurrent repacks would saturate), the broadcast follows either way.
     t_build = time.perf_counter()
-    if world > 1 and os.environ.get("REGENNET_SERIAL_ENGINE_BUILD"):
+    if multi and os.environ.get("REGENNET_SERIAL_ENGINE_BUILD"):
         eng = None
         for r in range(world):
             if r == rank:
@@ -248,7 +251,7 @@ def main(argv=None):
         eng._blob_synced = True
         model.weights_src = 0
     else:
-        model.weights_src = 0 if world > 1 else None        # ONE collective over xGMI for the engine every rank builds here (none at N = 1)
+        model.weights_src = 0 if multi else None        # ONE collective over xGMI for the engine every rank builds here (none at N = 1)
         eng, _ = model._get_engine(B)
     sync()
     build_s = time.perf_counter() - t_build
@@ -272,20 +275,20 @@ def main(argv=None):
     for w in range(a.warmup):
         out = one_call(10 + w)
     sync()
-    if world > 1:
+    if multi:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for k in range(a.steps):
         out = one_call(100 + k)
     sync()
-    if world > 1:
+    if multi:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
     assert torch.isfinite(out).all()
     devices = [str(dev)]
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -417,8 +420,21 @@ def main(argv=None):
         if world == 1 and not a.no_cpu_baseline and not a.engine_stub:
             line["cpu_baseline"] = cpu_baseline(cfg, synth.make_state_dict(cfg, seed=0), evals)
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
+    # The JSON line must be the LAST thing on stdout: RCCL prints a version banner through C stdio, which is flushed when the process
+    # exits - i.e. behind a line printed here. So: every rank flushes C stdio, the ranks meet, rank 0 prints the line, and from then
+    # on every rank's stdout goes to stderr.
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if multi:
+        dist.barrier()
+    if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    os.dup2(2, 1)
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

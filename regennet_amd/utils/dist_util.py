@@ -14,6 +14,12 @@ import torch.distributed as dist
 _device = None
 
 
+def collectives_active():
+    """True when this process takes the multi-rank code paths: a process group of more than one rank - or of ONE rank with
+    REGENNET_FORCE_DIST=1, which is how the collectives (RCCL init, blob broadcast, barriers, gathers) are exercised on a 1-GPU box."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or bool(os.environ.get("REGENNET_FORCE_DIST")))
+
+
 def setup_dist(device=None):
     """setup_dist() (dist_util.py:20-42): bind this process to its GPU; join the process group when launched
     under torchrun (RANK/WORLD_SIZE/MASTER_ADDR/MASTER_PORT/LOCAL_RANK)."""
@@ -26,7 +32,9 @@ def setup_dist(device=None):
         _device = torch.device(f"cuda:{idx}")
     else:
         _device = torch.device("cpu")
-    if world_size > 1 and not dist.is_initialized():
+    if (world_size > 1 or os.environ.get("REGENNET_FORCE_DIST")) and not dist.is_initialized():
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
@@ -66,7 +74,7 @@ def device_view(ptr, nbytes, device):
 
 def broadcast_flat(buf, src=0):
     """Broadcast one flat tensor from `src` (the packed weight blob): one collective over xGMI."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if collectives_active():
         dist.broadcast(buf, src)
     return buf
 
@@ -87,7 +95,7 @@ def broadcast_engine_weights(engine, device, src=0):
     is broadcast into every rank's blob over RCCL / xGMI — replaces the per-tensor `sync_params` of the reference
     (utils/dist_util.py:77-83). Callers must re-derive everything computed FROM the weights afterwards (the per-schedule
     tables: `engine.schedule_id = None`; the hoisted condition is rebound by every sampling call anyway)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not collectives_active():
         return
     ptr, nbytes = engine.weight_blob()
     view = ptr if torch.is_tensor(ptr) else device_view(ptr, nbytes, device)   # (a stub engine hands over a tensor)
@@ -116,7 +124,7 @@ def copy_engine_weights(src_engine, dst_engine, device):
 def sync_params(params):
     """dist_util.py:77-83, but as a single flattened broadcast instead of one per tensor."""
     params = list(params)
-    if not dist.is_initialized() or dist.get_world_size() == 1 or not params:
+    if not collectives_active() or not params:
         return
     flat = torch.cat([p.detach().reshape(-1) for p in params])
     dist.broadcast(flat, 0)
@@ -130,7 +138,7 @@ def sync_params(params):
 
 def all_gather_samples(local, total):
     """Gather per-rank sample shards [b_r, ...] back into [total, ...] on every rank."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not collectives_active():
         return local
     w = dist.get_world_size()
     sizes = [shard_bounds(total, r, w) for r in range(w)]
