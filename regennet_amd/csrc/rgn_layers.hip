@@ -23,6 +23,12 @@
 // of the softmaxed S^T agree as MFMA operands by construction); the activation operand comes from the RESIDENT image X, so the
 // k-loop has no barrier and no staging at all. Layer tail: the structure of rgn_mlp2.hip (MT = 2) on the resident images.
 // Weights: fragment-ordered planes streamed into register rings through buffer loads (scalar resource, compile-time offsets).
+//
+// Three instantiations: k_layers<false> - the stack of ONE evaluation (planes in, planes out); k_layers<true> - whole runs of sampler steps: after the
+// stack the step boundary of rgn_step.hip in per-sample form (output projection, sampler update of x in place - diffusion/gaussian_diffusion.py:508-560,
+// 744-794 - and the next evaluation's input embedding straight into X), looped `steps` times, the device-side loop index moved on by the last
+// workgroup; k_layers<true, true> - the same under classifier-free guidance (model/cfg_sampler.py:22-31): a workgroup owns a MOTION and runs its
+// conditional and its unconditional evaluation back to back, the conditional x0 parked in global scratch meanwhile.
 #include "rgn_internal.h"
 #include "rgn_philox.h"
 
