@@ -105,6 +105,7 @@ struct rgn_ctx {
     bool qkv_rs = true;                // plain-bf16 phase: k_qkv_attn with register-streamed weights (REGENNET_NO_QKV_RS=1: the DMA-fed loop)
     bool qkv_long = false;             // plain-bf16 phase, 65 .. 160 tokens: fused in_proj + attention per (sample, head) (REGENNET_NO_QKV_LONG=1: in_proj GEMM + k_attn_x3)
     bool sb = false;                   // small-batch engine: column-split GEMMs with consumer-side LayerNorm (k_sb_gemm)
+    bool sb_attn = false;              // small-batch engine: in_proj + attention as one launch per layer (k_sb_qkv_attn; REGENNET_SB_FUSED_ATTN=1: it loses below B ~ 6)
     int sb_rows = 640;                 // evaluations of at most this many token rows take it (rgn_set_small_batch_rows; 0 disables)
     int sb_rows_default = 640;         // (REGENNET_SB_ROWS): measured crossover with the throughput kernels at 60 tokens: between B = 10 and 11
                                        // (round 3, 250-step calls: B = 10 108 vs 116 ms, B = 11 122 vs 117, B = 12 123 vs 117; it was B = 12 .. 16 in round 2)
@@ -436,6 +437,7 @@ int run_layers_sb(rgn_ctx* c, const Dims& dm, bool sampling, const float* cond_r
             RGN_LAUNCH(c, KC_EMBED, s, launch_emb_rows(c->emb, nullptr, nullptr, c->dp<float>(c->off_pe), c->tmp, none, dm, c->cfg.wo_pos_emb, s));
     }
     const Planes att_p{c->att_hi, x3 ? c->att_lo : nullptr, M};
+    const bool fused_attn = c->sb_attn && sb_qkv_attn_supported(d, dm.dh, dm.Tq);
     for (int l = 0; l < c->L; ++l) {
         const LayerW& w = c->layers[l];
         {   // layer input = norm3 of the previous layer (layer 0: the embedding itself); in_proj -> q (pre-scaled), k, v
@@ -445,9 +447,14 @@ int run_layers_sb(rgn_ctx* c, const Dims& dm, bool sampling, const float* cond_r
             g.Qhi = c->q_hi; g.Khi = c->k_hi; g.Vhi = c->vt_hi;
             if (x3) { g.Qlo = c->q_lo; g.Klo = c->k_lo; g.Vlo = c->vt_lo; }
             g.d = d; g.H = c->H; g.dh = dm.dh; g.Tqp = c->Tqp; g.qscale = 1.0f / sqrtf((float)dm.dh);
-            RGN_LAUNCH(c, KC_SB, s, launch_sb_gemm(g, 1, 2, x3, s));
+            if (fused_attn) {   // ... and the attention, a (sample, head) per workgroup: one launch, q / k / v stay in LDS
+                g.att = att_p;
+                RGN_LAUNCH(c, KC_QKV, s, launch_sb_qkv_attn(g, dm.Bm, x3, s));
+            } else {
+                RGN_LAUNCH(c, KC_SB, s, launch_sb_gemm(g, 1, 2, x3, s));
+            }
         }
-        {
+        if (!fused_attn) {
             AttnX3Args a{};
             a.Qhi = c->q_hi; a.Qlo = c->q_lo; a.Khi = c->k_hi; a.Klo = c->k_lo; a.Vthi = c->vt_hi; a.Vtlo = c->vt_lo;
             a.out = att_p;
@@ -1152,8 +1159,10 @@ int rgn_finalize_weights(rgn_handle h) {
         c->qkv_long = c->cfg.precision == RGN_PREC_BF16_X3TAIL && qkv_attn_long_supported(c->Tq, d / c->H, d) && getenv("REGENNET_NO_QKV_LONG") == nullptr;
         if (c->qkv_long) RGN_HIP(c, configure_qkv_attn_long());
         c->sb = c->attn_x3 && sb_supported(d, ff, d / c->H);
+        if (const char* e = getenv("REGENNET_SB_FUSED_ATTN")) c->sb_attn = atoi(e) != 0;
         if (const char* e = getenv("REGENNET_SB_ROWS")) c->sb_rows = c->sb_rows_default = atoi(e) < 0 ? 0 : atoi(e);
         if (c->sb) RGN_HIP(c, configure_sb());
+        if (c->sb) RGN_HIP(c, configure_sb_qkv_attn());
     }
     if ((rc = ws_alloc(c, &c->d_tab, (size_t)1024))) return rc;
     if ((rc = ws_alloc(c, &c->d_step, (size_t)4 + 1 + B))) return rc;   // [0] loop index, [3] scratch, [4 ..] k_update's ticket counters

@@ -224,10 +224,16 @@ struct SbArgs {
     // POST 2: packed in_proj -> attention-ready q (pre-scaled) / k / v planes [Bm*H][Tqp][dh]
     __bf16 *Qhi, *Qlo, *Khi, *Klo, *Vhi, *Vlo;
     int d, H, dh, Tqp; float qscale;
+    // k_sb_qkv_attn (rgn_sb_attn.hip): the attention output, K32-blocked planes of the out_proj GEMM
+    Planes att;
 };
 bool sb_supported(int d, int ff, int dh);
 hipError_t configure_sb();
 hipError_t launch_sb_gemm(const SbArgs& g, int pre, int post, bool x3, hipStream_t s);
+// LayerNorm prologue + in_proj + causal self-attention of one (sample, head) per workgroup (rgn_sb_attn.hip): d = 512, dh = 128, <= 64 tokens
+bool sb_qkv_attn_supported(int d, int dh, int Tq);
+hipError_t configure_sb_qkv_attn();
+hipError_t launch_sb_qkv_attn(const SbArgs& g, int Bm, bool x3, hipStream_t s);
 
 // XCD-affine workgroup order: the hardware places workgroup id b on XCD b % 8. Remapping the id so that every XCD gets one
 // CONTIGUOUS range of tiles / samples makes the rows a kernel reads the rows the previous kernel of the chain wrote on the

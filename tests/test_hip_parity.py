@@ -662,6 +662,46 @@ def test_small_batch_engine_is_bit_exact_under_batch_composition(config, B, T):
             assert torch.equal(full[b:b + 1], one), (b, (full[b:b + 1] - one).abs().max().item())
 
 
+def test_small_batch_fused_in_proj_attention_kernel(golden, monkeypatch):
+    """k_sb_qkv_attn (rgn_sb_attn.hip; opt-in, REGENNET_SB_FUSED_ATTN=1 when the engine is created: it loses below B ~ 6,
+    profiles/r04_sb_fused_attn.txt): LayerNorm prologue + in_proj + attention of a (sample, head) per workgroup in place of
+    k_sb_gemm<1, 2> + k_attn_x3. Against the reference's outputs on identical noise (both phases of the precision schedule, the
+    guided golden, the 61-token emb_trans_dec one), and bit-exact under batch composition like the two-launch form."""
+    from regennet_amd import synth
+    from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    monkeypatch.setenv("REGENNET_SB_FUSED_ATTN", "1")
+    for name in ("ntu_ddpm50", "ntu_action_ddim100_cfg", "ntu_add_etd_ddpm20"):
+        g = golden(name)
+        cfg, sd, y, tape = fixture_inputs(g, loop=True)
+        model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision="bf16_x3tail")
+        fm = ClassifierFreeSampleModel(model) if bool(g["guided"]) else model
+        B = int(g["B"])
+        fn = diffusion.p_sample_loop if str(g["mode"]) == "ddpm" else diffusion.ddim_sample_loop
+        out = fn(fm, (B, cfg["njoints"], cfg["nfeats"], cfg["num_frames"]), clip_denoised=False, model_kwargs={"y": y_to_device(y)},
+                 noise_tape=torch.from_numpy(tape))
+        err = np.abs(out.cpu().numpy() - g["final"]).max()
+        print(f"\n[k_sb_qkv_attn] {name}: {err:.2e}")
+        assert err < 1e-3, (name, err)
+        model._engine.close()
+    cfg = synth.get_config("ntu_action")
+    model, diffusion = build_hip(cfg, synth.make_state_dict(cfg, seed=0), resp="ddim5", precision="bf16_x3tail", x3_tail=2)
+    B = 5
+    y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1)).cuda(),
+         "action": torch.from_numpy(synth.make_actions(cfg, B, seed=2)).cuda(), "scale": torch.full((B,), 2.5, device="cuda")}
+    fm = ClassifierFreeSampleModel(model)
+    full = diffusion.ddim_sample_loop(fm, (B, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y}, seed=13)
+    for b in (0, B - 1):
+        yb = {k: v[b:b + 1].contiguous() for k, v in y.items()}
+        one = diffusion.ddim_sample_loop(fm, (1, 56, 6, 60), clip_denoised=False, model_kwargs={"y": yb}, seed=13, sample_offset=b)
+        assert torch.equal(full[b:b + 1], one), (b, (full[b:b + 1] - one).abs().max().item())
+    # and it IS another kernel: the default engine's result differs in the last bits
+    monkeypatch.delenv("REGENNET_SB_FUSED_ATTN")
+    model2, diffusion2 = build_hip(cfg, synth.make_state_dict(cfg, seed=0), resp="ddim5", precision="bf16_x3tail", x3_tail=2)
+    two = diffusion2.ddim_sample_loop(ClassifierFreeSampleModel(model2), (B, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y}, seed=13)
+    dev = (full - two).abs().max().item()
+    assert 0.0 < dev < 5e-4, dev
+
+
 @pytest.mark.parametrize("precision,tail", [("bf16x3", None), ("bf16_x3tail", 2)])
 def test_chi3d_full_size_shard_is_row_independent(precision, tail):
     """BASELINE configs[3] per-GPU shard (Chi3D T=150, B=128 = 1024 / 8): the long-sequence kernels (in_proj GEMM with the
