@@ -241,7 +241,7 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
             const float var = __builtin_fmaxf(p[1][0] * invn - mean * mean, 0.f);
             const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
             rs[mt] = f32x2{rstd, rstd};
-            nm[mt] = f32x2{-mean, -mean};
+            nm[mt] = f32x2{-mean * rstd, -mean * rstd};
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -258,9 +258,8 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
-                        const f32x2 rg = f32x2{ga[i4][e], ga[i4][e + 1]} * rs[mt];
-                        const f32x2 b = __builtin_elementwise_fma(nm[mt], rg, f32x2{sh[i4][mt][e], sh[i4][mt][e + 1]});
-                        const f32x2 o = __builtin_elementwise_fma(f32x2{acc[nt][mt][4 * i4 + e], acc[nt][mt][4 * i4 + e + 1]}, rg, b);
+                        const f32x2 t = __builtin_elementwise_fma(f32x2{acc[nt][mt][4 * i4 + e], acc[nt][mt][4 * i4 + e + 1]}, rs[mt], nm[mt]);   // (v - mean) rstd
+                        const f32x2 o = __builtin_elementwise_fma(t, f32x2{ga[i4][e], ga[i4][e + 1]}, f32x2{sh[i4][mt][e], sh[i4][mt][e + 1]});
                         acc[nt][mt][4 * i4 + e] = o[0];
                         acc[nt][mt][4 * i4 + e + 1] = o[1];
                     }
