@@ -83,16 +83,15 @@ __device__ long long g_ly_st[1024][16];
 
 // GELU (erf form), see rgn_mlp2.hip
 __device__ __forceinline__ f32x2 ly_gelu2(f32x2 x) {
-    const f32x2 t = {__builtin_amdgcn_fmed3f(x[0], -4.5254834f, 4.5254834f), __builtin_amdgcn_fmed3f(x[1], -4.5254834f, 4.5254834f)};
+    const f32x2 t = {__builtin_amdgcn_fmed3f(x[0], -3.9f, 3.9f), __builtin_amdgcn_fmed3f(x[1], -3.9f, 3.9f)};
     const f32x2 z = t * t;
-    f32x2 p = f32x2{-7.433422766e-10f, -7.433422766e-10f};
-    p = __builtin_elementwise_fma(p, z, f32x2{6.994829249e-08f, 6.994829249e-08f});
-    p = __builtin_elementwise_fma(p, z, f32x2{-2.824688409e-06f, -2.824688409e-06f});
-    p = __builtin_elementwise_fma(p, z, f32x2{6.471458619e-05f, 6.471458619e-05f});
-    p = __builtin_elementwise_fma(p, z, f32x2{-9.421016439e-04f, -9.421016439e-04f});
-    p = __builtin_elementwise_fma(p, z, f32x2{9.306023829e-03f, 9.306023829e-03f});
-    p = __builtin_elementwise_fma(p, z, f32x2{-6.564749777e-02f, -6.564749777e-02f});
-    p = __builtin_elementwise_fma(p, z, f32x2{3.986273110e-01f, 3.986273110e-01f});
+    f32x2 p = f32x2{3.214928057e-08f, 3.214928057e-08f};
+    p = __builtin_elementwise_fma(p, z, f32x2{-2.075321845e-06f, -2.075321845e-06f});
+    p = __builtin_elementwise_fma(p, z, f32x2{5.740237248e-05f, 5.740237248e-05f});
+    p = __builtin_elementwise_fma(p, z, f32x2{-9.056383278e-04f, -9.056383278e-04f});
+    p = __builtin_elementwise_fma(p, z, f32x2{9.218782187e-03f, 9.218782187e-03f});
+    p = __builtin_elementwise_fma(p, z, f32x2{-6.556465477e-02f, -6.556465477e-02f});
+    p = __builtin_elementwise_fma(p, z, f32x2{3.986084461e-01f, 3.986084461e-01f});
     return x * __builtin_elementwise_fma(t, p, f32x2{0.5f, 0.5f});
 }
 
