@@ -146,7 +146,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
     int red_base = LY_RED + 4 * l31;
     asm volatile("" : "+v"(red_base));
     const float invn = 1.0f / 512.f;
-    const float qs2 = g.qscale * 1.44269504088896340736f;        // scores in log2 units: softmax = exp2(s - max)
+    const float qs2 = g.qscale * 1.44269504088896340736f;        // 1 / sqrt(dh) in log2 units, applied INSIDE the softmax's exponent: exp2(qs2 s - qs2 max), one FMA where the subtraction was
 
     struct Pass { __amdgpu_buffer_rsrc_t rs; int kstride, hs0; };
     bf16x8 wf[LY_RDM][2];
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const int i = 8 * sl + j;
-                            qh[ta][sl][j] = (__bf16)(acc[ta][0][i] * qs2);
+                            qh[ta][sl][j] = (__bf16)acc[ta][0][i];
                             kf[ta][sl][j] = (__bf16)acc[ta][1][i];
                             vh[ta][sl][j] = (__bf16)acc[ta][2][i];
                         }
@@ -523,11 +523,12 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                     mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mx), 0xB1, 0xf, 0xf, true)));   // quad_perm [1,0,3,2]
                     mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, mx), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]
                     float sum = 0.f;
+                    const float nmx = -mx * qs2;
 #pragma unroll
                     for (int c4 = 0; c4 < 4; ++c4)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            sv[c4][e] = __builtin_amdgcn_exp2f(sv[c4][e] - mx);
+                            sv[c4][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[c4][e], qs2, nmx));
                             sum += sv[c4][e];
                         }
                     sum += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sum), 0xB1, 0xf, 0xf, true));
