@@ -277,7 +277,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                 }
     };
     // acc += bf16 residual from the image X (this wave's own columns)
-    auto add_resid = [&](f32x16 (&acc)[2][2], const float* bias) {
+    auto add_resid = [&](f32x16 (&acc)[2][2]) {
         bf16x4 rr[2][2][4];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -288,14 +288,11 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                f32x4 bb = {0.f, 0.f, 0.f, 0.f};
-                if (bias) bb = *reinterpret_cast<const f32x4*>(bias + col4(nt, i4));
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int i4 = 0; i4 < 4; ++i4)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[nt][mt][4 * i4 + e] += (float)rr[nt][mt][i4][e] + bb[e];
-            }
+                    for (int e = 0; e < 4; ++e) acc[nt][mt][4 * i4 + e] += (float)rr[nt][mt][i4][e];
     };
 
     auto gemm32 = [&](f32x16 (&acc)[2][2], const int (&aoff)[2], const Pass& cur, const Pass& nxt, auto chain, auto extra) {
@@ -377,6 +374,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         RGN_LYT(0)
         // ========================= self-attention: in_proj + causal softmax + p . v, two heads at a time ===================
         bf16x4 attk[2][2][4];                                    // [round][query tile][run of 4 dh]: this wave's O^T tiles as bf16
+        float bo_r = 0.f;
         {
             struct PassA { __amdgpu_buffer_rsrc_t rs; };
             auto qrs = [&](int r) {
@@ -461,6 +459,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                             vh[ta][sl][j] = (__bf16)acc[ta][2][i];
                         }
                 if (r == 0) load_qbias(w.bqkv, 1);                // (the accumulators are dead: round 1's start value lands under this round's softmax)
+                else bo_r = w.bo[64 * wave + lane];              // out_proj's bias = its accumulators' start value: lands under round 1's softmax
                 // causal tiles of S^T: 0 = (keys 0-31, queries 0-31), 1 = (keys 0-31, queries 32-63), 2 = (keys 32-63, queries 32-63)
                 f32x16 st[3];
 #pragma unroll
@@ -587,13 +586,14 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
             p_w1b{wrs(w.W1, 16 + 2 * wave, 1024 * 512 * 2), 32 * 2048, 0}, p_w2a{wrs(w.W2, 2 * wave, 512 * 1024 * 2), 16 * 2048, 0},
             p_w2b{p_w2a.rs, 16 * 2048, 32};
         // ---- out_proj's first fragments and this layer's per-column vectors (this wave's 64 columns: lane = column)
+        vec[V_BO + lane] = bo_r;                                 // (wave-private; the exchange it lies in is dead: every wave passed the barrier behind the last round)
 #pragma unroll
         for (int s = 0; s < LY_RDM - 1; ++s) load_g(p_wo, s, s);
         const int cw = 64 * wave + lane;
         float vv[12];
         {
             const float* src[9] = {w.bo, w.g1, w.g2, w.b2, w.bf1, w.bf1 + 512, w.bf2, w.g3, w.b3};
-            vv[0] = src[0][cw]; vv[1] = src[1][cw]; vv[2] = src[2][cw]; vv[3] = src[3][cw];
+            vv[1] = src[1][cw]; vv[2] = src[2][cw]; vv[3] = src[3][cw];
             vv[4] = w.b1[cw] + (g.stepvec ? g.stepvec[(size_t)step * g.ldstep + (size_t)l * 512 + cw] : 0.f) +
                     (g.pervec ? g.pervec[((size_t)b + (size_t)pass * g.B) * g.ldper + (size_t)l * 512 + cw] : 0.f);   // norm1's beta + call_time[step] + call_cond[sample]
             vv[5] = src[4][cw]; vv[6] = src[5][cw]; vv[7] = src[6][cw]; vv[8] = src[7][cw]; vv[9] = src[8][cw];
@@ -610,19 +610,14 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         f32x16 acc[2][2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
+        init_bias(acc, vec + V_BO);
         RGN_LYT(7)
-        gemm32(acc, a_offy, p_wo, p_w1a, std::true_type{}, std::integral_constant<int, 12>{});
+        gemm32(acc, a_offy, p_wo, p_w1a, std::true_type{}, std::integral_constant<int, 11>{});
         RGN_LYT(8)
         // vectors -> the wave's LDS region (wave-private: program order suffices)
-        vec[V_BO + lane] = vv[0]; vec[V_G1 + lane] = vv[1]; vec[V_G2 + lane] = vv[2]; vec[V_B2 + lane] = vv[3]; vec[V_SPV + lane] = vv[4];
+        vec[V_G1 + lane] = vv[1]; vec[V_G2 + lane] = vv[2]; vec[V_B2 + lane] = vv[3]; vec[V_SPV + lane] = vv[4];
         vec[V_BF1 + lane] = vv[5]; vec[V_BF1 + 64 + lane] = vv[6]; vec[V_BF2 + lane] = vv[7]; vec[V_G3 + lane] = vv[8]; vec[V_B3 + lane] = vv[9];
-        add_resid(acc, vec + V_BO);
+        add_resid(acc);
         layernorm(acc, vec + V_G1, std::integral_constant<int, 0>{}, [&](int nt, int i4) { return *reinterpret_cast<const f32x4*>(vec + V_SPV + col4(nt, i4)); });
         layernorm(acc, vec + V_G2, std::integral_constant<int, 1>{}, [&](int nt, int i4) { return *reinterpret_cast<const f32x4*>(vec + V_B2 + col4(nt, i4)); });
         store_img(acc, LY_X);                                    // h' replaces h in place (this wave's columns: it read them above)
@@ -654,7 +649,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         }
         load_qbias(g.lw[l + 1 < g.L ? l + 1 : 0].bqkv, 0);      // the next layer's (next step's first layer's) round 0: lands under norm3
         RGN_LYT(10)
-        add_resid(acc2, nullptr);
+        add_resid(acc2);
         layernorm(acc2, vec + V_G3, std::integral_constant<int, 0>{}, [&](int nt, int i4) { return *reinterpret_cast<const f32x4*>(vec + V_B3 + col4(nt, i4)); });
         store_img(acc2, LY_X);                                   // the next layer's input, in place
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
