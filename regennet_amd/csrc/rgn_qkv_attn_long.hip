@@ -133,20 +133,30 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
     __bf16* sQ = reinterpret_cast<__bf16*>(smem + QL_Q);
     __bf16* sK = reinterpret_cast<__bf16*>(smem + QL_K);
     __bf16* sV = reinterpret_cast<__bf16*>(smem + QL_V);
-    if (which < 2) {
-        __bf16* dst = which == 0 ? sQ : sK;
-        const float sc = which == 0 ? g.qscale : 1.0f;
+    // (q is stored UNSCALED: 1 / sqrt(dh) goes into the softmax's exponent, one FMA where the subtraction was. k is stored WITHOUT its bias:
+    //  q . (k + b_k) = q . k + q . b_k adds the same number to every score of a query's row, which the softmax removes - exact in real arithmetic)
+    if (which == 0) {
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_s + which * QL_DH + wn * 32 + 8 * i4 + 4 * kh);
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_s + wn * 32 + 8 * i4 + 4 * kh);
 #pragma unroll
             for (int t = 0; t < QL_TT; ++t) {
                 bf16x4 h;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (__bf16)((acc[t][4 * i4 + e] + bq[e]) * sc);
-                *reinterpret_cast<bf16x4*>(dst + (t * 32 + l31) * QL_KLD + wn * 32 + 8 * i4 + 4 * kh) = h;
+                for (int e = 0; e < 4; ++e) h[e] = (__bf16)(acc[t][4 * i4 + e] + bq[e]);
+                *reinterpret_cast<bf16x4*>(sQ + (t * 32 + l31) * QL_KLD + wn * 32 + 8 * i4 + 4 * kh) = h;
             }
         }
+    } else if (which == 1) {
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+            for (int t = 0; t < QL_TT; ++t) {
+                bf16x4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (__bf16)acc[t][4 * i4 + e];
+                *reinterpret_cast<bf16x4*>(sK + (t * 32 + l31) * QL_KLD + wn * 32 + 8 * i4 + 4 * kh) = h;
+            }
     } else {   // v -> V^T[dh][token]: 2-byte writes, a wave's 32 lanes (consecutive tokens) fill one 64-byte run
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
@@ -178,6 +188,7 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
     const int k0 = w < 2 ? 0 : (w < 4 ? w - 1 : (w == 4 ? 4 : (w == 8 ? 2 : 0)));
     const int k1 = w < 5 ? w : (w == 5 ? 0 : (w == 8 ? 3 : 1));
     const int qrow = 32 * qt + l31;
+    const float qs2 = g.qscale * 1.44269504088896340736f;          // 1 / sqrt(dh) in log2 units: the scores stay unscaled, exp2(qs2 s - qs2 max)
     f32x16 oa[ND];
     float inv = 0.f, m_run = -INFINITY, l_run = 0.f;
     if (w < 9) {
@@ -212,11 +223,12 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
                 }
                 mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
                 const float m_new = fmaxf(fmaxf(m_run, mt), -1e30f);   // (a unit with no valid key at all - rows beyond Tq only - stays finite)
-                const float alpha = __expf(m_run - m_new);            // (first tile: exp(-inf) = 0)
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * qs2);   // (first tile: exp2(-inf) = 0)
+                const float nm = -m_new * qs2;
                 float ls = 0.f;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    st[i] = __expf(st[i] - m_new);
+                    st[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], qs2, nm));
                     ls += st[i];
                 }
                 l_run = l_run * alpha + ls;
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
                 lsec[u] = st2.y;
                 if (u < nd) m = fmaxf(m, ms[u]);
             }
-            const float fp = __expf(m_run - m);
+            const float fp = __builtin_amdgcn_exp2f((m_run - m) * qs2);
             l_run *= fp;
 #pragma unroll
             for (int dt = 0; dt < ND; ++dt)
@@ -278,7 +290,7 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 if (u < nd) {                                        // wave-uniform
-                    const float fs = __expf(ms[u] - m);
+                    const float fs = __builtin_amdgcn_exp2f((ms[u] - m) * qs2);
                     l_run = __builtin_fmaf(lsec[u], fs, l_run);
                     const char* dump = smem + QL_V + (d0 + u) * DUMP;
 #pragma unroll
