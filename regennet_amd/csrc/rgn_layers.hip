@@ -202,8 +202,14 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
             }
     };
     // LayerNorm over the 512 columns of every token, in place: one exchange of (sum, sum of squares) - rgn_mlp2.hip
+    // (v_permlane32_swap_b32 a, b: a' = [a.lo | b.lo], b' = [a.hi | b.hi] over the wave's two halves. Inline asm: the builtin's second result is
+    //  miscompiled by ROCm 7.2's clang - it adds a' to itself - and both operands must be DIFFERENT registers)
+    auto swap32 = [](float& a2, float& b2) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a2), "+v"(b2)); };
+    int red_base2 = red_base + 128 * kh;                         // post-barrier reads: lane (l31, kh) reduces token 32 kh + l31
+    asm volatile("" : "+v"(red_base2));
     auto layernorm = [&](f32x16 (&acc)[2][2], const float* gam, auto slot, auto shift /* (nt, i4) -> f32x4 */) {
         const char* buf = smem + red_base + decltype(slot)::value * LY_REDF * 4;
+        const char* buf2 = smem + red_base2 + decltype(slot)::value * LY_REDF * 4;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             f32x2 s2 = f32x2{0.f, 0.f}, q2 = f32x2{0.f, 0.f};
@@ -216,20 +222,19 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                     q2 = __builtin_elementwise_fma(v, v, q2);
                 }
             float s = s2[0] + s2[1], q = q2[0] + q2[1];
-            s += __shfl_xor(s, 32, 64);
-            q += __shfl_xor(q, 32, 64);
-            *reinterpret_cast<float*>(const_cast<char*>(buf) + (kh * 512 + wave * 64 + 32 * mt) * 4) = kh ? q : s;
+            swap32(s, q);                                        // s = [s.lo | q.lo], q = [s.hi | q.hi]
+            *reinterpret_cast<float*>(const_cast<char*>(buf) + (kh * 512 + wave * 64 + 32 * mt) * 4) = s + q;   // kh = 0: the sum, kh = 1: the sum of squares
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        // the halves share the work: lane (l31, kh) reduces the eight partials of token 32 kh + l31, then the two results change hands
         f32x2 rs[2], nm[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        {
             float p[2][8];
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
-                for (int ww = 0; ww < 8; ++ww) p[st][ww] = *reinterpret_cast<const float*>(buf + (st * 512 + ww * 64 + 32 * mt) * 4);
+                for (int ww = 0; ww < 8; ++ww) p[st][ww] = *reinterpret_cast<const float*>(buf2 + (st * 512 + ww * 64) * 4);
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -238,9 +243,13 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                     for (int ww = 0; ww < 8; ww += 2 * dd) p[st][ww] += p[st][ww + dd];
             const float mean = p[0][0] * invn;
             const float var = __builtin_fmaxf(p[1][0] * invn - mean * mean, 0.f);
-            const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
-            rs[mt] = f32x2{rstd, rstd};
-            nm[mt] = f32x2{-mean * rstd, -mean * rstd};
+            float r0 = __builtin_amdgcn_rsqf(var + 1e-5f), n0 = -mean * r0;
+            float r1 = r0, n1 = n0;
+            asm volatile("" : "+v"(r1), "+v"(n1));               // (copies in registers of their own)
+            swap32(r0, r1);                                      // r0 = token l31's (tile 0), r1 = token 32 + l31's (tile 1), in every lane
+            swap32(n0, n1);
+            rs[0] = f32x2{r0, r0}; rs[1] = f32x2{r1, r1};
+            nm[0] = f32x2{n0, n0}; nm[1] = f32x2{n1, n1};
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
