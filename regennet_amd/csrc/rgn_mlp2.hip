@@ -203,8 +203,13 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
     int red_base = C::RED + 4 * l31;
     asm volatile("" : "+v"(red_base));
     const float invn = 1.0f / 512.f;
+    // (v_permlane32_swap_b32 a, b: a' = [a.lo | b.lo], b' = [a.hi | b.hi] over the wave's two halves; inline asm, two DIFFERENT registers: see rgn_layers.hip)
+    auto swap32 = [](float& a2, float& b2) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a2), "+v"(b2)); };
+    int red_base2 = red_base + (MT == 2 ? 128 * kh : 0);        // MT = 2, post-barrier reads: lane (l31, kh) reduces token 32 kh + l31
+    asm volatile("" : "+v"(red_base2));
     auto layernorm = [&](f32x16 (&acc)[NT][MT], const float* gam, auto slot, auto shift /* (nt, i4, mt) -> f32x4 */) {
         const char* buf = smem + red_base + decltype(slot)::value * C::REDF * 4;   // two alternating buffers: a barrier separates each write from its reads
+        const char* buf2 = smem + red_base2 + decltype(slot)::value * C::REDF * 4;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             f32x2 s2 = f32x2{0.f, 0.f}, q2 = f32x2{0.f, 0.f};
@@ -217,20 +222,18 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
                     q2 = __builtin_elementwise_fma(v, v, q2);
                 }
             float s = s2[0] + s2[1], q = q2[0] + q2[1];
-            s += __shfl_xor(s, 32, 64);
-            q += __shfl_xor(q, 32, 64);
-            *reinterpret_cast<float*>(const_cast<char*>(buf) + (kh * (NW * R) + wave * R + 32 * mt) * 4) = kh ? q : s;
+            swap32(s, q);                                        // s = [s.lo | q.lo], q = [s.hi | q.hi]
+            *reinterpret_cast<float*>(const_cast<char*>(buf) + (kh * (NW * R) + wave * R + 32 * mt) * 4) = s + q;   // kh = 0: the sum, kh = 1: the sum of squares
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         f32x2 rs[MT], nm[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        {   // MT = 2: the halves share the work - lane (l31, kh) reduces the partials of token 32 kh + l31, two swaps hand the results over
             float p[2][NW];
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
-                for (int w = 0; w < NW; ++w) p[st][w] = *reinterpret_cast<const float*>(buf + (st * (NW * R) + w * R + 32 * mt) * 4);
+                for (int w = 0; w < NW; ++w) p[st][w] = *reinterpret_cast<const float*>(buf2 + (st * (NW * R) + w * R) * 4);
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -239,9 +242,17 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
                     for (int w = 0; w < NW; w += 2 * d) p[st][w] += p[st][w + d];
             const float mean = p[0][0] * invn;
             const float var = __builtin_fmaxf(p[1][0] * invn - mean * mean, 0.f);
-            const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
-            rs[mt] = f32x2{rstd, rstd};
-            nm[mt] = f32x2{-mean * rstd, -mean * rstd};
+            float r0 = __builtin_amdgcn_rsqf(var + 1e-5f), n0 = -mean * r0;
+            if constexpr (MT == 2) {
+                float r1 = r0, n1 = n0;
+                asm volatile("" : "+v"(r1), "+v"(n1));           // (copies in registers of their own)
+                swap32(r0, r1);
+                swap32(n0, n1);
+                rs[MT - 1] = f32x2{r1, r1};
+                nm[MT - 1] = f32x2{n1, n1};
+            }
+            rs[0] = f32x2{r0, r0};
+            nm[0] = f32x2{n0, n0};
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
