@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64 * NT) void k_attn_x3(AttnX3Args a) {
                 mx = fmaxf(mx, st[kj][i]);
             }
         }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = half_max(mx);
     float sum = 0.f;
 #pragma unroll
     for (int kj = 0; kj < NT; ++kj)
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64 * NT) void k_attn_x3(AttnX3Args a) {
                 sum += e;
             }
         }
-    sum += __shfl_xor(sum, 32, 64);
+    sum = half_sum(sum);
     const float inv = 1.0f / sum;
     __syncthreads();          // every wave is done with K
     // ---- V -> LDS transposed: Vt[dh][key] (row stride VLD); lanes run along key PAIRS so each ds_write_b32 packs

@@ -114,7 +114,7 @@ __device__ __forceinline__ void x3_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
                     for (int i = 0; i < 8; ++i) {
                         const float mine = (odd ? r[i + 8] : r[i]) * sc;
                         const float give = (odd ? r[i] : r[i + 8]) * sc;
-                        const float got = __shfl_xor(give, 1, 64);
+                        const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));   // lane ^ 1: quad_perm [1, 0, 3, 2]
                         const float c0 = odd ? got : mine, c1 = odd ? mine : got;
                         const int ii = odd ? i + 8 : i;
                         const unsigned m = (unsigned)(mb + (ii & 3) + 8 * (ii >> 2));
@@ -162,7 +162,7 @@ __device__ __forceinline__ void x3_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
                     for (int i = 0; i < 8; ++i) {
                         const float mine = odd ? r[i + 8] : r[i];          // value this lane contributes to its own store
                         const float give = odd ? r[i] : r[i + 8];          // value the partner needs
-                        const float got = __shfl_xor(give, 1, 64);
+                        const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));   // lane ^ 1: quad_perm [1, 0, 3, 2]
                         const float lo_col = odd ? got : mine, hi_col = odd ? mine : got;   // columns n&~1, (n&~1)+1
                         const int ii = odd ? i + 8 : i;
                         const int ro = (ii & 3) + 8 * (ii >> 2);

@@ -243,6 +243,23 @@ __device__ __forceinline__ int xcd_affine(int bid, int nwg) {
     return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
 }
 
+// The other half-wave's value (lane ^ 32): v_permlane32_swap_b32 a, b gives a' = [a.lo | b.lo], b' = [a.hi | b.hi], so with b a copy of a in a
+// register of its own b' and a' are the two halves' values in every lane - one VALU instruction where __shfl_xor(v, 32) is a ds_bpermute round trip.
+// (inline asm: the builtin's second result is miscompiled by ROCm 7.2's clang, it adds a' to itself; tools/permlane_check.hip)
+__device__ __forceinline__ void half_swap(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float half_max(float v) {
+    float o = v;
+    asm volatile("" : "+v"(o));
+    half_swap(v, o);
+    return fmaxf(v, o);
+}
+__device__ __forceinline__ float half_sum(float v) {
+    float o = v;
+    asm volatile("" : "+v"(o));
+    half_swap(v, o);
+    return v + o;
+}
+
 // Step boundary of the plain-bf16 phase as one kernel (rgn_step.hip): output projection + sampler update + the next
 // evaluation's input embedding for 64-row tiles; d = 512, no emb_trans_dec token; with or without guidance.
 struct StepCoef;

@@ -202,9 +202,6 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
             }
     };
     // LayerNorm over the 512 columns of every token, in place: one exchange of (sum, sum of squares) - rgn_mlp2.hip
-    // (v_permlane32_swap_b32 a, b: a' = [a.lo | b.lo], b' = [a.hi | b.hi] over the wave's two halves. Inline asm: the builtin's second result is
-    //  miscompiled by ROCm 7.2's clang - it adds a' to itself - and both operands must be DIFFERENT registers)
-    auto swap32 = [](float& a2, float& b2) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a2), "+v"(b2)); };
     int red_base2 = red_base + 128 * kh;                         // post-barrier reads: lane (l31, kh) reduces token 32 kh + l31
     asm volatile("" : "+v"(red_base2));
     auto layernorm = [&](f32x16 (&acc)[2][2], const float* gam, auto slot, auto shift /* (nt, i4) -> f32x4 */) {
@@ -222,7 +219,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                     q2 = __builtin_elementwise_fma(v, v, q2);
                 }
             float s = s2[0] + s2[1], q = q2[0] + q2[1];
-            swap32(s, q);                                        // s = [s.lo | q.lo], q = [s.hi | q.hi]
+            half_swap(s, q);                                        // s = [s.lo | q.lo], q = [s.hi | q.hi]
             *reinterpret_cast<float*>(const_cast<char*>(buf) + (kh * 512 + wave * 64 + 32 * mt) * 4) = s + q;   // kh = 0: the sum, kh = 1: the sum of squares
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -246,8 +243,8 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
             float r0 = __builtin_amdgcn_rsqf(var + 1e-5f), n0 = -mean * r0;
             float r1 = r0, n1 = n0;
             asm volatile("" : "+v"(r1), "+v"(n1));               // (copies in registers of their own)
-            swap32(r0, r1);                                      // r0 = token l31's (tile 0), r1 = token 32 + l31's (tile 1), in every lane
-            swap32(n0, n1);
+            half_swap(r0, r1);                                      // r0 = token l31's (tile 0), r1 = token 32 + l31's (tile 1), in every lane
+            half_swap(n0, n1);
             rs[0] = f32x2{r0, r0}; rs[1] = f32x2{r1, r1};
             nm[0] = f32x2{n0, n0}; nm[1] = f32x2{n1, n1};
         }

@@ -203,8 +203,6 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
     int red_base = C::RED + 4 * l31;
     asm volatile("" : "+v"(red_base));
     const float invn = 1.0f / 512.f;
-    // (v_permlane32_swap_b32 a, b: a' = [a.lo | b.lo], b' = [a.hi | b.hi] over the wave's two halves; inline asm, two DIFFERENT registers: see rgn_layers.hip)
-    auto swap32 = [](float& a2, float& b2) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a2), "+v"(b2)); };
     int red_base2 = red_base + (MT == 2 ? 128 * kh : 0);        // MT = 2, post-barrier reads: lane (l31, kh) reduces token 32 kh + l31
     asm volatile("" : "+v"(red_base2));
     auto layernorm = [&](f32x16 (&acc)[NT][MT], const float* gam, auto slot, auto shift /* (nt, i4, mt) -> f32x4 */) {
@@ -222,7 +220,7 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
                     q2 = __builtin_elementwise_fma(v, v, q2);
                 }
             float s = s2[0] + s2[1], q = q2[0] + q2[1];
-            swap32(s, q);                                        // s = [s.lo | q.lo], q = [s.hi | q.hi]
+            half_swap(s, q);                                        // s = [s.lo | q.lo], q = [s.hi | q.hi]
             *reinterpret_cast<float*>(const_cast<char*>(buf) + (kh * (NW * R) + wave * R + 32 * mt) * 4) = s + q;   // kh = 0: the sum, kh = 1: the sum of squares
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -246,8 +244,8 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
             if constexpr (MT == 2) {
                 float r1 = r0, n1 = n0;
                 asm volatile("" : "+v"(r1), "+v"(n1));           // (copies in registers of their own)
-                swap32(r0, r1);
-                swap32(n0, n1);
+                half_swap(r0, r1);
+                half_swap(n0, n1);
                 rs[MT - 1] = f32x2{r1, r1};
                 nm[MT - 1] = f32x2{n1, n1};
             }

@@ -167,7 +167,7 @@ __device__ __forceinline__ void qa_attention(f32x16 (&acc)[2][3], const QkvAttnA
                 mx = fmaxf(mx, st[tl][i]);
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = half_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int tl = qtile; tl <= 2 * qtile; ++tl)
@@ -177,7 +177,7 @@ __device__ __forceinline__ void qa_attention(f32x16 (&acc)[2][3], const QkvAttnA
                 st[tl][i] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 32, 64);
+        sum = half_sum(sum);
         inv[qtile] = 1.0f / sum;
     }
     RGN_QT(hslot * 8 + 5)

@@ -221,12 +221,7 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
                     st[i] = ok ? st[i] : -INFINITY;
                     mt = fmaxf(mt, st[i]);
                 }
-                {   // the other half-wave's maximum: one v_permlane32_swap (inline asm, two different registers: rgn_layers.hip) instead of a ds_bpermute round trip
-                    float mo = mt;
-                    asm volatile("" : "+v"(mo));
-                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(mt), "+v"(mo));
-                    mt = fmaxf(mt, mo);
-                }
+                mt = half_max(mt);                                    // (one v_permlane32_swap instead of a ds_bpermute round trip: rgn_internal.h)
                 const float m_new = fmaxf(fmaxf(m_run, mt), -1e30f);   // (a unit with no valid key at all - rows beyond Tq only - stays finite)
                 const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * qs2);   // (first tile: exp2(-inf) = 0)
                 const float nm = -m_new * qs2;
@@ -259,12 +254,7 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
                 }
             }
         }
-        {
-            float lo2 = l_run;
-            asm volatile("" : "+v"(lo2));
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(l_run), "+v"(lo2));
-            l_run += lo2;
-        }
+        l_run = half_sum(l_run);
     }
     RGN_LT(3)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512) void k_sb_qkv_attn(SbArgs g) {
                 mx = fmaxf(mx, st[kj][i]);
             }
         }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = half_max(mx);
     float sum = 0.f;
 #pragma unroll
     for (int kj = 0; kj < 2; ++kj)
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(512) void k_sb_qkv_attn(SbArgs g) {
                 sum += e;
             }
         }
-    sum += __shfl_xor(sum, 32, 64);
+    sum = half_sum(sum);
     const float inv = 1.0f / sum;
     f32x16 oa[ND];
 #pragma unroll
