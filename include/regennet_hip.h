@@ -160,6 +160,13 @@ int rgn_set_small_batch_rows(rgn_handle h, int32_t rows);
 /* Fills x_dev [B,njoints,nfeats,T] with N(0,1) from the same Philox stream (x_T, gaussian_diffusion.py:706). */
 int rgn_randn(rgn_handle h, float* x_dev, int32_t B, uint64_t seed, uint64_t sample_offset, void* stream);
 
+/* The noise rgn_sample_range adds at loop index `loop_index` (th.randn_like(x), gaussian_diffusion.py:544 / :792), for
+ * callers that run the reference's own per-step loop (p_sample / ddim_sample around rgn_denoise: inpainting masks,
+ * y['uncond']) and want the SAME draws as the fused loop for a given (seed, sample_offset): [B,njoints,nfeats,T],
+ * value (motion b, feature, frame) = Philox(seed; sample_offset + b, loop_index, feature * 4096 + frame).
+ * loop_index = -1 is rgn_randn's x_T draw; loop_index < -1: RGN_ERR_INVALID_ARG. */
+int rgn_randn_step(rgn_handle h, float* x_dev, int32_t B, uint64_t seed, uint64_t sample_offset, int32_t loop_index, void* stream);
+
 /* Post-processing rows next to the path:
  * rot6d -> rotation matrices, Gram-Schmidt (utils/rotation_conversions.py:513-534): d6 [n,6] -> [n,3,3] */
 int rgn_rot6d_to_matrix(rgn_handle h, const float* d6_dev, float* mat_dev, int64_t n, void* stream);

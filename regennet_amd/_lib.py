@@ -57,6 +57,7 @@ SYMBOLS = {
     "rgn_set_small_batch_rows": (C.c_int, [_vp, _i32]),
     "rgn_set_const_noise": (C.c_int, [_vp, _i32]),
     "rgn_randn": (C.c_int, [_vp, _vp, _i32, _u64, _u64, _vp]),
+    "rgn_randn_step": (C.c_int, [_vp, _vp, _i32, _u64, _u64, _i32, _vp]),
     "rgn_rot6d_to_matrix": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "rgn_gaussian_filter1d": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "rgn_profile_enable": (C.c_int, [_vp, _i32]),
@@ -219,6 +220,10 @@ class Engine:
 
     def randn(self, x, B, seed, sample_offset, stream):
         self._ck(self.lib.rgn_randn(self.h, _ptr(x), int(B), int(seed) & (2 ** 64 - 1), int(sample_offset), C.c_void_p(stream)))
+
+    def randn_step(self, x, B, seed, sample_offset, loop_index, stream):
+        """The fused loop's noise of loop index `loop_index` (-1: x_T) into x [B,njoints,nfeats,T]."""
+        self._ck(self.lib.rgn_randn_step(self.h, _ptr(x), int(B), int(seed) & (2 ** 64 - 1), int(sample_offset), int(loop_index), C.c_void_p(stream)))
 
     def rot6d_to_matrix(self, d6, mat, n, stream):
         self._ck(self.lib.rgn_rot6d_to_matrix(self.h, _ptr(d6), _ptr(mat), int(n), C.c_void_p(stream)))

@@ -1475,16 +1475,22 @@ int rgn_set_small_batch_rows(rgn_handle h, int32_t rows) {
     return RGN_OK;
 }
 
-int rgn_randn(rgn_handle h, float* x, int32_t B, uint64_t seed, uint64_t sample_offset, void* stream) {
+int rgn_randn_step(rgn_handle h, float* x, int32_t B, uint64_t seed, uint64_t sample_offset, int32_t loop_index, void* stream) {
     if (!h) return RGN_ERR_INVALID_ARG;
     if (!x || B <= 0) return h->fail(RGN_ERR_INVALID_ARG, "rgn_randn: null x or B <= 0");
+    if (loop_index < -1) return h->fail(RGN_ERR_INVALID_ARG, "rgn_randn_step: loop_index < -1");
     RGN_HIP(h, hipSetDevice(h->cfg.device));
     if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_randn: weights not finalized");
     hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = h->stream;
     int rc = stream_enter(h, us);
     if (rc) return rc;
-    RGN_LAUNCH(h, KC_UPDATE, s, launch_randn(x, B, h->F * h->cfg.num_frames, h->cfg.num_frames, seed, sample_offset, s));
+    // Philox stream word: the loop index of the step the noise belongs to; 0xFFFFFFFF (loop_index -1) is the x_T draw
+    RGN_LAUNCH(h, KC_UPDATE, s, launch_randn(x, B, h->F * h->cfg.num_frames, h->cfg.num_frames, seed, sample_offset, (uint32_t)loop_index, s));
     return stream_exit(h, us);
+}
+
+int rgn_randn(rgn_handle h, float* x, int32_t B, uint64_t seed, uint64_t sample_offset, void* stream) {
+    return rgn_randn_step(h, x, B, seed, sample_offset, -1, stream);
 }
 
 int rgn_rot6d_to_matrix(rgn_handle h, const float* d6, float* mat, int64_t n, void* stream) {

@@ -325,7 +325,7 @@ hipError_t launch_cond_rows(const float* table, const int64_t* action, float* ou
 hipError_t launch_fill_rows(float* out, const float* row, int rows, int d, hipStream_t s);
 hipError_t launch_cvt_bf16(const float* in, __bf16* out, size_t n, hipStream_t s);
 hipError_t launch_randn(float* x, int B, int FT, int T, unsigned long long seed, unsigned long long sample_offset,
-                        hipStream_t s);
+                        uint32_t noise_stream, hipStream_t s);
 hipError_t launch_rot6d(const float* d6, float* mat, long long n, hipStream_t s);
 hipError_t launch_gauss1d(const float* x, float* out, long long rows, int T, float sigma, hipStream_t s);
 

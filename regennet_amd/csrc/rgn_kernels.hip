@@ -838,15 +838,15 @@ hipError_t launch_pack_x(const float* x, float* xin, Planes xp, int copies, cons
 // The element counter is (feature * 4096 + frame), not the flat index: the draw for (sample, step, feature, frame) does
 // not depend on the sequence length, so a run truncated to the first frames (auto_regressive evaluation: frame f only
 // needs tokens 0..f of a causal decoder) sees the same noise as the full-length run.
-__global__ void k_randn(float* __restrict__ x, int B, int FT, int T, unsigned long long seed, unsigned long long off) {
+__global__ void k_randn(float* __restrict__ x, int B, int FT, int T, unsigned long long seed, unsigned long long off, uint32_t stream) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)B * FT) return;
     const int b = (int)(idx / FT), e = (int)(idx - (size_t)b * FT);
-    x[idx] = philox_normal(seed, off + b, 0xFFFFFFFFu, (uint32_t)((e / T) * 4096 + e % T));   // stream 0xFFFFFFFF = x_T draw
+    x[idx] = philox_normal(seed, off + b, stream, (uint32_t)((e / T) * 4096 + e % T));   // stream 0xFFFFFFFF = x_T draw, k = loop index k's noise
 }
-hipError_t launch_randn(float* x, int B, int FT, int T, unsigned long long seed, unsigned long long off, hipStream_t s) {
+hipError_t launch_randn(float* x, int B, int FT, int T, unsigned long long seed, unsigned long long off, uint32_t stream, hipStream_t s) {
     const size_t n = (size_t)B * FT;
-    hipLaunchKernelGGL(k_randn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, B, FT, T, seed, off);
+    hipLaunchKernelGGL(k_randn, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, B, FT, T, seed, off, stream);
     return hipGetLastError();
 }
 

@@ -9,6 +9,7 @@ ddim_sample_loop :891-909) so sample/cgenerate.py:121-135 and eval/a2m/stgcn_eva
 """
 import enum
 import math
+import os
 import sys
 from copy import deepcopy
 
@@ -325,8 +326,12 @@ class GaussianDiffusion:
         ys = {k: (v[:nb].contiguous() if th.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B else (v[:nb] if isinstance(v, (list, tuple)) and len(v) == B else v))
               for k, v in y.items()}
         saved, self._calibrating, self._last_calibration_dev = (inner.x3_tail, inner._auto_tail, inner.small_batch_rows), True, 0.0
-        if B * int(shape[3]) * (2 if inner is not model else 1) > 640:
-            inner.small_batch_rows = 0      # calibrate on the kernels the caller's batch will run (throughput engine), not the small-batch ones
+        # calibrate on the kernels the CALLER's batch will run: the small-batch engine takes evaluations of at most sb token rows
+        # (motions x tokens, doubled under guidance; rgn_set_small_batch_rows: the model's setting, else REGENNET_SB_ROWS, else 640)
+        sb = inner.small_batch_rows if inner.small_batch_rows is not None else int(os.environ.get("REGENNET_SB_ROWS", "640"))
+        Tq = int(shape[3]) + (1 if getattr(inner, "emb_trans_dec", False) else 0)
+        if B * Tq * (2 if inner is not model else 1) > int(sb):
+            inner.small_batch_rows = 0      # the 4 calibration motions alone would fall under the threshold: force the throughput engine
         fn = self.p_sample_loop if sampler == "ddpm" else self.ddim_sample_loop
         kw = dict(clip_denoised=False, model_kwargs={"y": ys}, seed=seed)
         if sampler == "ddim":
@@ -359,15 +364,13 @@ class GaussianDiffusion:
         return chosen
 
     @staticmethod
-    def _keyed_normal(shape, seed, sample_offset, stream, dev):
-        """N(0,1) [B, ...] in which motion b's values depend on (seed, sample_offset + b, stream) only: the per-step API's
-        counterpart of the engine's Philox keying (results do not depend on how a batch is split over ranks or calls)."""
-        g = th.Generator(device="cpu")
-        rows = []
-        for b in range(int(shape[0])):
-            g.manual_seed(((int(seed) * 1000003 + int(sample_offset) + b) * 8191 + int(stream) + 1) % (2 ** 63 - 1))
-            rows.append(th.randn(tuple(shape[1:]), generator=g))
-        return th.stack(rows).to(dev)
+    def _keyed_normal(eng, shape, seed, sample_offset, loop_index, dev):
+        """N(0,1) [B,njoints,nfeats,T] drawn ON THE DEVICE from the engine's Philox stream (rgn_randn_step): exactly the draw the
+        fused loop makes at loop index `loop_index` (-1: x_T) for (seed, sample_offset + b) - so a seeded call gives the same noise
+        whether it runs fused or per step, and a motion's noise does not depend on how a batch is split over ranks or calls."""
+        out = th.empty(tuple(shape), device=dev, dtype=th.float32)
+        eng.randn_step(out, int(shape[0]), seed, sample_offset, loop_index, th.cuda.current_stream(dev).cuda_stream)
+        return out
 
     def _loop_per_step(self, sampler, model, shape, noise, clip_denoised, model_kwargs, progress, skip_timesteps, init_image,
                        eta, noise_tape, const_noise=False, seed=None, sample_offset=0):
@@ -377,12 +380,16 @@ class GaussianDiffusion:
         like the reference."""
         dev = next(model.parameters()).device
         B, S = int(shape[0]), self.num_timesteps
+        eng = None
+        if seed is not None and noise_tape is None:
+            # the engine the per-step forward() will use (same cached bind): its Philox stream supplies the noise
+            eng, _, dev = _engine_of(model)(B, model_kwargs["y"], None, T=int(shape[3]), cache=True)
         if noise is not None:
             img = noise.to(dev)
         elif noise_tape is not None:
             img = noise_tape[0].to(device=dev, dtype=th.float32)
         elif seed is not None:
-            img = self._keyed_normal(shape, seed, sample_offset, -1, dev)
+            img = self._keyed_normal(eng, shape, seed, sample_offset, -1, dev)
         else:
             img = th.randn(*shape, device=dev)
         if skip_timesteps and init_image is None:
@@ -398,7 +405,7 @@ class GaussianDiffusion:
             t = th.tensor([i] * B, device=dev)
             eps = None if noise_tape is None else noise_tape[1 + k].to(device=dev, dtype=th.float32)
             if eps is None and seed is not None:
-                eps = self._keyed_normal(shape, seed, sample_offset, i, dev)
+                eps = self._keyed_normal(eng, shape, seed, sample_offset, i, dev)
             with th.no_grad():
                 if sampler == "ddpm":
                     out = self.p_sample(model, img, t, clip_denoised=clip_denoised, model_kwargs=model_kwargs, _noise=eps,

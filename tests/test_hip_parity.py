@@ -944,6 +944,20 @@ def test_model_kwargs_the_fused_loop_does_not_read():
     per_step = diffusion.p_sample_loop(model, shape, clip_denoised=False, noise_tape=tape,
                                        model_kwargs={"y": dict(y, inpainting_mask=none, inpainted_motion=target)})
     assert (per_step - fused).abs().max().item() < 1e-4      # same kernels; the per-step API evaluates the timestep MLP per call
+    # the same with a SEED instead of a tape: the per-step loop draws the fused loop's own Philox stream (rgn_randn_step), for x_T and
+    # for every step, and a motion's draws follow its GLOBAL index (sample_offset), not its place in the call
+    fused_s = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y}, seed=77, sample_offset=5)
+    per_step_s = diffusion.p_sample_loop(model, shape, clip_denoised=False, seed=77, sample_offset=5,
+                                         model_kwargs={"y": dict(y, inpainting_mask=none, inpainted_motion=target)})
+    assert (per_step_s - fused_s).abs().max().item() < 1e-4 and not torch.allclose(fused_s, fused, atol=1e-2)
+    y1 = {k: v[1:] for k, v in y.items()}
+    one = diffusion.p_sample_loop(model, (1,) + shape[1:], clip_denoised=False, seed=77, sample_offset=6,
+                                  model_kwargs={"y": dict(y1, inpainting_mask=none[1:], inpainted_motion=target[1:])})
+    assert (one[0] - per_step_s[1]).abs().max().item() < 1e-4
+    eng = model._rgn_bind(B, y)[0]
+    z = torch.empty(shape, device="cuda")
+    with pytest.raises(RuntimeError):
+        eng.randn_step(z, B, 77, 0, -2, 0)                    # loop_index < -1: RGN_ERR_INVALID_ARG
     # mask everything: x_0 is the inpainted motion (coef1[0] = 1, coef2[0] = 0, no noise at t = 0)
     every = torch.ones(shape, dtype=torch.bool, device="cuda")
     forced = diffusion.p_sample_loop(model, shape, clip_denoised=False, noise_tape=tape,
