@@ -722,6 +722,29 @@ def test_chi3d_full_size_shard_is_row_independent(precision, tail):
             assert torch.allclose(full[b:b + 1], one, atol=2e-5), (b, (full[b:b + 1] - one).abs().max().item())
 
 
+_BENCH_SHAPE_REF = {}
+
+
+def _bench_shape_reference(cfg_name, mode, resp, guided, B):
+    """Inputs + oracle result of one bench-shape case, computed once per session (the four precision cases share them: the oracle's
+    B=256 run is ~20 s of host CPU)."""
+    key = (cfg_name, mode, resp, guided, B)
+    if key not in _BENCH_SHAPE_REF:
+        from oracle import regennet_oracle as orc
+        from regennet_amd import synth
+        cfg = synth.get_config(cfg_name)
+        sd = synth.make_state_dict(cfg, seed=0)
+        y = {"cmotion": synth.make_cmotion(cfg, B, seed=41)}
+        if guided:
+            y["action"] = synth.make_actions(cfg, B, seed=42)
+            y["scale"] = np.full((B,), 2.5, dtype=np.float32)
+        tape = synth.make_noise_tape(cfg, B, 3, seed=43)
+        ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", resp), tape, {k: torch.from_numpy(v) for k, v in y.items()},
+                              mode=mode, guided=guided).numpy()
+        _BENCH_SHAPE_REF[key] = (cfg, sd, y, tape, ref)
+    return _BENCH_SHAPE_REF[key]
+
+
 @pytest.mark.parametrize("precision,tail,tol", [("f32", None, 2e-4), ("bf16x3", None, 1e-3), ("bf16_x3tail", None, 1e-3),
                                                  ("bf16_x3tail", 0, 0.15)])
 def test_bench_shape_against_the_oracle(precision, tail, tol):
@@ -733,15 +756,7 @@ def test_bench_shape_against_the_oracle(precision, tail, tol):
     from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
     B = 256
     for cfg_name, mode, resp, guided in (("ntu", "ddpm", "3", False), ("ntu_action", "ddim", "ddim3", True)):
-        cfg = synth.get_config(cfg_name)
-        sd = synth.make_state_dict(cfg, seed=0)
-        y = {"cmotion": synth.make_cmotion(cfg, B, seed=41)}
-        if guided:
-            y["action"] = synth.make_actions(cfg, B, seed=42)
-            y["scale"] = np.full((B,), 2.5, dtype=np.float32)
-        tape = synth.make_noise_tape(cfg, B, 3, seed=43)
-        ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", resp), tape, {k: torch.from_numpy(v) for k, v in y.items()},
-                              mode=mode, guided=guided).numpy()
+        cfg, sd, y, tape, ref = _bench_shape_reference(cfg_name, mode, resp, guided, B)
         model, diffusion = build_hip(cfg, sd, resp=resp, precision=precision, x3_tail=tail)
         fm = ClassifierFreeSampleModel(model) if guided else model
         fn = diffusion.p_sample_loop if mode == "ddpm" else diffusion.ddim_sample_loop
@@ -769,13 +784,17 @@ def test_bench_shape_bulk_phase_against_the_oracle():
             y["action"] = synth.make_actions(cfg, B, seed=52)
             y["scale"] = np.full((B,), 2.5, dtype=np.float32)
         tape = synth.make_noise_tape(cfg, B, 16, seed=53)
-        ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", resp), tape, {k: torch.from_numpy(v) for k, v in y.items()},
-                              mode=mode, guided=guided).numpy()
+        # the oracle (host CPU) runs every 4th motion - motions are independent, 64 of them sit on 64 different workgroups of all 8 XCDs -
+        # the HIP path runs the full bench batch
+        idx = np.arange(0, B, 4)
+        ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", resp), np.ascontiguousarray(tape[:, idx]),
+                              {k: torch.from_numpy(np.ascontiguousarray(v[idx])) for k, v in y.items()}, mode=mode, guided=guided).numpy()
         model, diffusion = build_hip(cfg, sd, resp=resp, precision="bf16_x3tail")
         fm = ClassifierFreeSampleModel(model) if guided else model
         fn = diffusion.p_sample_loop if mode == "ddpm" else diffusion.ddim_sample_loop
         out = fn(fm, (B, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
-        err = float(np.abs(out.cpu().numpy() - ref).max())
+        assert torch.isfinite(out).all()
+        err = float(np.abs(out.cpu().numpy()[idx] - ref).max())
         print(f"\n[bench shape, 11 bulk + 5 tail steps vs oracle] {cfg_name} {mode} guided={guided}: {err:.2e}")
         assert err < 1e-3, (cfg_name, err)
         model._engine.close()
