@@ -31,6 +31,7 @@ struct HostTensor {
 struct Lin {  // one packed nn.Linear: offsets (bytes) into the weight blob
     size_t w = 0, hi = 0, lo = 0, b = 0;   // fp32 [N,Kp]; bf16 hi/lo planes (row-major [N,Kp] or K32-blocked)
     size_t fr = 0;                         // bf16 hi plane in MFMA-fragment order (operand of k_rowgemm), optional
+    size_t fr_lo = 0;                      // bf16 lo plane in the same order (operand of k_mlp_x3), optional
     int N = 0, K = 0, Kp = 0;
     bool has_bias = false;
     bool blocked = false;                  // hi/lo are K32-blocked [Kp/32][N][32] (operands of k_gemm_x3)
@@ -95,6 +96,7 @@ struct rgn_ctx {
     int big_tile_rows = 7000;          // launches of at least this many rows per chain use the 256x256 GEMM tile
     bool rowgemm = false;              // plain-bf16 phase: row-complete GEMMs with fused LayerNorm / GELU (k_rowgemm)
     bool mlp = false;                  // plain-bf16 phase: the whole layer tail in one row-persistent kernel (k_mlp)
+    bool mlp_x3 = false;               // split-bf16 phase: the whole layer tail in one row-persistent kernel (k_mlp_x3, REGENNET_MLP_X3)
     bool step_fused = false;           // plain-bf16 phase: output projection (+ guidance) + sampler update + next input embedding in one kernel (REGENNET_NO_STEP_FUSION=1: three launches)
     bool layers_fused = false;         // plain-bf16 phase, <= 64 tokens: the whole decoder stack of an evaluation as one kernel, one sample per workgroup (k_layers; REGENNET_LAYERS=0: kernel per stage)
     int layers_min_b = 64;             // ... for evaluations of at least this many samples (REGENNET_LAYERS_MIN_B): one workgroup per sample is a latency chain of 8 layers (250-step calls: 114 ms at any B <= 256), the kernel-per-stage form spreads a sample over more CUs (B = 16 / 32 / 48: 110-111 ms; B = 64: 114.4 vs 113.6)
@@ -254,7 +256,7 @@ size_t blob_put(rgn_ctx* c, const void* src, size_t bytes) {
 }
 
 // Pack W[N,K] (row-major fp32) into fp32 [N,Kp] plus bf16 hi/lo planes; bias optional.
-Lin pack_linear(rgn_ctx* c, const float* W, const float* bias, int N, int K, bool blocked = false, bool frag = false) {
+Lin pack_linear(rgn_ctx* c, const float* W, const float* bias, int N, int K, bool blocked = false, bool frag = false, bool frag_lo = false) {
     Lin L;
     L.blocked = blocked;
     L.N = N;
@@ -286,6 +288,16 @@ Lin pack_linear(rgn_ctx* c, const float* W, const float* bias, int N, int K, boo
                 fr[(((kt * nb_all + n / 32) * 2 + ks) * 64 + lane) * 8 + k % 8] = f2bf(W[(size_t)n * K + k]);
             }
         L.fr = blob_put(c, fr.data(), fr.size() * 2);
+        if (frag_lo) {   // the lo plane of the split, same order: with fr the operand pair of k_mlp_x3
+            std::vector<uint16_t> fl(Np * L.Kp, 0);
+            for (int n = 0; n < N; ++n)
+                for (int k = 0; k < K; ++k) {
+                    const size_t kt = k / 32, ks = (k % 32) / 16, lane = 32 * ((k % 16) / 8) + n % 32;
+                    const float v = W[(size_t)n * K + k];
+                    fl[(((kt * nb_all + n / 32) * 2 + ks) * 64 + lane) * 8 + k % 8] = f2bf(v - bf2f(f2bf(v)));
+                }
+            L.fr_lo = blob_put(c, fl.data(), fl.size() * 2);
+        }
     }
     if (bias) {
         L.b = blob_put(c, bias, (size_t)N * 4);
@@ -667,6 +679,22 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
         const float* per_sample = sampling ? (ccond_rows ? ccond_rows + (size_t)s0 * Ld + (size_t)l * d : nullptr)
                                            : c->call + (size_t)s0 * Ld + (size_t)l * d;
         const float* step_vec = sampling ? c->call_time + (size_t)l * d : nullptr;
+        if (fast && x3 && c->mlp_x3 && h_p.lo && att_p.lo && w.out.fr_lo && w.ff1.fr_lo && w.ff2.fr_lo) {
+            // split-bf16 phase, d = 512 / ff = 1024: the same layer tail on (hi, lo) plane pairs, three MFMAs per product (rgn_mlp_x3.hip):
+            // one launch where k_gemm_x3 x 3 + k_layernorm x 2 were five; residual stream updated in place (both planes)
+            MlpX3Args gx{};
+            MlpArgs& g = gx.p;
+            g.att = att_p.hi; g.h = h_p.hi; g.out = h_p.hi; g.rows = h_p.rows; g.M = M;
+            gx.att_lo = att_p.lo; gx.h_lo = h_p.lo; gx.out_lo = h_p.lo;
+            g.Wo = c->dp<__bf16>(w.out.fr); g.W1 = c->dp<__bf16>(w.ff1.fr); g.W2 = c->dp<__bf16>(w.ff2.fr);
+            gx.Wo_lo = c->dp<__bf16>(w.out.fr_lo); gx.W1_lo = c->dp<__bf16>(w.ff1.fr_lo); gx.W2_lo = c->dp<__bf16>(w.ff2.fr_lo);
+            g.bo = c->dp<float>(w.out.b); g.bf1 = c->dp<float>(w.ff1.b); g.bf2 = c->dp<float>(w.ff2.b);
+            g.g1 = c->dp<float>(w.ln[0]); g.b1 = c->dp<float>(w.ln[1]); g.g2 = c->dp<float>(w.ln[2]); g.b2 = c->dp<float>(w.ln[3]);
+            g.g3 = c->dp<float>(w.ln[4]); g.b3 = c->dp<float>(w.ln[5]);
+            g.pervec = per_sample; g.ldper = Ld; g.stepvec = step_vec; g.ldstep = Ld; g.d_step = c->d_step; g.Tq = dm.Tq;
+            RGN_LAUNCH(c, KC_MLP, s, launch_mlp_x3(gx, s));
+            continue;
+        }
         if (fast && !x3 && c->mlp && !h_p.lo) {
             // plain-bf16 phase, d = 512 / ff = 1024: the whole layer tail (out_proj + norm1 + folded cross-attention + norm2 +
             // linear1 + GELU + linear2 + norm3) as ONE row-persistent kernel; residual stream updated in place (hi plane)
@@ -1045,9 +1073,11 @@ int rgn_finalize_weights(rgn_handle h) {
         lw.qkv = pack_linear(c, W(p + "self_attn.in_proj_weight"), W(p + "self_attn.in_proj_bias"), 3 * d, d, true,
                              c->cfg.precision == RGN_PREC_BF16_X3TAIL);   // fragment order: k_rowgemm (long sequences) / k_qkv_attn_rs
         const bool fr = c->cfg.precision == RGN_PREC_BF16_X3TAIL;   // k_rowgemm operands (plain-bf16 phase)
-        lw.out = pack_linear(c, W(p + "self_attn.out_proj.weight"), W(p + "self_attn.out_proj.bias"), d, d, true, fr);
-        lw.ff1 = pack_linear(c, W(p + "linear1.weight"), W(p + "linear1.bias"), ff, d, true, fr);
-        lw.ff2 = pack_linear(c, W(p + "linear2.weight"), W(p + "linear2.bias"), d, ff, true, fr);
+        // (+ lo fragment planes: the operand pairs of k_mlp_x3, the split-bf16 layer tail, in every mode that has a split-bf16 phase)
+        const bool frx = c->cfg.precision == RGN_PREC_BF16_X3TAIL || c->cfg.precision == RGN_PREC_BF16X3;
+        lw.out = pack_linear(c, W(p + "self_attn.out_proj.weight"), W(p + "self_attn.out_proj.bias"), d, d, true, fr || frx, frx);
+        lw.ff1 = pack_linear(c, W(p + "linear1.weight"), W(p + "linear1.bias"), ff, d, true, fr || frx, frx);
+        lw.ff2 = pack_linear(c, W(p + "linear2.weight"), W(p + "linear2.bias"), d, ff, true, fr || frx, frx);
         const char* names[6] = {"norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "norm3.weight", "norm3.bias"};
         for (int i = 0; i < 6; ++i) lw.ln[i] = blob_put(c, W(p + names[i]), (size_t)d * 4);
         const float* wv = W(p + "multihead_attn.in_proj_weight") + (size_t)2 * d * d;
@@ -1140,6 +1170,11 @@ int rgn_finalize_weights(rgn_handle h) {
         if (c->rowgemm) RGN_HIP(c, configure_rowgemm());
         c->mlp = c->rowgemm && mlp_supported(d, ff, c->Tq) && getenv("REGENNET_NO_MLP") == nullptr;
         if (c->mlp) RGN_HIP(c, configure_mlp());
+        {   // the split-bf16 layer tail as one kernel (REGENNET_MLP_X3=0: k_gemm_x3 x 3 + k_layernorm x 2 per layer instead)
+            const char* e = getenv("REGENNET_MLP_X3");
+            c->mlp_x3 = !(e && atoi(e) == 0) && mlp_x3_supported(d, ff, c->Tq);
+            if (c->mlp_x3) RGN_HIP(c, configure_mlp_x3());
+        }
         if (c->fuse_qkv) RGN_HIP(c, configure_qkv_attn());
         c->qkv_rs = getenv("REGENNET_NO_QKV_RS") == nullptr;
         c->step_fused = c->rowgemm && !c->etd && c->lin_x.fr && c->lin_out.fr && c->lin_out.has_bias && !c->lin_x.has_bias &&

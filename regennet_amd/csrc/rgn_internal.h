@@ -158,6 +158,17 @@ struct MlpArgs {
 bool mlp_supported(int d, int ff, int Tq);
 hipError_t configure_mlp();
 hipError_t launch_mlp(const MlpArgs& g, hipStream_t s);
+// the layer tail of the SPLIT-bf16 phase as one row-persistent kernel (rgn_mlp_x3.hip): 32-row tiles, (hi, lo) plane pairs everywhere, three MFMAs
+// per product, two-pass LayerNorm, erf GELU - replaces k_gemm_x3 x 3 + k_layernorm x 2 per layer. Weight planes fragment-ordered, hi and lo.
+struct MlpX3Args {
+    MlpArgs p;                            // hi planes / fragment planes and the vectors, as for k_mlp2
+    const __bf16 *att_lo, *h_lo;          // lo planes of the attention output and of the layer input (advanced like the hi planes)
+    __bf16* out_lo;                       // lo plane of the layer output (may alias h_lo)
+    const __bf16 *Wo_lo, *W1_lo, *W2_lo;  // lo fragment planes
+};
+bool mlp_x3_supported(int d, int ff, int Tq);
+hipError_t configure_mlp_x3();
+hipError_t launch_mlp_x3(const MlpX3Args& g, hipStream_t s);
 // second build of the layer tail (rgn_mlp2.hip): rows = 64 (8 waves, one workgroup per CU) or 32 (4 waves, two per CU)
 bool mlp2_supported(int rows, int d, int ff, int Tq);
 hipError_t configure_mlp2();

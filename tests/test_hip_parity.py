@@ -800,6 +800,41 @@ def test_bench_shape_bulk_phase_against_the_oracle():
         model._engine.close()
 
 
+@pytest.mark.parametrize("cfg_name,B,guided", [("ntu", 16, False), ("ntu", 3, False), ("ntu_action", 5, True), ("chi3d", 3, False)])
+def test_split_bf16_layer_tail_kernel_matches_the_five_kernel_form(cfg_name, B, guided, monkeypatch):
+    """k_mlp_x3 (rgn_mlp_x3.hip: the split-bf16 layer tail as ONE row-persistent kernel, 32-row tiles) against the kernels it replaced
+    (k_gemm_x3 x 3 + k_layernorm x 2 per layer, REGENNET_MLP_X3=0) and against the oracle: uniform split-bf16 arithmetic, throughput engine,
+    row counts that end in a partial tile (B = 3: 180 rows; chi3d: 450) and tiles that straddle two motions (T = 60 / 150 against 32-row tiles),
+    per-sample condition vectors, guidance."""
+    from oracle import regennet_oracle as orc
+    from regennet_amd import synth
+    from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    cfg = synth.get_config(cfg_name)
+    sd = synth.make_state_dict(cfg, seed=7)
+    T = cfg["num_frames"]
+    y = {"cmotion": synth.make_cmotion(cfg, B, seed=61)}
+    if cfg["cond_mode"] == "action":
+        y["action"] = synth.make_actions(cfg, B, seed=62)
+    if guided:
+        y["scale"] = np.linspace(1.0, 3.0, B).astype(np.float32)
+    resp, mode = ("ddim3", "ddim") if guided else ("3", "ddpm")
+    tape = synth.make_noise_tape(cfg, B, 3, seed=63)
+    ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", resp), tape, {k: torch.from_numpy(v) for k, v in y.items()},
+                          mode=mode, guided=guided).numpy()
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("REGENNET_MLP_X3", flag)               # read when the engine is built
+        model, diffusion = build_hip(cfg, sd, resp=resp, precision="bf16x3/throughput")
+        fm = ClassifierFreeSampleModel(model) if guided else model
+        fn = diffusion.p_sample_loop if mode == "ddpm" else diffusion.ddim_sample_loop
+        outs[flag] = fn(fm, (B, cfg["njoints"], cfg["nfeats"], T), clip_denoised=False, model_kwargs={"y": y_to_device(y)},
+                        noise_tape=torch.from_numpy(tape)).cpu().numpy()
+        model._engine.close()
+    e1, e0, d = np.abs(outs["1"] - ref).max(), np.abs(outs["0"] - ref).max(), np.abs(outs["1"] - outs["0"]).max()
+    print(f"\n[k_mlp_x3] {cfg_name} B={B} guided={guided}: vs oracle {e1:.2e} (five-kernel form {e0:.2e}), the two forms differ by {d:.2e}")
+    assert e1 < 1e-3 and e0 < 1e-3 and d < 2e-4 and e1 < 2.0 * e0 + 2e-5
+
+
 def test_text150_full_size_shard_is_row_independent():
     """BASELINE configs[4] per-GPU shard at FULL size (text-conditioned, T=150, B=256 = 2048 / 8, CFG: 76 800 token rows, 1200 row
     tiles, four kernel chains, the guided fused step at 150 frames): rows of the batch against the same motion drawn alone
