@@ -94,6 +94,9 @@ def flops_per_eval(cfg, B, guided, precision="bf16x3"):
     elif rowgemm_phase(cfg, precision):
         out["rowgemm_ln"] = M * (d * d + d * ff) * L
         out["rowgemm_act"] = M * d * ff * L
+    elif (precision == "bf16x3" and d == 512 and ff == 1024 and T + cfg.get("emb_trans_dec", 0) >= 32
+          and os.environ.get("REGENNET_MLP_X3", "1") != "0"):
+        out["mlp"] = M * (d * d + 2 * d * ff) * L                  # split-bf16 phase: the layer tail is one kernel too (k_mlp_x3, three MFMAs per product)
     else:
         out["gemm_mfma"] += M * (d * d + 2 * d * ff) * L
     if (rowgemm_phase(cfg, precision) and not cfg.get("emb_trans_dec") and F % 4 == 0 and 320 < F <= 352
@@ -326,7 +329,7 @@ def main(argv=None):
         eng.profile_enable(False)
         peak = PEAK_TFLOPS[a.precision]
         names = {"gemm_mfma": "k_gemm_x3", "qkv_attn": "k_qkv_attn", "attention": "k_attn_x3", "layernorm": "k_layernorm",
-                 "update": "k_update", "rowgemm_ln": "k_rowgemm<LN>", "rowgemm_act": "k_rowgemm<ACT>", "mlp": "k_mlp", "sb_gemm": "k_sb_gemm", "step_fused": "k_step", "layers": "k_layers", "steps_fused": "k_layers<steps>"}
+                 "update": "k_update", "rowgemm_ln": "k_rowgemm<LN>", "rowgemm_act": "k_rowgemm<ACT>", "mlp": "k_mlp_x3" if a.precision == "bf16x3" else "k_mlp", "sb_gemm": "k_sb_gemm", "step_fused": "k_step", "layers": "k_layers", "steps_fused": "k_layers<steps>"}
         if a.precision == "f32":
             names.update(gemm_mfma="k_gemm_f32", attention="k_attn_mfma")
         if fused_qkv_attention_long(cfg, a.precision):
