@@ -800,17 +800,20 @@ def test_bench_shape_bulk_phase_against_the_oracle():
         model._engine.close()
 
 
-@pytest.mark.parametrize("cfg_name,B,guided", [("ntu", 16, False), ("ntu", 3, False), ("ntu_action", 5, True), ("chi3d", 3, False)])
-def test_split_bf16_layer_tail_kernel_matches_the_five_kernel_form(cfg_name, B, guided, monkeypatch):
+@pytest.mark.parametrize("cfg_name,B,guided,frames", [("ntu", 16, False, None), ("ntu", 3, False, None), ("ntu_action", 5, True, None),
+                                                      ("chi3d", 3, False, None), ("ntu", 7, False, 40)])
+def test_split_bf16_layer_tail_kernel_matches_the_five_kernel_form(cfg_name, B, guided, frames, monkeypatch):
     """k_mlp_x3 (rgn_mlp_x3.hip: the split-bf16 layer tail as ONE row-persistent kernel, 32-row tiles) against the kernels it replaced
     (k_gemm_x3 x 3 + k_layernorm x 2 per layer, REGENNET_MLP_X3=0) and against the oracle: uniform split-bf16 arithmetic, throughput engine,
-    row counts that end in a partial tile (B = 3: 180 rows; chi3d: 450) and tiles that straddle two motions (T = 60 / 150 against 32-row tiles),
+    row counts that end in a partial tile (B = 3: 180 rows; chi3d: 450) and tiles that straddle two motions (T = 40 / 60 / 150 against 32-row tiles),
     per-sample condition vectors, guidance."""
     from oracle import regennet_oracle as orc
     from regennet_amd import synth
     from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
     cfg = synth.get_config(cfg_name)
     sd = synth.make_state_dict(cfg, seed=7)
+    if frames:                                                   # a shorter motion than the checkpoint's (--motion_length): 40-row motions against 32-row tiles
+        cfg = dict(cfg, num_frames=frames)
     T = cfg["num_frames"]
     y = {"cmotion": synth.make_cmotion(cfg, B, seed=61)}
     if cfg["cond_mode"] == "action":
