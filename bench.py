@@ -339,10 +339,21 @@ def main(argv=None):
             if cls == "steps_fused" and run_steps and n >= 1:
                 us = max(1e3 * (ms - n * ovh_ms) / n, 0.1)
                 tf = fl[cls] * run_steps / (us * 1e-6) / 1e12
+                # what the one-kernel form is really bound by: every workgroup (one per sample / motion) streams every layer's weight fragments from its
+                # XCD's L2 once per evaluation pass - the L2 -> CU stream, against the guide's aggregate L2 bandwidth (MI355X_MICROARCH.md: 34.5 TB/s)
+                d_, ff_, L_, Fp = cfg["latent_dim"], cfg["ff_size"], cfg["layers"], (cfg["njoints"] * cfg["nfeats"] + 31) // 32 * 32
+                passes = 2 if a.guided else 1
+                l2_bytes = B * (passes * (L_ * (4 * d_ * d_ + 2 * d_ * ff_) + Fp * d_) + Fp * d_) * 2.0
+                l2_tbps = l2_bytes * run_steps / (us * 1e-6) / 1e12
                 per_kernel.append({"kernel": names[cls], "launches_per_eval": round(n / run_steps, 6), "steps_per_launch": run_steps, "avg_us": round(us, 2),
                                    "us_per_step": round(us / run_steps, 2), "ms_per_eval": round(us / run_steps * 1e-3, 4), "bound": "mfma",
                                    "algo_gflop_per_launch": round(fl[cls] * run_steps / 1e9, 3), "achieved": round(tf, 1), "peak": peak,
-                                   "unit": "TFLOP/s", "frac": round(tf / peak, 4)})
+                                   "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                                   "l2_stream": {"bound": "l2", "achieved": round(l2_tbps, 2), "peak": 34.5, "unit": "TB/s", "frac": round(l2_tbps / 34.5, 4),
+                                                 "bytes_per_step": round(l2_bytes),
+                                                 "note": "weight fragments every workgroup pulls from its XCD's L2 per step (bf16, each layer once per evaluation pass) / "
+                                                         "the launch's duration; peak = the guide's aggregate L2 bandwidth at the full clock - at the ~1.95 GHz this kernel "
+                                                         "is given the same L2 delivers ~28 TB/s (DESIGN.md 4.0d)"}})
                 continue
             if n < n_eval or cls not in names:        # (classes that ran once per call, e.g. the embedding in front of the first fused step)
                 continue
@@ -374,6 +385,8 @@ def main(argv=None):
                         "steps_per_launch complete sampler steps (decoder stack + step boundary), exactly the launch the timed region issues "
                         "once per call; other forms: the timed region replays multi-chain hipGraphs in which kernels of different chains overlap",
                 "per_kernel": per_kernel}
+        if dom.get("l2_stream"):
+            roof["l2_stream"] = dom["l2_stream"]
         # HBM bytes per launch of the dominant kernel: NOT measured by this run (counters need rocprofv3 passes of their own, the
         # MI355X guide's recipe) - read from the newest committed PMC summary (tools/collect_pmc.sh + tools/summarize_pmc.py) and
         # labelled as such
