@@ -36,85 +36,80 @@ ALGO_GFLOP_PER_EVAL = {("ntu", "concat"): 2.154, ("ntu", "add"): 2.123, ("chi3d"
 PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "bf16_x3tail": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
 
 
-def fused_qkv_attention(cfg, precision):
-    """Mirrors qkv_attn_supported() in rgn_qkv_attn.hip: the in_proj GEMM and the attention run as one kernel."""
-    return (precision != "f32" and cfg["num_frames"] + int(bool(cfg.get("emb_trans_dec"))) <= 64
-            and cfg["latent_dim"] // cfg["num_heads"] == 128 and not os.environ.get("REGENNET_NO_FUSED_QKV"))
+def row_check(cfg, sd, a, dev, y, out, seed, lo, plan, fn_name, rows):
+    """Motion b of the last timed call against a B = 1 run of the SAME kernel form (model.layers_min_b = 1 where the batch ran the
+    one-kernel decoder stack, throughput kernels instead of the small-batch engine) with the motion's global Philox key: the launch the
+    headline number rests on - 256 workgroups x 995 steps - is checked at its real shape on every bench run, not only for isfinite."""
+    from regennet_amd import synth
+    from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    model1, diffusion1 = synth.build_model(cfg, sd, resp=a.respacing, precision=a.precision, device=str(dev), x3_tail=a.x3_tail)
+    model1.small_batch_rows = 0
+    if any(k in plan for k in ("layers", "steps_fused")):
+        model1.layers_min_b = 1
+    fm1 = ClassifierFreeSampleModel(model1) if a.guided else model1
+    fn1 = getattr(diffusion1, fn_name)
+    worst = 0.0
+    for b in rows:
+        yb = {k: v[b:b + 1].contiguous() for k, v in y.items()}
+        one = fn1(fm1, (1,) + tuple(out.shape[1:]), clip_denoised=False, model_kwargs={"y": yb}, seed=seed, sample_offset=lo + b,
+                  use_graph=not a.no_graph)
+        worst = max(worst, float((out[b:b + 1] - one).abs().max()))
+    model1._engine.close()
+    return worst
 
 
-def fused_qkv_attention_long(cfg, precision):
-    """Mirrors qkv_attn_long_supported() + the dispatch in rgn_api.cpp: plain-bf16 phase, 65 .. 160 tokens, d = 512, dh = 128."""
-    Tq = cfg["num_frames"] + int(bool(cfg.get("emb_trans_dec")))
-    return (precision == "bf16_x3tail" and 64 < Tq <= 160 and cfg["latent_dim"] == 512 and cfg["latent_dim"] // cfg["num_heads"] == 128
-            and not os.environ.get("REGENNET_NO_QKV_LONG"))
-
-
-def layers_fused(cfg, precision):
-    """Mirrors rgn_api.cpp (layers_fused): the whole decoder stack of an evaluation runs as ONE kernel, one sample per workgroup."""
-    Tq = cfg["num_frames"] + int(bool(cfg.get("emb_trans_dec")))
-    return (precision == "bf16_x3tail" and int(os.environ.get("REGENNET_LAYERS_MIN_TQ", "52")) <= Tq <= 64 and cfg["latent_dim"] == 512
-            and cfg["ff_size"] == 1024 and cfg["num_heads"] == 4 and cfg["layers"] <= 8 and os.environ.get("REGENNET_LAYERS", "1") != "0"
-            and not os.environ.get("REGENNET_NO_MLP") and not os.environ.get("REGENNET_NO_FUSED_QKV") and not os.environ.get("REGENNET_NO_QKV_RS")
-            and not os.environ.get("REGENNET_NO_ROWGEMM") and not os.environ.get("REGENNET_BULK_RESID_LO"))
-
-
-def layers_steps(cfg, precision, guided):
-    """Mirrors rgn_api.cpp (layers_steps): whole runs of sampler steps (stack + step boundary; guided: both evaluations of a motion) are ONE launch."""
-    F = cfg["njoints"] * cfg["nfeats"]
-    return (layers_fused(cfg, precision) and (not guided or os.environ.get("REGENNET_LAYERS_GUIDED", "1") != "0") and not cfg.get("emb_trans_dec")
-            and F % 4 == 0 and 320 < F <= 352 and os.environ.get("REGENNET_LAYERS_STEPS", "1") != "0" and not os.environ.get("REGENNET_NO_STEP_FUSION"))
-
-
-def rowgemm_phase(cfg, precision):
-    """Mirrors rgn_api.cpp: the plain-bf16 phase runs out_proj+LN / linear1+GELU / linear2+LN as row-complete kernels."""
-    return (precision == "bf16_x3tail" and cfg["latent_dim"] == 512 and cfg["ff_size"] in (384, 512, 1024)
-            and not os.environ.get("REGENNET_NO_ROWGEMM"))
-
-
-def flops_per_eval(cfg, B, guided, precision="bf16x3"):
-    """Algorithmic FLOPs (SURVEY.md §8d accounting: 2 x MAC, full T x T attention scores) of one denoiser evaluation in the
-    phase the profiled pass runs, per kernel class as the engine launches them. The timestep MLP and the folded 1-token
-    cross-attention are per-schedule work, not per-step."""
-    T, d, ff, L, F = cfg["num_frames"], cfg["latent_dim"], cfg["ff_size"], cfg["layers"], cfg["njoints"] * cfg["nfeats"]
-    Bm = 2 * B if guided else B
-    M = Bm * T
-    qkv = M * 3 * d * d * L
-    attn = M * 2 * T * d * L
-    embed = (B * T * F * d if precision == "f32" else M * F * d) + M * d * F       # input embedding, output projection
-    out = {"gemm_mfma": embed, "qkv_attn": 0, "attention": 0, "rowgemm_ln": 0, "rowgemm_act": 0, "mlp": 0, "sb_gemm": 0, "step_fused": 0, "layers": 0, "steps_fused": 0}
-    sb_rows = int(os.environ.get("REGENNET_SB_ROWS", "640"))
-    if precision != "f32" and d == 512 and ff % 32 == 0 and T + cfg.get("emb_trans_dec", 0) <= 160 and Bm * (T + cfg.get("emb_trans_dec", 0)) <= sb_rows:
-        # small-batch engine (rgn_sb.hip): every GEMM of the evaluation is a column-split k_sb_gemm launch
-        out["gemm_mfma"] = 0
-        out["sb_gemm"] = embed + qkv + M * (d * d + 2 * d * ff) * L
-        out["attention"] = attn
-        return {k: 2.0 * v for k, v in out.items()}
-    if rowgemm_phase(cfg, precision) and ff == 1024 and not os.environ.get("REGENNET_NO_MLP") and not os.environ.get("REGENNET_BULK_RESID_LO"):
-        out["mlp"] = M * (d * d + 2 * d * ff) * L
-    elif rowgemm_phase(cfg, precision):
-        out["rowgemm_ln"] = M * (d * d + d * ff) * L
-        out["rowgemm_act"] = M * d * ff * L
-    elif (precision == "bf16x3" and d == 512 and ff == 1024 and T + cfg.get("emb_trans_dec", 0) >= 32
-          and os.environ.get("REGENNET_MLP_X3", "1") != "0"):
-        out["mlp"] = M * (d * d + 2 * d * ff) * L                  # split-bf16 phase: the layer tail is one kernel too (k_mlp_x3, three MFMAs per product)
-    else:
-        out["gemm_mfma"] += M * (d * d + 2 * d * ff) * L
-    if (rowgemm_phase(cfg, precision) and not cfg.get("emb_trans_dec") and F % 4 == 0 and 320 < F <= 352
-            and not os.environ.get("REGENNET_NO_STEP_FUSION") and not os.environ.get("REGENNET_BULK_RESID_LO")):
-        out["step_fused"] = embed                                  # k_step: output projection + sampler update + next input embedding
-        out["gemm_mfma"] -= embed
-    if layers_fused(cfg, precision) and Bm >= int(os.environ.get("REGENNET_LAYERS_MIN_B", "64")):
-        out["layers"] = qkv + attn + out["mlp"]                    # k_layers: in_proj + attention + layer tail of all L layers, one launch per chain
-        out["mlp"] = 0
-        if layers_steps(cfg, precision, guided):                   # ... and the step boundary: one launch per RUN of steps
-            out["steps_fused"] = out["layers"] + out["step_fused"]
-            out["layers"] = out["step_fused"] = 0
-    elif fused_qkv_attention(cfg, precision) or fused_qkv_attention_long(cfg, precision):
-        out["qkv_attn"] = qkv + attn
-    else:
-        out["rowgemm_act" if rowgemm_phase(cfg, precision) else "gemm_mfma"] += qkv   # long sequences: in_proj GEMM + k_attn_x3
-        out["attention"] = attn
-    return {k: 2.0 * v for k, v in out.items()}
+def bench_stgcn(a):
+    """`--config stgcn`: the evaluation harness's recogniser (rgn_stgcn_forward; eval/a2m/recognition/models/stgcn.py:76-123) on N = --batch
+    two-person motions of 60 and 150 frames, timed with the same barrier / synchronize bracket, HIP events around every forward, against the
+    fp32 MFMA peak (its kernels are exact-product fp32). FLOPs: the ten st_gcn blocks of stgcn.py:51-62 (graph aggregation on the input
+    channels, 1x1 convolution over K C_in, 9x1 temporal convolution, residual 1x1 where the block has one), both persons."""
+    from regennet_amd import synth
+    from regennet_amd.eval import STGCN
+    dev = torch.device("cuda:0")
+    V, K, M, C = 56, 3, 2, 6
+    rng = np.random.default_rng(0)
+    A = np.zeros((K, V, V), np.float32)                       # a chain skeleton: self, inward and outward partitions (stgcnutils/graph.py 'spatial')
+    A[0] = np.eye(V)
+    for v in range(1, V):
+        A[1, v, v - 1] = 0.5
+        A[2, v - 1, v] = 0.5
+    sd = synth.make_stgcn_state_dict(A, num_class=26, seed=0)
+    model = STGCN(in_channels=M * C, num_class=26, num_person=M, graph_args={"layout": "smplx", "strategy": "spatial"}, device=str(dev))
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model.to(dev).eval()
+    blocks = [(C, 64, 1, False), (64, 64, 1, False), (64, 64, 1, False), (64, 64, 1, False), (64, 128, 2, True), (128, 128, 1, False),
+              (128, 128, 1, False), (128, 256, 2, True), (256, 256, 1, False), (256, 256, 1, False)]
+    lines = []
+    for T in (60, 150):
+        N = a.batch
+        x = torch.from_numpy(rng.standard_normal((N, V, M * C, T)).astype(np.float32)).to(dev)
+        mac, t = 0.0, T
+        for ci, co, st, res in blocks:
+            to = (t + st - 1) // st
+            mac += K * ci * t * V * V + t * V * K * ci * co + to * V * 9 * co * co + (to * V * ci * co if res else 0)
+            t = to
+        flops = 2.0 * mac * M * N
+        for _ in range(max(a.warmup, 1)):
+            model({"output": x})
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        t0 = time.perf_counter()
+        for e0, e1 in evs:
+            e0.record()
+            model({"output": x})
+            e1.record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+        tf = flops / (ms * 1e-3) / 1e12
+        lines.append({"T": T, "N": N, "ms_per_forward": round(ms, 3), "wall_ms_per_forward": round(1e3 * dt / a.steps, 3),
+                      "motions_per_s": round(N / (ms * 1e-3), 1), "algo_gflop_per_forward": round(flops / 1e9, 2),
+                      "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS["f32"], 4),
+                                   "traffic": None, "note": "fp32-input MFMA (exact products), the evaluator's arithmetic; all launches of one forward"}})
+    print(json.dumps({"metric": "ST-GCN recogniser forward (evaluation harness, SURVEY 8f next-4)", "value": lines[0]["motions_per_s"], "unit": "motions/s",
+                      "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": lines[0]["ms_per_forward"], "higher_is_better": True,
+                      "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": f"stgcn: N={a.batch} x [56, 12, 60 | 150]"},
+                      "roofline": lines[0]["roofline"], "per_length": lines}), flush=True)
 
 
 def cpu_baseline(cfg, sd, steps_total, seconds_budget=20.0):
@@ -205,11 +200,18 @@ def main(argv=None):
     ap.add_argument("--x3-tail", type=int, default=None, help="precision schedule: split-bf16 for the last N loop indices")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", default=bool(os.environ.get("REGENNET_FORCE_DIST")),
+                    help="take every multi-rank code path with a ONE-rank process group (RCCL init, blob broadcast, barriers, reductions)")
+    ap.add_argument("--serial-engine-build", action="store_true", default=bool(os.environ.get("REGENNET_SERIAL_ENGINE_BUILD")),
+                    help="ranks repack their checkpoints in turn instead of concurrently")
+    ap.add_argument("--no-row-check", action="store_true", help="skip the B = 1 re-run of motions 0 and B-1 of the last timed call")
     ap.add_argument("--profile-evals", type=int, default=3)
     ap.add_argument("--engine-stub", default="", help=argparse.SUPPRESS)   # tests only: "module:Class" replaces _lib.Engine (CPU, gloo);
     a = ap.parse_args(argv)                                                 # the line is then marked "data": "STUB ENGINE ..." and measures nothing
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a.gpus, argv))
+    if a.config == "stgcn":
+        return bench_stgcn(a)
 
     from regennet_amd import synth
     from regennet_amd._lib import default_x3_tail
@@ -220,7 +222,9 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     # REGENNET_FORCE_DIST=1 (tools): a ONE-rank process group takes every multi-rank code path below - RCCL init, the blob broadcast, the
     # barriers, the MAX all-reduce of the time, the gather of the device names - which is how they are exercised on a 1-GPU box
-    multi = world > 1 or bool(os.environ.get("REGENNET_FORCE_DIST"))
+    if a.force_dist:
+        os.environ["REGENNET_FORCE_DIST"] = "1"              # (dist_util.collectives_active reads it)
+    multi = world > 1 or a.force_dist
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a line for a different rank count")
     if a.engine_stub:
@@ -244,7 +248,7 @@ def main(argv=None):
     # reported ("engine_build_s": ~2 s of one host core at N = 1). N ranks repack concurrently by default; REGENNET_SERIAL_ENGINE_BUILD=1
     # makes them take turns (a host whose memory bandwidth 8 concurrent repacks would saturate), the broadcast follows either way.
     t_build = time.perf_counter()
-    if multi and os.environ.get("REGENNET_SERIAL_ENGINE_BUILD"):
+    if multi and a.serial_engine_build:
         eng = None
         for r in range(world):
             if r == rank:
@@ -298,6 +302,13 @@ def main(argv=None):
         devices = [None] * world
         dist.all_gather_object(devices, f"rank{rank}:{dev}" + (f" ({torch.cuda.get_device_name(dev)})" if dev.type == "cuda" else ""))
 
+    # ---- the timed launch at its real shape: motions 0 and B-1 of the LAST timed call against single-motion runs of the same kernel form
+    plan = {} if a.engine_stub else eng.plan_query(B, a.guided, split_phase=False)
+    row_dev = None
+    if rank == 0 and not a.engine_stub and not a.no_row_check and a.steps > 0:
+        row_dev = row_check(cfg, synth.make_state_dict(cfg, seed=0), a, dev, y, out, 100 + a.steps - 1, lo, plan,
+                            "p_sample_loop" if a.sampler == "ddpm" else "ddim_sample_loop", sorted({0, B - 1}))
+
     # ---- roofline: HIP events around every launch of a short eager single-chain pass on the engine's stream -----------
     # (the first loop indices: the plain-bf16 phase under the precision schedule = where >= 97 % of the evaluations run)
     roof = None
@@ -308,7 +319,7 @@ def main(argv=None):
         eng.randn(x, B, 5, lo, st)
         first = S - 1
         n_eval = min(a.profile_evals, S)
-        fl = flops_per_eval(cfg, B, a.guided, a.precision)
+        fl = {cls: rec["flops"] for cls, rec in plan.items()}     # the engine's own plan (rgn_plan_query): what it launches, priced by SURVEY 8(d)
         if not fl.get("steps_fused", 0.0) > 0:              # (the multi-step launch was warmed by the timed region; a 1-step launch of it would only
             eng.sample_range(a.sampler, a.guided, 0.0, x, None, 5, lo, first, 1, None, False, False, st)   # skew rocprofv3's average) warm (untimed)
         torch.cuda.synchronize()
@@ -328,12 +339,7 @@ def main(argv=None):
         ovh_ms = eng.profile_bracket_overhead_ms()
         eng.profile_enable(False)
         peak = PEAK_TFLOPS[a.precision]
-        names = {"gemm_mfma": "k_gemm_x3", "qkv_attn": "k_qkv_attn", "attention": "k_attn_x3", "layernorm": "k_layernorm",
-                 "update": "k_update", "rowgemm_ln": "k_rowgemm<LN>", "rowgemm_act": "k_rowgemm<ACT>", "mlp": "k_mlp_x3" if a.precision == "bf16x3" else "k_mlp", "sb_gemm": "k_sb_gemm", "step_fused": "k_step", "layers": "k_layers", "steps_fused": "k_layers<steps>"}
-        if a.precision == "f32":
-            names.update(gemm_mfma="k_gemm_f32", attention="k_attn_mfma")
-        if fused_qkv_attention_long(cfg, a.precision):
-            names.update(qkv_attn="k_qkv_attn_long")
+        names = {cls: rec["kernel"] for cls, rec in plan.items()}
         per_kernel = []
         for cls, (ms, n) in prof.items():
             if cls == "steps_fused" and run_steps and n >= 1:
@@ -341,9 +347,7 @@ def main(argv=None):
                 tf = fl[cls] * run_steps / (us * 1e-6) / 1e12
                 # what the one-kernel form is really bound by: every workgroup (one per sample / motion) streams every layer's weight fragments from its
                 # XCD's L2 once per evaluation pass - the L2 -> CU stream, against the guide's aggregate L2 bandwidth (MI355X_MICROARCH.md: 34.5 TB/s)
-                d_, ff_, L_, Fp = cfg["latent_dim"], cfg["ff_size"], cfg["layers"], (cfg["njoints"] * cfg["nfeats"] + 31) // 32 * 32
-                passes = 2 if a.guided else 1
-                l2_bytes = B * (passes * (L_ * (4 * d_ * d_ + 2 * d_ * ff_) + Fp * d_) + Fp * d_) * 2.0
+                l2_bytes = plan[cls]["l2_bytes"]
                 l2_tbps = l2_bytes * run_steps / (us * 1e-6) / 1e12
                 per_kernel.append({"kernel": names[cls], "launches_per_eval": round(n / run_steps, 6), "steps_per_launch": run_steps, "avg_us": round(us, 2),
                                    "us_per_step": round(us / run_steps, 2), "ms_per_eval": round(us / run_steps * 1e-3, 4), "bound": "mfma",
@@ -420,6 +424,9 @@ def main(argv=None):
             "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic" if not a.engine_stub else f"STUB ENGINE {a.engine_stub}: launcher test, nothing measured",
             "engine_build_s": round(build_s, 2),
+            "headline_row_check_max_abs": row_dev,
+            "headline_row_check": None if row_dev is None else f"motions 0 and {B - 1} of the last timed call vs B = 1 runs of the same kernel form "
+                                                               f"with the motion's global Philox key (bit-exact in the plain-bf16 phase; <= 2e-5 behind the split-bf16 tail)",
             "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
             "backend": dist.get_backend() if dist.is_initialized() else None, "devices": devices,
             "config": {"workload": f"{a.config}: [B={B}/GPU,56,6,{cfg['num_frames']}] online/{cfg['cm_mode']}/{cfg['cond_mode']} "

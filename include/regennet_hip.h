@@ -10,7 +10,8 @@
  *
  * Conventions
  *   - every function returns 0 on success or a negative rgn_status; rgn_last_error() gives text.
- *   - no exceptions cross the boundary; a handle is NOT thread-safe (one handle per device/stream).
+ *   - no exceptions cross the boundary (every entry point catches at the boundary: RGN_ERR_INTERNAL);
+ *     a handle is NOT thread-safe (one handle per device/stream).
  *   - "x" tensors are fp32 [B, njoints, nfeats, T] contiguous — the reference's boundary layout
  *     (model/cmdm.py:173-177); timesteps are int64 like the reference's `t` tensors.
  */
@@ -23,6 +24,13 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the entry points below are its ONLY dynamic symbols. */
+#if defined(__GNUC__) || defined(__clang__)
+#define RGN_API __attribute__((visibility("default")))
+#else
+#define RGN_API
+#endif
+
 typedef struct rgn_ctx* rgn_handle;
 
 typedef enum {
@@ -33,7 +41,8 @@ typedef enum {
     RGN_ERR_MISSING_KEY = -4,    /* finalize: a required key was never loaded (model_util.py:8) */
     RGN_ERR_STATE = -5,          /* call order violated (e.g. sample before set_schedule)       */
     RGN_ERR_HIP = -6,            /* HIP runtime error (text in rgn_last_error)                  */
-    RGN_ERR_UNSUPPORTED = -7     /* configuration outside the hot path (e.g. arch != online)    */
+    RGN_ERR_UNSUPPORTED = -7,    /* configuration outside the hot path (e.g. arch != online)    */
+    RGN_ERR_INTERNAL = -8        /* a host-side C++ exception (std::bad_alloc ...) caught at the boundary */
 } rgn_status;
 
 enum { RGN_CM_ADD = 0, RGN_CM_CONCAT = 1 };                 /* --cm_mode, model/cmdm.py:207-211  */
@@ -88,39 +97,39 @@ typedef struct {
 } rgn_schedule;
 
 /* Lifetime. Replaces: CMDM.__init__ (model/cmdm.py:13-111) + model.to(dev()) (sample/cgenerate.py:82). */
-int rgn_create(const rgn_config* cfg, rgn_handle* out);
-int rgn_destroy(rgn_handle h);
+RGN_API int rgn_create(const rgn_config* cfg, rgn_handle* out);
+RGN_API int rgn_destroy(rgn_handle h);
 /* Text of the most recent error on `h` (or of the last failed rgn_create when h == NULL). */
-const char* rgn_last_error(rgn_handle h);
+RGN_API const char* rgn_last_error(rgn_handle h);
 
 /* Checkpoint ingestion, keyed by the reference's state_dict names. Replaces
  * load_model_wo_clip / nn.Module.load_state_dict(strict=False) (utils/model_util.py:5-8):
  * an unexpected key -> RGN_ERR_BAD_KEY; keys starting with "clip_model." are accepted and ignored.
  * `host` is caller-owned fp32 host memory, copied during the call. */
-int rgn_load_weight(rgn_handle h, const char* ref_key, const float* host, const int64_t* shape, int32_t ndim);
+RGN_API int rgn_load_weight(rgn_handle h, const char* ref_key, const float* host, const int64_t* shape, int32_t ndim);
 /* Checks that no required key is missing (model_util.py:8), folds/packs weights for the kernels and
  * uploads them. Must be called once before any compute entry point. */
-int rgn_finalize_weights(rgn_handle h);
+RGN_API int rgn_finalize_weights(rgn_handle h);
 /* One flat device buffer holds every packed weight so multi-GPU start-up is ONE RCCL broadcast
  * (replaces utils/dist_util.py:54-83 sync_params / load_state_dict). */
-int rgn_weight_blob(rgn_handle h, void** dev_ptr, uint64_t* nbytes);
+RGN_API int rgn_weight_blob(rgn_handle h, void** dev_ptr, uint64_t* nbytes);
 
 /* Replaces SpacedDiffusion.__init__ + _WrappedModel timestep mapping (diffusion/respace.py:64-129)
  * and the per-step _extract_into_tensor gathers (gaussian_diffusion.py:1604-1617). */
-int rgn_set_schedule(rgn_handle h, const rgn_schedule* s);
+RGN_API int rgn_set_schedule(rgn_handle h, const rgn_schedule* s);
 
 /* Binds model_kwargs['y'] for subsequent denoise/sample calls (data_loaders/tensors.py:57-94):
  * cmotion_dev fp32 [B,njoints,nfeats,T]; action_dev int64 [B] (y['action'][:,0]) or NULL;
  * text_feat_dev fp32 [B,clip_dim] = CLIP text features (encode_text output, cmdm.py:153-166) or NULL;
  * scale_dev fp32 [B] (y['scale'], cfg_sampler.py:31) or NULL. Hoists cmo_process(cmotion) and its
  * fuse_process half out of the step loop (model/cmdm.py:202,207-211). Inputs are read, never written. */
-int rgn_set_condition(rgn_handle h, int32_t B, const float* cmotion_dev, const int64_t* action_dev,
+RGN_API int rgn_set_condition(rgn_handle h, int32_t B, const float* cmotion_dev, const int64_t* action_dev,
                       const float* text_feat_dev, const float* scale_dev, void* stream);
 
 /* One denoiser evaluation: out = CMDM.forward(x, t, y) (model/cmdm.py:173-252), or with
  * RGN_FLAG_GUIDED the ClassifierFreeSampleModel combination (model/cfg_sampler.py:24-31).
  * t_dev: int64 [B] ORIGINAL timestep indices (what _WrappedModel passes on, respace.py:124-129). */
-int rgn_denoise(rgn_handle h, const float* x_dev, const int64_t* t_dev, int32_t flags, float* out_dev, void* stream);
+RGN_API int rgn_denoise(rgn_handle h, const float* x_dev, const int64_t* t_dev, int32_t flags, float* out_dev, void* stream);
 
 /* Steps i = first_index, first_index-1, ..., first_index-count+1 of the sampling loop
  * (p_sample_loop_progressive gaussian_diffusion.py:711-742 / ddim :979-1005) applied in place to
@@ -133,7 +142,7 @@ int rgn_denoise(rgn_handle h, const float* x_dev, const int64_t* t_dev, int32_t 
  *               throughput kernels; the small-batch engine (<= 640 token rows) launches eagerly either way, which is faster
  *               there (one chain of short kernels; REGENNET_SB_GRAPH=1 forces graphs).
  *   clip_denoised : clamp pred_xstart to [-1,1] (process_xstart, gaussian_diffusion.py:366-372). */
-int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, float* x_dev,
+RGN_API int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, float* x_dev,
                      const float* noise_dev, uint64_t seed, uint64_t sample_offset,
                      int32_t first_index, int32_t count, float* x0_dev, int32_t use_graph,
                      int32_t clip_denoised, void* stream);
@@ -142,12 +151,12 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
  * split-bf16, all earlier ones plain bf16. -1 restores the default (max(5, ceil(S/200)) for models of >= 8 layers, max(8, ceil(S/100)) * 8/num_layers for shallower ones, at most S); 0 = plain bf16 throughout;
  * >= S = split-bf16 throughout. Why it is safe: p_sample scales the denoiser output by posterior_mean_coef1[t]
  * (gaussian_diffusion.py:265-276; 0.0016 at t=999, -> 1 at t=0), so early-step rounding is contracted away. */
-int rgn_set_x3_tail(rgn_handle h, int32_t tail_steps);
+RGN_API int rgn_set_x3_tail(rgn_handle h, int32_t tail_steps);
 
 /* const_noise of p_sample (gaussian_diffusion.py:544-547): every motion of the batch receives the per-step draw of the
  * batch's motion 0 (tape entry [k, 0] / the Philox stream of sample_offset + 0); x_T is not affected (:706). Holds for the
  * following rgn_sample_range calls until cleared. */
-int rgn_set_const_noise(rgn_handle h, int32_t on);
+RGN_API int rgn_set_const_noise(rgn_handle h, int32_t on);
 
 /* Evaluations of at most `rows` token rows (motions x tokens, doubled under guidance) run the small-batch engine:
  * column-split GEMMs that spread one row tile over 16-48 workgroups (rgn_sb.hip; d = 512 models, bf16 modes), the
@@ -155,33 +164,48 @@ int rgn_set_const_noise(rgn_handle h, int32_t on);
  * Larger evaluations run the row-complete throughput kernels. -1 restores the default (640, or REGENNET_SB_ROWS);
  * 0 switches the small-batch engine off. Results of the two engines agree within the precision mode's error (both are
  * checked against the same goldens), not bit for bit. */
-int rgn_set_small_batch_rows(rgn_handle h, int32_t rows);
+RGN_API int rgn_set_small_batch_rows(rgn_handle h, int32_t rows);
+
+/* Evaluations of at least `samples` samples of <= 64 tokens (motions, doubled under guidance) run the one-kernel decoder stack
+ * (rgn_layers.hip: one workgroup per sample, whole runs of sampler steps per launch); smaller ones the kernel-per-stage chain, which
+ * spreads a small batch over more CUs. -1 restores the default (64, or REGENNET_LAYERS_MIN_B). The two forms differ by bf16 roundings
+ * in the plain-bf16 phase (both inside the parity bound): callers that compare a motion drawn alone with its row of a batch - the
+ * precision-schedule calibration, bench.py's row check, the row-independence tests - select the batch's form with this knob. */
+RGN_API int rgn_set_layers_min_b(rgn_handle h, int32_t samples);
 
 /* Fills x_dev [B,njoints,nfeats,T] with N(0,1) from the same Philox stream (x_T, gaussian_diffusion.py:706). */
-int rgn_randn(rgn_handle h, float* x_dev, int32_t B, uint64_t seed, uint64_t sample_offset, void* stream);
+RGN_API int rgn_randn(rgn_handle h, float* x_dev, int32_t B, uint64_t seed, uint64_t sample_offset, void* stream);
 
 /* The noise rgn_sample_range adds at loop index `loop_index` (th.randn_like(x), gaussian_diffusion.py:544 / :792), for
  * callers that run the reference's own per-step loop (p_sample / ddim_sample around rgn_denoise: inpainting masks,
  * y['uncond']) and want the SAME draws as the fused loop for a given (seed, sample_offset): [B,njoints,nfeats,T],
  * value (motion b, feature, frame) = Philox(seed; sample_offset + b, loop_index, feature * 4096 + frame).
  * loop_index = -1 is rgn_randn's x_T draw; loop_index < -1: RGN_ERR_INVALID_ARG. */
-int rgn_randn_step(rgn_handle h, float* x_dev, int32_t B, uint64_t seed, uint64_t sample_offset, int32_t loop_index, void* stream);
+RGN_API int rgn_randn_step(rgn_handle h, float* x_dev, int32_t B, uint64_t seed, uint64_t sample_offset, int32_t loop_index, void* stream);
 
 /* Post-processing rows next to the path:
  * rot6d -> rotation matrices, Gram-Schmidt (utils/rotation_conversions.py:513-534): d6 [n,6] -> [n,3,3] */
-int rgn_rot6d_to_matrix(rgn_handle h, const float* d6_dev, float* mat_dev, int64_t n, void* stream);
+RGN_API int rgn_rot6d_to_matrix(rgn_handle h, const float* d6_dev, float* mat_dev, int64_t n, void* stream);
 /* scipy.ndimage.gaussian_filter1d(x, sigma, axis=-1, mode='reflect') on device (sample/cgenerate.py:142):
  * x [rows, T] -> out [rows, T] */
-int rgn_gaussian_filter1d(rgn_handle h, const float* x_dev, float* out_dev, int64_t rows, int32_t T,
+RGN_API int rgn_gaussian_filter1d(rgn_handle h, const float* x_dev, float* out_dev, int64_t rows, int32_t T,
                           float sigma, void* stream);
 
 /* Introspection for bench/profiling: name and accumulated HIP-event time (ms) + launch count of the
  * internal kernel classes since the last reset; timing is only collected when enabled. */
-int rgn_profile_enable(rgn_handle h, int32_t on);
-int rgn_profile_query(rgn_handle h, int32_t idx, const char** name, double* total_ms, int64_t* launches);
+RGN_API int rgn_profile_enable(rgn_handle h, int32_t on);
+RGN_API int rgn_profile_query(rgn_handle h, int32_t idx, const char** name, double* total_ms, int64_t* launches);
+/* The engine's own plan for ONE denoiser evaluation of a sampling loop over B motions (2 B rows when `guided`), in the plain-bf16
+ * phase of the precision schedule (split_phase = 0) or its split-bf16 tail (1): for kernel class idx (the classes of rgn_profile_query)
+ * the concrete kernel, launches per evaluation (single kernel chain; 0 for k_layers<true>, which is ONE launch per run of steps),
+ * the algorithmic FLOPs those launches carry (2 x MAC, full T x T scores) and, for the one-kernel forms, the weight
+ * fragment bytes their workgroups stream from L2. Filled by the code that dispatches (plan_eval in rgn_api.cpp), so a benchmark prices
+ * exactly what the engine launches. */
+RGN_API int rgn_plan_query(rgn_handle h, int32_t B, int32_t guided, int32_t split_phase, int32_t idx, const char** name,
+                           const char** kernel, double* launches_per_eval, double* algo_flops_per_eval, double* l2_bytes_per_eval);
 /* Time (ms) one event pair measures around a one-thread no-op kernel on this handle's stream: the dispatch + event
  * latency every bracket of rgn_profile_query carries on top of the kernel itself (calibrated at the first enable). */
-int rgn_profile_bracket_overhead(rgn_handle h, double* ms);
+RGN_API int rgn_profile_bracket_overhead(rgn_handle h, double* ms);
 
 /* ---- Evaluation harness next to the sampler: the ST-GCN feature extractor / action classifier ----
  * Replaces eval/a2m/recognition/models/stgcn.py:28-123 (STGCN) as used by eval/a2m/stgcn/evaluate.py:9-45: the features
@@ -198,16 +222,16 @@ typedef struct {
     int32_t max_batch;
     int32_t device;
 } rgn_stgcn_config;
-int rgn_stgcn_create(const rgn_stgcn_config* cfg, rgn_stgcn_handle* out);
-int rgn_stgcn_destroy(rgn_stgcn_handle h);
-const char* rgn_stgcn_last_error(rgn_stgcn_handle h);
+RGN_API int rgn_stgcn_create(const rgn_stgcn_config* cfg, rgn_stgcn_handle* out);
+RGN_API int rgn_stgcn_destroy(rgn_stgcn_handle h);
+RGN_API const char* rgn_stgcn_last_error(rgn_stgcn_handle h);
 /* host fp32 copies of the checkpoint tensors (model.load_state_dict, evaluate.py:24-25) */
-int rgn_stgcn_load_weight(rgn_stgcn_handle h, const char* ref_key, const float* host, const int64_t* shape, int32_t ndim);
+RGN_API int rgn_stgcn_load_weight(rgn_stgcn_handle h, const char* ref_key, const float* host, const int64_t* shape, int32_t ndim);
 /* folds every BatchNorm (eval mode) and the edge importance into the convolutions; RGN_ERR_MISSING_KEY names what is absent */
-int rgn_stgcn_finalize(rgn_stgcn_handle h);
+RGN_API int rgn_stgcn_finalize(rgn_stgcn_handle h);
 /* STGCN.forward (stgcn.py:76-123): output_dev fp32 [N, num_nodes, in_channels, T] (batch['output']) ->
  * features_dev fp32 [N, 256] (batch['features'], nullable) and yhat_dev fp32 [N, num_class] (batch['yhat'], nullable) */
-int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output_dev, float* features_dev, float* yhat_dev, void* stream);
+RGN_API int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output_dev, float* features_dev, float* yhat_dev, void* stream);
 
 #ifdef __cplusplus
 }

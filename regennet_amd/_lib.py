@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libregennet_hip.so")
 
 RGN_OK = 0
-ERR_NAMES = {-1: "INVALID_ARG", -2: "BAD_KEY", -3: "BAD_SHAPE", -4: "MISSING_KEY", -5: "STATE", -6: "HIP", -7: "UNSUPPORTED"}
+ERR_NAMES = {-1: "INVALID_ARG", -2: "BAD_KEY", -3: "BAD_SHAPE", -4: "MISSING_KEY", -5: "STATE", -6: "HIP", -7: "UNSUPPORTED", -8: "INTERNAL"}
 CM = {"add": 0, "concat": 1}
 COND = {"no_cond": 0, "action": 1, "text": 2}
 PREC = {"f32": 0, "bf16x3": 1, "bf16": 2, "bf16_x3tail": 3}
@@ -56,6 +56,9 @@ SYMBOLS = {
     "rgn_set_x3_tail": (C.c_int, [_vp, _i32]),
     "rgn_set_small_batch_rows": (C.c_int, [_vp, _i32]),
     "rgn_set_const_noise": (C.c_int, [_vp, _i32]),
+    "rgn_set_layers_min_b": (C.c_int, [_vp, _i32]),
+    "rgn_plan_query": (C.c_int, [_vp, _i32, _i32, _i32, _i32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rgn_randn": (C.c_int, [_vp, _vp, _i32, _u64, _u64, _vp]),
     "rgn_randn_step": (C.c_int, [_vp, _vp, _i32, _u64, _u64, _i32, _vp]),
     "rgn_rot6d_to_matrix": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
@@ -217,6 +220,24 @@ class Engine:
     def set_small_batch_rows(self, rows):
         """Evaluations of at most `rows` token rows run the small-batch (column-split) kernels; -1: default, 0: off."""
         self._ck(self.lib.rgn_set_small_batch_rows(self.h, int(rows)))
+
+    def set_layers_min_b(self, samples):
+        """Evaluations of at least `samples` samples (<= 64 tokens) run the one-kernel decoder stack (k_layers); -1: default (64)."""
+        self._ck(self.lib.rgn_set_layers_min_b(self.h, int(samples)))
+
+    def plan_query(self, B, guided=False, split_phase=False):
+        """The engine's plan for one denoiser evaluation of B motions: {class: dict(kernel, launches_per_eval, flops, l2_bytes)} for the
+        classes that take part (rgn_plan_query: filled by the dispatching code itself)."""
+        out = {}
+        for i in range(32):
+            name, kern, n, fl, l2 = C.c_char_p(), C.c_char_p(), C.c_double(), C.c_double(), C.c_double()
+            code = self.lib.rgn_plan_query(self.h, int(B), int(bool(guided)), int(bool(split_phase)), i, C.byref(name), C.byref(kern),
+                                           C.byref(n), C.byref(fl), C.byref(l2))
+            if code != RGN_OK:
+                break
+            if kern.value:
+                out[name.value.decode()] = {"kernel": kern.value.decode(), "launches_per_eval": n.value, "flops": fl.value, "l2_bytes": l2.value}
+        return out
 
     def randn(self, x, B, seed, sample_offset, stream):
         self._ck(self.lib.rgn_randn(self.h, _ptr(x), int(B), int(seed) & (2 ** 64 - 1), int(sample_offset), C.c_void_p(stream)))

@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -99,6 +101,7 @@ struct rgn_ctx {
     bool mlp_x3 = false;               // split-bf16 phase: the whole layer tail in one row-persistent kernel (k_mlp_x3, REGENNET_MLP_X3)
     bool step_fused = false;           // plain-bf16 phase: output projection (+ guidance) + sampler update + next input embedding in one kernel (REGENNET_NO_STEP_FUSION=1: three launches)
     bool layers_fused = false;         // plain-bf16 phase, <= 64 tokens: the whole decoder stack of an evaluation as one kernel, one sample per workgroup (k_layers; REGENNET_LAYERS=0: kernel per stage)
+    int layers_min_b_default = 64;     // (REGENNET_LAYERS_MIN_B)
     int layers_min_b = 64;             // ... for evaluations of at least this many samples (REGENNET_LAYERS_MIN_B): one workgroup per sample is a latency chain of 8 layers (250-step calls: 114 ms at any B <= 256), the kernel-per-stage form spreads a sample over more CUs (B = 16 / 32 / 48: 110-111 ms; B = 64: 114.4 vs 113.6)
     bool layers_steps = false;         // ... and, unguided, whole runs of sampler steps in ONE launch (k_layers<true>: stack + step boundary per sample; REGENNET_LAYERS_STEPS=0: one k_layers + one k_step per step)
     bool layers_guided = true;         // ... and guided runs too (a motion's two evaluations in one workgroup; REGENNET_LAYERS_GUIDED=0: k_layers per evaluation + the guided k_step)
@@ -425,6 +428,69 @@ int pack_state(rgn_ctx* c, const float* x, const Dims& dm, bool guided, hipStrea
 // residual stream in `h` (fp32), LayerNorms applied by the consuming GEMM.
 bool use_sb(const rgn_ctx* c, int rows) { return c->sb && c->cfg.precision != RGN_PREC_F32 && rows <= c->sb_rows; }
 
+// ---- the plan of one denoiser evaluation: WHICH kernels run it. The one place that decides - run_layers / run_eval /
+//      rgn_sample_range dispatch on it and rgn_plan_query reports it (launches, algorithmic FLOPs and L2 weight-stream bytes per
+//      kernel class), so that what bench.py prices is by construction what the engine launches.
+enum AttnForm { AF_LAYERS = 0, AF_QKV, AF_QKV_LONG, AF_ROWGEMM_ATTN, AF_GEMM_ATTN, AF_PLAIN };
+enum TailForm { TF_LAYERS = 0, TF_MLP_X3, TF_MLP, TF_ROWGEMM, TF_GEMM_LN };
+struct EvalPlan {
+    bool sb = false;          // small-batch engine (k_sb_gemm chain) for the whole evaluation
+    bool layers = false;      // k_layers: the whole decoder stack in one kernel, one sample per workgroup
+    bool steps = false;       // k_layers<true>: whole runs of sampler steps in one launch (sampling only)
+    bool step_fused = false;  // k_step: output projection + sampler update + next input embedding (sampling only)
+    AttnForm attn = AF_PLAIN;
+    TailForm tail = TF_GEMM_LN;
+};
+bool all_frag(const rgn_ctx* c) {
+    bool ok = true;
+    for (int l = 0; l < c->L; ++l) ok = ok && c->layers[l].qkv.fr && c->layers[l].out.fr && c->layers[l].ff1.fr && c->layers[l].ff2.fr;
+    return ok;
+}
+inline bool eval_x3_phase(const rgn_ctx* c, bool phase_x3) {
+    return c->cfg.precision == RGN_PREC_BF16X3 || (c->cfg.precision == RGN_PREC_BF16_X3TAIL && phase_x3);
+}
+// Can this evaluation end in the fused step boundary (rgn_step.hip)? Sampling step of the plain-bf16 phase on the
+// throughput kernels with hi-only residual planes; guided and unguided (guided sampling runs one k_step over the conditional rows
+// after the chains have joined).
+bool step_fusable(const rgn_ctx* c, bool x3, int rows) {
+    return c->step_fused && !x3 && c->cfg.precision == RGN_PREC_BF16_X3TAIL && !use_sb(c, rows) && !c->bulk_resid_lo;
+}
+// dm: the WHOLE evaluation (Bm = all rows of all chains); x3: split-bf16 arithmetic for it; sampling: inside a sampler loop
+EvalPlan plan_eval(const rgn_ctx* c, const Dims& dm, bool guided, bool x3, bool sampling) {
+    EvalPlan p;
+    const int prec = c->cfg.precision, rows = dm.Bm * dm.Tq;
+    const bool fast = prec != RGN_PREC_F32;
+    const bool lo_planes = prec == RGN_PREC_BF16X3 || prec == RGN_PREC_BF16_X3TAIL;     // has_lo()
+    const bool h_lo = x3 || (lo_planes && c->bulk_resid_lo);                              // residual stream carries a lo plane
+    p.sb = use_sb(c, rows);
+    if (p.sb) {
+        p.attn = (c->sb_attn && sb_qkv_attn_supported(c->d, dm.dh, dm.Tq)) ? AF_QKV : AF_GEMM_ATTN;
+        return p;
+    }
+    p.step_fused = sampling && step_fusable(c, x3, rows);
+    p.layers = fast && !x3 && c->layers_fused && dm.Bm >= c->layers_min_b && !h_lo && all_frag(c);
+    p.steps = p.layers && p.step_fused && c->layers_steps && (!guided || (c->layers_guided && c->ffn_hi &&
+              // the guided form parks a motion's conditional x0 (6 x 4096 floats) in the idle hidden-tensor planes: 2 max_batch Tq ffp bf16
+              (size_t)2 * c->cfg.max_batch * c->Tq * align_up((size_t)c->ff, 32) * 2 >= (size_t)dm.B * 6 * 4096 * 4));
+    if (p.layers) {
+        p.attn = AF_LAYERS;
+        p.tail = TF_LAYERS;
+        return p;
+    }
+    const bool fr0 = c->L > 0 && c->layers[0].qkv.fr != 0;
+    if (fast && c->fuse_qkv) p.attn = AF_QKV;
+    else if (fast && c->qkv_long && !x3 && fr0 && (size_t)rows * c->layers[0].qkv.Kp * 2 < (1ull << 31)) p.attn = AF_QKV_LONG;
+    else if (fast && c->attn_x3 && !x3 && c->rowgemm && dm.dh % 32 == 0 && fr0) p.attn = AF_ROWGEMM_ATTN;
+    else if (fast && c->attn_x3) p.attn = AF_GEMM_ATTN;
+    else p.attn = AF_PLAIN;
+    const bool frlo = c->L > 0 && c->layers[0].out.fr_lo && c->layers[0].ff1.fr_lo && c->layers[0].ff2.fr_lo;
+    if (fast && x3 && c->mlp_x3 && lo_planes && frlo) p.tail = TF_MLP_X3;
+    else if (fast && !x3 && c->mlp && !h_lo) p.tail = TF_MLP;
+    else if (fast && !x3 && c->rowgemm) p.tail = TF_ROWGEMM;
+    else p.tail = TF_GEMM_LN;
+    return p;
+}
+
 int run_layers_sb(rgn_ctx* c, const Dims& dm, bool sampling, const float* cond_rows, const float* ccond_rows, hipStream_t s) {
     const int d = c->d, Ld = c->L * c->d, M = dm.Bm * dm.Tq;
     const bool x3 = eval_x3(c);
@@ -449,7 +515,7 @@ int run_layers_sb(rgn_ctx* c, const Dims& dm, bool sampling, const float* cond_r
             RGN_LAUNCH(c, KC_EMBED, s, launch_emb_rows(c->emb, nullptr, nullptr, c->dp<float>(c->off_pe), c->tmp, none, dm, c->cfg.wo_pos_emb, s));
     }
     const Planes att_p{c->att_hi, x3 ? c->att_lo : nullptr, M};
-    const bool fused_attn = c->sb_attn && sb_qkv_attn_supported(d, dm.dh, dm.Tq);
+    const bool fused_attn = plan_eval(c, dm, false, x3, sampling).attn == AF_QKV;
     for (int l = 0; l < c->L; ++l) {
         const LayerW& w = c->layers[l];
         {   // layer input = norm3 of the previous layer (layer 0: the embedding itself); in_proj -> q (pre-scaled), k, v
@@ -531,7 +597,9 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
     const int prec = c->cfg.precision;
     const int d = c->d, Ld = c->L * c->d, Mtot = dmf.Bm * dmf.Tq, Mb = dmf.B * dmf.Tq;
     const int row0 = s0 * dmf.Tq, M = ns * dmf.Tq;
-    if (use_sb(c, Mtot)) return run_layers_sb(c, dmf, sampling, cond_rows, ccond_rows, s);   // (called with the full range)
+    const bool fast = prec != RGN_PREC_F32, x3 = eval_x3(c);
+    const EvalPlan pl = plan_eval(c, dmf, guided, x3, sampling);
+    if (pl.sb) return run_layers_sb(c, dmf, sampling, cond_rows, ccond_rows, s);   // (called with the full range)
     Dims dm = dmf;
     dm.Bm = ns;
     // ---- the big GEMMs: F32 mode keeps fp32 activations (k_gemm_f32); the bf16 modes chain pre-split
@@ -539,14 +607,13 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
     //      (32 elements each) while Planes::rows stays the row count of the whole evaluation.
     // x3: this evaluation's GEMMs form three MFMAs per product and read hi + lo planes. In the bulk phase of the precision
     // schedule every plane is written hi-only (the residual stream's lo plane is an option, bulk_resid_lo).
-    const bool fast = prec != RGN_PREC_F32, x3 = eval_x3(c);
-    auto pl = [&](__bf16* hi, __bf16* lo, bool with_lo) {
+    auto pln = [&](__bf16* hi, __bf16* lo, bool with_lo) {
         return Planes{fast ? hi + (size_t)row0 * 32 : nullptr, (fast && with_lo) ? lo + (size_t)row0 * 32 : nullptr, Mtot};
     };
     const Planes none{nullptr, nullptr, 0};
     const bool h_lo = x3 || (has_lo(c) && c->bulk_resid_lo);
-    const Planes xin_p = pl(c->xin_hi, c->xin_lo, has_lo(c)), h_p = pl(c->h_hi, c->h_lo, h_lo), att_p = pl(c->att_hi, c->att_lo, x3),
-                 ffn_p = pl(c->ffn_hi, c->ffn_lo, x3);
+    const Planes xin_p = pln(c->xin_hi, c->xin_lo, has_lo(c)), h_p = pln(c->h_hi, c->h_lo, h_lo), att_p = pln(c->att_hi, c->att_lo, x3),
+                 ffn_p = pln(c->ffn_hi, c->ffn_lo, x3);
     float* h = c->h + (size_t)row0 * d;
     float* tmp = c->tmp + (size_t)row0 * d;
     float* qkv = c->qkv + (size_t)row0 * 3 * d;
@@ -602,22 +669,18 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
     }
     const size_t slab0 = (size_t)s0 * c->H * c->Tqp * dm.dh;      // attention-ready planes: first slab of this range
     bool layers_done = false;
-    if (fast && !x3 && c->layers_fused && dmf.Bm >= c->layers_min_b && !h_p.lo) {
+    if (pl.layers) {
         // plain-bf16 phase, <= 64 tokens, d = 512 / ff = 1024 / 4 heads: ALL layers in one kernel, one sample per workgroup - the residual
         // stream stays in LDS from the input embedding to the last norm3, only the weights stream (rgn_layers.hip)
-        bool ok = true;
-        for (int l = 0; l < c->L; ++l) ok = ok && c->layers[l].qkv.fr && c->layers[l].out.fr && c->layers[l].ff1.fr && c->layers[l].ff2.fr;
-        if (ok) {
-            LayersArgs g{};
-            g.h = h_p.hi; g.out = h_p.hi; g.rows = h_p.rows; g.Bm = ns;
-            fill_layers_args(c, g, dm, sampling, ccond_rows, s0);
-            RGN_LAUNCH(c, KC_LAYERS, s, launch_layers(g, s));
-            layers_done = true;
-        }
+        LayersArgs g{};
+        g.h = h_p.hi; g.out = h_p.hi; g.rows = h_p.rows; g.Bm = ns;
+        fill_layers_args(c, g, dm, sampling, ccond_rows, s0);
+        RGN_LAUNCH(c, KC_LAYERS, s, launch_layers(g, s));
+        layers_done = true;
     }
     for (int l = layers_done ? c->L : 0; l < c->L; ++l) {
         const LayerW& w = c->layers[l];
-        if (fast && c->fuse_qkv) {
+        if (pl.attn == AF_QKV) {
             // in_proj + attention in one kernel (two samples x half the heads per workgroup): q, k, v only ever exist in LDS
             QkvAttnArgs g{};
             g.Ahi = h_p.hi; g.Alo = h_p.lo; g.a_rows = h_p.rows;
@@ -629,7 +692,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             g.qscale = 1.0f / sqrtf((float)dm.dh);
             g.Bm_eval = dmf.Bm;   // samples of the WHOLE evaluation (all kernel chains), not of this chain
             RGN_LAUNCH(c, KC_QKV, s, launch_qkv_attn(g, x3, s));   // 93 % of its MFMA work is the in_proj GEMM
-        } else if (fast && c->qkv_long && !x3 && w.qkv.fr && !att_p.lo && (size_t)h_p.rows * w.qkv.Kp * 2 < (1ull << 31)) {
+        } else if (pl.attn == AF_QKV_LONG) {
             // plain-bf16 phase, long sequence: in_proj + attention of one (sample, head) per workgroup, q / k / v stay in LDS
             QkvAttnArgs g{};
             g.Ahi = h_p.hi; g.a_rows = h_p.rows;
@@ -638,7 +701,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             g.Bm = ns; g.Kp = w.qkv.Kp; g.d = d; g.H = c->H; g.Tq = dm.Tq;
             g.qscale = 1.0f / sqrtf((float)dm.dh);
             RGN_LAUNCH(c, KC_QKV, s, launch_qkv_attn_long(g, s));
-        } else if (fast && c->attn_x3 && !x3 && c->rowgemm && dm.dh % 32 == 0 && w.qkv.fr) {
+        } else if (pl.attn == AF_ROWGEMM_ATTN) {
             // plain-bf16 phase, long sequence: packed in_proj as a row-complete GEMM that scatters q (pre-scaled), k, v as
             // attention-ready planes (weights streamed to registers, output through an LDS image), then k_attn_x3
             RowGemmArgs g{};
@@ -653,7 +716,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             a.out = att_p;
             a.Bm = ns; a.H = c->H; a.dh = dm.dh; a.d = d; a.Tq = dm.Tq; a.Tqp = c->Tqp; a.x3 = false;
             RGN_LAUNCH(c, KC_ATTN, s, launch_attn_x3(a, s));
-        } else if (fast && c->attn_x3) {
+        } else if (pl.attn == AF_GEMM_ATTN) {
             // in_proj GEMM scatters q (pre-scaled), k and v as attention-ready split planes; no fp32 qkv round trip
             GemmX3Args g{};
             g.Ahi = h_p.hi; g.Alo = h_p.lo; g.a_rows = h_p.rows;
@@ -679,7 +742,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
         const float* per_sample = sampling ? (ccond_rows ? ccond_rows + (size_t)s0 * Ld + (size_t)l * d : nullptr)
                                            : c->call + (size_t)s0 * Ld + (size_t)l * d;
         const float* step_vec = sampling ? c->call_time + (size_t)l * d : nullptr;
-        if (fast && x3 && c->mlp_x3 && h_p.lo && att_p.lo && w.out.fr_lo && w.ff1.fr_lo && w.ff2.fr_lo) {
+        if (pl.tail == TF_MLP_X3) {
             // split-bf16 phase, d = 512 / ff = 1024: the same layer tail on (hi, lo) plane pairs, three MFMAs per product (rgn_mlp_x3.hip):
             // one launch where k_gemm_x3 x 3 + k_layernorm x 2 were five; residual stream updated in place (both planes)
             MlpX3Args gx{};
@@ -695,7 +758,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             RGN_LAUNCH(c, KC_MLP, s, launch_mlp_x3(gx, s));
             continue;
         }
-        if (fast && !x3 && c->mlp && !h_p.lo) {
+        if (pl.tail == TF_MLP) {
             // plain-bf16 phase, d = 512 / ff = 1024: the whole layer tail (out_proj + norm1 + folded cross-attention + norm2 +
             // linear1 + GELU + linear2 + norm3) as ONE row-persistent kernel; residual stream updated in place (hi plane)
             MlpArgs g{};
@@ -708,7 +771,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             RGN_LAUNCH(c, KC_MLP, s, launch_mlp(g, s));
             continue;
         }
-        if (fast && !x3 && c->rowgemm) {
+        if (pl.tail == TF_ROWGEMM) {
             // plain-bf16 phase: out_proj + residual + norm1 + folded cross-attention + norm2 | linear1 + GELU |
             // linear2 + residual + norm3, three row-complete kernels; the residual stream is updated in place as planes
             RowGemmArgs g{};
@@ -747,12 +810,6 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
     return big(c->lin_out, h, d, h_p, c->x0tok + (size_t)row0 * c->F, c->F, none, nullptr, 0, M);
 }
 
-// Can this evaluation end in the fused step boundary (rgn_step.hip)? Sampling step of the plain-bf16 phase on the
-// throughput kernels with hi-only residual planes.
-bool step_fusable(const rgn_ctx* c, bool guided, bool x3, int rows) {
-    (void)guided;   // both forms fuse: guided sampling runs one k_step over the conditional rows after the chains have joined
-    return c->step_fused && !x3 && c->cfg.precision == RGN_PREC_BF16_X3TAIL && !use_sb(c, rows) && !c->bulk_resid_lo;
-}
 // The input embedding of ALL rows into the residual-stream planes (hi): what every fused step leaves behind for the next
 // one, needed once in front of the first fused step of a sampling call.
 int embed_all(rgn_ctx* c, const Dims& dm, hipStream_t s) {
@@ -774,6 +831,7 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
     const Dims dm = make_dims(c, B, guided);
     const int prec = c->cfg.precision;
     const int d = c->d, Ld = c->L * c->d, M = dm.Bm * dm.Tq, Mb = B * dm.Tq;
+    const EvalPlan pl = plan_eval(c, dm, guided, eval_x3(c), sampling);
 
     // timestep embedding (TimestepEmbedder cmdm.py:284-298) + condition embedding (cmdm.py:181-187).
     // Inside a sampling loop every sample shares t, so TE[s] and the folded cross-attention vectors were computed
@@ -815,7 +873,7 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
     // split-bf16 phase 246 vs 277; one chain in the bulk phase and four in the tail measured 120 - 137 ms against 111 with one throughout)
     // (B = 40 / 48: 114.3 / 113.8 vs 120.0 / 118.8 with four; B = 64, 60 tiles: the same with one, two and four)
     if (nch == 4 && !c->nchains_user && tiles64 <= 48) nch = 1;
-    if (use_sb(c, M)) nch = 1;                            // small-batch engine: one chain of column-split kernels
+    if (pl.sb) nch = 1;                                   // small-batch engine: one chain of column-split kernels
     if (nch > dm.Bm) nch = dm.Bm;
     if (nch > 1) RGN_HIP(c, hipEventRecord(c->ev_fork, s));
     const int per = dm.Bm / nch, extra = dm.Bm % nch;
@@ -826,7 +884,7 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
     // chains and the update waits for the join.
     const Planes xin_p{fast ? c->xin_hi : nullptr, (fast && has_lo(c)) ? c->xin_lo : nullptr, M};
     c->skip_embed_out = false;
-    const bool fused = sampling && step_fusable(c, guided, eval_x3(c), M);   // k_step instead of out GEMM + k_update + next in GEMM
+    const bool fused = pl.step_fused;                       // k_step instead of out GEMM + k_update + next in GEMM
     const bool own_update = !guided && (nch > 1 || fused);
     int total_tiles = 0;
     if (fused) {
@@ -908,6 +966,30 @@ int build_step_table(rgn_ctx* c, float eta) {
     return RGN_OK;
 }
 
+// No C++ exception crosses the C boundary (include/regennet_hip.h): every entry point runs its body inside this guard, and what the
+// host-side containers may throw (std::bad_alloc, std::length_error ...) comes back as RGN_ERR_INTERNAL with the text in rgn_last_error.
+int boundary_error(rgn_ctx* h, const char* fn, const char* what) noexcept {
+    try {
+        std::string m = std::string(fn) + ": C++ exception at the boundary: " + what;
+        if (h) h->err.swap(m);
+        else g_create_error.swap(m);
+    } catch (...) {   // (not even the message could be built: the code alone reports it)
+    }
+    return RGN_ERR_INTERNAL;
+}
+template <class F>
+int rgn_guard(rgn_ctx* h, const char* fn, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return boundary_error(h, fn, "std::bad_alloc (host memory)");
+    } catch (const std::exception& e) {
+        return boundary_error(h, fn, e.what());
+    } catch (...) {
+        return boundary_error(h, fn, "unknown exception");
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -915,706 +997,831 @@ extern "C" {
 const char* rgn_last_error(rgn_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int rgn_create(const rgn_config* cfg, rgn_handle* out) {
-    if (!cfg || !out) {
-        g_create_error = "rgn_create: null argument";
-        return RGN_ERR_INVALID_ARG;
-    }
-    *out = nullptr;
-    auto bad = [&](int code, const std::string& m) {
-        g_create_error = m;
-        return code;
-    };
-    if (cfg->njoints <= 0 || cfg->nfeats <= 0 || cfg->num_frames <= 0 || cfg->latent_dim <= 0 || cfg->ff_size <= 0 ||
-        cfg->num_heads <= 0 || cfg->num_layers <= 0 || cfg->max_batch <= 0)
-        return bad(RGN_ERR_INVALID_ARG, "rgn_create: non-positive dimension");
-    if (cfg->latent_dim % cfg->num_heads) return bad(RGN_ERR_INVALID_ARG, "rgn_create: latent_dim % num_heads != 0");
-    if (cfg->latent_dim % 64 || cfg->latent_dim > 1024 || (cfg->latent_dim / 64 & (cfg->latent_dim / 64 - 1)))
-        return bad(RGN_ERR_UNSUPPORTED, "rgn_create: latent_dim must be 64*2^k <= 1024");
-    if (cfg->num_frames > 4096) return bad(RGN_ERR_UNSUPPORTED, "rgn_create: more than 4096 frames (Philox element counter)");
-    if (cfg->latent_dim / cfg->num_heads > 128)
-        return bad(RGN_ERR_UNSUPPORTED, "rgn_create: head dim > 128 unsupported");
-    if (cfg->cm_mode != RGN_CM_ADD && cfg->cm_mode != RGN_CM_CONCAT) return bad(RGN_ERR_INVALID_ARG, "rgn_create: cm_mode");
-    if (cfg->cond_mode < RGN_COND_NONE || cfg->cond_mode > RGN_COND_TEXT) return bad(RGN_ERR_INVALID_ARG, "rgn_create: cond_mode");
-    if (cfg->precision < RGN_PREC_F32 || cfg->precision > RGN_PREC_BF16_X3TAIL) return bad(RGN_ERR_INVALID_ARG, "rgn_create: precision");
-    if (cfg->cond_mode == RGN_COND_ACTION && cfg->num_actions <= 0) return bad(RGN_ERR_INVALID_ARG, "rgn_create: num_actions");
-    if (cfg->cond_mode == RGN_COND_TEXT && cfg->clip_dim <= 0) return bad(RGN_ERR_INVALID_ARG, "rgn_create: clip_dim");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return bad(RGN_ERR_HIP, "rgn_create: no HIP device visible");
-    if (cfg->device < 0 || cfg->device >= ndev) return bad(RGN_ERR_INVALID_ARG, "rgn_create: device ordinal out of range");
-    if (hipSetDevice(cfg->device) != hipSuccess) return bad(RGN_ERR_HIP, "rgn_create: hipSetDevice failed");
+    return rgn_guard(static_cast<rgn_ctx*>(nullptr), "rgn_create", [&]() -> int {
+        if (!cfg || !out) {
+            g_create_error = "rgn_create: null argument";
+            return RGN_ERR_INVALID_ARG;
+        }
+        *out = nullptr;
+        auto bad = [&](int code, const std::string& m) {
+            g_create_error = m;
+            return code;
+        };
+        if (cfg->njoints <= 0 || cfg->nfeats <= 0 || cfg->num_frames <= 0 || cfg->latent_dim <= 0 || cfg->ff_size <= 0 ||
+            cfg->num_heads <= 0 || cfg->num_layers <= 0 || cfg->max_batch <= 0)
+            return bad(RGN_ERR_INVALID_ARG, "rgn_create: non-positive dimension");
+        if (cfg->latent_dim % cfg->num_heads) return bad(RGN_ERR_INVALID_ARG, "rgn_create: latent_dim % num_heads != 0");
+        if (cfg->latent_dim % 64 || cfg->latent_dim > 1024 || (cfg->latent_dim / 64 & (cfg->latent_dim / 64 - 1)))
+            return bad(RGN_ERR_UNSUPPORTED, "rgn_create: latent_dim must be 64*2^k <= 1024");
+        if (cfg->num_frames > 4096) return bad(RGN_ERR_UNSUPPORTED, "rgn_create: more than 4096 frames (Philox element counter)");
+        if (cfg->latent_dim / cfg->num_heads > 128)
+            return bad(RGN_ERR_UNSUPPORTED, "rgn_create: head dim > 128 unsupported");
+        if (cfg->cm_mode != RGN_CM_ADD && cfg->cm_mode != RGN_CM_CONCAT) return bad(RGN_ERR_INVALID_ARG, "rgn_create: cm_mode");
+        if (cfg->cond_mode < RGN_COND_NONE || cfg->cond_mode > RGN_COND_TEXT) return bad(RGN_ERR_INVALID_ARG, "rgn_create: cond_mode");
+        if (cfg->precision < RGN_PREC_F32 || cfg->precision > RGN_PREC_BF16_X3TAIL) return bad(RGN_ERR_INVALID_ARG, "rgn_create: precision");
+        if (cfg->cond_mode == RGN_COND_ACTION && cfg->num_actions <= 0) return bad(RGN_ERR_INVALID_ARG, "rgn_create: num_actions");
+        if (cfg->cond_mode == RGN_COND_TEXT && cfg->clip_dim <= 0) return bad(RGN_ERR_INVALID_ARG, "rgn_create: clip_dim");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return bad(RGN_ERR_HIP, "rgn_create: no HIP device visible");
+        if (cfg->device < 0 || cfg->device >= ndev) return bad(RGN_ERR_INVALID_ARG, "rgn_create: device ordinal out of range");
+        if (hipSetDevice(cfg->device) != hipSuccess) return bad(RGN_ERR_HIP, "rgn_create: hipSetDevice failed");
 
-    rgn_ctx* c = new rgn_ctx();
-    c->cfg = *cfg;
-    c->F = cfg->njoints * cfg->nfeats;
-    c->d = cfg->latent_dim;
-    c->etd = cfg->emb_trans_dec ? 1 : 0;
-    c->Tq = cfg->num_frames + c->etd;
-    c->L = cfg->num_layers;
-    c->H = cfg->num_heads;
-    c->ff = cfg->ff_size;
-    build_expected(c);
-    *out = c;
-    return RGN_OK;
+        std::unique_ptr<rgn_ctx> c(new rgn_ctx());
+        c->cfg = *cfg;
+        c->F = cfg->njoints * cfg->nfeats;
+        c->d = cfg->latent_dim;
+        c->etd = cfg->emb_trans_dec ? 1 : 0;
+        c->Tq = cfg->num_frames + c->etd;
+        c->L = cfg->num_layers;
+        c->H = cfg->num_heads;
+        c->ff = cfg->ff_size;
+        build_expected(c.get());
+        *out = c.release();
+        return RGN_OK;
+    });
 }
 
 int rgn_destroy(rgn_handle h) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->cfg.device);
-    (void)hipDeviceSynchronize();
-    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
-    for (auto& e : h->prof_pool) {
-        (void)hipEventDestroy(e.a);
-        (void)hipEventDestroy(e.b);
-    }
-    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
-    if (h->ev_out) (void)hipEventDestroy(h->ev_out);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
-    for (int i = 0; i < rgn_ctx::MAX_SIDE; ++i) {
-        if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
-        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
-    }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    for (void* p : h->allocs) (void)hipFree(p);
-    if (h->dblob) (void)hipFree(h->dblob);
-    delete h;
-    return RGN_OK;
+    return rgn_guard(h, "rgn_destroy", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        (void)hipSetDevice(h->cfg.device);
+        (void)hipDeviceSynchronize();
+        for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+        for (auto& e : h->prof_pool) {
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+        if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+        if (h->ev_out) (void)hipEventDestroy(h->ev_out);
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+        for (int i = 0; i < rgn_ctx::MAX_SIDE; ++i) {
+            if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
+            if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+        }
+        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+        for (void* p : h->allocs) (void)hipFree(p);
+        if (h->dblob) (void)hipFree(h->dblob);
+        delete h;
+        return RGN_OK;
+    });
 }
 
 int rgn_load_weight(rgn_handle h, const char* key, const float* host, const int64_t* shape, int32_t ndim) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    if (!key || !host || !shape || ndim <= 0) return h->fail(RGN_ERR_INVALID_ARG, "rgn_load_weight: null/empty argument");
-    if (h->finalized) return h->fail(RGN_ERR_STATE, "rgn_load_weight: weights already finalized");
-    const std::string k(key);
-    if (k.rfind("clip_model.", 0) == 0) return RGN_OK;  // accepted and ignored (model_util.py:8)
-    auto it = h->expected.find(k);
-    if (it == h->expected.end()) return h->fail(RGN_ERR_BAD_KEY, "unexpected key in state_dict: " + k);
-    const auto& es = it->second;
-    bool ok = (int)es.size() == ndim;
-    for (int i = 0; ok && i < ndim; ++i) ok = (es[i] == -1) ? (shape[i] > 0) : (es[i] == shape[i]);
-    if (!ok) {
-        std::string m = "size mismatch for " + k + ": got [";
-        for (int i = 0; i < ndim; ++i) m += std::to_string(shape[i]) + (i + 1 < ndim ? "," : "");
-        m += "], expected [";
-        for (size_t i = 0; i < es.size(); ++i) m += std::to_string(es[i]) + (i + 1 < es.size() ? "," : "");
-        return h->fail(RGN_ERR_BAD_SHAPE, m + "]");
-    }
-    size_t n = 1;
-    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
-    HostTensor t;
-    t.v.assign(host, host + n);
-    t.shape.assign(shape, shape + ndim);
-    h->sd[k] = std::move(t);
-    return RGN_OK;
+    return rgn_guard(h, "rgn_load_weight", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        if (!key || !host || !shape || ndim <= 0) return h->fail(RGN_ERR_INVALID_ARG, "rgn_load_weight: null/empty argument");
+        if (h->finalized) return h->fail(RGN_ERR_STATE, "rgn_load_weight: weights already finalized");
+        const std::string k(key);
+        if (k.rfind("clip_model.", 0) == 0) return RGN_OK;  // accepted and ignored (model_util.py:8)
+        auto it = h->expected.find(k);
+        if (it == h->expected.end()) return h->fail(RGN_ERR_BAD_KEY, "unexpected key in state_dict: " + k);
+        const auto& es = it->second;
+        bool ok = (int)es.size() == ndim;
+        for (int i = 0; ok && i < ndim; ++i) ok = (es[i] == -1) ? (shape[i] > 0) : (es[i] == shape[i]);
+        if (!ok) {
+            std::string m = "size mismatch for " + k + ": got [";
+            for (int i = 0; i < ndim; ++i) m += std::to_string(shape[i]) + (i + 1 < ndim ? "," : "");
+            m += "], expected [";
+            for (size_t i = 0; i < es.size(); ++i) m += std::to_string(es[i]) + (i + 1 < es.size() ? "," : "");
+            return h->fail(RGN_ERR_BAD_SHAPE, m + "]");
+        }
+        size_t n = 1;
+        for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+        HostTensor t;
+        t.v.assign(host, host + n);
+        t.shape.assign(shape, shape + ndim);
+        h->sd[k] = std::move(t);
+        return RGN_OK;
+    });
 }
 
 int rgn_finalize_weights(rgn_handle h) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    if (h->finalized) return h->fail(RGN_ERR_STATE, "rgn_finalize_weights: already finalized");
-    rgn_ctx* c = h;
-    std::string missing;
-    for (auto& kv : c->expected)
-        if (!c->sd.count(kv.first)) missing += (missing.empty() ? "" : ", ") + kv.first;
-    if (!missing.empty()) return c->fail(RGN_ERR_MISSING_KEY, "missing keys in state_dict: " + missing);
-    RGN_HIP(c, hipSetDevice(c->cfg.device));
-    auto W = [&](const std::string& k) -> const float* { return c->sd[k].v.data(); };
-    const int d = c->d, F = c->F, ff = c->ff;
+    return rgn_guard(h, "rgn_finalize_weights", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        if (h->finalized) return h->fail(RGN_ERR_STATE, "rgn_finalize_weights: already finalized");
+        rgn_ctx* c = h;
+        std::string missing;
+        for (auto& kv : c->expected)
+            if (!c->sd.count(kv.first)) missing += (missing.empty() ? "" : ", ") + kv.first;
+        if (!missing.empty()) return c->fail(RGN_ERR_MISSING_KEY, "missing keys in state_dict: " + missing);
+        RGN_HIP(c, hipSetDevice(c->cfg.device));
+        auto W = [&](const std::string& k) -> const float* { return c->sd[k].v.data(); };
+        const int d = c->d, F = c->F, ff = c->ff;
 
-    // --- positional table: the buffer both modules alias; load order makes the embed_timestep key win
-    const HostTensor& pe = c->sd["embed_timestep.sequence_pos_encoder.pe"];
-    c->pe_len = (int)pe.shape[0];
-    if (c->pe_len < c->Tq) return c->fail(RGN_ERR_BAD_SHAPE, "positional table shorter than the sequence");
-    c->off_pe = blob_put(c, pe.v.data(), pe.v.size() * 4);
+        // --- positional table: the buffer both modules alias; load order makes the embed_timestep key win
+        const HostTensor& pe = c->sd["embed_timestep.sequence_pos_encoder.pe"];
+        c->pe_len = (int)pe.shape[0];
+        if (c->pe_len < c->Tq) return c->fail(RGN_ERR_BAD_SHAPE, "positional table shorter than the sequence");
+        c->off_pe = blob_put(c, pe.v.data(), pe.v.size() * 4);
 
-    // --- input stage: fold fuse_process into the two pose embeddings (concat), fp64
-    {
-        std::vector<double> wx, wc;
-        std::vector<float> bconst(d), wxf((size_t)d * F), wcf((size_t)d * F);
-        const float* win = W("input_process.poseEmbedding.weight");
-        const float* wcm = W("cmo_process.poseEmbedding.weight");
-        const float* bin = W("input_process.poseEmbedding.bias");
-        const float* bcm = W("cmo_process.poseEmbedding.bias");
-        if (c->cfg.cm_mode == RGN_CM_CONCAT) {
-            const float* wf = W("fuse_process.weight");  // [d, 2d] = [Wf_x | Wf_c]
-            const float* bf = W("fuse_process.bias");
-            std::vector<float> wfx((size_t)d * d), wfc((size_t)d * d);
-            for (int n = 0; n < d; ++n)
-                for (int j = 0; j < d; ++j) {
-                    wfx[(size_t)n * d + j] = wf[(size_t)n * 2 * d + j];
-                    wfc[(size_t)n * d + j] = wf[(size_t)n * 2 * d + d + j];
+        // --- input stage: fold fuse_process into the two pose embeddings (concat), fp64
+        {
+            std::vector<double> wx, wc;
+            std::vector<float> bconst(d), wxf((size_t)d * F), wcf((size_t)d * F);
+            const float* win = W("input_process.poseEmbedding.weight");
+            const float* wcm = W("cmo_process.poseEmbedding.weight");
+            const float* bin = W("input_process.poseEmbedding.bias");
+            const float* bcm = W("cmo_process.poseEmbedding.bias");
+            if (c->cfg.cm_mode == RGN_CM_CONCAT) {
+                const float* wf = W("fuse_process.weight");  // [d, 2d] = [Wf_x | Wf_c]
+                const float* bf = W("fuse_process.bias");
+                std::vector<float> wfx((size_t)d * d), wfc((size_t)d * d);
+                for (int n = 0; n < d; ++n)
+                    for (int j = 0; j < d; ++j) {
+                        wfx[(size_t)n * d + j] = wf[(size_t)n * 2 * d + j];
+                        wfc[(size_t)n * d + j] = wf[(size_t)n * 2 * d + d + j];
+                    }
+                matmul64(wfx.data(), win, d, d, F, wx);
+                matmul64(wfc.data(), wcm, d, d, F, wc);
+                for (int n = 0; n < d; ++n) {
+                    double b = bf[n];
+                    for (int j = 0; j < d; ++j) b += (double)wfx[(size_t)n * d + j] * bin[j] + (double)wfc[(size_t)n * d + j] * bcm[j];
+                    bconst[n] = (float)b;
                 }
-            matmul64(wfx.data(), win, d, d, F, wx);
-            matmul64(wfc.data(), wcm, d, d, F, wc);
+                for (size_t i = 0; i < wx.size(); ++i) {
+                    wxf[i] = (float)wx[i];
+                    wcf[i] = (float)wc[i];
+                }
+            } else {
+                memcpy(wxf.data(), win, wxf.size() * 4);
+                memcpy(wcf.data(), wcm, wcf.size() * 4);
+                for (int n = 0; n < d; ++n) bconst[n] = (float)((double)bin[n] + (double)bcm[n]);
+            }
+            c->lin_x = pack_linear(c, wxf.data(), nullptr, d, F, true, c->cfg.precision == RGN_PREC_BF16_X3TAIL);   // fragment order: k_step
+            c->lin_c = pack_linear(c, wcf.data(), bconst.data(), d, F);
+        }
+        c->lin_t0 = pack_linear(c, W("embed_timestep.time_embed.0.weight"), W("embed_timestep.time_embed.0.bias"), d, d);
+        c->lin_t2 = pack_linear(c, W("embed_timestep.time_embed.2.weight"), W("embed_timestep.time_embed.2.bias"), d, d);
+
+        // --- layers; cross-attention folded: G_l = Wo_c * Wv_c, g_l = Wo_c * bv_c + bo_c (1-token memory)
+        std::vector<float> gall((size_t)c->L * d * d), gb((size_t)c->L * d);
+        c->layers.resize(c->L);
+        for (int l = 0; l < c->L; ++l) {
+            const std::string p = "seqTransDecoder.layers." + std::to_string(l) + ".";
+            LayerW& lw = c->layers[l];
+            lw.qkv = pack_linear(c, W(p + "self_attn.in_proj_weight"), W(p + "self_attn.in_proj_bias"), 3 * d, d, true,
+                                 c->cfg.precision == RGN_PREC_BF16_X3TAIL);   // fragment order: k_rowgemm (long sequences) / k_qkv_attn_rs
+            const bool fr = c->cfg.precision == RGN_PREC_BF16_X3TAIL;   // k_rowgemm operands (plain-bf16 phase)
+            // (+ lo fragment planes: the operand pairs of k_mlp_x3, the split-bf16 layer tail, in every mode that has a split-bf16 phase)
+            const bool frx = c->cfg.precision == RGN_PREC_BF16_X3TAIL || c->cfg.precision == RGN_PREC_BF16X3;
+            lw.out = pack_linear(c, W(p + "self_attn.out_proj.weight"), W(p + "self_attn.out_proj.bias"), d, d, true, fr || frx, frx);
+            lw.ff1 = pack_linear(c, W(p + "linear1.weight"), W(p + "linear1.bias"), ff, d, true, fr || frx, frx);
+            lw.ff2 = pack_linear(c, W(p + "linear2.weight"), W(p + "linear2.bias"), d, ff, true, fr || frx, frx);
+            const char* names[6] = {"norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "norm3.weight", "norm3.bias"};
+            for (int i = 0; i < 6; ++i) lw.ln[i] = blob_put(c, W(p + names[i]), (size_t)d * 4);
+            const float* wv = W(p + "multihead_attn.in_proj_weight") + (size_t)2 * d * d;
+            const float* bv = W(p + "multihead_attn.in_proj_bias") + 2 * d;
+            const float* wo = W(p + "multihead_attn.out_proj.weight");
+            const float* bo = W(p + "multihead_attn.out_proj.bias");
+            std::vector<double> G;
+            matmul64(wo, wv, d, d, d, G);
+            for (size_t i = 0; i < G.size(); ++i) gall[(size_t)l * d * d + i] = (float)G[i];
             for (int n = 0; n < d; ++n) {
-                double b = bf[n];
-                for (int j = 0; j < d; ++j) b += (double)wfx[(size_t)n * d + j] * bin[j] + (double)wfc[(size_t)n * d + j] * bcm[j];
-                bconst[n] = (float)b;
+                double b = bo[n];
+                for (int j = 0; j < d; ++j) b += (double)wo[(size_t)n * d + j] * bv[j];
+                gb[(size_t)l * d + n] = (float)b;
             }
-            for (size_t i = 0; i < wx.size(); ++i) {
-                wxf[i] = (float)wx[i];
-                wcf[i] = (float)wc[i];
-            }
-        } else {
-            memcpy(wxf.data(), win, wxf.size() * 4);
-            memcpy(wcf.data(), wcm, wcf.size() * 4);
-            for (int n = 0; n < d; ++n) bconst[n] = (float)((double)bin[n] + (double)bcm[n]);
         }
-        c->lin_x = pack_linear(c, wxf.data(), nullptr, d, F, true, c->cfg.precision == RGN_PREC_BF16_X3TAIL);   // fragment order: k_step
-        c->lin_c = pack_linear(c, wcf.data(), bconst.data(), d, F);
-    }
-    c->lin_t0 = pack_linear(c, W("embed_timestep.time_embed.0.weight"), W("embed_timestep.time_embed.0.bias"), d, d);
-    c->lin_t2 = pack_linear(c, W("embed_timestep.time_embed.2.weight"), W("embed_timestep.time_embed.2.bias"), d, d);
+        c->lin_g = pack_linear(c, gall.data(), gb.data(), c->L * d, d);
+        c->lin_out = pack_linear(c, W("output_process.poseFinal.weight"), W("output_process.poseFinal.bias"), F, d, true,
+                                 c->cfg.precision == RGN_PREC_BF16_X3TAIL);   // fragment order: k_step
+        if (c->cfg.cond_mode == RGN_COND_TEXT) {
+            c->lin_text = pack_linear(c, W("embed_text.weight"), W("embed_text.bias"), d, c->cfg.clip_dim);
+            c->off_bt = c->lin_text.b;
+        }
+        if (c->cfg.cond_mode == RGN_COND_ACTION) {
+            const HostTensor& a = c->sd["embed_action.action_embedding"];
+            c->off_action = blob_put(c, a.v.data(), a.v.size() * 4);
+        }
+        c->blob_bytes = align_up(c->hblob.size(), 256);
+        c->hblob.resize(c->blob_bytes);
+        RGN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->dblob), c->blob_bytes));
+        RGN_HIP(c, hipMemcpy(c->dblob, c->hblob.data(), c->blob_bytes, hipMemcpyHostToDevice));
+        c->hblob.clear();
+        c->hblob.shrink_to_fit();
+        c->sd.clear();
 
-    // --- layers; cross-attention folded: G_l = Wo_c * Wv_c, g_l = Wo_c * bv_c + bo_c (1-token memory)
-    std::vector<float> gall((size_t)c->L * d * d), gb((size_t)c->L * d);
-    c->layers.resize(c->L);
-    for (int l = 0; l < c->L; ++l) {
-        const std::string p = "seqTransDecoder.layers." + std::to_string(l) + ".";
-        LayerW& lw = c->layers[l];
-        lw.qkv = pack_linear(c, W(p + "self_attn.in_proj_weight"), W(p + "self_attn.in_proj_bias"), 3 * d, d, true,
-                             c->cfg.precision == RGN_PREC_BF16_X3TAIL);   // fragment order: k_rowgemm (long sequences) / k_qkv_attn_rs
-        const bool fr = c->cfg.precision == RGN_PREC_BF16_X3TAIL;   // k_rowgemm operands (plain-bf16 phase)
-        // (+ lo fragment planes: the operand pairs of k_mlp_x3, the split-bf16 layer tail, in every mode that has a split-bf16 phase)
-        const bool frx = c->cfg.precision == RGN_PREC_BF16_X3TAIL || c->cfg.precision == RGN_PREC_BF16X3;
-        lw.out = pack_linear(c, W(p + "self_attn.out_proj.weight"), W(p + "self_attn.out_proj.bias"), d, d, true, fr || frx, frx);
-        lw.ff1 = pack_linear(c, W(p + "linear1.weight"), W(p + "linear1.bias"), ff, d, true, fr || frx, frx);
-        lw.ff2 = pack_linear(c, W(p + "linear2.weight"), W(p + "linear2.bias"), d, ff, true, fr || frx, frx);
-        const char* names[6] = {"norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "norm3.weight", "norm3.bias"};
-        for (int i = 0; i < 6; ++i) lw.ln[i] = blob_put(c, W(p + names[i]), (size_t)d * 4);
-        const float* wv = W(p + "multihead_attn.in_proj_weight") + (size_t)2 * d * d;
-        const float* bv = W(p + "multihead_attn.in_proj_bias") + 2 * d;
-        const float* wo = W(p + "multihead_attn.out_proj.weight");
-        const float* bo = W(p + "multihead_attn.out_proj.bias");
-        std::vector<double> G;
-        matmul64(wo, wv, d, d, d, G);
-        for (size_t i = 0; i < G.size(); ++i) gall[(size_t)l * d * d + i] = (float)G[i];
-        for (int n = 0; n < d; ++n) {
-            double b = bo[n];
-            for (int j = 0; j < d; ++j) b += (double)wo[(size_t)n * d + j] * bv[j];
-            gb[(size_t)l * d + n] = (float)b;
-        }
-    }
-    c->lin_g = pack_linear(c, gall.data(), gb.data(), c->L * d, d);
-    c->lin_out = pack_linear(c, W("output_process.poseFinal.weight"), W("output_process.poseFinal.bias"), F, d, true,
-                             c->cfg.precision == RGN_PREC_BF16_X3TAIL);   // fragment order: k_step
-    if (c->cfg.cond_mode == RGN_COND_TEXT) {
-        c->lin_text = pack_linear(c, W("embed_text.weight"), W("embed_text.bias"), d, c->cfg.clip_dim);
-        c->off_bt = c->lin_text.b;
-    }
-    if (c->cfg.cond_mode == RGN_COND_ACTION) {
-        const HostTensor& a = c->sd["embed_action.action_embedding"];
-        c->off_action = blob_put(c, a.v.data(), a.v.size() * 4);
-    }
-    c->blob_bytes = align_up(c->hblob.size(), 256);
-    c->hblob.resize(c->blob_bytes);
-    RGN_HIP(c, hipMalloc(reinterpret_cast<void**>(&c->dblob), c->blob_bytes));
-    RGN_HIP(c, hipMemcpy(c->dblob, c->hblob.data(), c->blob_bytes, hipMemcpyHostToDevice));
-    c->hblob.clear();
-    c->hblob.shrink_to_fit();
-    c->sd.clear();
-
-    // --- workspace
-    const size_t B = c->cfg.max_batch, Bm = 2 * B, M = Bm * c->Tq, Mb = B * c->Tq;
-    int rc;
-    if ((rc = ws_alloc(c, &c->xin, Mb * F))) return rc;
-    if ((rc = ws_alloc(c, &c->cmo_in, Mb * F))) return rc;
-    if ((rc = ws_alloc(c, &c->c0, M * d))) return rc;
-    if ((rc = ws_alloc(c, &c->h, M * d))) return rc;
-    if ((rc = ws_alloc(c, &c->tmp, M * d))) return rc;
-    if ((rc = ws_alloc(c, &c->qkv, M * 3 * d))) return rc;
-    if ((rc = ws_alloc(c, &c->att, M * d))) return rc;
-    if ((rc = ws_alloc(c, &c->ffn, M * ff))) return rc;
-    if ((rc = ws_alloc(c, &c->x0tok, M * F))) return rc;
-    if ((rc = ws_alloc(c, &c->pe_rows, Bm * d))) return rc;
-    if ((rc = ws_alloc(c, &c->emb1, Bm * d))) return rc;
-    if ((rc = ws_alloc(c, &c->emb, Bm * d))) return rc;
-    if ((rc = ws_alloc(c, &c->call, Bm * c->L * d))) return rc;
-    if ((rc = ws_alloc(c, &c->condemb, Bm * d))) return rc;
-    if ((rc = ws_alloc(c, &c->scale, B))) return rc;
-    if ((rc = ws_alloc(c, &c->te_all, (size_t)1024 * d))) return rc;
-    if ((rc = ws_alloc(c, &c->sched_tmp, (size_t)2 * 1024 * d))) return rc;
-    if ((rc = ws_alloc(c, &c->call_time, (size_t)1024 * c->L * d))) return rc;
-    if ((rc = ws_alloc(c, &c->call_cond, Bm * c->L * d))) return rc;
-    if (c->cfg.precision != RGN_PREC_F32) {
-        const size_t Fp = align_up((size_t)F, 32), ffp = align_up((size_t)ff, 32);
-        if ((rc = ws_alloc(c, &c->xin_hi, M * Fp))) return rc;
-        if ((rc = ws_alloc(c, &c->xin_lo, M * Fp))) return rc;
-        if ((rc = ws_alloc(c, &c->c0h, M * d))) return rc;
-        if ((rc = ws_alloc(c, &c->h_hi, M * d))) return rc;
-        if ((rc = ws_alloc(c, &c->h_lo, M * d))) return rc;
-        if ((rc = ws_alloc(c, &c->att_hi, M * d))) return rc;
-        if ((rc = ws_alloc(c, &c->att_lo, M * d))) return rc;
-        if ((rc = ws_alloc(c, &c->ffn_hi, M * ffp))) return rc;
-        if ((rc = ws_alloc(c, &c->ffn_lo, M * ffp))) return rc;
-        RGN_HIP(c, hipMemset(c->xin_hi, 0, M * Fp * 2));   // K padding columns (and emb_trans_dec rows) must read as 0
-        RGN_HIP(c, hipMemset(c->xin_lo, 0, M * Fp * 2));
-        RGN_HIP(c, hipMemset(c->ffn_hi, 0, M * ffp * 2));
-        RGN_HIP(c, hipMemset(c->ffn_lo, 0, M * ffp * 2));
-        RGN_HIP(c, configure_gemm_x3());
-        // measured slower than GEMM + k_layernorm at B=256 (heavy epilogue, 64-row tiles): opt-in only
-        c->attn_x3 = attn_x3_supported(c->Tq, d / c->H);
-        if (c->attn_x3) {
-            c->Tqp = (c->Tq + 31) / 32 * 32;
-            const size_t n = Bm * c->H * (size_t)c->Tqp * (d / c->H);
-            __bf16** bufs[6] = {&c->q_hi, &c->q_lo, &c->k_hi, &c->k_lo, &c->vt_hi, &c->vt_lo};
-            for (auto bp : bufs) {
-                if ((rc = ws_alloc(c, bp, n))) return rc;
-                RGN_HIP(c, hipMemset(*bp, 0, n * 2));   // padding tokens (t >= Tq) are never written and must read as 0
+        // --- workspace
+        const size_t B = c->cfg.max_batch, Bm = 2 * B, M = Bm * c->Tq, Mb = B * c->Tq;
+        int rc;
+        if ((rc = ws_alloc(c, &c->xin, Mb * F))) return rc;
+        if ((rc = ws_alloc(c, &c->cmo_in, Mb * F))) return rc;
+        if ((rc = ws_alloc(c, &c->c0, M * d))) return rc;
+        if ((rc = ws_alloc(c, &c->h, M * d))) return rc;
+        if ((rc = ws_alloc(c, &c->tmp, M * d))) return rc;
+        if ((rc = ws_alloc(c, &c->qkv, M * 3 * d))) return rc;
+        if ((rc = ws_alloc(c, &c->att, M * d))) return rc;
+        if ((rc = ws_alloc(c, &c->ffn, M * ff))) return rc;
+        if ((rc = ws_alloc(c, &c->x0tok, M * F))) return rc;
+        if ((rc = ws_alloc(c, &c->pe_rows, Bm * d))) return rc;
+        if ((rc = ws_alloc(c, &c->emb1, Bm * d))) return rc;
+        if ((rc = ws_alloc(c, &c->emb, Bm * d))) return rc;
+        if ((rc = ws_alloc(c, &c->call, Bm * c->L * d))) return rc;
+        if ((rc = ws_alloc(c, &c->condemb, Bm * d))) return rc;
+        if ((rc = ws_alloc(c, &c->scale, B))) return rc;
+        if ((rc = ws_alloc(c, &c->te_all, (size_t)1024 * d))) return rc;
+        if ((rc = ws_alloc(c, &c->sched_tmp, (size_t)2 * 1024 * d))) return rc;
+        if ((rc = ws_alloc(c, &c->call_time, (size_t)1024 * c->L * d))) return rc;
+        if ((rc = ws_alloc(c, &c->call_cond, Bm * c->L * d))) return rc;
+        if (c->cfg.precision != RGN_PREC_F32) {
+            const size_t Fp = align_up((size_t)F, 32), ffp = align_up((size_t)ff, 32);
+            if ((rc = ws_alloc(c, &c->xin_hi, M * Fp))) return rc;
+            if ((rc = ws_alloc(c, &c->xin_lo, M * Fp))) return rc;
+            if ((rc = ws_alloc(c, &c->c0h, M * d))) return rc;
+            if ((rc = ws_alloc(c, &c->h_hi, M * d))) return rc;
+            if ((rc = ws_alloc(c, &c->h_lo, M * d))) return rc;
+            if ((rc = ws_alloc(c, &c->att_hi, M * d))) return rc;
+            if ((rc = ws_alloc(c, &c->att_lo, M * d))) return rc;
+            if ((rc = ws_alloc(c, &c->ffn_hi, M * ffp))) return rc;
+            if ((rc = ws_alloc(c, &c->ffn_lo, M * ffp))) return rc;
+            RGN_HIP(c, hipMemset(c->xin_hi, 0, M * Fp * 2));   // K padding columns (and emb_trans_dec rows) must read as 0
+            RGN_HIP(c, hipMemset(c->xin_lo, 0, M * Fp * 2));
+            RGN_HIP(c, hipMemset(c->ffn_hi, 0, M * ffp * 2));
+            RGN_HIP(c, hipMemset(c->ffn_lo, 0, M * ffp * 2));
+            RGN_HIP(c, configure_gemm_x3());
+            // measured slower than GEMM + k_layernorm at B=256 (heavy epilogue, 64-row tiles): opt-in only
+            c->attn_x3 = attn_x3_supported(c->Tq, d / c->H);
+            if (c->attn_x3) {
+                c->Tqp = (c->Tq + 31) / 32 * 32;
+                const size_t n = Bm * c->H * (size_t)c->Tqp * (d / c->H);
+                __bf16** bufs[6] = {&c->q_hi, &c->q_lo, &c->k_hi, &c->k_lo, &c->vt_hi, &c->vt_lo};
+                for (auto bp : bufs) {
+                    if ((rc = ws_alloc(c, bp, n))) return rc;
+                    RGN_HIP(c, hipMemset(*bp, 0, n * 2));   // padding tokens (t >= Tq) are never written and must read as 0
+                }
+                RGN_HIP(c, configure_attn_x3(c->Tq, d / c->H));
             }
-            RGN_HIP(c, configure_attn_x3(c->Tq, d / c->H));
+            c->fuse_qkv = qkv_attn_supported(c->Tq, d / c->H, d) && getenv("REGENNET_NO_FUSED_QKV") == nullptr;
+            if (const char* e = getenv("REGENNET_BIG_TILE_ROWS")) c->big_tile_rows = atoi(e);
+            c->rowgemm = c->cfg.precision == RGN_PREC_BF16_X3TAIL && getenv("REGENNET_NO_ROWGEMM") == nullptr && c->Tq >= 8 &&   // (8 rows of a wave: <= 2 samples)
+                         rowgemm_supported(d, d, true) && rowgemm_supported(d, (int)align_up((size_t)ff, 32), true) &&
+                         rowgemm_supported(ff, d, false);
+            if (c->rowgemm) RGN_HIP(c, configure_rowgemm());
+            c->mlp = c->rowgemm && mlp_supported(d, ff, c->Tq) && getenv("REGENNET_NO_MLP") == nullptr;
+            if (c->mlp) RGN_HIP(c, configure_mlp());
+            {   // the split-bf16 layer tail as one kernel (REGENNET_MLP_X3=0: k_gemm_x3 x 3 + k_layernorm x 2 per layer instead)
+                const char* e = getenv("REGENNET_MLP_X3");
+                c->mlp_x3 = !(e && atoi(e) == 0) && mlp_x3_supported(d, ff, c->Tq);
+                if (c->mlp_x3) RGN_HIP(c, configure_mlp_x3());
+            }
+            if (c->fuse_qkv) RGN_HIP(c, configure_qkv_attn());
+            c->qkv_rs = getenv("REGENNET_NO_QKV_RS") == nullptr;
+            c->step_fused = c->rowgemm && !c->etd && c->lin_x.fr && c->lin_out.fr && c->lin_out.has_bias && !c->lin_x.has_bias &&
+                            step_fused_supported(d, F, c->lin_x.Kp) && getenv("REGENNET_NO_STEP_FUSION") == nullptr;
+            if (c->step_fused) RGN_HIP(c, configure_step());
+            // one workgroup per sample costs a full 64-row tile whatever the length, the kernel-per-stage chain costs the rows there are, and the
+            // fused form is worth ~20 % of a layer: it takes evaluations of at least 52 tokens per sample (REGENNET_LAYERS_MIN_TQ overrides: tests)
+            const int ly_min_tq = getenv("REGENNET_LAYERS_MIN_TQ") ? atoi(getenv("REGENNET_LAYERS_MIN_TQ")) : 52;
+            c->layers_fused = c->mlp && c->fuse_qkv && c->qkv_rs && layers_supported(d, ff, c->H, c->Tq, c->L) && c->Tq >= ly_min_tq &&
+                              !(getenv("REGENNET_LAYERS") != nullptr && atoi(getenv("REGENNET_LAYERS")) == 0);
+            if (c->layers_fused) RGN_HIP(c, configure_layers());
+            if (const char* e = getenv("REGENNET_LAYERS_MIN_B")) c->layers_min_b = c->layers_min_b_default = atoi(e) < 1 ? 1 : atoi(e);
+            if (const char* e = getenv("REGENNET_LAYERS_GUIDED")) c->layers_guided = atoi(e) != 0;
+            c->layers_steps = c->layers_fused && c->step_fused && layers_steps_supported(d, F, c->lin_x.Kp) &&
+                              !(getenv("REGENNET_LAYERS_STEPS") != nullptr && atoi(getenv("REGENNET_LAYERS_STEPS")) == 0);
+            c->step_no_quads = getenv("REGENNET_STEP_NO_QUADS") != nullptr;
+            c->qkv_long = c->cfg.precision == RGN_PREC_BF16_X3TAIL && qkv_attn_long_supported(c->Tq, d / c->H, d) && getenv("REGENNET_NO_QKV_LONG") == nullptr;
+            if (c->qkv_long) RGN_HIP(c, configure_qkv_attn_long());
+            c->sb = c->attn_x3 && sb_supported(d, ff, d / c->H);
+            if (const char* e = getenv("REGENNET_SB_FUSED_ATTN")) c->sb_attn = atoi(e) != 0;
+            if (const char* e = getenv("REGENNET_SB_ROWS")) c->sb_rows = c->sb_rows_default = atoi(e) < 0 ? 0 : atoi(e);
+            if (c->sb) RGN_HIP(c, configure_sb());
+            if (c->sb) RGN_HIP(c, configure_sb_qkv_attn());
         }
-        c->fuse_qkv = qkv_attn_supported(c->Tq, d / c->H, d) && getenv("REGENNET_NO_FUSED_QKV") == nullptr;
-        if (const char* e = getenv("REGENNET_BIG_TILE_ROWS")) c->big_tile_rows = atoi(e);
-        c->rowgemm = c->cfg.precision == RGN_PREC_BF16_X3TAIL && getenv("REGENNET_NO_ROWGEMM") == nullptr && c->Tq >= 8 &&   // (8 rows of a wave: <= 2 samples)
-                     rowgemm_supported(d, d, true) && rowgemm_supported(d, (int)align_up((size_t)ff, 32), true) &&
-                     rowgemm_supported(ff, d, false);
-        if (c->rowgemm) RGN_HIP(c, configure_rowgemm());
-        c->mlp = c->rowgemm && mlp_supported(d, ff, c->Tq) && getenv("REGENNET_NO_MLP") == nullptr;
-        if (c->mlp) RGN_HIP(c, configure_mlp());
-        {   // the split-bf16 layer tail as one kernel (REGENNET_MLP_X3=0: k_gemm_x3 x 3 + k_layernorm x 2 per layer instead)
-            const char* e = getenv("REGENNET_MLP_X3");
-            c->mlp_x3 = !(e && atoi(e) == 0) && mlp_x3_supported(d, ff, c->Tq);
-            if (c->mlp_x3) RGN_HIP(c, configure_mlp_x3());
+        if ((rc = ws_alloc(c, &c->d_tab, (size_t)1024))) return rc;
+        if ((rc = ws_alloc(c, &c->d_step, (size_t)4 + 1 + B))) return rc;   // [0] loop index, [3] scratch, [4 ..] k_update's ticket counters
+        if ((rc = ws_alloc(c, &c->d_sp, (size_t)1))) return rc;
+        RGN_HIP(c, configure_attention(c->Tq, c->d / c->H));
+        RGN_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        RGN_HIP(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+        RGN_HIP(c, hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
+        for (int i = 0; i < rgn_ctx::MAX_SIDE; ++i) {
+            RGN_HIP(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+            RGN_HIP(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
         }
-        if (c->fuse_qkv) RGN_HIP(c, configure_qkv_attn());
-        c->qkv_rs = getenv("REGENNET_NO_QKV_RS") == nullptr;
-        c->step_fused = c->rowgemm && !c->etd && c->lin_x.fr && c->lin_out.fr && c->lin_out.has_bias && !c->lin_x.has_bias &&
-                        step_fused_supported(d, F, c->lin_x.Kp) && getenv("REGENNET_NO_STEP_FUSION") == nullptr;
-        if (c->step_fused) RGN_HIP(c, configure_step());
-        // one workgroup per sample costs a full 64-row tile whatever the length, the kernel-per-stage chain costs the rows there are, and the
-        // fused form is worth ~20 % of a layer: it takes evaluations of at least 52 tokens per sample (REGENNET_LAYERS_MIN_TQ overrides: tests)
-        const int ly_min_tq = getenv("REGENNET_LAYERS_MIN_TQ") ? atoi(getenv("REGENNET_LAYERS_MIN_TQ")) : 52;
-        c->layers_fused = c->mlp && c->fuse_qkv && c->qkv_rs && layers_supported(d, ff, c->H, c->Tq, c->L) && c->Tq >= ly_min_tq &&
-                          !(getenv("REGENNET_LAYERS") != nullptr && atoi(getenv("REGENNET_LAYERS")) == 0);
-        if (c->layers_fused) RGN_HIP(c, configure_layers());
-        if (const char* e = getenv("REGENNET_LAYERS_MIN_B")) c->layers_min_b = atoi(e);
-        if (const char* e = getenv("REGENNET_LAYERS_GUIDED")) c->layers_guided = atoi(e) != 0;
-        c->layers_steps = c->layers_fused && c->step_fused && layers_steps_supported(d, F, c->lin_x.Kp) &&
-                          !(getenv("REGENNET_LAYERS_STEPS") != nullptr && atoi(getenv("REGENNET_LAYERS_STEPS")) == 0);
-        c->step_no_quads = getenv("REGENNET_STEP_NO_QUADS") != nullptr;
-        c->qkv_long = c->cfg.precision == RGN_PREC_BF16_X3TAIL && qkv_attn_long_supported(c->Tq, d / c->H, d) && getenv("REGENNET_NO_QKV_LONG") == nullptr;
-        if (c->qkv_long) RGN_HIP(c, configure_qkv_attn_long());
-        c->sb = c->attn_x3 && sb_supported(d, ff, d / c->H);
-        if (const char* e = getenv("REGENNET_SB_FUSED_ATTN")) c->sb_attn = atoi(e) != 0;
-        if (const char* e = getenv("REGENNET_SB_ROWS")) c->sb_rows = c->sb_rows_default = atoi(e) < 0 ? 0 : atoi(e);
-        if (c->sb) RGN_HIP(c, configure_sb());
-        if (c->sb) RGN_HIP(c, configure_sb_qkv_attn());
-    }
-    if ((rc = ws_alloc(c, &c->d_tab, (size_t)1024))) return rc;
-    if ((rc = ws_alloc(c, &c->d_step, (size_t)4 + 1 + B))) return rc;   // [0] loop index, [3] scratch, [4 ..] k_update's ticket counters
-    if ((rc = ws_alloc(c, &c->d_sp, (size_t)1))) return rc;
-    RGN_HIP(c, configure_attention(c->Tq, c->d / c->H));
-    RGN_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    RGN_HIP(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
-    RGN_HIP(c, hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
-    for (int i = 0; i < rgn_ctx::MAX_SIDE; ++i) {
-        RGN_HIP(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
-        RGN_HIP(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
-    }
-    RGN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    if (const char* e = getenv("REGENNET_BULK_RESID_LO")) c->bulk_resid_lo = atoi(e) != 0;
-    if (const char* e = getenv("REGENNET_GRAPH_STEPS")) c->graph_steps = atoi(e) < 1 ? 1 : (atoi(e) > 100 ? 100 : atoi(e));
-    if (const char* e = getenv("REGENNET_STREAMS")) {
-        c->nchains = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
-        c->nchains_user = true;
-    }
-    RGN_HIP(c, hipMemset(c->xin, 0, Mb * F * sizeof(float)));
-    RGN_HIP(c, hipMemset(c->cmo_in, 0, Mb * F * sizeof(float)));
-    RGN_HIP(c, hipMemset(c->d_step, 0, (4 + 1 + B) * sizeof(int)));
-    c->finalized = true;
-    return RGN_OK;
+        RGN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        if (const char* e = getenv("REGENNET_BULK_RESID_LO")) c->bulk_resid_lo = atoi(e) != 0;
+        if (const char* e = getenv("REGENNET_GRAPH_STEPS")) c->graph_steps = atoi(e) < 1 ? 1 : (atoi(e) > 100 ? 100 : atoi(e));
+        if (const char* e = getenv("REGENNET_STREAMS")) {
+            c->nchains = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
+            c->nchains_user = true;
+        }
+        RGN_HIP(c, hipMemset(c->xin, 0, Mb * F * sizeof(float)));
+        RGN_HIP(c, hipMemset(c->cmo_in, 0, Mb * F * sizeof(float)));
+        RGN_HIP(c, hipMemset(c->d_step, 0, (4 + 1 + B) * sizeof(int)));
+        c->finalized = true;
+        return RGN_OK;
+    });
 }
 
 int rgn_weight_blob(rgn_handle h, void** dev_ptr, uint64_t* nbytes) {
-    if (!h || !dev_ptr || !nbytes) return RGN_ERR_INVALID_ARG;
-    if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_weight_blob: weights not finalized");
-    *dev_ptr = h->dblob;
-    *nbytes = h->blob_bytes;
-    return RGN_OK;
+    return rgn_guard(h, "rgn_weight_blob", [&]() -> int {
+        if (!h || !dev_ptr || !nbytes) return RGN_ERR_INVALID_ARG;
+        if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_weight_blob: weights not finalized");
+        *dev_ptr = h->dblob;
+        *nbytes = h->blob_bytes;
+        return RGN_OK;
+    });
 }
 
 int rgn_set_schedule(rgn_handle h, const rgn_schedule* s) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    if (!s || s->S <= 0 || !s->timestep_map || !s->posterior_mean_coef1 || !s->posterior_mean_coef2 || !s->model_log_variance ||
-        !s->sqrt_recip_alphas_cumprod || !s->sqrt_recipm1_alphas_cumprod || !s->alphas_cumprod || !s->alphas_cumprod_prev)
-        return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_schedule: null table or S <= 0");
-    if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_set_schedule: weights not finalized");
-    if (s->S > 1024) return h->fail(RGN_ERR_UNSUPPORTED, "rgn_set_schedule: more than 1024 steps");
-    for (int i = 0; i < s->S; ++i) {
-        if (s->timestep_map[i] < 0 || s->timestep_map[i] >= h->pe_len)
-            return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_schedule: timestep_map entry outside the positional table");
-        if (i && s->timestep_map[i] <= s->timestep_map[i - 1])
-            return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_schedule: timestep_map must be strictly increasing");
-    }
-    h->S = s->S;
-    h->tmap.assign(s->timestep_map, s->timestep_map + s->S);
-    h->coef1.assign(s->posterior_mean_coef1, s->posterior_mean_coef1 + s->S);
-    h->coef2.assign(s->posterior_mean_coef2, s->posterior_mean_coef2 + s->S);
-    h->logvar.assign(s->model_log_variance, s->model_log_variance + s->S);
-    h->srecip.assign(s->sqrt_recip_alphas_cumprod, s->sqrt_recip_alphas_cumprod + s->S);
-    h->srecipm1.assign(s->sqrt_recipm1_alphas_cumprod, s->sqrt_recipm1_alphas_cumprod + s->S);
-    h->ac.assign(s->alphas_cumprod, s->alphas_cumprod + s->S);
-    h->acp.assign(s->alphas_cumprod_prev, s->alphas_cumprod_prev + s->S);
-    h->tab_valid = false;
-    h->have_sched = true;
-    RGN_HIP(h, hipSetDevice(h->cfg.device));
-    int rc = build_step_table(h, 0.0f);
-    if (rc) return rc;
-    // per-step timestep embedding TE[i] = time_embed(pe[timestep_map[i]]) and its folded cross-attention image
-    // call_time[i] = TE[i] . G^T + g  (cmdm.py:297-298 + the 1-token multihead_attn of every layer), once per schedule
-    rgn_ctx* c = h;
-    hipStream_t es = c->stream;
-    const int d = c->d, S = c->S;
-    RGN_LAUNCH(c, KC_EMBED, es, launch_gather_pe_all(c->dp<float>(c->off_pe), c->d_tab, c->sched_tmp, S, d, es));
-    GemmArgs g = gemm_args(c, c->lin_t0, c->sched_tmp, d, c->sched_tmp + (size_t)1024 * d, d, S);
-    g.act = 2;
-    RGN_LAUNCH(c, KC_GEMM, es, launch_gemm(g, small_prec(c), es));
-    g = gemm_args(c, c->lin_t2, c->sched_tmp + (size_t)1024 * d, d, c->te_all, d, S);
-    RGN_LAUNCH(c, KC_GEMM, es, launch_gemm(g, small_prec(c), es));
-    g = gemm_args(c, c->lin_g, c->te_all, d, c->call_time, c->L * d, S);
-    RGN_LAUNCH(c, KC_GEMM, es, launch_gemm(g, small_prec(c), es));
-    RGN_HIP(c, hipStreamSynchronize(es));
-    return RGN_OK;
+    return rgn_guard(h, "rgn_set_schedule", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        if (!s || s->S <= 0 || !s->timestep_map || !s->posterior_mean_coef1 || !s->posterior_mean_coef2 || !s->model_log_variance ||
+            !s->sqrt_recip_alphas_cumprod || !s->sqrt_recipm1_alphas_cumprod || !s->alphas_cumprod || !s->alphas_cumprod_prev)
+            return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_schedule: null table or S <= 0");
+        if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_set_schedule: weights not finalized");
+        if (s->S > 1024) return h->fail(RGN_ERR_UNSUPPORTED, "rgn_set_schedule: more than 1024 steps");
+        for (int i = 0; i < s->S; ++i) {
+            if (s->timestep_map[i] < 0 || s->timestep_map[i] >= h->pe_len)
+                return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_schedule: timestep_map entry outside the positional table");
+            if (i && s->timestep_map[i] <= s->timestep_map[i - 1])
+                return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_schedule: timestep_map must be strictly increasing");
+        }
+        h->S = s->S;
+        h->tmap.assign(s->timestep_map, s->timestep_map + s->S);
+        h->coef1.assign(s->posterior_mean_coef1, s->posterior_mean_coef1 + s->S);
+        h->coef2.assign(s->posterior_mean_coef2, s->posterior_mean_coef2 + s->S);
+        h->logvar.assign(s->model_log_variance, s->model_log_variance + s->S);
+        h->srecip.assign(s->sqrt_recip_alphas_cumprod, s->sqrt_recip_alphas_cumprod + s->S);
+        h->srecipm1.assign(s->sqrt_recipm1_alphas_cumprod, s->sqrt_recipm1_alphas_cumprod + s->S);
+        h->ac.assign(s->alphas_cumprod, s->alphas_cumprod + s->S);
+        h->acp.assign(s->alphas_cumprod_prev, s->alphas_cumprod_prev + s->S);
+        h->tab_valid = false;
+        h->have_sched = true;
+        RGN_HIP(h, hipSetDevice(h->cfg.device));
+        int rc = build_step_table(h, 0.0f);
+        if (rc) return rc;
+        // per-step timestep embedding TE[i] = time_embed(pe[timestep_map[i]]) and its folded cross-attention image
+        // call_time[i] = TE[i] . G^T + g  (cmdm.py:297-298 + the 1-token multihead_attn of every layer), once per schedule
+        rgn_ctx* c = h;
+        hipStream_t es = c->stream;
+        const int d = c->d, S = c->S;
+        RGN_LAUNCH(c, KC_EMBED, es, launch_gather_pe_all(c->dp<float>(c->off_pe), c->d_tab, c->sched_tmp, S, d, es));
+        GemmArgs g = gemm_args(c, c->lin_t0, c->sched_tmp, d, c->sched_tmp + (size_t)1024 * d, d, S);
+        g.act = 2;
+        RGN_LAUNCH(c, KC_GEMM, es, launch_gemm(g, small_prec(c), es));
+        g = gemm_args(c, c->lin_t2, c->sched_tmp + (size_t)1024 * d, d, c->te_all, d, S);
+        RGN_LAUNCH(c, KC_GEMM, es, launch_gemm(g, small_prec(c), es));
+        g = gemm_args(c, c->lin_g, c->te_all, d, c->call_time, c->L * d, S);
+        RGN_LAUNCH(c, KC_GEMM, es, launch_gemm(g, small_prec(c), es));
+        RGN_HIP(c, hipStreamSynchronize(es));
+        return RGN_OK;
+    });
 }
 
 int rgn_set_condition(rgn_handle h, int32_t B, const float* cmotion, const int64_t* action, const float* text_feat,
                       const float* scale, void* stream) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    rgn_ctx* c = h;
-    if (!c->finalized) return c->fail(RGN_ERR_STATE, "rgn_set_condition: weights not finalized");
-    if (B <= 0 || B > c->cfg.max_batch) return c->fail(RGN_ERR_INVALID_ARG, "rgn_set_condition: B outside (0, max_batch]");
-    if (!cmotion) return c->fail(RGN_ERR_INVALID_ARG, "rgn_set_condition: y['cmotion'] is required (cmdm.py:189)");
-    if (c->cfg.cond_mode == RGN_COND_ACTION && !action) return c->fail(RGN_ERR_INVALID_ARG, "rgn_set_condition: y['action'] required");
-    if (c->cfg.cond_mode == RGN_COND_TEXT && !text_feat) return c->fail(RGN_ERR_INVALID_ARG, "rgn_set_condition: text features required");
-    hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = c->stream;
-    RGN_HIP(c, hipSetDevice(c->cfg.device));
-    int rc0 = stream_enter(c, us);
-    if (rc0) return rc0;
-    const Dims dm = make_dims(c, B, false);
-    const int d = c->d;
-    // hoisted: c0 = cmo_process(cmotion) -> fuse half + all constant biases + positional encoding
-    RGN_LAUNCH(c, KC_UPDATE, s, launch_pack_x(cmotion, c->cmo_in, Planes{nullptr, nullptr, 0}, 1, dm, s));
-    GemmArgs g = gemm_args(c, c->lin_c, c->cmo_in, c->F, c->c0, d, B * dm.Tq);
-    RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, small_prec(c), s));
-    if (!c->cfg.wo_pos_emb) RGN_LAUNCH(c, KC_EMBED, s, launch_add_pe(c->c0, c->dp<float>(c->off_pe), dm, s));
-    RGN_HIP(c, hipMemcpyAsync(c->c0 + (size_t)B * dm.Tq * d, c->c0, (size_t)B * dm.Tq * d * sizeof(float), hipMemcpyDeviceToDevice, s));   // uncond half
-    if (c->c0h) RGN_LAUNCH(c, KC_EMBED, s, launch_cvt_bf16(c->c0, c->c0h, (size_t)2 * B * dm.Tq * d, s));   // k_step's copy (plain-bf16 phase only)
-    // condition embedding rows: [0,B) conditional, [B,2B) what mask_cond(force_mask=True) leaves
-    if (c->cfg.cond_mode == RGN_COND_ACTION) {
-        RGN_LAUNCH(c, KC_EMBED, s, launch_cond_rows(c->dp<float>(c->off_action), action, c->condemb, B, d, c->cfg.num_actions, s));
-        RGN_LAUNCH(c, KC_EMBED, s, launch_fill_rows(c->condemb + (size_t)B * d, nullptr, B, d, s));
-    } else if (c->cfg.cond_mode == RGN_COND_TEXT) {
-        GemmArgs t = gemm_args(c, c->lin_text, text_feat, c->cfg.clip_dim, c->condemb, d, B);
-        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(t, small_prec(c), s));
-        RGN_LAUNCH(c, KC_EMBED, s, launch_fill_rows(c->condemb + (size_t)B * d, c->dp<float>(c->off_bt), B, d, s));  // embed_text(0) = bias
-    }
-    if (c->cfg.cond_mode != RGN_COND_NONE) {   // folded cross-attention image of the condition rows (cond | uncond)
-        GemmArgs cg = gemm_args(c, c->lin_g, c->condemb, d, c->call_cond, c->L * d, 2 * B);
-        cg.bias = nullptr;
-        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(cg, small_prec(c), s));
-    }
-    c->cond_has_scale = scale != nullptr;
-    if (scale) RGN_HIP(c, hipMemcpyAsync(c->scale, scale, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
-    c->B = B;
-    c->have_cond = true;
-    return stream_exit(c, us);
+    return rgn_guard(h, "rgn_set_condition", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        rgn_ctx* c = h;
+        if (!c->finalized) return c->fail(RGN_ERR_STATE, "rgn_set_condition: weights not finalized");
+        if (B <= 0 || B > c->cfg.max_batch) return c->fail(RGN_ERR_INVALID_ARG, "rgn_set_condition: B outside (0, max_batch]");
+        if (!cmotion) return c->fail(RGN_ERR_INVALID_ARG, "rgn_set_condition: y['cmotion'] is required (cmdm.py:189)");
+        if (c->cfg.cond_mode == RGN_COND_ACTION && !action) return c->fail(RGN_ERR_INVALID_ARG, "rgn_set_condition: y['action'] required");
+        if (c->cfg.cond_mode == RGN_COND_TEXT && !text_feat) return c->fail(RGN_ERR_INVALID_ARG, "rgn_set_condition: text features required");
+        hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = c->stream;
+        RGN_HIP(c, hipSetDevice(c->cfg.device));
+        int rc0 = stream_enter(c, us);
+        if (rc0) return rc0;
+        const Dims dm = make_dims(c, B, false);
+        const int d = c->d;
+        // hoisted: c0 = cmo_process(cmotion) -> fuse half + all constant biases + positional encoding
+        RGN_LAUNCH(c, KC_UPDATE, s, launch_pack_x(cmotion, c->cmo_in, Planes{nullptr, nullptr, 0}, 1, dm, s));
+        GemmArgs g = gemm_args(c, c->lin_c, c->cmo_in, c->F, c->c0, d, B * dm.Tq);
+        RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(g, small_prec(c), s));
+        if (!c->cfg.wo_pos_emb) RGN_LAUNCH(c, KC_EMBED, s, launch_add_pe(c->c0, c->dp<float>(c->off_pe), dm, s));
+        RGN_HIP(c, hipMemcpyAsync(c->c0 + (size_t)B * dm.Tq * d, c->c0, (size_t)B * dm.Tq * d * sizeof(float), hipMemcpyDeviceToDevice, s));   // uncond half
+        if (c->c0h) RGN_LAUNCH(c, KC_EMBED, s, launch_cvt_bf16(c->c0, c->c0h, (size_t)2 * B * dm.Tq * d, s));   // k_step's copy (plain-bf16 phase only)
+        // condition embedding rows: [0,B) conditional, [B,2B) what mask_cond(force_mask=True) leaves
+        if (c->cfg.cond_mode == RGN_COND_ACTION) {
+            RGN_LAUNCH(c, KC_EMBED, s, launch_cond_rows(c->dp<float>(c->off_action), action, c->condemb, B, d, c->cfg.num_actions, s));
+            RGN_LAUNCH(c, KC_EMBED, s, launch_fill_rows(c->condemb + (size_t)B * d, nullptr, B, d, s));
+        } else if (c->cfg.cond_mode == RGN_COND_TEXT) {
+            GemmArgs t = gemm_args(c, c->lin_text, text_feat, c->cfg.clip_dim, c->condemb, d, B);
+            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(t, small_prec(c), s));
+            RGN_LAUNCH(c, KC_EMBED, s, launch_fill_rows(c->condemb + (size_t)B * d, c->dp<float>(c->off_bt), B, d, s));  // embed_text(0) = bias
+        }
+        if (c->cfg.cond_mode != RGN_COND_NONE) {   // folded cross-attention image of the condition rows (cond | uncond)
+            GemmArgs cg = gemm_args(c, c->lin_g, c->condemb, d, c->call_cond, c->L * d, 2 * B);
+            cg.bias = nullptr;
+            RGN_LAUNCH(c, KC_GEMM, s, launch_gemm(cg, small_prec(c), s));
+        }
+        c->cond_has_scale = scale != nullptr;
+        if (scale) RGN_HIP(c, hipMemcpyAsync(c->scale, scale, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
+        c->B = B;
+        c->have_cond = true;
+        return stream_exit(c, us);
+    });
 }
 
 int rgn_denoise(rgn_handle h, const float* x, const int64_t* t, int32_t flags, float* out, void* stream) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    rgn_ctx* c = h;
-    if (!c->have_cond) return c->fail(RGN_ERR_STATE, "rgn_denoise: no condition bound (rgn_set_condition)");
-    if (!x || !t || !out) return c->fail(RGN_ERR_INVALID_ARG, "rgn_denoise: null pointer");
-    const bool guided = flags & RGN_FLAG_GUIDED, uncond = flags & RGN_FLAG_UNCOND;
-    if (guided && c->cfg.cond_mode == RGN_COND_NONE)
-        return c->fail(RGN_ERR_INVALID_ARG, "rgn_denoise: guidance needs cond_mode text/action (cfg_sampler.py:26)");
-    if (guided && !c->cond_has_scale) return c->fail(RGN_ERR_STATE, "rgn_denoise: guided evaluation needs y['scale']");
-    hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = c->stream;
-    RGN_HIP(c, hipSetDevice(c->cfg.device));
-    int rc = stream_enter(c, us);
-    if (rc) return rc;
-    const Dims dm = make_dims(c, c->B, guided);
-    SampleParams sp{};
-    sp.x0_out = out;
-    sp.t_ext = t;
-    sp.mode = 1;
-    sp.guided = guided;
-    RGN_HIP(c, hipMemcpyAsync(c->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
-    rc = pack_state(c, x, dm, guided, s);
-    if (rc) return rc;
-    c->phase_x3 = true;               // a single evaluation is always split-bf16 under the precision schedule
-    rc = run_eval(c, c->B, guided, uncond, false, s);
-    if (rc) return rc;
-    return stream_exit(c, us);
+    return rgn_guard(h, "rgn_denoise", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        rgn_ctx* c = h;
+        if (!c->have_cond) return c->fail(RGN_ERR_STATE, "rgn_denoise: no condition bound (rgn_set_condition)");
+        if (!x || !t || !out) return c->fail(RGN_ERR_INVALID_ARG, "rgn_denoise: null pointer");
+        const bool guided = flags & RGN_FLAG_GUIDED, uncond = flags & RGN_FLAG_UNCOND;
+        if (guided && c->cfg.cond_mode == RGN_COND_NONE)
+            return c->fail(RGN_ERR_INVALID_ARG, "rgn_denoise: guidance needs cond_mode text/action (cfg_sampler.py:26)");
+        if (guided && !c->cond_has_scale) return c->fail(RGN_ERR_STATE, "rgn_denoise: guided evaluation needs y['scale']");
+        hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = c->stream;
+        RGN_HIP(c, hipSetDevice(c->cfg.device));
+        int rc = stream_enter(c, us);
+        if (rc) return rc;
+        const Dims dm = make_dims(c, c->B, guided);
+        SampleParams sp{};
+        sp.x0_out = out;
+        sp.t_ext = t;
+        sp.mode = 1;
+        sp.guided = guided;
+        RGN_HIP(c, hipMemcpyAsync(c->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
+        rc = pack_state(c, x, dm, guided, s);
+        if (rc) return rc;
+        c->phase_x3 = true;               // a single evaluation is always split-bf16 under the precision schedule
+        rc = run_eval(c, c->B, guided, uncond, false, s);
+        if (rc) return rc;
+        return stream_exit(c, us);
+    });
 }
 
 int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, float* x, const float* noise, uint64_t seed,
                      uint64_t sample_offset, int32_t first_index, int32_t count, float* x0_out, int32_t use_graph,
                      int32_t clip_denoised, void* stream) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    rgn_ctx* c = h;
-    if (!c->have_sched) return c->fail(RGN_ERR_STATE, "rgn_sample_range: no schedule (rgn_set_schedule)");
-    if (!c->have_cond) return c->fail(RGN_ERR_STATE, "rgn_sample_range: no condition bound (rgn_set_condition)");
-    if (!x) return c->fail(RGN_ERR_INVALID_ARG, "rgn_sample_range: null x");
-    if (sampler != RGN_SAMPLER_DDPM && sampler != RGN_SAMPLER_DDIM) return c->fail(RGN_ERR_INVALID_ARG, "rgn_sample_range: sampler");
-    if (count <= 0 || first_index >= c->S || first_index - count + 1 < 0)
-        return c->fail(RGN_ERR_INVALID_ARG, "rgn_sample_range: step range outside [0, S)");
-    if (guided && c->cfg.cond_mode == RGN_COND_NONE)
-        return c->fail(RGN_ERR_INVALID_ARG, "rgn_sample_range: guidance needs cond_mode text/action (cfg_sampler.py:26)");
-    if (guided && !c->cond_has_scale) return c->fail(RGN_ERR_STATE, "rgn_sample_range: guided sampling needs y['scale']");
-    hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = c->stream;
-    RGN_HIP(c, hipSetDevice(c->cfg.device));
-    int rc = build_step_table(c, eta);
-    if (rc) return rc;
-    if ((rc = stream_enter(c, us))) return rc;
-    const Dims dm = make_dims(c, c->B, guided != 0);
-    SampleParams sp{};
-    sp.x = x;
-    sp.noise = noise;
-    sp.x0_out = x0_out;
-    sp.t_ext = nullptr;
-    sp.seed = seed;
-    sp.sample_offset = sample_offset;
-    sp.first_index = first_index;
-    sp.sampler = sampler;
-    sp.mode = 0;
-    sp.guided = guided != 0;
-    sp.clip = clip_denoised != 0;
-    sp.const_noise = c->const_noise;
-    RGN_HIP(c, hipMemcpyAsync(c->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
-    RGN_HIP(c, hipMemcpyAsync(c->d_step, &first_index, sizeof(int), hipMemcpyHostToDevice, s));
-    RGN_HIP(c, hipMemsetAsync(c->d_step + 4, 0, (size_t)(1 + c->cfg.max_batch) * sizeof(int), s));   // k_update's ticket counters (clean even after an aborted call)
-    if ((rc = pack_state(c, x, dm, guided != 0, s))) return rc;
+    return rgn_guard(h, "rgn_sample_range", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        rgn_ctx* c = h;
+        if (!c->have_sched) return c->fail(RGN_ERR_STATE, "rgn_sample_range: no schedule (rgn_set_schedule)");
+        if (!c->have_cond) return c->fail(RGN_ERR_STATE, "rgn_sample_range: no condition bound (rgn_set_condition)");
+        if (!x) return c->fail(RGN_ERR_INVALID_ARG, "rgn_sample_range: null x");
+        if (sampler != RGN_SAMPLER_DDPM && sampler != RGN_SAMPLER_DDIM) return c->fail(RGN_ERR_INVALID_ARG, "rgn_sample_range: sampler");
+        if (count <= 0 || first_index >= c->S || first_index - count + 1 < 0)
+            return c->fail(RGN_ERR_INVALID_ARG, "rgn_sample_range: step range outside [0, S)");
+        if (guided && c->cfg.cond_mode == RGN_COND_NONE)
+            return c->fail(RGN_ERR_INVALID_ARG, "rgn_sample_range: guidance needs cond_mode text/action (cfg_sampler.py:26)");
+        if (guided && !c->cond_has_scale) return c->fail(RGN_ERR_STATE, "rgn_sample_range: guided sampling needs y['scale']");
+        hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = c->stream;
+        RGN_HIP(c, hipSetDevice(c->cfg.device));
+        int rc = build_step_table(c, eta);
+        if (rc) return rc;
+        if ((rc = stream_enter(c, us))) return rc;
+        const Dims dm = make_dims(c, c->B, guided != 0);
+        SampleParams sp{};
+        sp.x = x;
+        sp.noise = noise;
+        sp.x0_out = x0_out;
+        sp.t_ext = nullptr;
+        sp.seed = seed;
+        sp.sample_offset = sample_offset;
+        sp.first_index = first_index;
+        sp.sampler = sampler;
+        sp.mode = 0;
+        sp.guided = guided != 0;
+        sp.clip = clip_denoised != 0;
+        sp.const_noise = c->const_noise;
+        RGN_HIP(c, hipMemcpyAsync(c->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, s));
+        RGN_HIP(c, hipMemcpyAsync(c->d_step, &first_index, sizeof(int), hipMemcpyHostToDevice, s));
+        RGN_HIP(c, hipMemsetAsync(c->d_step + 4, 0, (size_t)(1 + c->cfg.max_batch) * sizeof(int), s));   // k_update's ticket counters (clean even after an aborted call)
+        if ((rc = pack_state(c, x, dm, guided != 0, s))) return rc;
 
-    // Precision schedule: loop indices >= tail run the plain-bf16 phase, the last `tail` indices the split-bf16 one.
-    // One captured step graph per phase; everything t-dependent is read on the device, so each serves all its steps.
-    const bool sched = c->cfg.precision == RGN_PREC_BF16_X3TAIL;
-    const int tail = !sched ? 0 : (c->x3_tail >= 0 ? c->x3_tail : default_tail(c->S, c->L, c->etd != 0));
-    // A graph holds `steps` consecutive loop iterations (evaluation + sampler update + counter decrement each): the loop
-    // index lives on the device, so one instantiated graph serves any starting index. Long ranges replay the multi-step
-    // graph (graph_steps iterations per host launch; a 4-branch launch costs the host ~1 ms, as much as the GPU needs for
-    // a step at B = 256), the remainder single-step graphs.
-    auto graph_for = [&](bool x3, int steps, hipGraphExec_t* out) -> int {
-        const uint64_t key = (uint64_t)c->B | ((uint64_t)(guided != 0) << 20) | ((uint64_t)sampler << 21) | ((uint64_t)x3 << 23) |
-                             ((uint64_t)steps << 24);
-        auto it = c->graphs.find(key);
-        if (it != c->graphs.end()) {
-            *out = it->second;
+        // Precision schedule: loop indices >= tail run the plain-bf16 phase, the last `tail` indices the split-bf16 one.
+        // One captured step graph per phase; everything t-dependent is read on the device, so each serves all its steps.
+        const bool sched = c->cfg.precision == RGN_PREC_BF16_X3TAIL;
+        const int tail = !sched ? 0 : (c->x3_tail >= 0 ? c->x3_tail : default_tail(c->S, c->L, c->etd != 0));
+        // A graph holds `steps` consecutive loop iterations (evaluation + sampler update + counter decrement each): the loop
+        // index lives on the device, so one instantiated graph serves any starting index. Long ranges replay the multi-step
+        // graph (graph_steps iterations per host launch; a 4-branch launch costs the host ~1 ms, as much as the GPU needs for
+        // a step at B = 256), the remainder single-step graphs.
+        auto graph_for = [&](bool x3, int steps, hipGraphExec_t* out) -> int {
+            const uint64_t key = (uint64_t)c->B | ((uint64_t)(guided != 0) << 20) | ((uint64_t)sampler << 21) | ((uint64_t)x3 << 23) |
+                                 ((uint64_t)steps << 24);
+            auto it = c->graphs.find(key);
+            if (it != c->graphs.end()) {
+                *out = it->second;
+                return RGN_OK;
+            }
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t ge = nullptr;
+            c->phase_x3 = x3;
+            RGN_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            int r = RGN_OK;
+            for (int k = 0; k < steps && r == RGN_OK; ++k) {
+                r = run_eval(c, c->B, guided != 0, false, true, s);   // (its k_update also moves the device-side loop index on)
+            }
+            hipError_t e = hipStreamEndCapture(s, &graph);
+            if (r) {
+                if (graph) (void)hipGraphDestroy(graph);
+                return r;
+            }
+            RGN_HIP(c, e);
+            RGN_HIP(c, hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            c->graphs[key] = ge;
+            *out = ge;
             return RGN_OK;
-        }
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t ge = nullptr;
-        c->phase_x3 = x3;
-        RGN_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        int r = RGN_OK;
-        for (int k = 0; k < steps && r == RGN_OK; ++k) {
-            r = run_eval(c, c->B, guided != 0, false, true, s);   // (its k_update also moves the device-side loop index on)
-        }
-        hipError_t e = hipStreamEndCapture(s, &graph);
-        if (r) {
-            if (graph) (void)hipGraphDestroy(graph);
-            return r;
-        }
-        RGN_HIP(c, e);
-        RGN_HIP(c, hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(graph);
-        c->graphs[key] = ge;
-        *out = ge;
-        return RGN_OK;
-    };
-    // Graph replay is what the throughput engine needs (a step is 2-4 concurrent kernel chains the host could not feed: eager
-    // launches are 2x slower at B = 16). The small-batch engine is one chain of ~43 short kernels per step, and there every graph
-    // node costs ~0.4 us more than the same kernel launched from this loop (B = 1: 278 vs 261 ms per 1000 steps, B = 4: 351 vs 338,
-    // B = 12: 492 vs 487; the host needs ~150 ms per 1000 steps to issue them): it launches eagerly unless REGENNET_SB_GRAPH is set.
-    static const bool sb_graph = getenv("REGENNET_SB_GRAPH") != nullptr;
-    const bool graphs = use_graph && !c->prof && (sb_graph || !use_sb(c, dm.Bm * dm.Tq));
-    const int multi = c->graph_steps;
-    int k = 0;
-    // Fused step boundaries (k_step) hand the next evaluation's input embedding over in the residual-stream planes and no
-    // longer write the token-major x planes: the first fused step of the call needs the embedding made once up front, and
-    // the first un-fused step behind fused ones (the split-bf16 tail) needs the planes re-made from the sampler state.
-    bool prev_fused = false;
-    while (k < count) {
-        const int i = first_index - k;                       // loop index of the next step
-        const bool x3 = !sched || i < tail;
-        const int phase_left = x3 ? (count - k) : ((i - tail + 1) < (count - k) ? (i - tail + 1) : (count - k));   // steps left in this phase
-        const bool fused_now = step_fusable(c, guided != 0, x3, dm.Bm * dm.Tq);
-        if (fused_now && !prev_fused && (rc = embed_all(c, dm, s))) return rc;
-        if (!fused_now && prev_fused && (rc = pack_state(c, x, dm, guided != 0, s))) return rc;
-        prev_fused = fused_now;
-        if (fused_now && !x3 && c->layers_steps && dm.Bm >= c->layers_min_b && (!guided || (c->layers_guided && c->ffn_hi))) {
-            // unguided plain-bf16 phase, <= 64 tokens: ALL remaining steps of the phase in one launch - a workgroup carries its sample
-            // through decoder stack and step boundary step after step; nothing but x, the condition rows and the weights is read
-            bool ok = true;
-            for (int l = 0; l < c->L; ++l) ok = ok && c->layers[l].qkv.fr && c->layers[l].out.fr && c->layers[l].ff1.fr && c->layers[l].ff2.fr;
-            if (ok) {
-                const int M = dm.Bm * dm.Tq;
-                const bool has_cond = c->cfg.cond_mode != RGN_COND_NONE;
-                LayersArgs g{};
-                g.h = c->h_hi; g.out = c->h_hi; g.rows = M; g.Bm = dm.B;   // one workgroup per MOTION (guided: its two evaluations back to back)
-                fill_layers_args(c, g, dm, true, has_cond ? c->call_cond : nullptr, 0);
-                g.steps = phase_left;
-                if (guided) {
-                    g.scale = c->scale; g.half = dm.B * dm.Tq;
-                    g.park = reinterpret_cast<float*>(c->ffn_hi);           // (the hidden-tensor planes are idle on this path: 2B * T * ff * 2 bytes >= B * 96 KiB)
+        };
+        // Graph replay is what the throughput engine needs (a step is 2-4 concurrent kernel chains the host could not feed: eager
+        // launches are 2x slower at B = 16). The small-batch engine is one chain of ~43 short kernels per step, and there every graph
+        // node costs ~0.4 us more than the same kernel launched from this loop (B = 1: 278 vs 261 ms per 1000 steps, B = 4: 351 vs 338,
+        // B = 12: 492 vs 487; the host needs ~150 ms per 1000 steps to issue them): it launches eagerly unless REGENNET_SB_GRAPH is set.
+        static const bool sb_graph = getenv("REGENNET_SB_GRAPH") != nullptr;
+        const bool graphs = use_graph && !c->prof && (sb_graph || !use_sb(c, dm.Bm * dm.Tq));
+        const int multi = c->graph_steps;
+        int k = 0;
+        // Fused step boundaries (k_step) hand the next evaluation's input embedding over in the residual-stream planes and no
+        // longer write the token-major x planes: the first fused step of the call needs the embedding made once up front, and
+        // the first un-fused step behind fused ones (the split-bf16 tail) needs the planes re-made from the sampler state.
+        bool prev_fused = false;
+        while (k < count) {
+            const int i = first_index - k;                       // loop index of the next step
+            const bool x3 = !sched || i < tail;
+            const int phase_left = x3 ? (count - k) : ((i - tail + 1) < (count - k) ? (i - tail + 1) : (count - k));   // steps left in this phase
+            const EvalPlan pl = plan_eval(c, dm, guided != 0, x3, true);
+            const bool fused_now = pl.step_fused;
+            if (fused_now && !prev_fused && (rc = embed_all(c, dm, s))) return rc;
+            if (!fused_now && prev_fused && (rc = pack_state(c, x, dm, guided != 0, s))) return rc;
+            prev_fused = fused_now;
+            if (pl.steps) {
+                // plain-bf16 phase, <= 64 tokens: ALL remaining steps of the phase in one launch - a workgroup carries its sample (guided: its
+                // motion's two evaluations) through decoder stack and step boundary step after step; nothing but x, the condition rows and the
+                // weights is read
+                {
+                    const int M = dm.Bm * dm.Tq;
+                    const bool has_cond = c->cfg.cond_mode != RGN_COND_NONE;
+                    LayersArgs g{};
+                    g.h = c->h_hi; g.out = c->h_hi; g.rows = M; g.Bm = dm.B;   // one workgroup per MOTION (guided: its two evaluations back to back)
+                    fill_layers_args(c, g, dm, true, has_cond ? c->call_cond : nullptr, 0);
+                    g.steps = phase_left;
+                    if (guided) {
+                        g.scale = c->scale; g.half = dm.B * dm.Tq;
+                        g.park = reinterpret_cast<float*>(c->ffn_hi);           // (the hidden-tensor planes are idle on this path: 2B * T * ff * 2 bytes >= B * 96 KiB)
+                    }
+                    g.Wout = c->dp<__bf16>(c->lin_out.fr); g.bout = c->dp<float>(c->lin_out.b); g.F = c->F; g.nb_out = (c->F + 31) / 32;
+                    g.Wx = c->dp<__bf16>(c->lin_x.fr);
+                    g.c0 = c->c0h;
+                    g.tab = c->d_tab; g.d_stepw = c->d_step; g.sp = c->d_sp;
+                    g.B = dm.B; g.s0 = 0; g.no_quads = c->step_no_quads;
+                    RGN_LAUNCH(c, KC_STEPS, s, launch_layers(g, s));
+                    k += phase_left;
+                    continue;
                 }
-                g.Wout = c->dp<__bf16>(c->lin_out.fr); g.bout = c->dp<float>(c->lin_out.b); g.F = c->F; g.nb_out = (c->F + 31) / 32;
-                g.Wx = c->dp<__bf16>(c->lin_x.fr);
-                g.c0 = c->c0h;
-                g.tab = c->d_tab; g.d_stepw = c->d_step; g.sp = c->d_sp;
-                g.B = dm.B; g.s0 = 0; g.no_quads = c->step_no_quads;
-                RGN_LAUNCH(c, KC_STEPS, s, launch_layers(g, s));
-                k += phase_left;
-                continue;
+            }
+            if (graphs) {
+                const int steps = (multi > 1 && phase_left >= multi) ? multi : 1;
+                hipGraphExec_t ge = nullptr;
+                if ((rc = graph_for(x3, steps, &ge))) return rc;
+                RGN_HIP(c, hipGraphLaunch(ge, s));
+                k += steps;
+            } else {
+                c->phase_x3 = x3;
+                rc = run_eval(c, c->B, guided != 0, false, true, s);
+                if (rc) return rc;
+                k += 1;
             }
         }
-        if (graphs) {
-            const int steps = (multi > 1 && phase_left >= multi) ? multi : 1;
-            hipGraphExec_t ge = nullptr;
-            if ((rc = graph_for(x3, steps, &ge))) return rc;
-            RGN_HIP(c, hipGraphLaunch(ge, s));
-            k += steps;
-        } else {
-            c->phase_x3 = x3;
-            rc = run_eval(c, c->B, guided != 0, false, true, s);
-            if (rc) return rc;
-            k += 1;
-        }
-    }
-    c->phase_x3 = true;
-    return stream_exit(c, us);
+        c->phase_x3 = true;
+        return stream_exit(c, us);
+    });
 }
 
 int rgn_set_x3_tail(rgn_handle h, int32_t tail_steps) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    if (tail_steps < -1) return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_x3_tail: tail_steps < -1");
-    h->x3_tail = tail_steps;
-    return RGN_OK;
+    return rgn_guard(h, "rgn_set_x3_tail", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        if (tail_steps < -1) return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_x3_tail: tail_steps < -1");
+        h->x3_tail = tail_steps;
+        return RGN_OK;
+    });
 }
 
 int rgn_set_const_noise(rgn_handle h, int32_t on) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    h->const_noise = on != 0;
-    return RGN_OK;
+    return rgn_guard(h, "rgn_set_const_noise", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        h->const_noise = on != 0;
+        return RGN_OK;
+    });
 }
 
 int rgn_set_small_batch_rows(rgn_handle h, int32_t rows) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    if (rows < -1) return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_small_batch_rows: rows < -1");
-    const int v = rows < 0 ? h->sb_rows_default : rows;
-    if (v != h->sb_rows) {   // captured graphs hold the kernels of the engine that was selected when they were recorded
-        if (h->stream) RGN_HIP(h, hipStreamSynchronize(h->stream));
-        for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
-        h->graphs.clear();
-        h->sb_rows = v;
-    }
-    return RGN_OK;
+    return rgn_guard(h, "rgn_set_small_batch_rows", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        if (rows < -1) return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_small_batch_rows: rows < -1");
+        const int v = rows < 0 ? h->sb_rows_default : rows;
+        if (v != h->sb_rows) {   // captured graphs hold the kernels of the engine that was selected when they were recorded
+            if (h->stream) RGN_HIP(h, hipStreamSynchronize(h->stream));
+            for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+            h->graphs.clear();
+            h->sb_rows = v;
+        }
+        return RGN_OK;
+    });
+}
+
+int rgn_set_layers_min_b(rgn_handle h, int32_t samples) {
+    return rgn_guard(h, "rgn_set_layers_min_b", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        if (samples < -1) return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_layers_min_b: samples < -1");
+        const int v = samples < 0 ? h->layers_min_b_default : (samples < 1 ? 1 : samples);
+        if (v != h->layers_min_b) {   // captured graphs hold the kernels of the form that was selected when they were recorded
+            if (h->stream) RGN_HIP(h, hipStreamSynchronize(h->stream));
+            for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+            h->graphs.clear();
+            h->layers_min_b = v;
+        }
+        return RGN_OK;
+    });
+}
+
+int rgn_plan_query(rgn_handle h, int32_t B, int32_t guided, int32_t split_phase, int32_t idx, const char** name, const char** kernel,
+                   double* launches_per_eval, double* algo_flops_per_eval, double* l2_bytes_per_eval) {
+    return rgn_guard(h, "rgn_plan_query", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        rgn_ctx* c = h;
+        if (idx < 0 || idx >= KC_COUNT || !name || !kernel || !launches_per_eval || !algo_flops_per_eval || !l2_bytes_per_eval)
+            return c->fail(RGN_ERR_INVALID_ARG, "rgn_plan_query: bad argument");
+        if (!c->finalized) return c->fail(RGN_ERR_STATE, "rgn_plan_query: weights not finalized");
+        if (B <= 0 || B > c->cfg.max_batch) return c->fail(RGN_ERR_INVALID_ARG, "rgn_plan_query: B outside (0, max_batch]");
+        const Dims dm = make_dims(c, B, guided != 0);
+        const bool x3 = eval_x3_phase(c, split_phase != 0);
+        const EvalPlan pl = plan_eval(c, dm, guided != 0, x3, true);
+        // SURVEY.md 8(d) accounting: MACs of ONE evaluation of the bound batch (2 B rows under guidance), full T x T attention scores; the
+        // timestep MLP and the folded 1-token cross-attention are per-schedule / per-condition work, not per step
+        const double T = dm.T, d = c->d, ff = c->ff, L = c->L, F = c->F, M = (double)dm.Bm * T;
+        const double qkv = M * 3 * d * d * L, attn = M * 2 * T * d * L, tail = M * (d * d + 2 * d * ff) * L;
+        const double embed = (c->cfg.precision == RGN_PREC_F32 ? (double)dm.B * T * F * d : M * F * d) + M * d * F;   // input embedding + output projection
+        double mac[KC_COUNT] = {0}, n[KC_COUNT] = {0}, l2[KC_COUNT] = {0};
+        const char* kn[KC_COUNT] = {nullptr};
+        for (int i = 0; i < KC_COUNT; ++i) kn[i] = "";
+        const double Fp = (double)align_up((size_t)c->F, 32), wl = L * (4 * d * d + 2 * d * ff);
+        if (pl.sb) {
+            const bool fa = pl.attn == AF_QKV;
+            mac[KC_SB] = embed + tail + (fa ? 0.0 : qkv); n[KC_SB] = 2 + L * (fa ? 3 : 4); kn[KC_SB] = "k_sb_gemm";
+            if (fa) { mac[KC_QKV] = qkv + attn; n[KC_QKV] = L; kn[KC_QKV] = "k_sb_qkv_attn"; }
+            else { mac[KC_ATTN] = attn; n[KC_ATTN] = L; kn[KC_ATTN] = "k_attn_x3"; }
+            n[KC_UPDATE] = 1; kn[KC_UPDATE] = "k_update";
+        } else {
+            const bool f32 = c->cfg.precision == RGN_PREC_F32;
+            const char* gemm = f32 ? "k_gemm_f32" : "k_gemm_x3";
+            kn[KC_GEMM] = gemm;
+            if (pl.steps) {
+                mac[KC_STEPS] = qkv + attn + tail + embed; kn[KC_STEPS] = guided ? "k_layers<true, true>" : "k_layers<true>";
+                n[KC_STEPS] = 0;   // ONE launch per run of steps (rgn_sample_range), not per evaluation
+                const double passes = guided ? 2 : 1;
+                l2[KC_STEPS] = (double)dm.B * (passes * (wl + Fp * d) + Fp * d) * 2.0;
+            } else {
+                if (pl.layers) {
+                    mac[KC_LAYERS] = qkv + attn + tail; n[KC_LAYERS] = 1; kn[KC_LAYERS] = "k_layers<false>";
+                    l2[KC_LAYERS] = (double)dm.Bm * wl * 2.0;
+                } else {
+                    switch (pl.attn) {
+                    case AF_QKV: mac[KC_QKV] = qkv + attn; n[KC_QKV] = L; kn[KC_QKV] = (x3 || !c->qkv_rs) ? "k_qkv_attn" : "k_qkv_attn_rs"; break;
+                    case AF_QKV_LONG: mac[KC_QKV] = qkv + attn; n[KC_QKV] = L; kn[KC_QKV] = "k_qkv_attn_long"; break;
+                    case AF_ROWGEMM_ATTN: mac[KC_ROWACT] += qkv; n[KC_ROWACT] += L; mac[KC_ATTN] = attn; n[KC_ATTN] = L; kn[KC_ATTN] = "k_attn_x3"; break;
+                    case AF_GEMM_ATTN: mac[KC_GEMM] += qkv; n[KC_GEMM] += L; mac[KC_ATTN] = attn; n[KC_ATTN] = L; kn[KC_ATTN] = "k_attn_x3"; break;
+                    default: mac[KC_GEMM] += qkv; n[KC_GEMM] += L; mac[KC_ATTN] = attn; n[KC_ATTN] = L; kn[KC_ATTN] = f32 ? "k_attn_mfma" : "k_attention"; break;
+                    }
+                    switch (pl.tail) {
+                    case TF_MLP_X3: mac[KC_MLP] = tail; n[KC_MLP] = L; kn[KC_MLP] = "k_mlp_x3"; break;
+                    case TF_MLP: mac[KC_MLP] = tail; n[KC_MLP] = L; kn[KC_MLP] = "k_mlp2"; break;
+                    case TF_ROWGEMM:
+                        mac[KC_ROWLN] = M * (d * d + d * ff) * L; n[KC_ROWLN] = 2 * L; kn[KC_ROWLN] = "k_rowgemm<LN>";
+                        mac[KC_ROWACT] += M * d * ff * L; n[KC_ROWACT] += L;
+                        break;
+                    default: mac[KC_GEMM] += tail; n[KC_GEMM] += 3 * L; n[KC_LN] = 2 * L; kn[KC_LN] = "k_layernorm"; break;
+                    }
+                    kn[KC_ROWACT] = "k_rowgemm<ACT>";
+                }
+                if (pl.step_fused) { mac[KC_STEP] = embed; n[KC_STEP] = 1; kn[KC_STEP] = guided ? "k_step<guided>" : "k_step"; }
+                else { mac[KC_GEMM] += embed; n[KC_GEMM] += 2; n[KC_UPDATE] = 1; kn[KC_UPDATE] = "k_update"; }
+            }
+        }
+        *name = kclass_names[idx];
+        *kernel = kn[idx];
+        *launches_per_eval = n[idx];
+        *algo_flops_per_eval = 2.0 * mac[idx];
+        *l2_bytes_per_eval = l2[idx];
+        return RGN_OK;
+    });
 }
 
 int rgn_randn_step(rgn_handle h, float* x, int32_t B, uint64_t seed, uint64_t sample_offset, int32_t loop_index, void* stream) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    if (!x || B <= 0) return h->fail(RGN_ERR_INVALID_ARG, "rgn_randn: null x or B <= 0");
-    if (loop_index < -1) return h->fail(RGN_ERR_INVALID_ARG, "rgn_randn_step: loop_index < -1");
-    RGN_HIP(h, hipSetDevice(h->cfg.device));
-    if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_randn: weights not finalized");
-    hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = h->stream;
-    int rc = stream_enter(h, us);
-    if (rc) return rc;
-    // Philox stream word: the loop index of the step the noise belongs to; 0xFFFFFFFF (loop_index -1) is the x_T draw
-    RGN_LAUNCH(h, KC_UPDATE, s, launch_randn(x, B, h->F * h->cfg.num_frames, h->cfg.num_frames, seed, sample_offset, (uint32_t)loop_index, s));
-    return stream_exit(h, us);
+    return rgn_guard(h, "rgn_randn_step", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        if (!x || B <= 0) return h->fail(RGN_ERR_INVALID_ARG, "rgn_randn: null x or B <= 0");
+        if (loop_index < -1) return h->fail(RGN_ERR_INVALID_ARG, "rgn_randn_step: loop_index < -1");
+        RGN_HIP(h, hipSetDevice(h->cfg.device));
+        if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_randn: weights not finalized");
+        hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = h->stream;
+        int rc = stream_enter(h, us);
+        if (rc) return rc;
+        // Philox stream word: the loop index of the step the noise belongs to; 0xFFFFFFFF (loop_index -1) is the x_T draw
+        RGN_LAUNCH(h, KC_UPDATE, s, launch_randn(x, B, h->F * h->cfg.num_frames, h->cfg.num_frames, seed, sample_offset, (uint32_t)loop_index, s));
+        return stream_exit(h, us);
+    });
 }
 
 int rgn_randn(rgn_handle h, float* x, int32_t B, uint64_t seed, uint64_t sample_offset, void* stream) {
-    return rgn_randn_step(h, x, B, seed, sample_offset, -1, stream);
+    return rgn_guard(h, "rgn_randn", [&]() -> int {
+        return rgn_randn_step(h, x, B, seed, sample_offset, -1, stream);
+    });
 }
 
 int rgn_rot6d_to_matrix(rgn_handle h, const float* d6, float* mat, int64_t n, void* stream) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    if (n < 0 || (n > 0 && (!d6 || !mat))) return h->fail(RGN_ERR_INVALID_ARG, "rgn_rot6d_to_matrix: bad argument");
-    RGN_HIP(h, hipSetDevice(h->cfg.device));
-    if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_rot6d_to_matrix: weights not finalized");
-    hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = h->stream;
-    int rc = stream_enter(h, us);
-    if (rc) return rc;
-    RGN_LAUNCH(h, KC_MISC, s, launch_rot6d(d6, mat, n, s));
-    return stream_exit(h, us);
+    return rgn_guard(h, "rgn_rot6d_to_matrix", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        if (n < 0 || (n > 0 && (!d6 || !mat))) return h->fail(RGN_ERR_INVALID_ARG, "rgn_rot6d_to_matrix: bad argument");
+        RGN_HIP(h, hipSetDevice(h->cfg.device));
+        if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_rot6d_to_matrix: weights not finalized");
+        hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = h->stream;
+        int rc = stream_enter(h, us);
+        if (rc) return rc;
+        RGN_LAUNCH(h, KC_MISC, s, launch_rot6d(d6, mat, n, s));
+        return stream_exit(h, us);
+    });
 }
 
 int rgn_gaussian_filter1d(rgn_handle h, const float* x, float* out, int64_t rows, int32_t T, float sigma, void* stream) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    if (rows < 0 || T <= 0 || !(sigma > 0.f) || (rows > 0 && (!x || !out)))
-        return h->fail(RGN_ERR_INVALID_ARG, "rgn_gaussian_filter1d: bad argument");
-    RGN_HIP(h, hipSetDevice(h->cfg.device));
-    if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_gaussian_filter1d: weights not finalized");
-    hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = h->stream;
-    int rc = stream_enter(h, us);
-    if (rc) return rc;
-    RGN_LAUNCH(h, KC_MISC, s, launch_gauss1d(x, out, rows, T, sigma, s));
-    return stream_exit(h, us);
+    return rgn_guard(h, "rgn_gaussian_filter1d", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        if (rows < 0 || T <= 0 || !(sigma > 0.f) || (rows > 0 && (!x || !out)))
+            return h->fail(RGN_ERR_INVALID_ARG, "rgn_gaussian_filter1d: bad argument");
+        RGN_HIP(h, hipSetDevice(h->cfg.device));
+        if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_gaussian_filter1d: weights not finalized");
+        hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = h->stream;
+        int rc = stream_enter(h, us);
+        if (rc) return rc;
+        RGN_LAUNCH(h, KC_MISC, s, launch_gauss1d(x, out, rows, T, sigma, s));
+        return stream_exit(h, us);
+    });
 }
 
 int rgn_profile_enable(rgn_handle h, int32_t on) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->cfg.device);
-    (void)hipDeviceSynchronize();
-    if (on && h->prof_pool.empty()) {
-        h->prof_pool.resize(1024);
-        for (auto& e : h->prof_pool) {
-            RGN_HIP(h, hipEventCreate(&e.a));
-            RGN_HIP(h, hipEventCreate(&e.b));
-        }
-    }
-    h->prof_used = 0;
-    for (int i = 0; i < KC_COUNT; ++i) {
-        h->prof_ms[i] = 0;
-        h->prof_n[i] = 0;
-    }
-    if (on && h->prof_bracket_ms < 0) {
-        // What an event pair adds around ANY kernel (dispatch + event latency): the same bracket around a one-thread
-        // no-op kernel, median of 64. rgn_profile_query reports it so that callers can subtract it per launch.
-        std::vector<float> v;
-        for (int i = 0; i < 64 && i < (int)h->prof_pool.size(); ++i) {
-            (void)hipEventRecord(h->prof_pool[i].a, h->stream);
-            (void)launch_advance(h->d_step + 3, h->stream);      // scratch slot of d_step[4]
-            (void)hipEventRecord(h->prof_pool[i].b, h->stream);
-        }
-        (void)hipStreamSynchronize(h->stream);
-        for (int i = 0; i < 64 && i < (int)h->prof_pool.size(); ++i) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, h->prof_pool[i].a, h->prof_pool[i].b) == hipSuccess) v.push_back(ms);
-        }
-        std::sort(v.begin(), v.end());
-        h->prof_bracket_ms = v.empty() ? 0.0 : v[v.size() / 2];
-    }
-    h->prof = on != 0;
-    return RGN_OK;
-}
-
-int rgn_profile_bracket_overhead(rgn_handle h, double* ms) {
-    if (!h || !ms) return RGN_ERR_INVALID_ARG;
-    *ms = h->prof_bracket_ms < 0 ? 0.0 : h->prof_bracket_ms;
-    return RGN_OK;
-}
-
-int rgn_profile_query(rgn_handle h, int32_t idx, const char** name, double* total_ms, int64_t* launches) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    if (idx < 0 || idx >= KC_COUNT || !name || !total_ms || !launches) return h->fail(RGN_ERR_INVALID_ARG, "rgn_profile_query: bad argument");
-    if (h->prof_used > 0) {
+    return rgn_guard(h, "rgn_profile_enable", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
         (void)hipSetDevice(h->cfg.device);
         (void)hipDeviceSynchronize();
-        for (size_t i = 0; i < h->prof_used; ++i) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, h->prof_pool[i].a, h->prof_pool[i].b) == hipSuccess) {
-                h->prof_ms[h->prof_pool[i].kc] += ms;
-                h->prof_n[h->prof_pool[i].kc] += 1;
+        if (on && h->prof_pool.empty()) {
+            h->prof_pool.resize(1024);
+            for (auto& e : h->prof_pool) {
+                RGN_HIP(h, hipEventCreate(&e.a));
+                RGN_HIP(h, hipEventCreate(&e.b));
             }
         }
         h->prof_used = 0;
-    }
-    *name = kclass_names[idx];
-    *total_ms = h->prof_ms[idx];
-    *launches = h->prof_n[idx];
-    return RGN_OK;
+        for (int i = 0; i < KC_COUNT; ++i) {
+            h->prof_ms[i] = 0;
+            h->prof_n[i] = 0;
+        }
+        if (on && h->prof_bracket_ms < 0) {
+            // What an event pair adds around ANY kernel (dispatch + event latency): the same bracket around a one-thread
+            // no-op kernel, median of 64. rgn_profile_query reports it so that callers can subtract it per launch.
+            std::vector<float> v;
+            for (int i = 0; i < 64 && i < (int)h->prof_pool.size(); ++i) {
+                (void)hipEventRecord(h->prof_pool[i].a, h->stream);
+                (void)launch_advance(h->d_step + 3, h->stream);      // scratch slot of d_step[4]
+                (void)hipEventRecord(h->prof_pool[i].b, h->stream);
+            }
+            (void)hipStreamSynchronize(h->stream);
+            for (int i = 0; i < 64 && i < (int)h->prof_pool.size(); ++i) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, h->prof_pool[i].a, h->prof_pool[i].b) == hipSuccess) v.push_back(ms);
+            }
+            std::sort(v.begin(), v.end());
+            h->prof_bracket_ms = v.empty() ? 0.0 : v[v.size() / 2];
+        }
+        h->prof = on != 0;
+        return RGN_OK;
+    });
+}
+
+int rgn_profile_bracket_overhead(rgn_handle h, double* ms) {
+    return rgn_guard(h, "rgn_profile_bracket_overhead", [&]() -> int {
+        if (!h || !ms) return RGN_ERR_INVALID_ARG;
+        *ms = h->prof_bracket_ms < 0 ? 0.0 : h->prof_bracket_ms;
+        return RGN_OK;
+    });
+}
+
+int rgn_profile_query(rgn_handle h, int32_t idx, const char** name, double* total_ms, int64_t* launches) {
+    return rgn_guard(h, "rgn_profile_query", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        if (idx < 0 || idx >= KC_COUNT || !name || !total_ms || !launches) return h->fail(RGN_ERR_INVALID_ARG, "rgn_profile_query: bad argument");
+        if (h->prof_used > 0) {
+            (void)hipSetDevice(h->cfg.device);
+            (void)hipDeviceSynchronize();
+            for (size_t i = 0; i < h->prof_used; ++i) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, h->prof_pool[i].a, h->prof_pool[i].b) == hipSuccess) {
+                    h->prof_ms[h->prof_pool[i].kc] += ms;
+                    h->prof_n[h->prof_pool[i].kc] += 1;
+                }
+            }
+            h->prof_used = 0;
+        }
+        *name = kclass_names[idx];
+        *total_ms = h->prof_ms[idx];
+        *launches = h->prof_n[idx];
+        return RGN_OK;
+    });
 }
 
 }  // extern "C"

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -189,6 +190,29 @@ GemmArgs sg_gemm(const float* A, int lda, const float* W, int Kp, int K, const f
     return g;
 }
 
+int sg_boundary_error(rgn_stgcn_ctx* h, const char* fn, const char* what) noexcept {
+    try {
+        std::string m = std::string(fn) + ": C++ exception at the boundary: " + what;
+        if (h) h->err.swap(m);
+        else g_sg_create_error.swap(m);
+    } catch (...) {
+    }
+    return RGN_ERR_INTERNAL;
+}
+// no C++ exception crosses the C boundary (see rgn_guard in rgn_api.cpp)
+template <class F>
+int sg_guard(rgn_stgcn_ctx* h, const char* fn, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return sg_boundary_error(h, fn, "std::bad_alloc (host memory)");
+    } catch (const std::exception& e) {
+        return sg_boundary_error(h, fn, e.what());
+    } catch (...) {
+        return sg_boundary_error(h, fn, "unknown exception");
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -196,263 +220,273 @@ extern "C" {
 const char* rgn_stgcn_last_error(rgn_stgcn_handle h) { return h ? h->err.c_str() : g_sg_create_error.c_str(); }
 
 int rgn_stgcn_create(const rgn_stgcn_config* cfg, rgn_stgcn_handle* out) {
-    if (!cfg || !out) {
-        g_sg_create_error = "rgn_stgcn_create: null argument";
-        return RGN_ERR_INVALID_ARG;
-    }
-    *out = nullptr;
-    if (cfg->in_channels <= 0 || cfg->num_person <= 0 || cfg->in_channels % cfg->num_person || cfg->num_class <= 0 || cfg->num_nodes <= 0 ||
-        cfg->num_frames <= 0 || cfg->max_batch <= 0) {
-        g_sg_create_error = "rgn_stgcn_create: non-positive dimension or in_channels % num_person != 0";
-        return RGN_ERR_INVALID_ARG;
-    }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
-        g_sg_create_error = "rgn_stgcn_create: no such HIP device";
-        return RGN_ERR_HIP;
-    }
-    rgn_stgcn_ctx* c = new rgn_stgcn_ctx();
-    c->cfg = *cfg;
-    c->V = cfg->num_nodes;
-    c->C0 = cfg->in_channels / cfg->num_person;
-    *out = c;
-    return RGN_OK;
+    return sg_guard(static_cast<rgn_stgcn_ctx*>(nullptr), "rgn_stgcn_create", [&]() -> int {
+        if (!cfg || !out) {
+            g_sg_create_error = "rgn_stgcn_create: null argument";
+            return RGN_ERR_INVALID_ARG;
+        }
+        *out = nullptr;
+        if (cfg->in_channels <= 0 || cfg->num_person <= 0 || cfg->in_channels % cfg->num_person || cfg->num_class <= 0 || cfg->num_nodes <= 0 ||
+            cfg->num_frames <= 0 || cfg->max_batch <= 0) {
+            g_sg_create_error = "rgn_stgcn_create: non-positive dimension or in_channels % num_person != 0";
+            return RGN_ERR_INVALID_ARG;
+        }
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+            g_sg_create_error = "rgn_stgcn_create: no such HIP device";
+            return RGN_ERR_HIP;
+        }
+        rgn_stgcn_ctx* c = new rgn_stgcn_ctx();
+        c->cfg = *cfg;
+        c->V = cfg->num_nodes;
+        c->C0 = cfg->in_channels / cfg->num_person;
+        *out = c;
+        return RGN_OK;
+    });
 }
 
 int rgn_stgcn_destroy(rgn_stgcn_handle h) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->cfg.device);
-    (void)hipDeviceSynchronize();
-    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
-    if (h->ev_out) (void)hipEventDestroy(h->ev_out);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
-    for (void* p : h->allocs) (void)hipFree(p);
-    delete h;
-    return RGN_OK;
+    return sg_guard(h, "rgn_stgcn_destroy", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        (void)hipSetDevice(h->cfg.device);
+        (void)hipDeviceSynchronize();
+        if (h->ev_in) (void)hipEventDestroy(h->ev_in);
+        if (h->ev_out) (void)hipEventDestroy(h->ev_out);
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+        for (void* p : h->allocs) (void)hipFree(p);
+        delete h;
+        return RGN_OK;
+    });
 }
 
 int rgn_stgcn_load_weight(rgn_stgcn_handle h, const char* key, const float* host, const int64_t* shape, int32_t ndim) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    if (!key || !host || ndim < 0 || (ndim > 0 && !shape)) return h->fail(RGN_ERR_INVALID_ARG, "rgn_stgcn_load_weight: null/empty argument");
-    if (h->finalized) return h->fail(RGN_ERR_STATE, "rgn_stgcn_load_weight: already finalized");
-    size_t n = 1;
-    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
-    h->sd[key].assign(host, host + n);
-    h->shapes[key].assign(shape, shape + ndim);
-    return RGN_OK;
+    return sg_guard(h, "rgn_stgcn_load_weight", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        if (!key || !host || ndim < 0 || (ndim > 0 && !shape)) return h->fail(RGN_ERR_INVALID_ARG, "rgn_stgcn_load_weight: null/empty argument");
+        if (h->finalized) return h->fail(RGN_ERR_STATE, "rgn_stgcn_load_weight: already finalized");
+        size_t n = 1;
+        for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+        h->sd[key].assign(host, host + n);
+        h->shapes[key].assign(shape, shape + ndim);
+        return RGN_OK;
+    });
 }
 
 int rgn_stgcn_finalize(rgn_stgcn_handle h) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    rgn_stgcn_ctx* c = h;
-    if (c->finalized) return c->fail(RGN_ERR_STATE, "rgn_stgcn_finalize: already finalized");
-    SG_HIP(c, hipSetDevice(c->cfg.device));
-    std::string missing;
-    auto need = [&](const std::string& k, size_t n) -> const float* {
-        auto it = c->sd.find(k);
-        if (it == c->sd.end()) {
-            missing += (missing.empty() ? "" : ", ") + k;
-            return nullptr;
-        }
-        if (it->second.size() != n) {
-            missing += (missing.empty() ? "" : ", ") + k + " (size " + std::to_string(it->second.size()) + " != " + std::to_string(n) + ")";
-            return nullptr;
-        }
-        return it->second.data();
-    };
-    auto itA = c->sd.find("A");
-    if (itA == c->sd.end() || c->shapes["A"].size() != 3 || c->shapes["A"][1] != c->V || c->shapes["A"][2] != c->V)
-        return c->fail(RGN_ERR_MISSING_KEY, "rgn_stgcn_finalize: adjacency buffer 'A' [K, V, V] missing or of the wrong shape");
-    c->K = (int)c->shapes["A"][0];
-    const int V = c->V, K = c->K, M = c->cfg.num_person, C0 = c->C0;
-    const float* A0 = itA->second.data();
-    // BatchNorm (eval): y = x * s + t with s = gamma / sqrt(var + eps), t = beta - mean * s
-    auto bn_fold = [&](const std::string& p, int n, std::vector<double>& s, std::vector<double>& t) -> bool {
-        const float *w = need(p + ".weight", n), *b = need(p + ".bias", n), *mu = need(p + ".running_mean", n), *var = need(p + ".running_var", n);
-        if (!w || !b || !mu || !var) return false;
-        s.resize(n);
-        t.resize(n);
-        for (int i = 0; i < n; ++i) {
-            s[i] = (double)w[i] / std::sqrt((double)var[i] + 1e-5);
-            t[i] = (double)b[i] - (double)mu[i] * s[i];
-        }
-        return true;
-    };
-    int rc;
-    {
-        std::vector<double> s, t;
-        if (bn_fold("data_bn", M * V * C0, s, t)) {
-            std::vector<float> sf(s.begin(), s.end()), tf(t.begin(), t.end());
-            if ((rc = sg_upload(c, &c->bn_s, sf)) || (rc = sg_upload(c, &c->bn_t, tf))) return rc;
-        }
-    }
-    c->blocks.resize(10);
-    for (int i = 0; i < 10; ++i) {
-        SgBlock& b = c->blocks[i];
-        const std::string p = "st_gcn_networks." + std::to_string(i) + ".";
-        b.ci = i == 0 ? C0 : kBlocks[i].ci;
-        b.co = kBlocks[i].co;
-        b.stride = kBlocks[i].stride;
-        b.res_conv = kBlocks[i].res_conv;
-        b.res_id = kBlocks[i].res_id;
-        const int ci = b.ci, co = b.co, K1 = K * ci;
-        b.kp1 = (int)up16(K1);
-        const float* imp = need("edge_importance." + std::to_string(i), (size_t)K * V * V);
-        const float *wg = need(p + "gcn.conv.weight", (size_t)K * co * ci), *bg = need(p + "gcn.conv.bias", (size_t)K * co);
-        const float *wt = need(p + "tcn.2.weight", (size_t)co * co * 9), *bt = need(p + "tcn.2.bias", co);
-        std::vector<double> s1, t1, s2, t2, sr, tr;
-        const bool ok1 = bn_fold(p + "tcn.0", co, s1, t1), ok2 = bn_fold(p + "tcn.3", co, s2, t2);
-        const float *wr = nullptr, *brs = nullptr;
-        bool okr = true;
-        if (b.res_conv) {
-            wr = need(p + "residual.0.weight", (size_t)co * ci);
-            brs = need(p + "residual.0.bias", co);
-            okr = bn_fold(p + "residual.1", co, sr, tr);
-        }
-        if (!imp || !wg || !bg || !wt || !bt || !ok1 || !ok2 || !okr || (b.res_conv && (!wr || !brs))) continue;
-        std::vector<float> Ak((size_t)K * V * V);
-        for (size_t j = 0; j < Ak.size(); ++j) Ak[j] = A0[j] * imp[j];                       // stgcn.py:105 (fp32 product, as there)
-        // W1'[co][(k, ci)] = s1[co] * Wg[k*co_n + co][ci];  b1'[w][co] = s1 * sum_k bg[k*co_n + co] * colsum_k[w] + t1
-        std::vector<float> W1((size_t)co * b.kp1, 0.f), b1((size_t)V * co);
-        for (int o = 0; o < co; ++o)
-            for (int k = 0; k < K; ++k)
-                for (int q = 0; q < ci; ++q) W1[(size_t)o * b.kp1 + k * ci + q] = (float)(s1[o] * (double)wg[((size_t)k * co + o) * ci + q]);
-        for (int w = 0; w < V; ++w)
-            for (int o = 0; o < co; ++o) {
-                double acc = 0.0;
-                for (int k = 0; k < K; ++k) {
-                    double cs = 0.0;
-                    for (int v = 0; v < V; ++v) cs += (double)Ak[((size_t)k * V + v) * V + w];
-                    acc += (double)bg[(size_t)k * co + o] * cs;
-                }
-                b1[(size_t)w * co + o] = (float)(s1[o] * acc + t1[o]);
+    return sg_guard(h, "rgn_stgcn_finalize", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        rgn_stgcn_ctx* c = h;
+        if (c->finalized) return c->fail(RGN_ERR_STATE, "rgn_stgcn_finalize: already finalized");
+        SG_HIP(c, hipSetDevice(c->cfg.device));
+        std::string missing;
+        auto need = [&](const std::string& k, size_t n) -> const float* {
+            auto it = c->sd.find(k);
+            if (it == c->sd.end()) {
+                missing += (missing.empty() ? "" : ", ") + k;
+                return nullptr;
             }
-        // W2'[dt][co][ci] = s2[co] * Wt[co][ci][dt];  b2' = s2 * bt + t2
-        const int kp2 = (int)up16(co);
-        std::vector<float> W2((size_t)9 * co * kp2, 0.f), b2(co);
-        for (int dt = 0; dt < 9; ++dt)
-            for (int o = 0; o < co; ++o)
-                for (int q = 0; q < co; ++q) W2[((size_t)dt * co + o) * kp2 + q] = (float)(s2[o] * (double)wt[((size_t)o * co + q) * 9 + dt]);
-        for (int o = 0; o < co; ++o) b2[o] = (float)(s2[o] * (double)bt[o] + t2[o]);
-        if ((rc = sg_upload(c, &b.A, Ak)) || (rc = sg_upload(c, &b.W1, W1)) || (rc = sg_upload(c, &b.b1, b1)) || (rc = sg_upload(c, &b.W2, W2)) ||
-            (rc = sg_upload(c, &b.b2, b2)))
-            return rc;
-        if (b.res_conv) {
-            const int kpr = (int)up16(ci);
-            std::vector<float> Wr((size_t)co * kpr, 0.f), br(co);
-            for (int o = 0; o < co; ++o) {
-                for (int q = 0; q < ci; ++q) Wr[(size_t)o * kpr + q] = (float)(sr[o] * (double)wr[(size_t)o * ci + q]);
-                br[o] = (float)(sr[o] * (double)brs[o] + tr[o]);
+            if (it->second.size() != n) {
+                missing += (missing.empty() ? "" : ", ") + k + " (size " + std::to_string(it->second.size()) + " != " + std::to_string(n) + ")";
+                return nullptr;
             }
-            if ((rc = sg_upload(c, &b.Wr, Wr)) || (rc = sg_upload(c, &b.br, br))) return rc;
+            return it->second.data();
+        };
+        auto itA = c->sd.find("A");
+        if (itA == c->sd.end() || c->shapes["A"].size() != 3 || c->shapes["A"][1] != c->V || c->shapes["A"][2] != c->V)
+            return c->fail(RGN_ERR_MISSING_KEY, "rgn_stgcn_finalize: adjacency buffer 'A' [K, V, V] missing or of the wrong shape");
+        c->K = (int)c->shapes["A"][0];
+        const int V = c->V, K = c->K, M = c->cfg.num_person, C0 = c->C0;
+        const float* A0 = itA->second.data();
+        // BatchNorm (eval): y = x * s + t with s = gamma / sqrt(var + eps), t = beta - mean * s
+        auto bn_fold = [&](const std::string& p, int n, std::vector<double>& s, std::vector<double>& t) -> bool {
+            const float *w = need(p + ".weight", n), *b = need(p + ".bias", n), *mu = need(p + ".running_mean", n), *var = need(p + ".running_var", n);
+            if (!w || !b || !mu || !var) return false;
+            s.resize(n);
+            t.resize(n);
+            for (int i = 0; i < n; ++i) {
+                s[i] = (double)w[i] / std::sqrt((double)var[i] + 1e-5);
+                t[i] = (double)b[i] - (double)mu[i] * s[i];
+            }
+            return true;
+        };
+        int rc;
+        {
+            std::vector<double> s, t;
+            if (bn_fold("data_bn", M * V * C0, s, t)) {
+                std::vector<float> sf(s.begin(), s.end()), tf(t.begin(), t.end());
+                if ((rc = sg_upload(c, &c->bn_s, sf)) || (rc = sg_upload(c, &c->bn_t, tf))) return rc;
+            }
         }
-    }
-    {
-        const int nc = c->cfg.num_class;
-        const float *wf = need("fcn.weight", (size_t)nc * 256), *bf = need("fcn.bias", nc);
-        if (wf && bf) {
-            std::vector<float> W(wf, wf + (size_t)nc * 256), B(bf, bf + nc);
-            if ((rc = sg_upload(c, &c->Wf, W)) || (rc = sg_upload(c, &c->bf, B))) return rc;
-        }
-    }
-    if (!missing.empty()) return c->fail(RGN_ERR_MISSING_KEY, "missing / mis-shaped keys in the ST-GCN state_dict: " + missing);
-    c->sd.clear();
-    // workspace: padded activations sized for the largest block (the 8 pad frames make the late, short blocks the big ones),
-    // with guard rows so that the +-4-frame row shifts of the temporal convolution never leave the allocation
-    const size_t NMV = (size_t)c->cfg.max_batch * M * V;
-    size_t act = ((size_t)c->cfg.num_frames + 2 * SG_PAD) * C0, zmax = 0, cmax = 0;
-    {
-        int T = c->cfg.num_frames;
+        c->blocks.resize(10);
         for (int i = 0; i < 10; ++i) {
-            const SgBlock& b = c->blocks[i];
-            const size_t tp = (size_t)T + 2 * SG_PAD;
-            zmax = std::max(zmax, tp * K * b.ci);
-            cmax = std::max(cmax, tp * b.co);                         // g / conv / rfull live at the block's INPUT rate
-            T = (T + b.stride - 1) / b.stride;
-            act = std::max(act, ((size_t)T + 2 * SG_PAD) * b.co);
+            SgBlock& b = c->blocks[i];
+            const std::string p = "st_gcn_networks." + std::to_string(i) + ".";
+            b.ci = i == 0 ? C0 : kBlocks[i].ci;
+            b.co = kBlocks[i].co;
+            b.stride = kBlocks[i].stride;
+            b.res_conv = kBlocks[i].res_conv;
+            b.res_id = kBlocks[i].res_id;
+            const int ci = b.ci, co = b.co, K1 = K * ci;
+            b.kp1 = (int)up16(K1);
+            const float* imp = need("edge_importance." + std::to_string(i), (size_t)K * V * V);
+            const float *wg = need(p + "gcn.conv.weight", (size_t)K * co * ci), *bg = need(p + "gcn.conv.bias", (size_t)K * co);
+            const float *wt = need(p + "tcn.2.weight", (size_t)co * co * 9), *bt = need(p + "tcn.2.bias", co);
+            std::vector<double> s1, t1, s2, t2, sr, tr;
+            const bool ok1 = bn_fold(p + "tcn.0", co, s1, t1), ok2 = bn_fold(p + "tcn.3", co, s2, t2);
+            const float *wr = nullptr, *brs = nullptr;
+            bool okr = true;
+            if (b.res_conv) {
+                wr = need(p + "residual.0.weight", (size_t)co * ci);
+                brs = need(p + "residual.0.bias", co);
+                okr = bn_fold(p + "residual.1", co, sr, tr);
+            }
+            if (!imp || !wg || !bg || !wt || !bt || !ok1 || !ok2 || !okr || (b.res_conv && (!wr || !brs))) continue;
+            std::vector<float> Ak((size_t)K * V * V);
+            for (size_t j = 0; j < Ak.size(); ++j) Ak[j] = A0[j] * imp[j];                       // stgcn.py:105 (fp32 product, as there)
+            // W1'[co][(k, ci)] = s1[co] * Wg[k*co_n + co][ci];  b1'[w][co] = s1 * sum_k bg[k*co_n + co] * colsum_k[w] + t1
+            std::vector<float> W1((size_t)co * b.kp1, 0.f), b1((size_t)V * co);
+            for (int o = 0; o < co; ++o)
+                for (int k = 0; k < K; ++k)
+                    for (int q = 0; q < ci; ++q) W1[(size_t)o * b.kp1 + k * ci + q] = (float)(s1[o] * (double)wg[((size_t)k * co + o) * ci + q]);
+            for (int w = 0; w < V; ++w)
+                for (int o = 0; o < co; ++o) {
+                    double acc = 0.0;
+                    for (int k = 0; k < K; ++k) {
+                        double cs = 0.0;
+                        for (int v = 0; v < V; ++v) cs += (double)Ak[((size_t)k * V + v) * V + w];
+                        acc += (double)bg[(size_t)k * co + o] * cs;
+                    }
+                    b1[(size_t)w * co + o] = (float)(s1[o] * acc + t1[o]);
+                }
+            // W2'[dt][co][ci] = s2[co] * Wt[co][ci][dt];  b2' = s2 * bt + t2
+            const int kp2 = (int)up16(co);
+            std::vector<float> W2((size_t)9 * co * kp2, 0.f), b2(co);
+            for (int dt = 0; dt < 9; ++dt)
+                for (int o = 0; o < co; ++o)
+                    for (int q = 0; q < co; ++q) W2[((size_t)dt * co + o) * kp2 + q] = (float)(s2[o] * (double)wt[((size_t)o * co + q) * 9 + dt]);
+            for (int o = 0; o < co; ++o) b2[o] = (float)(s2[o] * (double)bt[o] + t2[o]);
+            if ((rc = sg_upload(c, &b.A, Ak)) || (rc = sg_upload(c, &b.W1, W1)) || (rc = sg_upload(c, &b.b1, b1)) || (rc = sg_upload(c, &b.W2, W2)) ||
+                (rc = sg_upload(c, &b.b2, b2)))
+                return rc;
+            if (b.res_conv) {
+                const int kpr = (int)up16(ci);
+                std::vector<float> Wr((size_t)co * kpr, 0.f), br(co);
+                for (int o = 0; o < co; ++o) {
+                    for (int q = 0; q < ci; ++q) Wr[(size_t)o * kpr + q] = (float)(sr[o] * (double)wr[(size_t)o * ci + q]);
+                    br[o] = (float)(sr[o] * (double)brs[o] + tr[o]);
+                }
+                if ((rc = sg_upload(c, &b.Wr, Wr)) || (rc = sg_upload(c, &b.br, br))) return rc;
+            }
         }
-    }
-    c->guard = (size_t)SG_PAD * V * 256;
-    float* base;
-    if ((rc = sg_alloc(c, &base, NMV * act + 2 * c->guard))) return rc;
-    c->xa = base + c->guard;
-    if ((rc = sg_alloc(c, &base, NMV * act + 2 * c->guard))) return rc;
-    c->xb = base + c->guard;
-    if ((rc = sg_alloc(c, &base, NMV * cmax + 2 * c->guard))) return rc;
-    c->g = base + c->guard;
-    if ((rc = sg_alloc(c, &c->z, NMV * zmax))) return rc;
-    if ((rc = sg_alloc(c, &c->conv, NMV * cmax))) return rc;
-    if ((rc = sg_alloc(c, &c->rfull, NMV * cmax))) return rc;
-    if ((rc = sg_alloc(c, &c->pooled, (size_t)c->cfg.max_batch * 256))) return rc;
-    SG_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    SG_HIP(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
-    SG_HIP(c, hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
-    c->finalized = true;
-    return RGN_OK;
+        {
+            const int nc = c->cfg.num_class;
+            const float *wf = need("fcn.weight", (size_t)nc * 256), *bf = need("fcn.bias", nc);
+            if (wf && bf) {
+                std::vector<float> W(wf, wf + (size_t)nc * 256), B(bf, bf + nc);
+                if ((rc = sg_upload(c, &c->Wf, W)) || (rc = sg_upload(c, &c->bf, B))) return rc;
+            }
+        }
+        if (!missing.empty()) return c->fail(RGN_ERR_MISSING_KEY, "missing / mis-shaped keys in the ST-GCN state_dict: " + missing);
+        c->sd.clear();
+        // workspace: padded activations sized for the largest block (the 8 pad frames make the late, short blocks the big ones),
+        // with guard rows so that the +-4-frame row shifts of the temporal convolution never leave the allocation
+        const size_t NMV = (size_t)c->cfg.max_batch * M * V;
+        size_t act = ((size_t)c->cfg.num_frames + 2 * SG_PAD) * C0, zmax = 0, cmax = 0;
+        {
+            int T = c->cfg.num_frames;
+            for (int i = 0; i < 10; ++i) {
+                const SgBlock& b = c->blocks[i];
+                const size_t tp = (size_t)T + 2 * SG_PAD;
+                zmax = std::max(zmax, tp * K * b.ci);
+                cmax = std::max(cmax, tp * b.co);                         // g / conv / rfull live at the block's INPUT rate
+                T = (T + b.stride - 1) / b.stride;
+                act = std::max(act, ((size_t)T + 2 * SG_PAD) * b.co);
+            }
+        }
+        c->guard = (size_t)SG_PAD * V * 256;
+        float* base;
+        if ((rc = sg_alloc(c, &base, NMV * act + 2 * c->guard))) return rc;
+        c->xa = base + c->guard;
+        if ((rc = sg_alloc(c, &base, NMV * act + 2 * c->guard))) return rc;
+        c->xb = base + c->guard;
+        if ((rc = sg_alloc(c, &base, NMV * cmax + 2 * c->guard))) return rc;
+        c->g = base + c->guard;
+        if ((rc = sg_alloc(c, &c->z, NMV * zmax))) return rc;
+        if ((rc = sg_alloc(c, &c->conv, NMV * cmax))) return rc;
+        if ((rc = sg_alloc(c, &c->rfull, NMV * cmax))) return rc;
+        if ((rc = sg_alloc(c, &c->pooled, (size_t)c->cfg.max_batch * 256))) return rc;
+        SG_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        SG_HIP(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+        SG_HIP(c, hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
+        c->finalized = true;
+        return RGN_OK;
+    });
 }
 
 int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float* features, float* yhat, void* stream) {
-    if (!h) return RGN_ERR_INVALID_ARG;
-    rgn_stgcn_ctx* c = h;
-    if (!c->finalized) return c->fail(RGN_ERR_STATE, "rgn_stgcn_forward: weights not finalized");
-    if (N <= 0 || N > c->cfg.max_batch) return c->fail(RGN_ERR_INVALID_ARG, "rgn_stgcn_forward: N outside (0, max_batch]");
-    if (!output || (!features && !yhat)) return c->fail(RGN_ERR_INVALID_ARG, "rgn_stgcn_forward: null pointer");
-    SG_HIP(c, hipSetDevice(c->cfg.device));
-    hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = c->stream;
-    SG_HIP(c, hipEventRecord(c->ev_in, us));
-    SG_HIP(c, hipStreamWaitEvent(s, c->ev_in, 0));
-    const int V = c->V, K = c->K, M = c->cfg.num_person, NM = N * M;
-    int T = c->cfg.num_frames;
-    {
-        const size_t total = (size_t)NM * (T + 2 * SG_PAD) * V * c->C0;
-        hipLaunchKernelGGL(k_stgcn_in, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, output, c->xa, c->bn_s, c->bn_t, N, V, M, c->C0, T);
-    }
-    float *x = c->xa, *xn = c->xb;
-    for (int i = 0; i < 10; ++i) {
-        const SgBlock& b = c->blocks[i];
-        const int Tp = T + 2 * SG_PAD, rows = NM * Tp * V, To = (T + b.stride - 1) / b.stride;   // Conv2d(9x1, pad 4, stride s): ceil(T / s) frames
-        hipLaunchKernelGGL(k_stgcn_agg, dim3((unsigned)(NM * Tp)), dim3(256), (size_t)V * b.ci * sizeof(float), s, x, b.A, c->z, V, K, b.ci);
-        GemmArgs g1 = sg_gemm(c->z, K * b.ci, b.W1, b.kp1, K * b.ci, nullptr, c->g, b.co, rows, b.co);
-        g1.add = b.b1; g1.ldadd = b.co; g1.add_mod = V; g1.act = 3;                          // + b1'[row % V], ReLU
-        SG_HIP(c, launch_gemm(g1, RGN_PREC_F32, s));
+    return sg_guard(h, "rgn_stgcn_forward", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        rgn_stgcn_ctx* c = h;
+        if (!c->finalized) return c->fail(RGN_ERR_STATE, "rgn_stgcn_forward: weights not finalized");
+        if (N <= 0 || N > c->cfg.max_batch) return c->fail(RGN_ERR_INVALID_ARG, "rgn_stgcn_forward: N outside (0, max_batch]");
+        if (!output || (!features && !yhat)) return c->fail(RGN_ERR_INVALID_ARG, "rgn_stgcn_forward: null pointer");
+        SG_HIP(c, hipSetDevice(c->cfg.device));
+        hipStream_t us = reinterpret_cast<hipStream_t>(stream), s = c->stream;
+        SG_HIP(c, hipEventRecord(c->ev_in, us));
+        SG_HIP(c, hipStreamWaitEvent(s, c->ev_in, 0));
+        const int V = c->V, K = c->K, M = c->cfg.num_person, NM = N * M;
+        int T = c->cfg.num_frames;
         {
-            const size_t n = (size_t)NM * 2 * SG_PAD * V * b.co;
-            hipLaunchKernelGGL(k_stgcn_zero_pads, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->g, NM, T, V * b.co);
+            const size_t total = (size_t)NM * (T + 2 * SG_PAD) * V * c->C0;
+            hipLaunchKernelGGL(k_stgcn_in, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, output, c->xa, c->bn_s, c->bn_t, N, V, M, c->C0, T);
         }
-        const int kp2 = (int)up16(b.co);
-        for (int dt = 0; dt < 9; ++dt) {
-            // frame shift dt - 4: rows move by (dt - 4) * V; guard rows (zero) absorb the first / last frames' reach
-            GemmArgs g2 = sg_gemm(c->g + (ptrdiff_t)(dt - SG_PAD) * V * b.co, b.co, b.W2 + (size_t)dt * b.co * kp2, kp2, b.co, nullptr, c->conv, b.co, rows, b.co);
-            if (dt) {
-                g2.add = c->conv;
-                g2.ldadd = b.co;
+        float *x = c->xa, *xn = c->xb;
+        for (int i = 0; i < 10; ++i) {
+            const SgBlock& b = c->blocks[i];
+            const int Tp = T + 2 * SG_PAD, rows = NM * Tp * V, To = (T + b.stride - 1) / b.stride;   // Conv2d(9x1, pad 4, stride s): ceil(T / s) frames
+            hipLaunchKernelGGL(k_stgcn_agg, dim3((unsigned)(NM * Tp)), dim3(256), (size_t)V * b.ci * sizeof(float), s, x, b.A, c->z, V, K, b.ci);
+            GemmArgs g1 = sg_gemm(c->z, K * b.ci, b.W1, b.kp1, K * b.ci, nullptr, c->g, b.co, rows, b.co);
+            g1.add = b.b1; g1.ldadd = b.co; g1.add_mod = V; g1.act = 3;                          // + b1'[row % V], ReLU
+            SG_HIP(c, launch_gemm(g1, RGN_PREC_F32, s));
+            {
+                const size_t n = (size_t)NM * 2 * SG_PAD * V * b.co;
+                hipLaunchKernelGGL(k_stgcn_zero_pads, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->g, NM, T, V * b.co);
             }
-            SG_HIP(c, launch_gemm(g2, RGN_PREC_F32, s));
+            const int kp2 = (int)up16(b.co);
+            for (int dt = 0; dt < 9; ++dt) {
+                // frame shift dt - 4: rows move by (dt - 4) * V; guard rows (zero) absorb the first / last frames' reach
+                GemmArgs g2 = sg_gemm(c->g + (ptrdiff_t)(dt - SG_PAD) * V * b.co, b.co, b.W2 + (size_t)dt * b.co * kp2, kp2, b.co, nullptr, c->conv, b.co, rows, b.co);
+                if (dt) {
+                    g2.add = c->conv;
+                    g2.ldadd = b.co;
+                }
+                SG_HIP(c, launch_gemm(g2, RGN_PREC_F32, s));
+            }
+            if (b.res_conv) {
+                GemmArgs gr = sg_gemm(x, b.ci, b.Wr, (int)up16(b.ci), b.ci, nullptr, c->rfull, b.co, rows, b.co);
+                SG_HIP(c, launch_gemm(gr, RGN_PREC_F32, s));
+            }
+            {
+                const size_t total = (size_t)NM * (To + 2 * SG_PAD) * V * b.co;
+                hipLaunchKernelGGL(k_stgcn_post, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c->conv, b.b2, b.res_id ? x : nullptr,
+                                   b.res_conv ? c->rfull : nullptr, b.br, xn, NM, T, To, b.stride, V, b.co);
+            }
+            float* t = x;
+            x = xn;
+            xn = t;
+            T = To;
         }
-        if (b.res_conv) {
-            GemmArgs gr = sg_gemm(x, b.ci, b.Wr, (int)up16(b.ci), b.ci, nullptr, c->rfull, b.co, rows, b.co);
-            SG_HIP(c, launch_gemm(gr, RGN_PREC_F32, s));
+        hipLaunchKernelGGL(k_stgcn_pool, dim3(N), dim3(256), 0, s, x, c->pooled, M, T, V, 256);
+        if (features) SG_HIP(c, hipMemcpyAsync(features, c->pooled, (size_t)N * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (yhat) {
+            GemmArgs gf = sg_gemm(c->pooled, 256, c->Wf, 256, 256, c->bf, yhat, c->cfg.num_class, N, c->cfg.num_class);
+            SG_HIP(c, launch_gemm(gf, RGN_PREC_F32, s));
         }
-        {
-            const size_t total = (size_t)NM * (To + 2 * SG_PAD) * V * b.co;
-            hipLaunchKernelGGL(k_stgcn_post, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c->conv, b.b2, b.res_id ? x : nullptr,
-                               b.res_conv ? c->rfull : nullptr, b.br, xn, NM, T, To, b.stride, V, b.co);
-        }
-        float* t = x;
-        x = xn;
-        xn = t;
-        T = To;
-    }
-    hipLaunchKernelGGL(k_stgcn_pool, dim3(N), dim3(256), 0, s, x, c->pooled, M, T, V, 256);
-    if (features) SG_HIP(c, hipMemcpyAsync(features, c->pooled, (size_t)N * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (yhat) {
-        GemmArgs gf = sg_gemm(c->pooled, 256, c->Wf, 256, 256, c->bf, yhat, c->cfg.num_class, N, c->cfg.num_class);
-        SG_HIP(c, launch_gemm(gf, RGN_PREC_F32, s));
-    }
-    SG_HIP(c, hipGetLastError());
-    SG_HIP(c, hipEventRecord(c->ev_out, s));
-    SG_HIP(c, hipStreamWaitEvent(us, c->ev_out, 0));
-    return RGN_OK;
+        SG_HIP(c, hipGetLastError());
+        SG_HIP(c, hipEventRecord(c->ev_out, s));
+        SG_HIP(c, hipStreamWaitEvent(us, c->ev_out, 0));
+        return RGN_OK;
+    });
 }
 
 }  // extern "C"

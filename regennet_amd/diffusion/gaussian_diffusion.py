@@ -285,34 +285,68 @@ class GaussianDiffusion:
             yield {"sample": img, "pred_xstart": None}
 
     # ---- precision-schedule calibration (x3_tail="auto") -------------------------------------------------------------------
+    def _tail_key(self, sampler, model, eta):
+        inner = getattr(model, "model", model)
+        return (id(self._sched_token), sampler, inner is not model, float(eta))
+
     def _maybe_calibrate_tail(self, sampler, model, shape, y, eta):
         inner = getattr(model, "model", model)
         if getattr(inner, "x3_tail", None) != "auto" or getattr(inner, "precision", "") != "bf16_x3tail" or getattr(self, "_calibrating", False):
             return
         # one calibration per (schedule, sampler, guidance, eta): measured at the longest sequence seen so far and reused for every shorter
         # one (auto_regressive evaluation samples a ladder of lengths: the first, longest-needed calibration serves them all)
-        key = (id(self._sched_token), sampler, inner is not model, float(eta))
+        key = self._tail_key(sampler, model, eta)
         T = int(shape[3])
         if key not in inner._auto_tails or inner._auto_tails[key][0] < T:
+            # NO collective here: this point is reached by the ranks that sample and miss their own cache - ranks with an empty shard, or
+            # with another history of lengths, never arrive (a collective gated on per-rank state hangs the others). Multi-rank callers agree
+            # on ONE switch point up front, at a point every rank passes: agree_x3_tail() (cgenerate calls it at start-up).
+            from ..utils import dist_util
+            if dist_util.collectives_active() and th.distributed.get_world_size() > 1 and not getattr(inner, "_warned_local_tail", False):
+                inner._warned_local_tail = True
+                print("[regennet_amd] precision schedule: this rank calibrates its switch point on its own shard - call "
+                      "diffusion.agree_x3_tail(model, shape, model_kwargs, sampler) on EVERY rank at start-up to make the ranks use one",
+                      file=sys.stderr, flush=True)
             tail = self.calibrate_x3_tail(model, shape, {"y": y}, sampler=sampler, eta=eta)
             if key in inner._auto_tails:
                 tail = max(tail, inner._auto_tails[key][1])
-            # every rank of a sharded run must use ONE switch point (a sample's result may not depend on the rank it landed on): the
-            # ranks calibrate on their own first motions and agree on the longest tail any of them needs
-            if th.distributed.is_available() and th.distributed.is_initialized() and th.distributed.get_world_size() > 1:
-                t_all = th.tensor([tail], device=y["cmotion"].device if th.is_tensor(y.get("cmotion")) else "cpu", dtype=th.int64)
-                if th.distributed.get_backend() == "gloo":
-                    t_all = t_all.cpu()
-                th.distributed.all_reduce(t_all, op=th.distributed.ReduceOp.MAX)
-                tail = int(t_all.item())
             inner._auto_tails[key] = (T, tail)
-            dev = getattr(self, "_last_calibration_dev", float("nan"))
-            print(f"[regennet_amd] precision schedule calibrated on this checkpoint: split-bf16 for the last {tail} of "
-                  f"{self.num_timesteps} {sampler} steps{' (guided)' if inner is not model else ''}, T={T} "
-                  f"(max |dev| vs uniform split-bf16 on {min(int(shape[0]), 4)} motions: {dev:.1e}; one full {self.num_timesteps}-step run plus the candidates, "
-                  f"once per schedule; override: x3_tail= / REGENNET_X3_TAIL)",
-                  file=sys.stderr, flush=True)
+            self._log_tail(inner, model, sampler, tail, T, min(int(shape[0]), 4))
         inner._auto_tail = inner._auto_tails[key][1]
+
+    def _log_tail(self, inner, model, sampler, tail, T, nb, agreed=False):
+        dev = getattr(self, "_last_calibration_dev", float("nan"))
+        print(f"[regennet_amd] precision schedule calibrated on this checkpoint: split-bf16 for the last {tail} of "
+              f"{self.num_timesteps} {sampler} steps{' (guided)' if inner is not model else ''}, T={T}"
+              f"{' (agreed across the ranks: MAX)' if agreed else ''} "
+              f"(max |dev| vs uniform split-bf16 on {nb} motions: {dev:.1e}; one full {self.num_timesteps}-step run plus the candidates, "
+              f"once per schedule; override: x3_tail= / REGENNET_X3_TAIL)",
+              file=sys.stderr, flush=True)
+
+    def agree_x3_tail(self, model, shape, model_kwargs, sampler="ddpm", eta=0.0):
+        """Sharded runs with x3_tail="auto": every rank must use ONE switch point (a motion's result may not depend on the rank it landed
+        on). EVERY rank calls this once at start-up, unconditionally - a rank whose shard is empty passes model_kwargs=None and contributes
+        0 - so the MAX all-reduce inside is symmetric by construction (the reference's counterpart of a start-up collective is
+        utils/dist_util.py:77-83 sync_params). The agreed switch point holds for every sequence length of this (schedule, sampler,
+        guidance, eta): no later sampling call recalibrates on its own. Single-process runs and models without "auto": a no-op."""
+        inner = getattr(model, "model", model)
+        if getattr(inner, "x3_tail", None) != "auto" or getattr(inner, "precision", "") != "bf16_x3tail":
+            return None
+        tail, nb = 0, 0
+        if model_kwargs is not None and int(shape[0]) > 0:
+            tail, nb = self.calibrate_x3_tail(model, shape, model_kwargs, sampler=sampler, eta=eta), min(int(shape[0]), 4)
+        from ..utils import dist_util
+        if dist_util.collectives_active():
+            y = (model_kwargs or {}).get("y", {})
+            t_all = th.tensor([tail], device=y["cmotion"].device if th.is_tensor(y.get("cmotion")) else next(inner.parameters()).device, dtype=th.int64)
+            if th.distributed.get_backend() == "gloo":
+                t_all = t_all.cpu()
+            th.distributed.all_reduce(t_all, op=th.distributed.ReduceOp.MAX)
+            tail = int(t_all.item())
+        inner._auto_tails[self._tail_key(sampler, model, eta)] = (1 << 30, tail)      # every length: nothing recalibrates behind the agreement
+        inner._auto_tail = tail
+        self._log_tail(inner, model, sampler, tail, int(shape[3]), nb, agreed=dist_util.collectives_active())
+        return tail
 
     def calibrate_x3_tail(self, model, shape, model_kwargs, sampler="ddpm", eta=0.0, tol=2.5e-4, max_batch=4, seed=1234, verbose=False):
         """How many split-bf16 steps THIS checkpoint needs at the end of THIS schedule: the precision schedule's validity
@@ -325,13 +359,19 @@ class GaussianDiffusion:
         B, nb, S = int(shape[0]), min(int(shape[0]), max_batch), self.num_timesteps
         ys = {k: (v[:nb].contiguous() if th.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B else (v[:nb] if isinstance(v, (list, tuple)) and len(v) == B else v))
               for k, v in y.items()}
-        saved, self._calibrating, self._last_calibration_dev = (inner.x3_tail, inner._auto_tail, inner.small_batch_rows), True, 0.0
+        saved, self._calibrating, self._last_calibration_dev = (inner.x3_tail, inner._auto_tail, inner.small_batch_rows, getattr(inner, "layers_min_b", None)), True, 0.0
         # calibrate on the kernels the CALLER's batch will run: the small-batch engine takes evaluations of at most sb token rows
         # (motions x tokens, doubled under guidance; rgn_set_small_batch_rows: the model's setting, else REGENNET_SB_ROWS, else 640)
         sb = inner.small_batch_rows if inner.small_batch_rows is not None else int(os.environ.get("REGENNET_SB_ROWS", "640"))
         Tq = int(shape[3]) + (1 if getattr(inner, "emb_trans_dec", False) else 0)
         if B * Tq * (2 if inner is not model else 1) > int(sb):
             inner.small_batch_rows = 0      # the 4 calibration motions alone would fall under the threshold: force the throughput engine
+        # ... and in the caller's kernel FORM: evaluations of >= layers_min_b samples (64 by default; motions doubled under guidance) run the
+        # one-kernel decoder stack (k_layers), smaller ones the kernel-per-stage chain, and the two differ by bf16 roundings in the
+        # plain-bf16 phase - the 4 calibration motions take the form the caller's batch gets (rgn_set_layers_min_b)
+        lmb = inner.layers_min_b if getattr(inner, "layers_min_b", None) is not None else int(os.environ.get("REGENNET_LAYERS_MIN_B", "64"))
+        if B * (2 if inner is not model else 1) >= lmb:
+            inner.layers_min_b = 1
         fn = self.p_sample_loop if sampler == "ddpm" else self.ddim_sample_loop
         kw = dict(clip_denoised=False, model_kwargs={"y": ys}, seed=seed)
         if sampler == "ddim":
@@ -359,7 +399,7 @@ class GaussianDiffusion:
             if chosen == S:
                 self._last_calibration_dev = 0.0      # (no shorter tail passed: the schedule stays uniform split-bf16)
         finally:
-            inner.x3_tail, inner._auto_tail, inner.small_batch_rows = saved
+            inner.x3_tail, inner._auto_tail, inner.small_batch_rows, inner.layers_min_b = saved
             self._calibrating = False
         return chosen
 

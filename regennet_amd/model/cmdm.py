@@ -141,10 +141,13 @@ class CMDM(nn.Module):
         self.x3_tail = kargs.get("x3_tail", None)
         # evaluations of at most this many token rows run the small-batch engine (None: engine default, 0: never)
         self.small_batch_rows = kargs.get("small_batch_rows", None)
+        # evaluations of at least this many samples run the one-kernel decoder stack (k_layers; None: engine default 64, 1: always)
+        self.layers_min_b = kargs.get("layers_min_b", None)
         self._auto_tail, self._auto_tails = None, {}
         # multi-GPU runs: rank `weights_src`'s packed blob is broadcast (one RCCL collective) into EVERY engine this model
         # builds — also the ones built later for another length, a larger batch or after an eviction (None: single process)
         self.weights_src = None
+        self._ever_synced = False        # an engine of this model has taken part in the start-up broadcast
         self._engine = None
         self._engines = {}
         self._engine_stale = True
@@ -202,18 +205,22 @@ class CMDM(nn.Module):
             for e in self._engines.values():
                 e.close()
             self._engines.clear()
-            self._engine, self._engine_stale = None, False
+            self._engine, self._engine_stale, self._ever_synced = None, False, False
         T = int(T or (self._engine.cfg["num_frames"] if self._engine is not None else self.num_frames))
         eng = self._engines.pop(T, None)
+        outgoing = None
         if eng is not None and (B > eng.max_batch or eng.precision != self.precision):
             dist_util.synchronize(dev)
             B = max(B, eng.max_batch)
-            eng.close()
-            eng = None
+            outgoing, eng = eng, None            # (kept alive until the new engine is finalized: it may be the only holder of the synchronised blob)
         if eng is None:
             while len(self._engines) >= self.MAX_ENGINES:
                 dist_util.synchronize(dev)
-                self._engines.pop(next(iter(self._engines))).close()
+                victim = self._engines.pop(next(iter(self._engines)))
+                if outgoing is None and getattr(victim, "_blob_synced", False):
+                    outgoing = victim
+                else:
+                    victim.close()
             eng = _lib.Engine(self.engine_config(T), B, dev.index or 0, self.precision)
             for k, v in self.state_dict().items():
                 if k.startswith("clip_model."):
@@ -224,12 +231,24 @@ class CMDM(nn.Module):
                 # The RCCL broadcast is a collective: it may only run where EVERY rank builds an engine - the first one (the callers
                 # build it at start-up, whatever their shard size). Engines built later by one rank alone (a new sequence length, a
                 # larger batch, an evicted length) take the already-synchronised blob of a live engine of this model instead.
-                donor = next((e for e in self._engines.values() if getattr(e, "_blob_synced", False)), None)
-                if donor is not None and not dist_util.copy_engine_weights(donor, eng, dev):
-                    donor = None
-                if donor is None:
+                # Donors: the engine this one replaces (larger batch of the same length: same blob layout), then any other live engine.
+                donors = ([outgoing] if outgoing is not None and getattr(outgoing, "_blob_synced", False) else []) + \
+                         [e for e in self._engines.values() if getattr(e, "_blob_synced", False)]
+                copied = any(dist_util.copy_engine_weights(dn, eng, dev) for dn in donors)
+                if not copied:
+                    if self._ever_synced:
+                        # a lone broadcast would be a one-rank collective (the other ranks are not here): never issue it
+                        if outgoing is not None:
+                            outgoing.close()
+                        eng.close()
+                        raise RuntimeError("regennet_amd: this rank needs a new engine after start-up and holds no engine with the synchronised weight "
+                                           "blob to copy from (blob layouts differ?) - build every engine the run needs at start-up, where all ranks "
+                                           "take part in the RCCL broadcast (model._get_engine(B, T) on every rank)")
                     dist_util.broadcast_engine_weights(eng, dev, int(self.weights_src))
                 eng._blob_synced = True
+                self._ever_synced = True
+            if outgoing is not None:
+                outgoing.close()
         self._engines[T] = eng                                # (re)inserted last = most recently used
         if eng is not self._engine:
             self._engine, self._cond_key, self._keep = eng, None, None
@@ -238,6 +257,7 @@ class CMDM(nn.Module):
             tail = self._auto_tail
         eng.set_x3_tail(-1 if tail is None else int(tail))
         eng.set_small_batch_rows(-1 if self.small_batch_rows is None else int(self.small_batch_rows))
+        eng.set_layers_min_b(-1 if self.layers_min_b is None else int(self.layers_min_b))
         return eng, dev
 
     def _rgn_bind(self, B, y, device=None, guided=False, T=None, cache=False):

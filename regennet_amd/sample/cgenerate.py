@@ -77,9 +77,9 @@ def main(argv=None):
     inner.weights_src = 0 if world > 1 else None            # rank 0's packed blob -> every engine this model builds (one RCCL broadcast each)
     eng, _ = inner._get_engine(max(Bl, 1), n_frames)
     all_outputs, all_cmotions, time_all = [], [], 0.0
-    for rep_i in range(args.num_repetitions):
-        if rank == 0:
-            print(f"### Sampling [repetitions #{rep_i}]")
+    shape = (Bl, inner.njoints, inner.nfeats, n_frames)
+
+    def make_y(rep_i):
         idx = (np.arange(lo, hi) + rep_i * B) % len(clips)
         y = {"cmotion": torch.from_numpy(np.ascontiguousarray(clips[idx])).to(dev), "lengths": torch.full((Bl,), n_frames),
              "mask": torch.ones(Bl, 1, 1, n_frames, dtype=torch.bool)}
@@ -87,9 +87,18 @@ def main(argv=None):
             y["action"] = torch.from_numpy(actions[idx]).to(dev)
         if args.guidance_param != 1:
             y["scale"] = torch.ones(Bl, device=dev) * args.guidance_param
+        return y
+
+    if world > 1:
+        # one precision-schedule switch point for all ranks (x3_tail="auto": measured on the loaded checkpoint), agreed HERE, where every
+        # rank passes whatever its shard - a rank with no samples contributes 0 and still takes part in the all-reduce
+        diffusion.agree_x3_tail(model, shape, {"y": make_y(0)} if Bl > 0 else None, sampler="ddim" if args.use_ddim else "ddpm")
+    for rep_i in range(args.num_repetitions):
+        if rank == 0:
+            print(f"### Sampling [repetitions #{rep_i}]")
+        y = make_y(rep_i)
         dist_util.synchronize()
         t_start = time.time()
-        shape = (Bl, inner.njoints, inner.nfeats, n_frames)
         if Bl > 0:
             sample = sample_fn(model, shape, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=0, init_image=None,
                                progress=(rank == 0), dump_steps=None, noise=None, const_noise=False,

@@ -31,6 +31,20 @@ def test_library_builds_and_exports_every_declared_symbol():
         getattr(raw, name)
 
 
+def test_the_c_abi_is_the_only_dynamic_symbol_set():
+    """Built with -fvisibility=hidden + a linker version script (regennet_amd/csrc/exports.map): `nm -D --defined-only` lists exactly
+    the entry points include/regennet_hip.h declares - no rgn::launch_*, no __device_stub__*, no weak libstdc++ instantiations."""
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    from regennet_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    rows = [ln.split() for ln in out.splitlines() if ln.strip()]
+    exported = sorted(r[-1] for r in rows)
+    assert exported == _declared_symbols(), sorted(set(exported) ^ set(_declared_symbols()))
+    assert all(r[-2] == "T" for r in rows), [r for r in rows if r[-2] != "T"]
+
+
 def test_null_and_bad_arguments_return_status_codes():
     from regennet_amd import _lib
     lib = _lib.load()
@@ -38,6 +52,8 @@ def test_null_and_bad_arguments_return_status_codes():
     assert b"null" in lib.rgn_last_error(None)
     assert lib.rgn_destroy(None) == -1
     assert lib.rgn_finalize_weights(None) == -1
+    assert lib.rgn_set_layers_min_b(None, 1) == -1
+    assert lib.rgn_plan_query(None, 1, 0, 0, 0, None, None, None, None, None) == -1
     cfg = _lib.RgnConfig(njoints=56, nfeats=6, num_frames=60, latent_dim=500, ff_size=1024, num_heads=4, num_layers=8,
                          cm_mode=1, cond_mode=0, num_actions=1, clip_dim=512, emb_trans_dec=0, wo_pos_emb=0, max_batch=1,
                          precision=0, device=0)

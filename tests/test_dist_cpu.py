@@ -96,6 +96,9 @@ class FakeEngine:
     def set_x3_tail(self, n):
         self.knobs = dict(getattr(self, "knobs", {}), x3_tail=int(n))
 
+    def set_layers_min_b(self, n):
+        self.knobs = dict(getattr(self, "knobs", {}), layers_min_b=int(n))
+
     def set_const_noise(self, on):
         self.const_noise = bool(on)
 
@@ -163,6 +166,55 @@ def test_cgenerate_entry_point_shards_broadcasts_and_gathers(tmp_path, monkeypat
     assert np.abs(one["output"][0] - one["output"][3]).max() > 1e-4      # samples differ (global index, condition)
 
 
+def _cgen_worker_small(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from regennet_amd import _lib
+    from regennet_amd.sample import cgenerate
+    _lib.Engine = FakeEngine
+    args = [a for a in _cgen_args(out_dir)]
+    args[args.index("--num_samples") + 1] = "1"                # one motion for two ranks: rank 1's shard is EMPTY
+    path = cgenerate.main(args)
+    assert (path is not None) == (rank == 0)
+    dist.destroy_process_group()
+
+
+def test_cgenerate_with_an_empty_shard_does_not_hang_in_the_calibration(tmp_path):
+    """num_samples < world size: rank 1 samples nothing and never reaches the sampler's calibration. The switch point of the precision
+    schedule (x3_tail="auto", the default for a loaded checkpoint) is agreed at start-up, where every rank passes
+    (diffusion.agree_x3_tail: the empty rank contributes 0) - a collective inside the sampling call would leave rank 0 waiting forever
+    (mp.spawn would time the test out)."""
+    mp.spawn(_cgen_worker_small, args=(2, _free_port(), str(tmp_path / "w2")), nprocs=2, join=True)
+    two = np.load(str(tmp_path / "w2" / "results.npy"), allow_pickle=True).item()
+    assert two["output"].shape == (2, 56, 6, 40) and two["world_size"] == 2
+
+
+def test_a_rebuilt_engine_takes_the_blob_of_the_engine_it_replaces(monkeypatch):
+    """Multi-rank run, ONE cached length (the normal cgenerate case), a larger batch arrives on this rank alone: the engine being replaced is
+    the only holder of the synchronised blob, so it must stay alive as the donor until the new engine is finalized - and where no donor is
+    left the model raises instead of issuing a one-rank broadcast (which would hang)."""
+    from regennet_amd import _lib, synth
+    from regennet_amd.utils import dist_util as du
+    monkeypatch.setattr(_lib, "Engine", FakeEngine)
+    calls = []
+    monkeypatch.setattr(du, "broadcast_engine_weights", lambda eng, dev, src=0: calls.append("broadcast"))
+    real_copy = du.copy_engine_weights
+    monkeypatch.setattr(du, "copy_engine_weights", lambda a, b, dev: (calls.append("copy"), real_copy(a, b, dev))[1])
+    monkeypatch.setattr(du, "synchronize", lambda device=None: None)
+    cfg = synth.get_config("tiny")
+    model, _ = synth.build_model(cfg, synth.make_state_dict(cfg, seed=0), precision="bf16_x3tail", device="cpu")
+    model.weights_src = 0
+    e1, _dev = model._get_engine(2)
+    assert calls == ["broadcast"] and e1._blob_synced
+    e2, _dev = model._get_engine(5)                             # larger batch, same length: rebuild
+    assert e2 is not e1 and calls == ["broadcast", "copy"] and e2._blob_synced and e2.max_batch == 5
+    e3, _dev = model._get_engine(5, T=cfg["num_frames"] - 2)    # another length: copies from the live engine
+    assert calls == ["broadcast", "copy", "copy"] and e3._blob_synced
+    monkeypatch.setattr(du, "copy_engine_weights", lambda a, b, dev: False)
+    with pytest.raises(RuntimeError, match="start-up"):
+        model._get_engine(9)
+    assert calls == ["broadcast", "copy", "copy"]               # no lone collective was issued
+
+
 def test_model_knobs_reach_the_engine(monkeypatch):
     """CMDM(..., x3_tail=, small_batch_rows=) / the attributes of the same name are handed to the engine on every bind
     (-1 = the engine's default), through the _lib.Engine seam on a CPU-only host."""
@@ -171,10 +223,10 @@ def test_model_knobs_reach_the_engine(monkeypatch):
     cfg = synth.get_config("tiny")
     model, _ = synth.build_model(cfg, synth.make_state_dict(cfg, seed=0), precision="bf16_x3tail", device="cpu")
     eng, _dev = model._get_engine(2)
-    assert eng.knobs == {"x3_tail": -1, "small_batch_rows": -1}
-    model.x3_tail, model.small_batch_rows = 5, 0
+    assert eng.knobs == {"x3_tail": -1, "small_batch_rows": -1, "layers_min_b": -1}
+    model.x3_tail, model.small_batch_rows, model.layers_min_b = 5, 0, 1
     eng2, _dev = model._get_engine(2)
-    assert eng2 is eng and eng.knobs == {"x3_tail": 5, "small_batch_rows": 0}
+    assert eng2 is eng and eng.knobs == {"x3_tail": 5, "small_batch_rows": 0, "layers_min_b": 1}
 
 
 # ---- bench.py launches its own ranks (the counterpart of the reference's rank bootstrap, utils/dist_util.py:20-42) ---------------

@@ -108,3 +108,17 @@ def test_evaluation_pipeline_end_to_end(golden):
     acc = ev.evaluate_acc(type("M", (), {"cond_mode": "action"})(), loaders, "cmdm")       # evaluate.py:127-162 (acc_only runs)
     assert sorted(acc) == sorted(f"accuracy_{k}_{s}" for k in ("gt", "gen") for s in ("train", "test"))
     assert all(acc[k] == m[k] for k in acc)
+
+
+def test_fid_delta_proxy_of_hip_sampled_against_oracle_sampled_motions():
+    """north_star: "FID within +-0.1 of reference". 1024 action-conditioned NTU motions, the reference's shipped evaluation setting (ddim5
+    through p_sample_loop), default precision schedule, HIP vs the oracle on the same noise tape, through the same recogniser
+    (tests/fid_proxy.py; eval/a2m/stgcn/evaluate.py:55-124, fid.py:11-61, stgcn_eval.py:61-81). The synthetic recogniser's FID scale is
+    not NTU120's, so the bounds are stated relative to FID(gt*, oracle) as well as absolutely."""
+    from tests.fid_proxy import run
+    r = run(1024)
+    print(f"\n[fid proxy] {r}")
+    assert r["max_abs_motion_dev"] < 1e-3
+    assert r["fid_oracle_hip"] < 1e-3, r
+    assert r["delta_vs_gt"] < max(0.01, 1e-4 * r["fid_gt_oracle"]), r
+    assert r["argmax_agree"] >= 0.999, r

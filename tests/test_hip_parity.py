@@ -1,6 +1,8 @@
 """GPU: the HIP path (through the C-ABI) against golden vectors recorded from the reference and against
 the oracle on the same seeded inputs. Tolerance from BASELINE.json north_star: 1e-3 abs on rot6d
 (written per test); timestep indices bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1183,3 +1185,47 @@ def test_long_sequence_attention_units_against_the_unfused_path(T):
     assert np.isfinite(outs[0]).all()
     assert d_ref < 2.0 * d_ref_unfused + 2e-3, (T, d_ref, d_ref_unfused)
     assert d_paths < 2.0 * d_ref_unfused + 2e-3, (T, d_paths, d_ref_unfused)
+
+
+def test_rccl_one_rank_group_takes_the_multi_gpu_code_paths():
+    """utils/dist_util.py:20-83's counterpart on the pool's hardware, every round: a ONE-rank RCCL group (two ranks cannot share a GPU) in a
+    subprocess - backend init with the environment bench.py gives its ranks, the broadcast of the engine's packed weight blob through the
+    zero-copy view (rgn_weight_blob), the MAX all-reduce of the calibration agreement, a gather - and `bench.py --force-dist` end to end:
+    process-group init, blob broadcast into the engine, barriers around the timed region, MAX all-reduce of the time."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_single_rank_check.py")], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "[rccl] ok" in p.stdout and "bytes unchanged: True" in p.stdout, p.stdout + p.stderr
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "1", "--warmup", "1", "--respacing", "50", "--batch", "64",
+                        "--no-cpu-baseline", "--profile-evals", "0"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and lines, p.stdout + p.stderr
+    line = json.loads(lines[-1])
+    assert line["backend"] == "nccl" and line["rccl_world_size"] == 1 and line["value"] > 0, line
+    assert line["headline_row_check_max_abs"] is not None and line["headline_row_check_max_abs"] <= 2e-5, line
+
+
+def test_exceptions_do_not_cross_the_c_boundary():
+    """include/regennet_hip.h: "no exceptions cross the boundary". A positional table of 2^40 rows (its first dimension is free) makes the
+    host-side copy throw std::length_error / std::bad_alloc inside rgn_load_weight: it must come back as RGN_ERR_INTERNAL with the text in
+    rgn_last_error - not unwind into ctypes - and the handle stays usable."""
+    import ctypes as C
+    from regennet_amd import _lib, synth
+    cfg = synth.get_config("tiny")
+    eng = _lib.Engine(cfg, 1, 0, "f32")
+    host = np.zeros(16, np.float32)
+    shape = (C.c_int64 * 3)(1 << 40, 1, cfg["latent_dim"])
+    code = eng.lib.rgn_load_weight(eng.h, b"sequence_pos_encoder.pe", host.ctypes.data_as(C.c_void_p), shape, 3)
+    assert code == -8, code
+    msg = eng.lib.rgn_last_error(eng.h).decode()
+    assert "rgn_load_weight" in msg and "exception" in msg, msg
+    for k, v in synth.make_state_dict(cfg, seed=0).items():      # the handle is intact: a checkpoint still loads and finalizes
+        eng.load_weight(k, v)
+    eng.finalize()
+    eng.close()

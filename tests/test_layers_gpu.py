@@ -153,3 +153,71 @@ def test_decoder_stack_kernel_lengths_and_partial_ranges(monkeypatch):
             torch.cuda.synchronize()
             assert (x - out).abs().max().item() < 2e-4, (x - out).abs().max().item()
         model._engine.close()
+
+
+HEADLINE_ROWS = (0, 31, 32, 128, 255)   # first / last sample of XCD 0's range, first of XCD 1's, the middle, the last workgroup of the launch
+
+
+@pytest.mark.parametrize("tail", [0, None])
+def test_headline_launch_at_its_real_shape_rows_equal_single_sample_runs(monkeypatch, tail):
+    """BASELINE configs[1] EXACTLY as bench.py issues it (gaussian_diffusion.py:675-742): NTU B = 256, the full 1000-step DDPM call, default
+    engine and schedule, on-device Philox - ONE k_layers<true> launch of 256 workgroups x 995 steps (1000 with tail = 0), where the
+    XCD-affine block map, the last-workgroup index hand-off and 995 iterations of the in-kernel Philox run together. Rows
+    {0, 31, 32, 128, 255} against B = 1 runs of the same kernel form with the motion's global Philox key (sample_offset = b):
+    bit for bit in the plain-bf16 phase (tail = 0), within 2e-5 behind the default split-bf16 tail."""
+    from regennet_amd import synth
+    cfg = synth.get_config("ntu")
+    sd = synth.make_state_dict(cfg, seed=0)
+    B = 256
+    y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1)).cuda()}
+    model, diffusion = synth.build_model(cfg, sd, resp="", precision="bf16_x3tail", device="cuda:0", x3_tail=tail)   # (bench.py's construction)
+    assert diffusion.num_timesteps == 1000
+    full = diffusion.p_sample_loop(model, (B, 56, 6, 60), clip_denoised=False, model_kwargs={"y": y}, seed=100, sample_offset=0)
+    assert torch.isfinite(full).all()
+    model._engine.close()
+    model1, diffusion1 = build_hip(cfg, sd, resp="", precision="bf16_x3tail/throughput", x3_tail=tail)
+    _engine_with(monkeypatch, FORMS["multi-step"], model1, 1)
+    worst = 0.0
+    for b in HEADLINE_ROWS:
+        yb = {k: v[b:b + 1].contiguous() for k, v in y.items()}
+        one = diffusion1.p_sample_loop(model1, (1, 56, 6, 60), clip_denoised=False, model_kwargs={"y": yb}, seed=100, sample_offset=b)
+        dev = (full[b:b + 1] - one).abs().max().item()
+        worst = max(worst, dev)
+        if tail == 0:
+            assert torch.equal(full[b:b + 1], one), (b, dev)
+        else:
+            assert dev <= 2e-5, (b, dev)
+    print(f"\n[headline launch, B = 256 x 1000 steps, tail = {tail}] rows {HEADLINE_ROWS} vs single-sample runs: max |dev| = {worst:.1e}")
+    model1._engine.close()
+
+
+def test_headline_launch_shape_against_the_oracle_on_a_100_step_schedule():
+    """The same launch shape (256 workgroups, default engine, default precision schedule, on-device Philox) on a 100-step DDPM schedule,
+    every 16th motion (two workgroups of every XCD) against the ORACLE on the very noise the kernel drew: x_T and the 100 per-step draws
+    are re-drawn through rgn_randn_step - the fused loop's own Philox stream, element for element
+    (test_model_kwargs_the_fused_loop_does_not_read) - and handed to the oracle as its tape. Bound: north_star's 1e-3."""
+    from oracle import regennet_oracle as orc
+    from regennet_amd import synth
+    cfg = synth.get_config("ntu")
+    sd = synth.make_state_dict(cfg, seed=0)
+    B, S, seed = 256, 100, 77
+    y = {"cmotion": synth.make_cmotion(cfg, B, seed=71)}
+    model, diffusion = synth.build_model(cfg, sd, resp=str(S), precision="bf16_x3tail", device="cuda:0")
+    yd = y_to_device(y)
+    shape = (B, 56, 6, 60)
+    out = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": yd}, seed=seed, sample_offset=0)
+    assert torch.isfinite(out).all()
+    idx = np.arange(0, B, 16)
+    eng = model._engine
+    st = torch.cuda.current_stream().cuda_stream
+    buf = torch.empty(shape, device="cuda")
+    tape = np.empty((S + 1, len(idx)) + shape[1:], dtype=np.float32)
+    for k, loop_index in enumerate([-1] + list(range(S - 1, -1, -1))):     # draw order: x_T, then loop indices S-1 .. 0
+        eng.randn_step(buf, B, seed, 0, loop_index, st)
+        tape[k] = buf[idx].cpu().numpy()
+    ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", str(S)), tape,
+                          {k: torch.from_numpy(np.ascontiguousarray(v[idx])) for k, v in y.items()}, mode="ddpm").numpy()
+    err = float(np.abs(out.cpu().numpy()[idx] - ref).max())
+    print(f"\n[headline launch shape, 95 + 5 steps, B = 256, on-device Philox] every 16th motion vs oracle: {err:.2e}")
+    assert err < 1e-3, err
+    model._engine.close()
