@@ -113,6 +113,9 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
     const int l31 = lane & 31, kh = lane >> 5;
     const int b = xcd_affine(blockIdx.x, gridDim.x), Tq = g.Tq;
     const size_t row0 = (size_t)b * Tq;
+#ifdef RGN_LY_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(RGN_LY_PRIO);      // the second-dispatched half loses every age arbitration on its SIMD otherwise (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+#endif
     float* vec = reinterpret_cast<float*>(smem + LY_VEC) + wave * LY_VECW;   // this wave's private region
     const int lane16 = lane * 16;
     const int swz = (l31 >> 2) & 3;
@@ -654,6 +657,23 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
             else gemm32(acc2, a_offy, p_w2b, p_w2b, std::false_type{}, std::integral_constant<int, 0>{});
         }
         load_qbias(g.lw[l + 1 < g.L ? l + 1 : 0].bqkv, 0);      // the next layer's (next step's first layer's) round 0: lands under norm3
+#ifndef RGN_LY_NO_PREFETCH
+        if constexpr (STEPS) {
+            // ---- the step boundary's weights (Wout: 16 x nb_out KiB-pairs, Wx: 352 KiB) were evicted from this XCD's L2 by the 33 MB of layer
+            //      weights that streamed through it since the last step: the CUs of the XCD touch them once more, each 1 / nsl of the lines,
+            //      while the last layer's norm3 runs - the output projection then finds them in L2 instead of waiting a fabric round trip per granule
+            if (l == g.L - 1) {
+                const int nsl = (int)(gridDim.x >> 3) >= 32 ? 32 : ((int)(gridDim.x >> 3) > 0 ? (int)(gridDim.x >> 3) : 1);
+                const int sl = (int)(blockIdx.x >> 3) % nsl;
+                const int n_out = 16 * g.nb_out * 16, n_all = n_out + LY_NKX * 16 * 16;           // 128-byte lines
+                for (int ln = sl + nsl * tid; ln < n_all; ln += nsl * LY_NTH) {
+                    const char* pp = ln < n_out ? reinterpret_cast<const char*>(g.Wout) + (size_t)ln * 128 : reinterpret_cast<const char*>(g.Wx) + (size_t)(ln - n_out) * 128;
+                    int dummy;
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(pp) : "memory");
+                }
+            }
+        }
+#endif
         RGN_LYT(10)
         add_resid(acc2);
         layernorm(acc2, vec + V_G3, std::integral_constant<int, 0>{}, [&](int nt, int i4) { return *reinterpret_cast<const f32x4*>(vec + V_B3 + col4(nt, i4)); });
