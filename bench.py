@@ -61,8 +61,9 @@ def row_check(cfg, sd, a, dev, y, out, seed, lo, plan, fn_name, rows):
 def bench_stgcn(a):
     """`--config stgcn`: the evaluation harness's recogniser (rgn_stgcn_forward; eval/a2m/recognition/models/stgcn.py:76-123) on N = --batch
     two-person motions of 60 and 150 frames, timed with the same barrier / synchronize bracket, HIP events around every forward, against the
-    fp32 MFMA peak (its kernels are exact-product fp32). FLOPs: the ten st_gcn blocks of stgcn.py:51-62 (graph aggregation on the input
-    channels, 1x1 convolution over K C_in, 9x1 temporal convolution, residual 1x1 where the block has one), both persons."""
+    dense bf16 MFMA peak (its GEMMs are split-bf16: three MFMAs per product, so the ceiling for ALGORITHMIC FLOPs is a third of it). FLOPs:
+    the ten st_gcn blocks of stgcn.py:51-62 (graph aggregation on the input channels - dense count, the kernel walks the skeleton's nonzeros -
+    1x1 convolution over K C_in, 9x1 temporal convolution, residual 1x1 where the block has one), both persons."""
     from regennet_amd import synth
     from regennet_amd.eval import STGCN
     dev = torch.device("cuda:0")
@@ -104,11 +105,12 @@ def bench_stgcn(a):
         tf = flops / (ms * 1e-3) / 1e12
         lines.append({"T": T, "N": N, "ms_per_forward": round(ms, 3), "wall_ms_per_forward": round(1e3 * dt / a.steps, 3),
                       "motions_per_s": round(N / (ms * 1e-3), 1), "algo_gflop_per_forward": round(flops / 1e9, 2),
-                      "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS["f32"], 4),
-                                   "traffic": None, "note": "fp32-input MFMA (exact products), the evaluator's arithmetic; all launches of one forward"}})
+                      "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS["bf16x3"], "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS["bf16x3"], 4),
+                                   "traffic": None, "note": "algorithmic FLOPs of one forward (all its launches) / its duration; split-bf16 GEMMs: three MFMAs per product, "
+                                                            "ceiling for algorithmic FLOPs = peak / 3; the 4 + 4 zero pad frames per sequence are computed too"}})
     print(json.dumps({"metric": "ST-GCN recogniser forward (evaluation harness, SURVEY 8f next-4)", "value": lines[0]["motions_per_s"], "unit": "motions/s",
                       "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": lines[0]["ms_per_forward"], "higher_is_better": True,
-                      "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": f"stgcn: N={a.batch} x [56, 12, 60 | 150]"},
+                      "scaling": "weak", "vs_baseline": None, "dtype": "split-bf16 (x3) MFMA, fp32 accumulate", "data": "synthetic", "config": {"workload": f"stgcn: N={a.batch} x [56, 12, 60 | 150]"},
                       "roofline": lines[0]["roofline"], "per_length": lines}), flush=True)
 
 

@@ -55,6 +55,7 @@ __device__ __forceinline__ float fast_erf(float x) {
 __device__ __forceinline__ float x3_act(float v, int act) {
     if (act == 1) return v * 0.5f * (1.0f + fast_erf(v * 0.70710678118654752440f));
     if (act == 2) return v / (1.0f + __expf(-v));
+    if (act == 3) return fmaxf(v, 0.f);
     return v;
 }
 
@@ -76,8 +77,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // planes. Interior blocks take a branch-free path (CHECK = false): one pointer per tile, constant row strides,
 // residual loads batched per tile; only edge blocks pay per-element bounds checks.
 // mw / nw: first row / column of this wave's TM x TN tiles of 32x32.
-template <int TM, int TN, bool QKV, bool CHECK>
+// EPI: 0 plain, 1 the attention-ready scatter of the packed in_proj output, 2 the ST-GCN evaluator's GEMMs ((row % add_mod) addend)
+template <int TM, int TN, int EPI, bool CHECK>
 __device__ __forceinline__ void x3_epilogue(const GemmX3Args& g, f32x16 (&acc)[TM][TN], int mw, int nw, int lane) {
+    constexpr bool QKV = EPI == 1;
     const int l31 = lane & 31, kh = lane >> 5;
         #pragma unroll
     for (int tb = 0; tb < TN; ++tb) {
@@ -88,7 +91,17 @@ __device__ __forceinline__ void x3_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
         for (int ta = 0; ta < TM; ++ta) {
             const int mb = mw + ta * 32 + 4 * kh;      // row of register 0
             float r[16];
-            if (g.add) {
+            if (EPI == 2 && g.add && g.add_mod > 0) {      // addend row = row % add_mod (a per-vertex bias: rows run (frame, vertex); add_mod >= 28)
+                const int base = (int)((unsigned)mb % (unsigned)g.add_mod);
+                const float* ap = g.add + n;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ro = (i & 3) + 8 * (i >> 2);
+                    int rr = base + ro;
+                    rr = rr >= g.add_mod ? rr - g.add_mod : rr;
+                    r[i] = n_ok ? ap[rr * g.ldadd] : 0.f;
+                }
+            } else if (g.add) {
                 const float* ap = g.add + (size_t)mb * g.ldadd + n;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -200,7 +213,7 @@ __device__ long long g_prof[1024];   // tools only: per-k-step cycle stamps of o
 // ILV = false: two barriers per k-step, the whole next tile's DMA issued at the top of the step (128x128, 2 WG / CU).
 // ILV = true : one barrier per k-step, DMA pieces interleaved with the MFMAs of the first K half, fragments fetched one
 //              MFMA group ahead (256x256, 1 WG / CU).
-template <int BM, int BN, int WM, int WN, bool X3, bool ILV, bool QKV>
+template <int BM, int BN, int WM, int WN, bool X3, bool ILV, int EPI>
 __global__ __launch_bounds__(64 * WM * WN, (2 * 2 * (BM + BN) * 64 <= 80 * 1024) ? 2 : 1) void k_gemm_x3(GemmX3Args g, int nbx, int nby) {
     constexpr int NT = 64 * WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -239,7 +252,12 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * 2 * (BM + BN) * 64 <= 80 * 1024)
     }
     // DMA piece idx of tile kt into stage buffer sb (idx is a compile-time constant after unrolling)
     auto piece = [&](int idx, int kt, char* sb) {
-        const size_t ka = (size_t)kt * g.a_rows * 64, kw = (size_t)kt * g.N * 64;
+        ptrdiff_t ka = (ptrdiff_t)kt * g.a_rows * 64;
+        if constexpr (EPI == 2) {   // temporal convolution as one GEMM: k-block -> (tap, channel block), the tap shifts the rows
+            if (g.a_klog >= 0)
+                ka = ((ptrdiff_t)(kt & ((1 << g.a_klog) - 1)) * g.a_rows + (ptrdiff_t)((kt >> g.a_klog) - g.a_kbias) * g.a_kshift) * 64;
+        }
+        const size_t kw = (size_t)kt * g.N * 64;
         if (idx < NPL * A_IT) {
             const int it = idx / NPL, pl = idx % NPL;
             const int lo = (it * NT + (tid & ~63)) * 16;   // wave-uniform LDS byte offset of this 1 KiB piece
@@ -391,8 +409,8 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * 2 * (BM + BN) * 64 <= 80 * 1024)
 #undef RGN_T
 
     const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
-    if (interior) x3_epilogue<TM, TN, QKV, false>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
-    else x3_epilogue<TM, TN, QKV, true>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+    if (interior) x3_epilogue<TM, TN, EPI, false>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+    else x3_epilogue<TM, TN, EPI, true>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
 }
 
 template <int BM, int BN, int WM, int WN, bool ILV>
@@ -405,8 +423,8 @@ static hipError_t x3_launch(const GemmX3Args& g, bool x3, hipStream_t s, bool co
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_x3<BM, BN, WM, WN, X3V, ILV, QV>),                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);                                        \
         if (e != hipSuccess) return e;
-        RGN_CFG(true, false, big) RGN_CFG(false, false, small)
-        if constexpr (BM == 128 && !ILV) { RGN_CFG(true, true, big) RGN_CFG(false, true, small) }
+        RGN_CFG(true, 0, big) RGN_CFG(false, 0, small)
+        if constexpr (BM == 128 && !ILV) { RGN_CFG(true, 1, big) RGN_CFG(false, 1, small) }
 #undef RGN_CFG
         return hipSuccess;
     }
@@ -415,16 +433,38 @@ static hipError_t x3_launch(const GemmX3Args& g, bool x3, hipStream_t s, bool co
     const bool qkv = g.Qhi != nullptr;
     if constexpr (BM == 128 && !ILV) {   // the attention-ready scatter exists for the default tile only
         if (qkv) {
-            if (x3) hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, true, ILV, true>), grid, block, lds, s, g, nbx, nby);
-            else hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, false, ILV, true>), grid, block, lds, s, g, nbx, nby);
+            if (x3) hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, true, ILV, 1>), grid, block, lds, s, g, nbx, nby);
+            else hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, false, ILV, 1>), grid, block, lds, s, g, nbx, nby);
             return hipGetLastError();
         }
     } else if (qkv) {
         return hipErrorInvalidValue;
     }
-    if (x3) hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, true, ILV, false>), grid, block, lds, s, g, nbx, nby);
-    else hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, false, ILV, false>), grid, block, lds, s, g, nbx, nby);
+    if (x3) hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, true, ILV, 0>), grid, block, lds, s, g, nbx, nby);
+    else hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, false, ILV, 0>), grid, block, lds, s, g, nbx, nby);
     return hipGetLastError();
+}
+
+// ---- the ST-GCN evaluator's GEMMs (rgn_stgcn.hip): millions of rows x 64 / 128 / 256 channels, split-bf16 throughout. 256-row tiles with
+//      the interleaved one-barrier loop; the tile is as wide as the layer (a 64-channel layer on a 128-wide tile would idle half its MFMAs)
+template <int BN, int WN>
+static hipError_t sg_launch(const GemmX3Args& g, hipStream_t s, bool configure_only) {
+    constexpr int BM = 256, WM = 4;
+    const int lds = 2 * 2 * (BM * 64 + BN * 64);
+    if (configure_only)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_x3<BM, BN, WM, WN, true, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int nbx = (g.N + BN - 1) / BN, nby = (g.M + BM - 1) / BM;
+    hipLaunchKernelGGL((k_gemm_x3<BM, BN, WM, WN, true, true, 2>), dim3(nbx * nby), dim3(64 * WM * WN), lds, s, g, nbx, nby);
+    return hipGetLastError();
+}
+hipError_t launch_gemm_x3_sg(const GemmX3Args& g, hipStream_t s) {
+    if (g.N <= 64) return sg_launch<64, 1>(g, s, false);
+    return sg_launch<128, 2>(g, s, false);      // (256 channels: two column blocks - the 256-wide tile spills 123 SGPRs + 576 B of scratch in this form)
+}
+hipError_t configure_gemm_x3_sg() {
+    GemmX3Args g{};
+    hipError_t e = sg_launch<64, 1>(g, nullptr, true);
+    return e != hipSuccess ? e : sg_launch<128, 2>(g, nullptr, true);
 }
 
 // variant 0 = 128x128 / 4 waves (two workgroups per CU): the default. variant 1 = 256x256 / 8 waves / interleaved DMA (one

@@ -86,6 +86,10 @@ struct GemmX3Args {
     int d, H, dh, Tq, Tqp;
     unsigned tq_magic;                               // floor(2^32 / Tq) + 1: m / Tq == umulhi(m, tq_magic) for m * Tq < 2^32
     float qscale;
+    // launch_gemm_x3_sg only (rgn_stgcn.hip): a temporal convolution as ONE GEMM over K = taps x channels - k-block kt reads plane block
+    // kt & (2^a_klog - 1) with its rows shifted by ((kt >> a_klog) - a_kbias) * a_kshift (a_klog < 0: plain addressing; the planes carry
+    // zero guard rows for the shifts' reach); the addend row is (row % add_mod) when add_mod > 0; act 3 = ReLU
+    int a_klog, a_kshift, a_kbias, add_mod;
 };
 
 // Split-bf16 activation planes in the K32-blocked layout; hi == nullptr means "not requested".
@@ -306,6 +310,10 @@ struct Dims {
 hipError_t launch_gemm(const GemmArgs& g, int precision, hipStream_t s);
 hipError_t launch_gemm_x3(const GemmX3Args& g, bool x3, int variant, hipStream_t s);
 hipError_t configure_gemm_x3();
+// split-bf16 GEMMs of the ST-GCN evaluator (rgn_stgcn.hip): 256-row tiles x the layer's channel count (64 / 128 / 256), shifted-row
+// A addressing for the 9 x 1 temporal convolution, (row % V) addend, ReLU
+hipError_t launch_gemm_x3_sg(const GemmX3Args& g, hipStream_t s);
+hipError_t configure_gemm_x3_sg();
 hipError_t configure_attention(int Tq, int dh);
 struct AttnX3Args {
     const __bf16 *Qhi, *Qlo, *Khi, *Klo, *Vthi, *Vtlo;   // layouts above

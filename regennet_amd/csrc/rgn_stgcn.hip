@@ -3,16 +3,21 @@
 // Replaces eval/a2m/recognition/models/stgcn.py:76-123 (STGCN.forward, eval mode) with its ten st_gcn blocks (:145-228)
 // and ConvTemporalGraphical (stgcnutils/tgcn.py:61-71). What runs per block, all BatchNorms folded at load time (fp64):
 //
-//   z[(n,t,w),(k,ci)] = sum_v A'_k[v,w] x[(n,t,v),ci]                       k_stgcn_agg   (graph aggregation first: the 1x1
-//                                                                            conv and the vertex mixing commute)
-//   g = relu(z . W1'^T + b1'[w])                                            fp32 MFMA GEMM (k_gemm_f32), K = 3 C_in
-//   c = sum_dt g[t + dt - 4] . W2'_dt^T                                     nine accumulating GEMMs over the time-PADDED
-//                                                                            activation (rows shifted by (dt - 4) V)
-//   x' = relu(c[s t'] + b2' + residual)                                     k_stgcn_post  (stride s subsampling here)
+//   z[(n,t,w),(k,ci)] = sum_v A'_k[v,w] x[(n,t,v),ci]                       k_sg_agg      (graph aggregation first: the 1x1 conv and the
+//                                                                            vertex mixing commute; A' = A * edge_importance keeps the
+//                                                                            skeleton's sparsity - 166 of 3 x 56 x 56 entries for SMPL-X -
+//                                                                            so the kernel walks per-(k, w) nonzero lists)
+//   g = relu(z . W1'^T + b1'[w])                                            split-bf16 MFMA GEMM, K = 3 C_in
+//   c = sum_dt g[t + dt - 4] . W2'_dt^T                                     ONE split-bf16 MFMA GEMM over K = 9 C_out: k-block (dt, channel
+//                                                                            block) reads the time-PADDED activation with its rows
+//                                                                            shifted by (dt - 4) V (no im2col buffer, no read-modify-write)
+//   x' = relu(c[s t'] + b2' + residual)                                     k_sg_post     (stride s subsampling here)
 //
-// Activations are channel-last and padded in time: [N*M][T + 8][V][C], the 4 + 4 pad frames stay zero, so the temporal
-// convolution is plain row-shifted GEMMs (no im2col buffer). fp32 throughout (exact-product MFMA): this is evaluation
-// glue next to the sampler, sized by simplicity, not a hot path (~3 TFLOP per 256-motion batch).
+// Activations are split-bf16 operand planes (hi = rne(x), lo = rne(x - hi)) in the K32-blocked layout of rgn_gemm_x3.hip,
+// [C/32][R][32] with rows (n m, padded frame, vertex): the 4 + 4 pad frames of every sequence and 4 V guard rows at both ends of a
+// plane block stay zero, so the temporal convolution is plain row-shifted operand reads. Products are formed as a_lo w_hi + a_hi w_lo +
+// a_hi w_hi (fp32 accumulate): ~2^-16 per product, measured <= 2e-5 relative on the reference's features (the fp32-MFMA build this replaces
+// measured the same parity at 173 ms per 256 two-person motions of 60 frames; profiles/r05).
 #include "../../include/regennet_hip.h"
 #include "rgn_internal.h"
 
@@ -34,9 +39,19 @@ constexpr int SG_PAD = 4;                      // temporal kernel 9 -> 4 zero fr
 struct SgBlockDef { int ci, co, stride; bool res_conv, res_id; };
 
 struct SgBlock {
-    int ci = 0, co = 0, stride = 1, kp1 = 0;
+    int ci = 0, co = 0, stride = 1, kp1 = 0, kpr = 0;
     bool res_conv = false, res_id = false;
-    float *A = nullptr, *W1 = nullptr, *b1 = nullptr, *W2 = nullptr, *b2 = nullptr, *Wr = nullptr, *br = nullptr;
+    int *nz_ptr = nullptr, *nz_v = nullptr;          // nonzeros of A'_k[:, w]: list (k V + w) = [nz_ptr[k V + w], nz_ptr[k V + w + 1])
+    float* nz_a = nullptr;
+    __bf16 *W1h = nullptr, *W1l = nullptr, *W2h = nullptr, *W2l = nullptr, *Wrh = nullptr, *Wrl = nullptr;   // K32-blocked weight planes [Kp/32][co][32]
+    float *b1 = nullptr, *b2 = nullptr, *br = nullptr;
+};
+
+// split-bf16 activation planes [C/32][R][32]; hi / lo point at row 0 (behind the leading guard rows), R = block stride in rows
+struct SgPl {
+    __bf16* hi;
+    __bf16* lo;
+    long long R;
 };
 
 }  // namespace
@@ -50,8 +65,9 @@ struct rgn_stgcn_ctx {
     int V = 0, K = 0, C0 = 0;
     std::vector<SgBlock> blocks;
     float *bn_s = nullptr, *bn_t = nullptr, *Wf = nullptr, *bf = nullptr;
-    float *xa = nullptr, *xb = nullptr, *z = nullptr, *g = nullptr, *conv = nullptr, *rfull = nullptr, *pooled = nullptr;
-    size_t guard = 0;
+    __bf16 *xa[2] = {nullptr, nullptr}, *xb[2] = {nullptr, nullptr}, *z[2] = {nullptr, nullptr}, *g[2] = {nullptr, nullptr};   // (hi, lo) plane buffers
+    float *conv = nullptr, *rfull = nullptr, *pooled = nullptr;
+    size_t guard = 0;                            // guard rows at both ends of every plane block (the temporal taps' reach: 4 V)
     std::vector<void*> allocs;
     hipStream_t stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -71,92 +87,179 @@ thread_local std::string g_sg_create_error;
         if (_e != hipSuccess) return (h)->fail(RGN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
-// data_bn + layout: output [N, V, M*C, T] (batch['output'], stgcn.py:83-101) -> x[(n*M + m)][SG_PAD + t][v][c], BatchNorm1d
-// channel index (m*V + v)*C + c; pad frames are written as zeros
-__global__ void k_stgcn_in(const float* __restrict__ out, float* __restrict__ x, const float* __restrict__ s, const float* __restrict__ t,
-                           int N, int V, int M, int C, int T) {
+typedef __bf16 sg_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void sg_split8(const float (&v)[8], sg_bf16x8& h, sg_bf16x8& l) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h[j] = (__bf16)v[j];
+        l[j] = (__bf16)(v[j] - (float)h[j]);
+    }
+}
+
+// data_bn + layout: output [N, V, M*C, T] (batch['output'], stgcn.py:83-101) -> x planes, rows (n M + m, SG_PAD + t, v), channels c < C (the
+// rest of the 32-channel block zero), BatchNorm1d channel index (m*V + v)*C + c; pad frames are written as zeros. One thread per row.
+__global__ void k_sg_in(const float* __restrict__ out, SgPl x, const float* __restrict__ s, const float* __restrict__ t, int N, int V, int M, int C, int T) {
     const int Tp = T + 2 * SG_PAD;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)N * M * Tp * V * C;
-    if (idx >= total) return;
-    const int c = (int)(idx % C);
-    const int v = (int)((idx / C) % V);
-    const int tp = (int)((idx / ((size_t)C * V)) % Tp);
-    const int nm = (int)(idx / ((size_t)C * V * Tp));
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= (size_t)N * M * Tp * V) return;
+    const int v = (int)(row % V);
+    const int tp = (int)((row / V) % Tp);
+    const int nm = (int)(row / ((size_t)V * Tp));
     const int tt = tp - SG_PAD;
-    float val = 0.f;
+    float val[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) val[c] = 0.f;
     if (tt >= 0 && tt < T) {
-        const int n = nm / M, m = nm % M, ch = (m * V + v) * C + c;
-        val = out[(((size_t)n * V + v) * (M * C) + m * C + c) * T + tt] * s[ch] + t[ch];
+        const int n = nm / M, m = nm % M;
+        for (int c = 0; c < C && c < 32; ++c) {
+            const int ch = (m * V + v) * C + c;
+            val[c] = out[(((size_t)n * V + v) * (M * C) + m * C + c) * T + tt] * s[ch] + t[ch];
+        }
     }
-    x[idx] = val;
-}
-
-// z[(r), k*C + ci] = sum_v A_k[v, w] x[(frame, v), ci] for every row r = (frame, w); one workgroup per frame
-__global__ __launch_bounds__(256) void k_stgcn_agg(const float* __restrict__ x, const float* __restrict__ A, float* __restrict__ z, int V, int K,
-                                                    int C) {
-    extern __shared__ float sm[];                 // x frame [V][C]
-    const size_t frame = blockIdx.x;
-    const float* xf = x + frame * V * C;
-    for (int i = threadIdx.x; i < V * C; i += 256) sm[i] = xf[i];
-    __syncthreads();
-    const int KC = K * C;
-    for (int o = threadIdx.x; o < V * KC; o += 256) {
-        const int w = o / KC, kc = o - w * KC, k = kc / C, ci = kc - k * C;
-        const float* a = A + (size_t)k * V * V + w;   // A_k[v, w], stride V over v
-        float acc = 0.f;
-        for (int v = 0; v < V; ++v) acc = fmaf(a[(size_t)v * V], sm[v * C + ci], acc);
-        z[(frame * V + w) * KC + kc] = acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = val[8 * q + j];
+        sg_bf16x8 h, l;
+        sg_split8(v8, h, l);
+        *reinterpret_cast<sg_bf16x8*>(x.hi + row * 32 + 8 * q) = h;
+        *reinterpret_cast<sg_bf16x8*>(x.lo + row * 32 + 8 * q) = l;
     }
 }
 
-// zero the pad frames of a padded activation [NM][Tp][V][C]
-__global__ void k_stgcn_zero_pads(float* __restrict__ g, int NM, int T, int VC) {
+// z[(frame, w), k C + ci] = sum_v A'_k[v, w] x[(frame, v), ci] over the nonzeros of A'_k[:, w]. C % 32 == 0: one thread per (row, k, run of 8
+// channels); the output channel k C + ci lies in plane block k C / 32 + ci / 32.
+__global__ void k_sg_agg(SgPl x, SgPl z, const int* __restrict__ nz_ptr, const int* __restrict__ nz_v, const float* __restrict__ nz_a, size_t rows, int V, int K, int C) {
+    const int c8n = C / 8;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rows * K * c8n) return;
+    const int c8 = (int)(gid % c8n), k = (int)((gid / c8n) % K);
+    const size_t row = gid / ((size_t)c8n * K);
+    const size_t frame = row / V;
+    const int w = (int)(row - frame * V);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const size_t in_off = ((size_t)(c8 >> 2) * x.R) * 32 + 8 * (c8 & 3);
+    for (int j = nz_ptr[k * V + w]; j < nz_ptr[k * V + w + 1]; ++j) {
+        const size_t src = in_off + (frame * V + nz_v[j]) * 32;
+        const float a = nz_a[j];
+        const sg_bf16x8 h = *reinterpret_cast<const sg_bf16x8*>(x.hi + src), l = *reinterpret_cast<const sg_bf16x8*>(x.lo + src);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(a, (float)h[e] + (float)l[e], acc[e]);
+    }
+    sg_bf16x8 h, l;
+    sg_split8(acc, h, l);
+    const size_t dst = ((size_t)(k * (C / 32) + (c8 >> 2)) * z.R + row) * 32 + 8 * (c8 & 3);
+    *reinterpret_cast<sg_bf16x8*>(z.hi + dst) = h;
+    *reinterpret_cast<sg_bf16x8*>(z.lo + dst) = l;
+}
+// the first block (C = in_channels / persons = 6, K C <= 32): one thread per row writes the whole 32-channel output row
+__global__ void k_sg_agg_small(SgPl x, SgPl z, const int* __restrict__ nz_ptr, const int* __restrict__ nz_v, const float* __restrict__ nz_a, size_t rows, int V, int K, int C) {
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const size_t frame = row / V;
+    const int w = (int)(row - frame * V);
+    float val[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) val[c] = 0.f;
+    for (int k = 0; k < K; ++k)
+        for (int j = nz_ptr[k * V + w]; j < nz_ptr[k * V + w + 1]; ++j) {
+            const size_t src = (frame * V + nz_v[j]) * 32;
+            const float a = nz_a[j];
+            for (int c = 0; c < C; ++c) val[k * C + c] = fmaf(a, (float)x.hi[src + c] + (float)x.lo[src + c], val[k * C + c]);
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = val[8 * q + j];
+        sg_bf16x8 h, l;
+        sg_split8(v8, h, l);
+        *reinterpret_cast<sg_bf16x8*>(z.hi + row * 32 + 8 * q) = h;
+        *reinterpret_cast<sg_bf16x8*>(z.lo + row * 32 + 8 * q) = l;
+    }
+}
+
+// zero the pad frames (4 + 4 per sequence) and the guard rows (at both ends of every plane block) of padded planes with `cb` channel blocks
+__global__ void k_sg_zero(SgPl g, int NM, int T, int V, int cb, int guard) {
     const int Tp = T + 2 * SG_PAD;
+    const size_t npad = (size_t)NM * 2 * SG_PAD * V, per = npad + 2 * (size_t)guard;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t per = (size_t)2 * SG_PAD * VC;
-    if (idx >= per * NM) return;
-    const int nm = (int)(idx / per);
-    size_t r = idx % per;
-    const int f = (int)(r / VC);
-    const int tp = f < SG_PAD ? f : T + f;        // frames 0..3 and T+4..T+7
-    g[((size_t)nm * Tp + tp) * VC + (r % VC)] = 0.f;
+    if (idx >= per * cb * 4) return;
+    const int q = (int)(idx & 3);
+    const size_t e = (idx >> 2) % per;
+    const int b = (int)((idx >> 2) / per);
+    long long row;
+    if (e < npad) {
+        const int nm = (int)(e / ((size_t)2 * SG_PAD * V));
+        const int r = (int)(e % ((size_t)2 * SG_PAD * V));
+        const int f = r / V;
+        const int tp = f < SG_PAD ? f : T + f;            // frames 0..3 and T+4..T+7
+        row = ((long long)nm * Tp + tp) * V + (r % V);
+    } else {
+        const long long j = (long long)(e - npad);
+        row = j < guard ? j - guard : (long long)NM * Tp * V + (j - guard);
+    }
+    sg_bf16x8 zero;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero[j] = (__bf16)0.f;
+    const long long o = ((long long)b * g.R + row) * 32 + 8 * q;
+    *reinterpret_cast<sg_bf16x8*>(g.hi + o) = zero;
+    *reinterpret_cast<sg_bf16x8*>(g.lo + o) = zero;
 }
 
-// x'[nm][SG_PAD + t'][v][co] = relu(conv[nm][SG_PAD + s t'][v][co] + b2[co] + res), pads of x' zero
-//   res: none | identity x[nm][SG_PAD + t'][v][co] | rfull[nm][SG_PAD + s t'][v][co] + br[co] (1x1 conv + BN computed at full rate)
-__global__ void k_stgcn_post(const float* __restrict__ conv, const float* __restrict__ b2, const float* __restrict__ xin,
-                             const float* __restrict__ rfull, const float* __restrict__ br, float* __restrict__ xout, int NM, int T, int To,
-                             int stride, int V, int C) {
-    const int Tp = T + 2 * SG_PAD, Tpo = To + 2 * SG_PAD;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)NM * Tpo * V * C;
-    if (idx >= total) return;
-    const int c = (int)(idx % C);
-    const int v = (int)((idx / C) % V);
-    const int tpo = (int)((idx / ((size_t)C * V)) % Tpo);
-    const int nm = (int)(idx / ((size_t)C * V * Tpo));
+// x'[nm][SG_PAD + t'][v][co] = relu(conv[nm][SG_PAD + s t'][v][co] + b2[co] + res) as planes, pads of x' zero
+//   res: none | identity x[nm][SG_PAD + t'][v][co] (planes) | rfull[nm][SG_PAD + s t'][v][co] + br[co] (1x1 conv + BN computed at full rate)
+// one thread per (output row, run of 8 channels)
+__global__ void k_sg_post(const float* __restrict__ conv, const float* __restrict__ b2, SgPl xin, int res_id, const float* __restrict__ rfull,
+                          const float* __restrict__ br, SgPl xout, int NM, int T, int To, int stride, int V, int C) {
+    const int Tp = T + 2 * SG_PAD, Tpo = To + 2 * SG_PAD, c8n = C / 8;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)NM * Tpo * V * c8n) return;
+    const int c8 = (int)(gid % c8n);
+    const size_t orow = gid / c8n;
+    const int v = (int)(orow % V);
+    const int tpo = (int)((orow / V) % Tpo);
+    const int nm = (int)(orow / ((size_t)V * Tpo));
     const int to = tpo - SG_PAD;
-    float val = 0.f;
+    float val[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (to >= 0 && to < To) {
-        const size_t src = (((size_t)nm * Tp + SG_PAD + (size_t)stride * to) * V + v) * C + c;
-        val = conv[src] + b2[c];
-        if (rfull) val += rfull[src] + br[c];
-        else if (xin) val += xin[src];            // identity residual: stride 1, same channel count
-        val = fmaxf(val, 0.f);
+        const size_t srow = ((size_t)nm * Tp + SG_PAD + (size_t)stride * to) * V + v;
+        const float4 c0 = *reinterpret_cast<const float4*>(conv + srow * C + 8 * c8), c1 = *reinterpret_cast<const float4*>(conv + srow * C + 8 * c8 + 4);
+        const float4 bb0 = *reinterpret_cast<const float4*>(b2 + 8 * c8), bb1 = *reinterpret_cast<const float4*>(b2 + 8 * c8 + 4);
+        val[0] = c0.x + bb0.x; val[1] = c0.y + bb0.y; val[2] = c0.z + bb0.z; val[3] = c0.w + bb0.w;
+        val[4] = c1.x + bb1.x; val[5] = c1.y + bb1.y; val[6] = c1.z + bb1.z; val[7] = c1.w + bb1.w;
+        if (rfull) {
+            const float4 r0 = *reinterpret_cast<const float4*>(rfull + srow * C + 8 * c8), r1 = *reinterpret_cast<const float4*>(rfull + srow * C + 8 * c8 + 4);
+            const float4 q0 = *reinterpret_cast<const float4*>(br + 8 * c8), q1 = *reinterpret_cast<const float4*>(br + 8 * c8 + 4);
+            val[0] += r0.x + q0.x; val[1] += r0.y + q0.y; val[2] += r0.z + q0.z; val[3] += r0.w + q0.w;
+            val[4] += r1.x + q1.x; val[5] += r1.y + q1.y; val[6] += r1.z + q1.z; val[7] += r1.w + q1.w;
+        } else if (res_id) {                       // identity residual: stride 1, same channel count
+            const size_t o = ((size_t)(c8 >> 2) * xin.R + srow) * 32 + 8 * (c8 & 3);
+            const sg_bf16x8 h = *reinterpret_cast<const sg_bf16x8*>(xin.hi + o), l = *reinterpret_cast<const sg_bf16x8*>(xin.lo + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) val[e] += (float)h[e] + (float)l[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) val[e] = fmaxf(val[e], 0.f);
     }
-    xout[idx] = val;
+    sg_bf16x8 h, l;
+    sg_split8(val, h, l);
+    const size_t o = ((size_t)(c8 >> 2) * xout.R + orow) * 32 + 8 * (c8 & 3);
+    *reinterpret_cast<sg_bf16x8*>(xout.hi + o) = h;
+    *reinterpret_cast<sg_bf16x8*>(xout.lo + o) = l;
 }
 
 // global average pool over (t, v) and mean over the M persons (stgcn.py:113-114): pooled[n][c]
-__global__ void k_stgcn_pool(const float* __restrict__ x, float* __restrict__ pooled, int M, int T, int V, int C) {
+__global__ void k_sg_pool(SgPl x, float* __restrict__ pooled, int M, int T, int V, int C) {
     const int n = blockIdx.x, Tp = T + 2 * SG_PAD;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float acc = 0.f;
         for (int m = 0; m < M; ++m) {
             float a = 0.f;
-            const float* p = x + (((size_t)(n * M + m) * Tp + SG_PAD) * V) * C + c;
-            for (int i = 0; i < T * V; ++i) a += p[(size_t)i * C];
+            const size_t o = ((size_t)(c >> 5) * x.R + ((size_t)(n * M + m) * Tp + SG_PAD) * V) * 32 + (c & 31);
+            for (int i = 0; i < T * V; ++i) a += (float)x.hi[o + (size_t)i * 32] + (float)x.lo[o + (size_t)i * 32];
             acc += a / (float)(T * V);
         }
         pooled[(size_t)n * C + c] = acc / (float)M;
@@ -178,15 +281,60 @@ int sg_upload(rgn_stgcn_ctx* c, float** p, const std::vector<float>& v) {
     SG_HIP(c, hipMemcpy(*p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
     return RGN_OK;
 }
-inline size_t up16(size_t x) { return (x + 15) / 16 * 16; }
+inline size_t up32(size_t x) { return (x + 31) / 32 * 32; }
+inline uint16_t sg_f2bf(float f) {   // round-to-nearest-even fp32 -> bf16 bits
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float sg_bf2f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// W [N][Kp] (row-major fp32, Kp % 32 == 0) -> split-bf16 weight planes [Kp/32][N][32] (the B operand layout of k_gemm_x3)
+int sg_upload_planes(rgn_stgcn_ctx* c, const std::vector<float>& W, int N, int Kp, __bf16** hi, __bf16** lo) {
+    std::vector<uint16_t> h((size_t)N * Kp), l((size_t)N * Kp);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < Kp; ++k) {
+            const float v = W[(size_t)n * Kp + k];
+            const size_t o = ((size_t)(k / 32) * N + n) * 32 + k % 32;
+            h[o] = sg_f2bf(v);
+            l[o] = sg_f2bf(v - sg_bf2f(h[o]));
+        }
+    int rc;
+    if ((rc = sg_alloc(c, hi, h.size())) || (rc = sg_alloc(c, lo, l.size()))) return rc;
+    SG_HIP(c, hipMemcpy(*hi, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    SG_HIP(c, hipMemcpy(*lo, l.data(), l.size() * 2, hipMemcpyHostToDevice));
+    return RGN_OK;
+}
+int sg_upload_ints(rgn_stgcn_ctx* c, int** p, const std::vector<int>& v) {
+    int rc = sg_alloc(c, p, v.size());
+    if (rc) return rc;
+    SG_HIP(c, hipMemcpy(*p, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+    return RGN_OK;
+}
 
 const SgBlockDef kBlocks[10] = {{0, 64, 1, false, false},   {64, 64, 1, false, true},   {64, 64, 1, false, true},  {64, 64, 1, false, true},
                                 {64, 128, 2, true, false},  {128, 128, 1, false, true}, {128, 128, 1, false, true}, {128, 256, 2, true, false},
                                 {256, 256, 1, false, true}, {256, 256, 1, false, true}};   // stgcn.py:51-62
 
+
 GemmArgs sg_gemm(const float* A, int lda, const float* W, int Kp, int K, const float* bias, float* C, int ldc, int M, int N) {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.Kp = Kp;
+    return g;
+}
+// split-bf16 GEMM over activation planes A (kblocks x [R][32]) and weight planes [Kp/32][N][32]
+GemmX3Args sg_gemm_x3(const SgPl& A, const __bf16* Wh, const __bf16* Wl, int M, int N, int Kp) {
+    GemmX3Args g{};
+    g.Ahi = A.hi; g.Alo = A.lo; g.a_rows = (int)A.R;
+    g.Whi = Wh; g.Wlo = Wl;
+    g.M = M; g.N = N; g.Kp = Kp;
+    g.a_klog = -1;
     return g;
 }
 
@@ -327,7 +475,6 @@ int rgn_stgcn_finalize(rgn_stgcn_handle h) {
             b.res_conv = kBlocks[i].res_conv;
             b.res_id = kBlocks[i].res_id;
             const int ci = b.ci, co = b.co, K1 = K * ci;
-            b.kp1 = (int)up16(K1);
             const float* imp = need("edge_importance." + std::to_string(i), (size_t)K * V * V);
             const float *wg = need(p + "gcn.conv.weight", (size_t)K * co * ci), *bg = need(p + "gcn.conv.bias", (size_t)K * co);
             const float *wt = need(p + "tcn.2.weight", (size_t)co * co * 9), *bt = need(p + "tcn.2.bias", co);
@@ -343,7 +490,21 @@ int rgn_stgcn_finalize(rgn_stgcn_handle h) {
             if (!imp || !wg || !bg || !wt || !bt || !ok1 || !ok2 || !okr || (b.res_conv && (!wr || !brs))) continue;
             std::vector<float> Ak((size_t)K * V * V);
             for (size_t j = 0; j < Ak.size(); ++j) Ak[j] = A0[j] * imp[j];                       // stgcn.py:105 (fp32 product, as there)
+            // nonzero lists of A'_k[:, w] (the skeleton graph is sparse; a dense A simply gives V entries per list)
+            std::vector<int> nzp((size_t)K * V + 1, 0), nzv;
+            std::vector<float> nza;
+            for (int k = 0; k < K; ++k)
+                for (int w = 0; w < V; ++w) {
+                    for (int v = 0; v < V; ++v)
+                        if (Ak[((size_t)k * V + v) * V + w] != 0.f) {
+                            nzv.push_back(v);
+                            nza.push_back(Ak[((size_t)k * V + v) * V + w]);
+                        }
+                    nzp[(size_t)k * V + w + 1] = (int)nzv.size();
+                }
+            if (nzv.empty()) { nzv.push_back(0); nza.push_back(0.f); }
             // W1'[co][(k, ci)] = s1[co] * Wg[k*co_n + co][ci];  b1'[w][co] = s1 * sum_k bg[k*co_n + co] * colsum_k[w] + t1
+            b.kp1 = (int)up32((size_t)K1);
             std::vector<float> W1((size_t)co * b.kp1, 0.f), b1((size_t)V * co);
             for (int o = 0; o < co; ++o)
                 for (int k = 0; k < K; ++k)
@@ -358,24 +519,24 @@ int rgn_stgcn_finalize(rgn_stgcn_handle h) {
                     }
                     b1[(size_t)w * co + o] = (float)(s1[o] * acc + t1[o]);
                 }
-            // W2'[dt][co][ci] = s2[co] * Wt[co][ci][dt];  b2' = s2 * bt + t2
-            const int kp2 = (int)up16(co);
-            std::vector<float> W2((size_t)9 * co * kp2, 0.f), b2(co);
+            // W2'[co][(dt, ci)] = s2[co] * Wt[co][ci][dt] (K = 9 co: tap-major, the order the shifted-row GEMM walks);  b2' = s2 * bt + t2
+            std::vector<float> W2((size_t)co * 9 * co, 0.f), b2(co);
             for (int dt = 0; dt < 9; ++dt)
                 for (int o = 0; o < co; ++o)
-                    for (int q = 0; q < co; ++q) W2[((size_t)dt * co + o) * kp2 + q] = (float)(s2[o] * (double)wt[((size_t)o * co + q) * 9 + dt]);
+                    for (int q = 0; q < co; ++q) W2[(size_t)o * 9 * co + (size_t)dt * co + q] = (float)(s2[o] * (double)wt[((size_t)o * co + q) * 9 + dt]);
             for (int o = 0; o < co; ++o) b2[o] = (float)(s2[o] * (double)bt[o] + t2[o]);
-            if ((rc = sg_upload(c, &b.A, Ak)) || (rc = sg_upload(c, &b.W1, W1)) || (rc = sg_upload(c, &b.b1, b1)) || (rc = sg_upload(c, &b.W2, W2)) ||
-                (rc = sg_upload(c, &b.b2, b2)))
+            if ((rc = sg_upload_ints(c, &b.nz_ptr, nzp)) || (rc = sg_upload_ints(c, &b.nz_v, nzv)) || (rc = sg_upload(c, &b.nz_a, nza)) ||
+                (rc = sg_upload_planes(c, W1, co, b.kp1, &b.W1h, &b.W1l)) || (rc = sg_upload(c, &b.b1, b1)) ||
+                (rc = sg_upload_planes(c, W2, co, 9 * co, &b.W2h, &b.W2l)) || (rc = sg_upload(c, &b.b2, b2)))
                 return rc;
             if (b.res_conv) {
-                const int kpr = (int)up16(ci);
-                std::vector<float> Wr((size_t)co * kpr, 0.f), br(co);
+                b.kpr = (int)up32((size_t)ci);
+                std::vector<float> Wr((size_t)co * b.kpr, 0.f), br(co);
                 for (int o = 0; o < co; ++o) {
-                    for (int q = 0; q < ci; ++q) Wr[(size_t)o * kpr + q] = (float)(sr[o] * (double)wr[(size_t)o * ci + q]);
+                    for (int q = 0; q < ci; ++q) Wr[(size_t)o * b.kpr + q] = (float)(sr[o] * (double)wr[(size_t)o * ci + q]);
                     br[o] = (float)(sr[o] * (double)brs[o] + tr[o]);
                 }
-                if ((rc = sg_upload(c, &b.Wr, Wr)) || (rc = sg_upload(c, &b.br, br))) return rc;
+                if ((rc = sg_upload_planes(c, Wr, co, b.kpr, &b.Wrh, &b.Wrl)) || (rc = sg_upload(c, &b.br, br))) return rc;
             }
         }
         {
@@ -388,33 +549,35 @@ int rgn_stgcn_finalize(rgn_stgcn_handle h) {
         }
         if (!missing.empty()) return c->fail(RGN_ERR_MISSING_KEY, "missing / mis-shaped keys in the ST-GCN state_dict: " + missing);
         c->sd.clear();
-        // workspace: padded activations sized for the largest block (the 8 pad frames make the late, short blocks the big ones),
-        // with guard rows so that the +-4-frame row shifts of the temporal convolution never leave the allocation
-        const size_t NMV = (size_t)c->cfg.max_batch * M * V;
-        size_t act = ((size_t)c->cfg.num_frames + 2 * SG_PAD) * C0, zmax = 0, cmax = 0;
+        // The plane kernels assume: channel counts of the blocks are multiples of 32 (64 / 128 / 256) behind a first block whose K C_in fits one
+        // 32-channel block, and the vertex bias row (row % V) wraps at most once inside a 32-row MFMA tile
+        if (K * C0 > 32 || C0 > 32 || V < 28) return c->fail(RGN_ERR_UNSUPPORTED, "rgn_stgcn_finalize: needs K * (in_channels / persons) <= 32 and >= 28 graph nodes");
+        // workspace: padded activation planes sized for the largest block (the 8 pad frames make the late, short blocks the big ones),
+        // with guard rows at both ends of every plane block so that the +-4-frame row shifts of the temporal convolution never leave it
+        c->guard = (size_t)SG_PAD * V;
+        size_t xmax = 0, zmax = 0, gmax = 0, cmax = 0;     // elements per plane / fp32 tensor
         {
             int T = c->cfg.num_frames;
             for (int i = 0; i < 10; ++i) {
                 const SgBlock& b = c->blocks[i];
-                const size_t tp = (size_t)T + 2 * SG_PAD;
-                zmax = std::max(zmax, tp * K * b.ci);
-                cmax = std::max(cmax, tp * b.co);                         // g / conv / rfull live at the block's INPUT rate
+                const size_t rows = (size_t)c->cfg.max_batch * M * ((size_t)T + 2 * SG_PAD) * V, R = rows + 2 * c->guard;
+                if (rows >= ((size_t)1 << 26)) return c->fail(RGN_ERR_UNSUPPORTED, "rgn_stgcn_finalize: max_batch x persons x frames x nodes beyond 2^26 rows");
+                xmax = std::max(xmax, up32((size_t)b.ci) * R);
+                zmax = std::max(zmax, (size_t)b.kp1 * R);
+                gmax = std::max(gmax, (size_t)b.co * R);
+                cmax = std::max(cmax, rows * b.co);                        // conv / rfull live at the block's INPUT rate
                 T = (T + b.stride - 1) / b.stride;
-                act = std::max(act, ((size_t)T + 2 * SG_PAD) * b.co);
+                const size_t rows_o = (size_t)c->cfg.max_batch * M * ((size_t)T + 2 * SG_PAD) * V;
+                xmax = std::max(xmax, (size_t)b.co * (rows_o + 2 * c->guard));
             }
         }
-        c->guard = (size_t)SG_PAD * V * 256;
-        float* base;
-        if ((rc = sg_alloc(c, &base, NMV * act + 2 * c->guard))) return rc;
-        c->xa = base + c->guard;
-        if ((rc = sg_alloc(c, &base, NMV * act + 2 * c->guard))) return rc;
-        c->xb = base + c->guard;
-        if ((rc = sg_alloc(c, &base, NMV * cmax + 2 * c->guard))) return rc;
-        c->g = base + c->guard;
-        if ((rc = sg_alloc(c, &c->z, NMV * zmax))) return rc;
-        if ((rc = sg_alloc(c, &c->conv, NMV * cmax))) return rc;
-        if ((rc = sg_alloc(c, &c->rfull, NMV * cmax))) return rc;
+        for (int pl = 0; pl < 2; ++pl)
+            if ((rc = sg_alloc(c, &c->xa[pl], xmax)) || (rc = sg_alloc(c, &c->xb[pl], xmax)) || (rc = sg_alloc(c, &c->z[pl], zmax)) || (rc = sg_alloc(c, &c->g[pl], gmax)))
+                return rc;
+        if ((rc = sg_alloc(c, &c->conv, cmax))) return rc;
+        if ((rc = sg_alloc(c, &c->rfull, cmax))) return rc;
         if ((rc = sg_alloc(c, &c->pooled, (size_t)c->cfg.max_batch * 256))) return rc;
+        SG_HIP(c, configure_gemm_x3_sg());
         SG_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         SG_HIP(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
         SG_HIP(c, hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
@@ -435,48 +598,49 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
         SG_HIP(c, hipEventRecord(c->ev_in, us));
         SG_HIP(c, hipStreamWaitEvent(s, c->ev_in, 0));
         const int V = c->V, K = c->K, M = c->cfg.num_person, NM = N * M;
+        const int guard = (int)c->guard;
         int T = c->cfg.num_frames;
+        auto planes = [&](__bf16* const (&buf)[2], size_t rows) { return SgPl{buf[0] + (size_t)guard * 32, buf[1] + (size_t)guard * 32, (long long)(rows + 2 * (size_t)guard)}; };
+        auto blocks1d = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
         {
-            const size_t total = (size_t)NM * (T + 2 * SG_PAD) * V * c->C0;
-            hipLaunchKernelGGL(k_stgcn_in, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, output, c->xa, c->bn_s, c->bn_t, N, V, M, c->C0, T);
+            const size_t rows = (size_t)NM * (T + 2 * SG_PAD) * V;
+            hipLaunchKernelGGL(k_sg_in, blocks1d(rows), dim3(256), 0, s, output, planes(c->xa, rows), c->bn_s, c->bn_t, N, V, M, c->C0, T);
         }
-        float *x = c->xa, *xn = c->xb;
+        __bf16 *(*x)[2] = &c->xa, *(*xn)[2] = &c->xb;
         for (int i = 0; i < 10; ++i) {
             const SgBlock& b = c->blocks[i];
-            const int Tp = T + 2 * SG_PAD, rows = NM * Tp * V, To = (T + b.stride - 1) / b.stride;   // Conv2d(9x1, pad 4, stride s): ceil(T / s) frames
-            hipLaunchKernelGGL(k_stgcn_agg, dim3((unsigned)(NM * Tp)), dim3(256), (size_t)V * b.ci * sizeof(float), s, x, b.A, c->z, V, K, b.ci);
-            GemmArgs g1 = sg_gemm(c->z, K * b.ci, b.W1, b.kp1, K * b.ci, nullptr, c->g, b.co, rows, b.co);
+            const int Tp = T + 2 * SG_PAD, To = (T + b.stride - 1) / b.stride;   // Conv2d(9x1, pad 4, stride s): ceil(T / s) frames
+            const size_t rows = (size_t)NM * Tp * V, rows_o = (size_t)NM * (To + 2 * SG_PAD) * V;
+            const SgPl xp = planes(*x, rows), zp = planes(c->z, rows), gp = planes(c->g, rows), xo = planes(*xn, rows_o);
+            // graph aggregation on the input channels (sparse A'), then the 1x1 convolution over K C_in (+ folded BN, vertex bias, ReLU)
+            if (b.ci % 32 == 0) hipLaunchKernelGGL(k_sg_agg, blocks1d(rows * K * (b.ci / 8)), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
+            else hipLaunchKernelGGL(k_sg_agg_small, blocks1d(rows), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
+            GemmX3Args g1 = sg_gemm_x3(zp, b.W1h, b.W1l, (int)rows, b.co, b.kp1);
             g1.add = b.b1; g1.ldadd = b.co; g1.add_mod = V; g1.act = 3;                          // + b1'[row % V], ReLU
-            SG_HIP(c, launch_gemm(g1, RGN_PREC_F32, s));
-            {
-                const size_t n = (size_t)NM * 2 * SG_PAD * V * b.co;
-                hipLaunchKernelGGL(k_stgcn_zero_pads, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->g, NM, T, V * b.co);
+            g1.Chi = gp.hi; g1.Clo = gp.lo; g1.c_rows = (int)gp.R;
+            SG_HIP(c, launch_gemm_x3_sg(g1, s));
+            {   // pad frames and guard rows of g back to zero: what the temporal taps read beyond a sequence
+                const size_t n = ((size_t)NM * 2 * SG_PAD * V + 2 * (size_t)guard) * (b.co / 32) * 4;
+                hipLaunchKernelGGL(k_sg_zero, blocks1d(n), dim3(256), 0, s, gp, NM, T, V, b.co / 32, guard);
             }
-            const int kp2 = (int)up16(b.co);
-            for (int dt = 0; dt < 9; ++dt) {
-                // frame shift dt - 4: rows move by (dt - 4) * V; guard rows (zero) absorb the first / last frames' reach
-                GemmArgs g2 = sg_gemm(c->g + (ptrdiff_t)(dt - SG_PAD) * V * b.co, b.co, b.W2 + (size_t)dt * b.co * kp2, kp2, b.co, nullptr, c->conv, b.co, rows, b.co);
-                if (dt) {
-                    g2.add = c->conv;
-                    g2.ldadd = b.co;
-                }
-                SG_HIP(c, launch_gemm(g2, RGN_PREC_F32, s));
-            }
+            // 9x1 temporal convolution: ONE GEMM over K = 9 C_out, k-block (dt, channel block) reads g with its rows shifted by (dt - 4) V
+            GemmX3Args g2 = sg_gemm_x3(gp, b.W2h, b.W2l, (int)rows, b.co, 9 * b.co);
+            int klog = 0;
+            while ((1 << klog) < b.co / 32) ++klog;
+            g2.a_klog = klog; g2.a_kshift = V; g2.a_kbias = SG_PAD;
+            g2.C = c->conv; g2.ldc = b.co;
+            SG_HIP(c, launch_gemm_x3_sg(g2, s));
             if (b.res_conv) {
-                GemmArgs gr = sg_gemm(x, b.ci, b.Wr, (int)up16(b.ci), b.ci, nullptr, c->rfull, b.co, rows, b.co);
-                SG_HIP(c, launch_gemm(gr, RGN_PREC_F32, s));
+                GemmX3Args gr = sg_gemm_x3(xp, b.Wrh, b.Wrl, (int)rows, b.co, b.kpr);
+                gr.C = c->rfull; gr.ldc = b.co;
+                SG_HIP(c, launch_gemm_x3_sg(gr, s));
             }
-            {
-                const size_t total = (size_t)NM * (To + 2 * SG_PAD) * V * b.co;
-                hipLaunchKernelGGL(k_stgcn_post, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c->conv, b.b2, b.res_id ? x : nullptr,
-                                   b.res_conv ? c->rfull : nullptr, b.br, xn, NM, T, To, b.stride, V, b.co);
-            }
-            float* t = x;
-            x = xn;
-            xn = t;
+            hipLaunchKernelGGL(k_sg_post, blocks1d(rows_o * (b.co / 8)), dim3(256), 0, s, c->conv, b.b2, xp, b.res_id ? 1 : 0, b.res_conv ? c->rfull : nullptr, b.br,
+                               xo, NM, T, To, b.stride, V, b.co);
+            std::swap(x, xn);
             T = To;
         }
-        hipLaunchKernelGGL(k_stgcn_pool, dim3(N), dim3(256), 0, s, x, c->pooled, M, T, V, 256);
+        hipLaunchKernelGGL(k_sg_pool, dim3(N), dim3(256), 0, s, planes(*x, (size_t)NM * (T + 2 * SG_PAD) * V), c->pooled, M, T, V, 256);
         if (features) SG_HIP(c, hipMemcpyAsync(features, c->pooled, (size_t)N * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (yhat) {
             GemmArgs gf = sg_gemm(c->pooled, 256, c->Wf, 256, 256, c->bf, yhat, c->cfg.num_class, N, c->cfg.num_class);

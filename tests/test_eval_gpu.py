@@ -29,6 +29,8 @@ def test_stgcn_features_and_logits_match_reference(golden, tag):
     batch = model({"output": x})
     feats = batch["features"].reshape(x.shape[0], -1).cpu().numpy()
     ref_f, ref_y = g[f"features_{tag}"], g[f"yhat_{tag}"]
+    print(f"\n[stgcn {tag}] max |features - reference| = {np.abs(feats - ref_f).max():.2e} (|ref| max {np.abs(ref_f).max():.2f}), "
+          f"logits {np.abs(batch['yhat'].cpu().numpy() - ref_y).max():.2e}")
     assert np.abs(feats - ref_f).max() < 1e-4 * max(1.0, np.abs(ref_f).max()), np.abs(feats - ref_f).max()
     assert np.abs(batch["yhat"].cpu().numpy() - ref_y).max() < 1e-4 * max(1.0, np.abs(ref_y).max())
     assert batch["features"].shape == torch.from_numpy(ref_f).squeeze().shape           # N == 1 squeezes to [256] (stgcn.py:117)
