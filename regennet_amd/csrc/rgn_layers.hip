@@ -56,7 +56,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int LY_NTH = 512, LY_KB = 4096;
 constexpr int LY_X = 0, LY_Y = 64 * 1024, LY_EXCH = LY_Y, LY_RED = 128 * 1024, LY_REDF = 2 * 8 * 64, LY_VEC = LY_RED + 2 * LY_REDF * 4, LY_VECW = 640,
               LY_LDS = 160 * 1024;
-static_assert(LY_VEC + 8 * LY_VECW * 4 <= LY_LDS, "LDS map");
+constexpr int LY_PF = LY_VEC + 8 * LY_VECW * 4;   // 4 KiB nobody reads: the landing zone of the step-boundary weight prefetch (8 waves x 256 B)
+static_assert(LY_PF + 8 * 256 <= LY_LDS, "LDS map");
 // wave-private vector region (floats, 64 columns each)
 enum { V_BO = 0, V_G1 = 64, V_G2 = 128, V_B2 = 192, V_SPV = 256, V_BF1 = 320 /* 2 x 64: hidden halves */, V_BF2 = 448, V_G3 = 512, V_B3 = 576 };
 constexpr int LY_RDA = 6;   // in_proj weight ring: granules (half k-steps) of 3 fragments (q | k | v): 72 registers
@@ -666,10 +667,13 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                 const int nsl = (int)(gridDim.x >> 3) >= 32 ? 32 : ((int)(gridDim.x >> 3) > 0 ? (int)(gridDim.x >> 3) : 1);
                 const int sl = (int)(blockIdx.x >> 3) % nsl;
                 const int n_out = 16 * g.nb_out * 16, n_all = n_out + LY_NKX * 16 * 16;           // 128-byte lines
+                // (direct-to-LDS loads into 2 KiB of LDS nothing ever reads: a load into a VGPR would land asynchronously, long after the compiler
+                //  has given that register to something else. As inline asm: behind the BUILTIN the compiler drains vmcnt(0) before the next
+                //  ds_read - norm3's residual reads - and the prefetch would be waited for instead of flying under norm3)
+                const unsigned pf_lds = (unsigned)(size_t)((RGN_AS3 char*)(smem + LY_PF)) + (unsigned)wave * 256u;
                 for (int ln = sl + nsl * tid; ln < n_all; ln += nsl * LY_NTH) {
                     const char* pp = ln < n_out ? reinterpret_cast<const char*>(g.Wout) + (size_t)ln * 128 : reinterpret_cast<const char*>(g.Wx) + (size_t)(ln - n_out) * 128;
-                    int dummy;
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(pp) : "memory");
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(pp), "s"(pf_lds) : "memory", "m0");
                 }
             }
         }

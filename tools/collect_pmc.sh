@@ -18,9 +18,12 @@ i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY GRBM_GUI_ACTIVE"; do
     i=$((i + 1))
-    REGENNET_STREAMS=1 timeout 300 rocprofv3 --pmc $grp --output-format csv -d "$R/gpurun_out/pmc" -o "pass$i" -- \
-        python "$R/bench.py" --respacing 3 --x3-tail 0 --steps 1 --warmup 0 --no-graph --no-cpu-baseline --profile-evals 0 "$@" \
+    # PMC_FULL=1: the timed region's own launch - the default schedule (1000-step DDPM: ONE k_layers<steps> dispatch of 995 steps per call) instead
+    # of a 3-step schedule, so that roofline.traffic is COUNTED on the launch bench.py times, not scaled from a short one
+    if [ -n "${PMC_FULL:-}" ]; then SCHED=""; else SCHED="--respacing 3 --x3-tail 0"; fi
+    REGENNET_STREAMS=1 timeout 600 rocprofv3 --pmc $grp --output-format csv -d "$R/gpurun_out/pmc" -o "pass$i" -- \
+        python "$R/bench.py" $SCHED --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-row-check --profile-evals 0 "$@" \
         > "$R/gpurun_out/pmc/pass$i.log" 2>&1 < /dev/null
     echo "pass $i ($grp): rc=$?"
 done
-python "$R/tools/summarize_pmc.py" "$R/gpurun_out/pmc" "$OUT" $KEY 3   # (3-step schedules above: a k_layers<steps> dispatch covers 3 steps)
+python "$R/tools/summarize_pmc.py" "$R/gpurun_out/pmc" "$OUT" $KEY ${PMC_STEPS:-3}   # (3-step schedules: a k_layers<steps> dispatch covers 3 steps; PMC_FULL: PMC_STEPS=995)
