@@ -166,6 +166,14 @@ RGN_API int rgn_set_const_noise(rgn_handle h, int32_t on);
  * checked against the same goldens), not bit for bit. */
 RGN_API int rgn_set_small_batch_rows(rgn_handle h, int32_t rows);
 
+/* Kernel-selection switches of ONE handle, set between rgn_create and rgn_finalize_weights (afterwards: RGN_ERR_STATE): the names of the
+ * REGENNET_<KEY> environment variables without the prefix - "LAYERS" (0: kernel per stage instead of the one-kernel decoder stack), "LAYERS_STEPS",
+ * "LAYERS_GUIDED", "LAYERS_MIN_B", "LAYERS_MIN_TQ", "NO_STEP_FUSION", "NO_MLP", "MLP_X3", "NO_ROWGEMM", "NO_FUSED_QKV", "NO_QKV_RS", "NO_QKV_LONG",
+ * "SB_ROWS", "SB_FUSED_ATTN", "SB_GRAPH", "STREAMS", "GRAPH_STEPS", "BIG_TILE_ROWS", "BULK_RESID_LO", "STEP_NO_QUADS"; an unknown name is
+ * RGN_ERR_BAD_KEY. A handle's option takes precedence over the environment, which remains the process-wide default (tools, A/B runs): tests and
+ * library users address one engine without touching global state. Every selectable form meets the same parity bound. */
+RGN_API int rgn_set_option(rgn_handle h, const char* key, int32_t value);
+
 /* Evaluations of at least `samples` samples of <= 64 tokens (motions, doubled under guidance) run the one-kernel decoder stack
  * (rgn_layers.hip: one workgroup per sample, whole runs of sampler steps per launch); smaller ones the kernel-per-stage chain, which
  * spreads a small batch over more CUs. -1 restores the default (64, or REGENNET_LAYERS_MIN_B). The two forms differ by bf16 roundings

@@ -56,6 +56,7 @@ SYMBOLS = {
     "rgn_set_x3_tail": (C.c_int, [_vp, _i32]),
     "rgn_set_small_batch_rows": (C.c_int, [_vp, _i32]),
     "rgn_set_const_noise": (C.c_int, [_vp, _i32]),
+    "rgn_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
     "rgn_set_layers_min_b": (C.c_int, [_vp, _i32]),
     "rgn_plan_query": (C.c_int, [_vp, _i32, _i32, _i32, _i32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -128,7 +129,8 @@ def _ptr(t):
 class Engine:
     """Owns one rgn_handle. Thin, typed wrappers; tensors are torch CUDA(HIP) tensors, fp32/int64 contiguous."""
 
-    def __init__(self, cfg, max_batch, device_index, precision="f32"):
+    def __init__(self, cfg, max_batch, device_index, precision="f32", options=None):
+        """options: {switch: int} for rgn_set_option - the REGENNET_<KEY> kernel-selection switches for THIS engine only."""
         self.lib = load()
         self.cfg = dict(cfg)
         self.max_batch = int(max_batch)
@@ -146,6 +148,8 @@ class Engine:
         self.h = h
         self.schedule_id = None
         self.cond_key = None
+        for k, v in (options or {}).items():
+            self._ck(self.lib.rgn_set_option(self.h, str(k).encode(), int(v)))
 
     def _ck(self, code):
         if code != RGN_OK:

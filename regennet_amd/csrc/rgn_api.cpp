@@ -73,6 +73,7 @@ struct rgn_ctx {
     std::string err;
     std::map<std::string, std::vector<int64_t>> expected;  // key -> shape (pe: shape[0] free)
     std::map<std::string, HostTensor> sd;
+    std::map<std::string, int> opts;   // rgn_set_option: per-handle kernel-selection switches (they take precedence over REGENNET_<KEY> in the environment)
     bool finalized = false, have_sched = false, have_cond = false;
     int F = 0, d = 0, Tq = 0, etd = 0, L = 0, H = 0, ff = 0, pe_len = 0;
 
@@ -421,6 +422,29 @@ int pack_state(rgn_ctx* c, const float* x, const Dims& dm, bool guided, hipStrea
         RGN_LAUNCH(c, KC_UPDATE, s, launch_pack_x(x, nullptr, xp, guided ? 2 : 1, dm, s));
     }
     return RGN_OK;
+}
+
+// A kernel-selection switch of this handle: rgn_set_option(h, "KEY", v) if given, else the environment variable REGENNET_KEY, else absent.
+// (The environment stays as the process-wide default - tools, A/B runs; a library user or a test addresses ONE handle.)
+bool opt_get(const rgn_ctx* c, const char* key, int* value) {
+    auto it = c->opts.find(key);
+    if (it != c->opts.end()) {
+        *value = it->second;
+        return true;
+    }
+    const std::string env = std::string("REGENNET_") + key;
+    if (const char* e = getenv(env.c_str())) {
+        *value = atoi(e);
+        return true;
+    }
+    return false;
+}
+// "flag" switches (REGENNET_NO_MLP ...): on when the variable exists at all / when the option was set to a non-zero value
+bool opt_flag(const rgn_ctx* c, const char* key) {
+    auto it = c->opts.find(key);
+    if (it != c->opts.end()) return it->second != 0;
+    const std::string env = std::string("REGENNET_") + key;
+    return getenv(env.c_str()) != nullptr;
 }
 
 // Small-batch evaluation (rgn_sb.hip): the same embedding GEMM + L decoder layers + output projection as run_layers for ALL
@@ -1251,40 +1275,44 @@ int rgn_finalize_weights(rgn_handle h) {
                 }
                 RGN_HIP(c, configure_attn_x3(c->Tq, d / c->H));
             }
-            c->fuse_qkv = qkv_attn_supported(c->Tq, d / c->H, d) && getenv("REGENNET_NO_FUSED_QKV") == nullptr;
-            if (const char* e = getenv("REGENNET_BIG_TILE_ROWS")) c->big_tile_rows = atoi(e);
-            c->rowgemm = c->cfg.precision == RGN_PREC_BF16_X3TAIL && getenv("REGENNET_NO_ROWGEMM") == nullptr && c->Tq >= 8 &&   // (8 rows of a wave: <= 2 samples)
+            c->fuse_qkv = qkv_attn_supported(c->Tq, d / c->H, d) && !opt_flag(c, "NO_FUSED_QKV");
+            { int v; if (opt_get(c, "BIG_TILE_ROWS", &v)) c->big_tile_rows = v; }
+            c->rowgemm = c->cfg.precision == RGN_PREC_BF16_X3TAIL && !opt_flag(c, "NO_ROWGEMM") && c->Tq >= 8 &&   // (8 rows of a wave: <= 2 samples)
                          rowgemm_supported(d, d, true) && rowgemm_supported(d, (int)align_up((size_t)ff, 32), true) &&
                          rowgemm_supported(ff, d, false);
             if (c->rowgemm) RGN_HIP(c, configure_rowgemm());
-            c->mlp = c->rowgemm && mlp_supported(d, ff, c->Tq) && getenv("REGENNET_NO_MLP") == nullptr;
+            c->mlp = c->rowgemm && mlp_supported(d, ff, c->Tq) && !opt_flag(c, "NO_MLP");
             if (c->mlp) RGN_HIP(c, configure_mlp());
             {   // the split-bf16 layer tail as one kernel (REGENNET_MLP_X3=0: k_gemm_x3 x 3 + k_layernorm x 2 per layer instead)
-                const char* e = getenv("REGENNET_MLP_X3");
-                c->mlp_x3 = !(e && atoi(e) == 0) && mlp_x3_supported(d, ff, c->Tq);
+                int v = 1;
+                (void)opt_get(c, "MLP_X3", &v);
+                c->mlp_x3 = v != 0 && mlp_x3_supported(d, ff, c->Tq);
                 if (c->mlp_x3) RGN_HIP(c, configure_mlp_x3());
             }
             if (c->fuse_qkv) RGN_HIP(c, configure_qkv_attn());
-            c->qkv_rs = getenv("REGENNET_NO_QKV_RS") == nullptr;
+            c->qkv_rs = !opt_flag(c, "NO_QKV_RS");
             c->step_fused = c->rowgemm && !c->etd && c->lin_x.fr && c->lin_out.fr && c->lin_out.has_bias && !c->lin_x.has_bias &&
-                            step_fused_supported(d, F, c->lin_x.Kp) && getenv("REGENNET_NO_STEP_FUSION") == nullptr;
+                            step_fused_supported(d, F, c->lin_x.Kp) && !opt_flag(c, "NO_STEP_FUSION");
             if (c->step_fused) RGN_HIP(c, configure_step());
             // one workgroup per sample costs a full 64-row tile whatever the length, the kernel-per-stage chain costs the rows there are, and the
             // fused form is worth ~20 % of a layer: it takes evaluations of at least 52 tokens per sample (REGENNET_LAYERS_MIN_TQ overrides: tests)
-            const int ly_min_tq = getenv("REGENNET_LAYERS_MIN_TQ") ? atoi(getenv("REGENNET_LAYERS_MIN_TQ")) : 52;
+            int ly_min_tq = 52, ly_on = 1, ly_steps = 1;
+            (void)opt_get(c, "LAYERS_MIN_TQ", &ly_min_tq);
+            (void)opt_get(c, "LAYERS", &ly_on);
+            (void)opt_get(c, "LAYERS_STEPS", &ly_steps);
             c->layers_fused = c->mlp && c->fuse_qkv && c->qkv_rs && layers_supported(d, ff, c->H, c->Tq, c->L) && c->Tq >= ly_min_tq &&
-                              !(getenv("REGENNET_LAYERS") != nullptr && atoi(getenv("REGENNET_LAYERS")) == 0);
+                              ly_on != 0;
             if (c->layers_fused) RGN_HIP(c, configure_layers());
-            if (const char* e = getenv("REGENNET_LAYERS_MIN_B")) c->layers_min_b = c->layers_min_b_default = atoi(e) < 1 ? 1 : atoi(e);
-            if (const char* e = getenv("REGENNET_LAYERS_GUIDED")) c->layers_guided = atoi(e) != 0;
+            { int v; if (opt_get(c, "LAYERS_MIN_B", &v)) c->layers_min_b = c->layers_min_b_default = v < 1 ? 1 : v; }
+            { int v; if (opt_get(c, "LAYERS_GUIDED", &v)) c->layers_guided = v != 0; }
             c->layers_steps = c->layers_fused && c->step_fused && layers_steps_supported(d, F, c->lin_x.Kp) &&
-                              !(getenv("REGENNET_LAYERS_STEPS") != nullptr && atoi(getenv("REGENNET_LAYERS_STEPS")) == 0);
-            c->step_no_quads = getenv("REGENNET_STEP_NO_QUADS") != nullptr;
-            c->qkv_long = c->cfg.precision == RGN_PREC_BF16_X3TAIL && qkv_attn_long_supported(c->Tq, d / c->H, d) && getenv("REGENNET_NO_QKV_LONG") == nullptr;
+                              ly_steps != 0;
+            c->step_no_quads = opt_flag(c, "STEP_NO_QUADS");
+            c->qkv_long = c->cfg.precision == RGN_PREC_BF16_X3TAIL && qkv_attn_long_supported(c->Tq, d / c->H, d) && !opt_flag(c, "NO_QKV_LONG");
             if (c->qkv_long) RGN_HIP(c, configure_qkv_attn_long());
             c->sb = c->attn_x3 && sb_supported(d, ff, d / c->H);
-            if (const char* e = getenv("REGENNET_SB_FUSED_ATTN")) c->sb_attn = atoi(e) != 0;
-            if (const char* e = getenv("REGENNET_SB_ROWS")) c->sb_rows = c->sb_rows_default = atoi(e) < 0 ? 0 : atoi(e);
+            { int v; if (opt_get(c, "SB_FUSED_ATTN", &v)) c->sb_attn = v != 0; }
+            { int v; if (opt_get(c, "SB_ROWS", &v)) c->sb_rows = c->sb_rows_default = v < 0 ? 0 : v; }
             if (c->sb) RGN_HIP(c, configure_sb());
             if (c->sb) RGN_HIP(c, configure_sb_qkv_attn());
         }
@@ -1300,10 +1328,11 @@ int rgn_finalize_weights(rgn_handle h) {
             RGN_HIP(c, hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
         }
         RGN_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        if (const char* e = getenv("REGENNET_BULK_RESID_LO")) c->bulk_resid_lo = atoi(e) != 0;
-        if (const char* e = getenv("REGENNET_GRAPH_STEPS")) c->graph_steps = atoi(e) < 1 ? 1 : (atoi(e) > 100 ? 100 : atoi(e));
-        if (const char* e = getenv("REGENNET_STREAMS")) {
-            c->nchains = atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
+        { int v; if (opt_get(c, "BULK_RESID_LO", &v)) c->bulk_resid_lo = v != 0; }
+        { int v; if (opt_get(c, "GRAPH_STEPS", &v)) c->graph_steps = v < 1 ? 1 : (v > 100 ? 100 : v); }
+        int v_streams;
+        if (opt_get(c, "STREAMS", &v_streams)) {
+            c->nchains = v_streams < 1 ? 1 : (v_streams > 16 ? 16 : v_streams);
             c->nchains_user = true;
         }
         RGN_HIP(c, hipMemset(c->xin, 0, Mb * F * sizeof(float)));
@@ -1524,7 +1553,7 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
         // launches are 2x slower at B = 16). The small-batch engine is one chain of ~43 short kernels per step, and there every graph
         // node costs ~0.4 us more than the same kernel launched from this loop (B = 1: 278 vs 261 ms per 1000 steps, B = 4: 351 vs 338,
         // B = 12: 492 vs 487; the host needs ~150 ms per 1000 steps to issue them): it launches eagerly unless REGENNET_SB_GRAPH is set.
-        static const bool sb_graph = getenv("REGENNET_SB_GRAPH") != nullptr;
+        const bool sb_graph = opt_flag(c, "SB_GRAPH");
         const bool graphs = use_graph && !c->prof && (sb_graph || !use_sb(c, dm.Bm * dm.Tq));
         const int multi = c->graph_steps;
         int k = 0;
@@ -1612,6 +1641,21 @@ int rgn_set_small_batch_rows(rgn_handle h, int32_t rows) {
             h->graphs.clear();
             h->sb_rows = v;
         }
+        return RGN_OK;
+    });
+}
+
+int rgn_set_option(rgn_handle h, const char* key, int32_t value) {
+    return rgn_guard(h, "rgn_set_option", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        if (!key || !*key) return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_option: empty key");
+        if (h->finalized) return h->fail(RGN_ERR_STATE, "rgn_set_option: the switches select kernels when the weights are packed - set them before rgn_finalize_weights");
+        static const char* known[] = {"NO_FUSED_QKV", "BIG_TILE_ROWS", "NO_ROWGEMM", "NO_MLP", "MLP_X3", "NO_QKV_RS", "NO_STEP_FUSION", "LAYERS_MIN_TQ", "LAYERS", "LAYERS_STEPS",
+                                      "LAYERS_MIN_B", "LAYERS_GUIDED", "STEP_NO_QUADS", "NO_QKV_LONG", "SB_FUSED_ATTN", "SB_ROWS", "BULK_RESID_LO", "GRAPH_STEPS", "STREAMS", "SB_GRAPH"};
+        bool ok = false;
+        for (const char* k : known) ok = ok || strcmp(k, key) == 0;
+        if (!ok) return h->fail(RGN_ERR_BAD_KEY, std::string("rgn_set_option: unknown switch '") + key + "'");
+        h->opts[key] = value;
         return RGN_OK;
     });
 }

@@ -143,6 +143,9 @@ class CMDM(nn.Module):
         self.small_batch_rows = kargs.get("small_batch_rows", None)
         # evaluations of at least this many samples run the one-kernel decoder stack (k_layers; None: engine default 64, 1: always)
         self.layers_min_b = kargs.get("layers_min_b", None)
+        # kernel-selection switches handed to every engine this model builds (rgn_set_option: {"LAYERS": 0, "STREAMS": 1, ...}); changing the
+        # dict takes effect for engines built afterwards (model._engine_stale = True rebuilds)
+        self.engine_options = dict(kargs.get("engine_options", None) or {})
         self._auto_tail, self._auto_tails = None, {}
         # multi-GPU runs: rank `weights_src`'s packed blob is broadcast (one RCCL collective) into EVERY engine this model
         # builds — also the ones built later for another length, a larger batch or after an eviction (None: single process)
@@ -221,7 +224,7 @@ class CMDM(nn.Module):
                     outgoing = victim
                 else:
                     victim.close()
-            eng = _lib.Engine(self.engine_config(T), B, dev.index or 0, self.precision)
+            eng = _lib.Engine(self.engine_config(T), B, dev.index or 0, self.precision, **({"options": self.engine_options} if self.engine_options else {}))
             for k, v in self.state_dict().items():
                 if k.startswith("clip_model."):
                     continue

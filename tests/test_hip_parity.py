@@ -1211,6 +1211,29 @@ def test_rccl_one_rank_group_takes_the_multi_gpu_code_paths():
     assert line["headline_row_check_max_abs"] is not None and line["headline_row_check_max_abs"] <= 2e-5, line
 
 
+def test_per_handle_kernel_switches():
+    """rgn_set_option: the REGENNET_<KEY> switches for ONE handle - unknown names and calls behind rgn_finalize_weights are refused, and a
+    handle's option wins over the environment (here: the one-kernel decoder stack switched off for one engine while the environment asks for it)."""
+    from regennet_amd import _lib, synth
+    cfg = synth.get_config("ntu")
+    eng = _lib.Engine(cfg, 64, 0, "bf16_x3tail", options={"LAYERS": 0})
+    assert eng.lib.rgn_set_option(eng.h, b"NO_SUCH_SWITCH", 1) == -2
+    for k, v in synth.make_state_dict(cfg, seed=0).items():
+        eng.load_weight(k, v)
+    eng.finalize()
+    assert eng.lib.rgn_set_option(eng.h, b"LAYERS", 1) == -5
+    assert "layers" not in eng.plan_query(64) and "steps_fused" not in eng.plan_query(64) and "mlp" in eng.plan_query(64)
+    eng.close()
+    eng2 = _lib.Engine(cfg, 64, 0, "bf16_x3tail")
+    for k, v in synth.make_state_dict(cfg, seed=0).items():
+        eng2.load_weight(k, v)
+    eng2.finalize()
+    plan = eng2.plan_query(64)
+    assert plan["steps_fused"]["kernel"] == "k_layers<true>" and plan["steps_fused"]["flops"] > 0, plan
+    assert eng2.plan_query(8) and "sb_gemm" in eng2.plan_query(8), eng2.plan_query(8)          # 480 token rows: the small-batch engine
+    eng2.close()
+
+
 def test_exceptions_do_not_cross_the_c_boundary():
     """include/regennet_hip.h: "no exceptions cross the boundary". A positional table of 2^40 rows (its first dimension is free) makes the
     host-side copy throw std::length_error / std::bad_alloc inside rgn_load_weight: it must come back as RGN_ERR_INTERNAL with the text in

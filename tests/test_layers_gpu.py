@@ -16,12 +16,12 @@ FORMS = {"per-step": {"REGENNET_LAYERS_MIN_B": "1", "REGENNET_LAYERS_STEPS": "0"
 
 
 def _engine_with(monkeypatch, env, model, B):
-    """The switches are read when the engine is built."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    """The kernel-selection switches of THIS model's engines (rgn_set_option through CMDM.engine_options: per handle, no process-wide
+    environment involved); they are read when an engine is built."""
+    del monkeypatch
+    model.engine_options = {k[len("REGENNET_"):]: int(v) for k, v in env.items()}
+    model._engine_stale = True
     model._get_engine(B)
-    for k in env:
-        monkeypatch.delenv(k)
 
 
 def _wrap(model, guided):
