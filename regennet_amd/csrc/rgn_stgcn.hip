@@ -14,8 +14,8 @@
 //   x' = relu(c[s t'] + b2' + residual)                                     k_sg_post     (stride s subsampling here)
 //
 // Activations are split-bf16 operand planes (hi = rne(x), lo = rne(x - hi)) in the K32-blocked layout of rgn_gemm_x3.hip,
-// [C/32][R][32] with rows (n m, padded frame, vertex): the 4 + 4 pad frames of every sequence and 4 V guard rows at both ends of a
-// plane block stay zero, so the temporal convolution is plain row-shifted operand reads. Products are formed as a_lo w_hi + a_hi w_lo +
+// [C/32][R][32] with rows (n m, frame, vertex): 4 zero pad frames behind every sequence (= in front of the next one) and 4 V zero guard rows
+// at both ends of a plane block, so the temporal convolution is plain row-shifted operand reads. Products are formed as a_lo w_hi + a_hi w_lo +
 // a_hi w_hi (fp32 accumulate): ~2^-16 per product, measured <= 2e-5 relative on the reference's features (the fp32-MFMA build this replaces
 // measured the same parity at 173 ms per 256 two-person motions of 60 frames; profiles/r05).
 #include "../../include/regennet_hip.h"
@@ -35,7 +35,8 @@ using namespace rgn;
 
 namespace {
 
-constexpr int SG_PAD = 4;                      // temporal kernel 9 -> 4 zero frames on each side
+constexpr int SG_PAD = 4;                      // temporal kernel 9 -> 4 zero frames BEHIND every sequence: they are also the pad in front of the next
+                                               // one (the guard rows in front of the first), so a sequence costs T + 4 frames of rows, not T + 8
 struct SgBlockDef { int ci, co, stride; bool res_conv, res_id; };
 
 struct SgBlock {
@@ -97,16 +98,16 @@ __device__ __forceinline__ void sg_split8(const float (&v)[8], sg_bf16x8& h, sg_
     }
 }
 
-// data_bn + layout: output [N, V, M*C, T] (batch['output'], stgcn.py:83-101) -> x planes, rows (n M + m, SG_PAD + t, v), channels c < C (the
+// data_bn + layout: output [N, V, M*C, T] (batch['output'], stgcn.py:83-101) -> x planes, rows (n M + m, t, v) with t < T + SG_PAD, channels c < C (the
 // rest of the 32-channel block zero), BatchNorm1d channel index (m*V + v)*C + c; pad frames are written as zeros. One thread per row.
 __global__ void k_sg_in(const float* __restrict__ out, SgPl x, const float* __restrict__ s, const float* __restrict__ t, int N, int V, int M, int C, int T) {
-    const int Tp = T + 2 * SG_PAD;
+    const int Tp = T + SG_PAD;
     const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= (size_t)N * M * Tp * V) return;
     const int v = (int)(row % V);
     const int tp = (int)((row / V) % Tp);
     const int nm = (int)(row / ((size_t)V * Tp));
-    const int tt = tp - SG_PAD;
+    const int tt = tp;
     float val[32];
 #pragma unroll
     for (int c = 0; c < 32; ++c) val[c] = 0.f;
@@ -181,10 +182,10 @@ __global__ void k_sg_agg_small(SgPl x, SgPl z, const int* __restrict__ nz_ptr, c
     }
 }
 
-// zero the pad frames (4 + 4 per sequence) and the guard rows (at both ends of every plane block) of padded planes with `cb` channel blocks
+// zero the pad frames (4 behind every sequence) and the guard rows (at both ends of every plane block) of padded planes with `cb` channel blocks
 __global__ void k_sg_zero(SgPl g, int NM, int T, int V, int cb, int guard) {
-    const int Tp = T + 2 * SG_PAD;
-    const size_t npad = (size_t)NM * 2 * SG_PAD * V, per = npad + 2 * (size_t)guard;
+    const int Tp = T + SG_PAD;
+    const size_t npad = (size_t)NM * SG_PAD * V, per = npad + 2 * (size_t)guard;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= per * cb * 4) return;
     const int q = (int)(idx & 3);
@@ -192,10 +193,10 @@ __global__ void k_sg_zero(SgPl g, int NM, int T, int V, int cb, int guard) {
     const int b = (int)((idx >> 2) / per);
     long long row;
     if (e < npad) {
-        const int nm = (int)(e / ((size_t)2 * SG_PAD * V));
-        const int r = (int)(e % ((size_t)2 * SG_PAD * V));
+        const int nm = (int)(e / ((size_t)SG_PAD * V));
+        const int r = (int)(e % ((size_t)SG_PAD * V));
         const int f = r / V;
-        const int tp = f < SG_PAD ? f : T + f;            // frames 0..3 and T+4..T+7
+        const int tp = T + f;                             // frames T .. T+3
         row = ((long long)nm * Tp + tp) * V + (r % V);
     } else {
         const long long j = (long long)(e - npad);
@@ -209,12 +210,12 @@ __global__ void k_sg_zero(SgPl g, int NM, int T, int V, int cb, int guard) {
     *reinterpret_cast<sg_bf16x8*>(g.lo + o) = zero;
 }
 
-// x'[nm][SG_PAD + t'][v][co] = relu(conv[nm][SG_PAD + s t'][v][co] + b2[co] + res) as planes, pads of x' zero
-//   res: none | identity x[nm][SG_PAD + t'][v][co] (planes) | rfull[nm][SG_PAD + s t'][v][co] + br[co] (1x1 conv + BN computed at full rate)
+// x'[nm][t'][v][co] = relu(conv[nm][s t'][v][co] + b2[co] + res) as planes, pads of x' zero
+//   res: none | identity x[nm][t'][v][co] (planes) | rfull[nm][s t'][v][co] + br[co] (1x1 conv + BN computed at full rate)
 // one thread per (output row, run of 8 channels)
 __global__ void k_sg_post(const float* __restrict__ conv, const float* __restrict__ b2, SgPl xin, int res_id, const float* __restrict__ rfull,
                           const float* __restrict__ br, SgPl xout, int NM, int T, int To, int stride, int V, int C) {
-    const int Tp = T + 2 * SG_PAD, Tpo = To + 2 * SG_PAD, c8n = C / 8;
+    const int Tp = T + SG_PAD, Tpo = To + SG_PAD, c8n = C / 8;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)NM * Tpo * V * c8n) return;
     const int c8 = (int)(gid % c8n);
@@ -222,10 +223,10 @@ __global__ void k_sg_post(const float* __restrict__ conv, const float* __restric
     const int v = (int)(orow % V);
     const int tpo = (int)((orow / V) % Tpo);
     const int nm = (int)(orow / ((size_t)V * Tpo));
-    const int to = tpo - SG_PAD;
+    const int to = tpo;
     float val[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (to >= 0 && to < To) {
-        const size_t srow = ((size_t)nm * Tp + SG_PAD + (size_t)stride * to) * V + v;
+        const size_t srow = ((size_t)nm * Tp + (size_t)stride * to) * V + v;
         const float4 c0 = *reinterpret_cast<const float4*>(conv + srow * C + 8 * c8), c1 = *reinterpret_cast<const float4*>(conv + srow * C + 8 * c8 + 4);
         const float4 bb0 = *reinterpret_cast<const float4*>(b2 + 8 * c8), bb1 = *reinterpret_cast<const float4*>(b2 + 8 * c8 + 4);
         val[0] = c0.x + bb0.x; val[1] = c0.y + bb0.y; val[2] = c0.z + bb0.z; val[3] = c0.w + bb0.w;
@@ -253,12 +254,12 @@ __global__ void k_sg_post(const float* __restrict__ conv, const float* __restric
 
 // global average pool over (t, v) and mean over the M persons (stgcn.py:113-114): pooled[n][c]
 __global__ void k_sg_pool(SgPl x, float* __restrict__ pooled, int M, int T, int V, int C) {
-    const int n = blockIdx.x, Tp = T + 2 * SG_PAD;
+    const int n = blockIdx.x, Tp = T + SG_PAD;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float acc = 0.f;
         for (int m = 0; m < M; ++m) {
             float a = 0.f;
-            const size_t o = ((size_t)(c >> 5) * x.R + ((size_t)(n * M + m) * Tp + SG_PAD) * V) * 32 + (c & 31);
+            const size_t o = ((size_t)(c >> 5) * x.R + ((size_t)(n * M + m) * Tp) * V) * 32 + (c & 31);
             for (int i = 0; i < T * V; ++i) a += (float)x.hi[o + (size_t)i * 32] + (float)x.lo[o + (size_t)i * 32];
             acc += a / (float)(T * V);
         }
@@ -560,14 +561,14 @@ int rgn_stgcn_finalize(rgn_stgcn_handle h) {
             int T = c->cfg.num_frames;
             for (int i = 0; i < 10; ++i) {
                 const SgBlock& b = c->blocks[i];
-                const size_t rows = (size_t)c->cfg.max_batch * M * ((size_t)T + 2 * SG_PAD) * V, R = rows + 2 * c->guard;
+                const size_t rows = (size_t)c->cfg.max_batch * M * ((size_t)T + SG_PAD) * V, R = rows + 2 * c->guard;
                 if (rows >= ((size_t)1 << 26)) return c->fail(RGN_ERR_UNSUPPORTED, "rgn_stgcn_finalize: max_batch x persons x frames x nodes beyond 2^26 rows");
                 xmax = std::max(xmax, up32((size_t)b.ci) * R);
                 zmax = std::max(zmax, (size_t)b.kp1 * R);
                 gmax = std::max(gmax, (size_t)b.co * R);
                 cmax = std::max(cmax, rows * b.co);                        // conv / rfull live at the block's INPUT rate
                 T = (T + b.stride - 1) / b.stride;
-                const size_t rows_o = (size_t)c->cfg.max_batch * M * ((size_t)T + 2 * SG_PAD) * V;
+                const size_t rows_o = (size_t)c->cfg.max_batch * M * ((size_t)T + SG_PAD) * V;
                 xmax = std::max(xmax, (size_t)b.co * (rows_o + 2 * c->guard));
             }
         }
@@ -603,14 +604,14 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
         auto planes = [&](__bf16* const (&buf)[2], size_t rows) { return SgPl{buf[0] + (size_t)guard * 32, buf[1] + (size_t)guard * 32, (long long)(rows + 2 * (size_t)guard)}; };
         auto blocks1d = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
         {
-            const size_t rows = (size_t)NM * (T + 2 * SG_PAD) * V;
+            const size_t rows = (size_t)NM * (T + SG_PAD) * V;
             hipLaunchKernelGGL(k_sg_in, blocks1d(rows), dim3(256), 0, s, output, planes(c->xa, rows), c->bn_s, c->bn_t, N, V, M, c->C0, T);
         }
         __bf16 *(*x)[2] = &c->xa, *(*xn)[2] = &c->xb;
         for (int i = 0; i < 10; ++i) {
             const SgBlock& b = c->blocks[i];
-            const int Tp = T + 2 * SG_PAD, To = (T + b.stride - 1) / b.stride;   // Conv2d(9x1, pad 4, stride s): ceil(T / s) frames
-            const size_t rows = (size_t)NM * Tp * V, rows_o = (size_t)NM * (To + 2 * SG_PAD) * V;
+            const int Tp = T + SG_PAD, To = (T + b.stride - 1) / b.stride;   // Conv2d(9x1, pad 4, stride s): ceil(T / s) frames
+            const size_t rows = (size_t)NM * Tp * V, rows_o = (size_t)NM * (To + SG_PAD) * V;
             const SgPl xp = planes(*x, rows), zp = planes(c->z, rows), gp = planes(c->g, rows), xo = planes(*xn, rows_o);
             // graph aggregation on the input channels (sparse A'), then the 1x1 convolution over K C_in (+ folded BN, vertex bias, ReLU)
             if (b.ci % 32 == 0) hipLaunchKernelGGL(k_sg_agg, blocks1d(rows * K * (b.ci / 8)), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
@@ -620,7 +621,7 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
             g1.Chi = gp.hi; g1.Clo = gp.lo; g1.c_rows = (int)gp.R;
             SG_HIP(c, launch_gemm_x3_sg(g1, s));
             {   // pad frames and guard rows of g back to zero: what the temporal taps read beyond a sequence
-                const size_t n = ((size_t)NM * 2 * SG_PAD * V + 2 * (size_t)guard) * (b.co / 32) * 4;
+                const size_t n = ((size_t)NM * SG_PAD * V + 2 * (size_t)guard) * (b.co / 32) * 4;
                 hipLaunchKernelGGL(k_sg_zero, blocks1d(n), dim3(256), 0, s, gp, NM, T, V, b.co / 32, guard);
             }
             // 9x1 temporal convolution: ONE GEMM over K = 9 C_out, k-block (dt, channel block) reads g with its rows shifted by (dt - 4) V
@@ -640,7 +641,7 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
             std::swap(x, xn);
             T = To;
         }
-        hipLaunchKernelGGL(k_sg_pool, dim3(N), dim3(256), 0, s, planes(*x, (size_t)NM * (T + 2 * SG_PAD) * V), c->pooled, M, T, V, 256);
+        hipLaunchKernelGGL(k_sg_pool, dim3(N), dim3(256), 0, s, planes(*x, (size_t)NM * (T + SG_PAD) * V), c->pooled, M, T, V, 256);
         if (features) SG_HIP(c, hipMemcpyAsync(features, c->pooled, (size_t)N * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (yhat) {
             GemmArgs gf = sg_gemm(c->pooled, 256, c->Wf, 256, 256, c->bf, yhat, c->cfg.num_class, N, c->cfg.num_class);
