@@ -43,7 +43,8 @@ def row_check(cfg, sd, a, dev, y, out, seed, lo, plan, fn_name, rows):
     from regennet_amd import synth
     from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
     model1, diffusion1 = synth.build_model(cfg, sd, resp=a.respacing, precision=a.precision, device=str(dev), x3_tail=a.x3_tail)
-    model1.small_batch_rows = 0
+    if "sb_gemm" not in plan:                       # (a batch the small-batch engine ran is bit-exact under batch composition by itself)
+        model1.small_batch_rows = 0
     if any(k in plan for k in ("layers", "steps_fused")):
         model1.layers_min_b = 1
     fm1 = ClassifierFreeSampleModel(model1) if a.guided else model1
@@ -397,18 +398,21 @@ def main(argv=None):
         # MI355X guide's recipe) - read from the newest committed PMC summary (tools/collect_pmc.sh + tools/summarize_pmc.py) and
         # labelled as such
         key = f"{a.config}_B{B}_{a.precision}_{'cfg' if a.guided else 'plain'}"
-        for name in ("r04_pmc_bench.json", "r03_pmc_bench.json", "r02_pmc_bench.json"):
+        for name in ("r05_pmc_bench.json", "r04_pmc_bench.json", "r03_pmc_bench.json", "r02_pmc_bench.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 with open(pmc) as fh:
                     rec = json.load(fh).get(key, {}).get(dom["kernel"], {})
                 if rec.get("hbm_bytes_per_launch"):
                     roof["traffic"] = rec["hbm_bytes_per_launch"]
-                    if rec.get("steps_per_launch") and dom.get("steps_per_launch"):   # counted on a short run: scale to the timed launch's step count
-                        roof["traffic"] = round(rec["hbm_bytes_per_launch"] / rec["steps_per_launch"] * dom["steps_per_launch"])
+                    counted = "counted on a launch of the same step count"
+                    if rec.get("steps_per_launch") and dom.get("steps_per_launch"):
                         roof["traffic_per_step"] = round(rec["hbm_bytes_per_launch"] / rec["steps_per_launch"])
+                        if rec["steps_per_launch"] != dom["steps_per_launch"]:   # counted on a launch of another length: scale to the timed launch's step count
+                            roof["traffic"] = round(rec["hbm_bytes_per_launch"] / rec["steps_per_launch"] * dom["steps_per_launch"])
+                            counted = f"counted on a {rec['steps_per_launch']}-step launch and scaled to {dom['steps_per_launch']} steps"
                     roof["traffic_source"] = (f"profiles/{name} [{key}][{dom['kernel']}]: FETCH_SIZE x 2 (gfx950) + WRITE_SIZE from separate "
-                                              "rocprofv3 --pmc passes of a committed earlier run of this command; not measured in this run")
+                                              f"rocprofv3 --pmc passes of a committed earlier run of this command ({counted}); not measured in this run")
                     roof["mfma_util_pmc"] = rec.get("mfma_util")
                     break
 
