@@ -254,8 +254,7 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * 2 * (BM + BN) * 64 <= 80 * 1024)
     auto piece = [&](int idx, int kt, char* sb) {
         ptrdiff_t ka = (ptrdiff_t)kt * g.a_rows * 64;
         if constexpr (EPI == 2) {   // temporal convolution as one GEMM: k-block -> (tap, channel block), the tap shifts the rows
-            if (g.a_klog >= 0)
-                ka = ((ptrdiff_t)(kt & ((1 << g.a_klog) - 1)) * g.a_rows + (ptrdiff_t)((kt >> g.a_klog) - g.a_kbias) * g.a_kshift) * 64;
+            if (g.a_klog >= 0) ka = (ptrdiff_t)(kt & ((1 << g.a_klog) - 1)) * g.a_rows * 64 + (ptrdiff_t)g.a_tap[kt >> g.a_klog];
         }
         const size_t kw = (size_t)kt * g.N * 64;
         if (idx < NPL * A_IT) {

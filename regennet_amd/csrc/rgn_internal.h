@@ -87,9 +87,11 @@ struct GemmX3Args {
     unsigned tq_magic;                               // floor(2^32 / Tq) + 1: m / Tq == umulhi(m, tq_magic) for m * Tq < 2^32
     float qscale;
     // launch_gemm_x3_sg only (rgn_stgcn.hip): a temporal convolution as ONE GEMM over K = taps x channels - k-block kt reads plane block
-    // kt & (2^a_klog - 1) with its rows shifted by ((kt >> a_klog) - a_kbias) * a_kshift (a_klog < 0: plain addressing; the planes carry
-    // zero guard rows for the shifts' reach); the addend row is (row % add_mod) when add_mod > 0; act 3 = ReLU
-    int a_klog, a_kshift, a_kbias, add_mod;
+    // kt & (2^a_klog - 1) at the byte offset a_tap[kt >> a_klog] of tap kt >> a_klog (a row shift for a stride-1 convolution; for stride 2 the
+    // even- / odd-frame region of a polyphase plane plus a row shift; a_klog < 0: plain addressing; the planes carry zero pad frames and guard
+    // rows for the taps' reach); the addend row is (row % add_mod) when add_mod > 0; act 3 = ReLU
+    int a_klog, add_mod;
+    long long a_tap[9];
 };
 
 // Split-bf16 activation planes in the K32-blocked layout; hi == nullptr means "not requested".

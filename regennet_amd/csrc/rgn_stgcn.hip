@@ -132,19 +132,35 @@ __global__ void k_sg_in(const float* __restrict__ out, SgPl x, const float* __re
 
 // z[(frame, w), k C + ci] = sum_v A'_k[v, w] x[(frame, v), ci] over the nonzeros of A'_k[:, w]. C % 32 == 0: one thread per (row, k, run of 8
 // channels); the output channel k C + ci lies in plane block k C / 32 + ci / 32.
-__global__ void k_sg_agg(SgPl x, SgPl z, const int* __restrict__ nz_ptr, const int* __restrict__ nz_v, const float* __restrict__ nz_a, size_t rows, int V, int K, int C) {
-    const int c8n = C / 8;
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= rows * K * c8n) return;
-    const int c8 = (int)(gid % c8n), k = (int)((gid / c8n) % K);
-    const size_t row = gid / ((size_t)c8n * K);
-    const size_t frame = row / V;
-    const int w = (int)(row - frame * V);
+constexpr int SG_NZ_LDS = 1024;                // nonzero lists up to this many entries are staged in LDS (the SMPL-X skeleton has 166)
+__global__ __launch_bounds__(256) void k_sg_agg(SgPl x, SgPl z, const int* __restrict__ nz_ptr, const int* __restrict__ nz_v, const float* __restrict__ nz_a, size_t rows, int V, int K, int C) {
+    // lanes run along (16-byte quarter of a 64-byte plane row, row): a wave reads and writes contiguous 1 KiB runs of one plane block
+    __shared__ int s_ptr[513], s_v[SG_NZ_LDS];
+    __shared__ float s_a[SG_NZ_LDS];
+    const int nlists = K * V, nnz = nz_ptr[nlists];
+    const bool staged = nlists <= 512 && nnz <= SG_NZ_LDS;     // (uniform)
+    if (staged) {
+        for (int i = threadIdx.x; i <= nlists; i += 256) s_ptr[i] = nz_ptr[i];
+        for (int i = threadIdx.x; i < nnz; i += 256) {
+            s_v[i] = nz_v[i];
+            s_a[i] = nz_a[i];
+        }
+        __syncthreads();
+    }
+    // grid: x over (row, quarter), y = output plane block (k, channel block): 32-bit index arithmetic only (64-bit div / mod per thread cost more than the
+    // 64 bytes the thread moves)
+    const int cbn = C / 32;
+    const unsigned gx = blockIdx.x * 256u + threadIdx.x, row = gx >> 2;
+    if (row >= (unsigned)rows) return;
+    const int kb = blockIdx.y, k = kb / cbn, c8 = (kb - k * cbn) * 4 + (int)(gx & 3);
+    const unsigned frame = row / (unsigned)V;
+    const int w = (int)(row - frame * (unsigned)V);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const size_t in_off = ((size_t)(c8 >> 2) * x.R) * 32 + 8 * (c8 & 3);
-    for (int j = nz_ptr[k * V + w]; j < nz_ptr[k * V + w + 1]; ++j) {
-        const size_t src = in_off + (frame * V + nz_v[j]) * 32;
-        const float a = nz_a[j];
+    const int j0 = staged ? s_ptr[k * V + w] : nz_ptr[k * V + w], j1 = staged ? s_ptr[k * V + w + 1] : nz_ptr[k * V + w + 1];
+    for (int j = j0; j < j1; ++j) {
+        const size_t src = in_off + (size_t)(frame * (unsigned)V + (unsigned)(staged ? s_v[j] : nz_v[j])) * 32;
+        const float a = staged ? s_a[j] : nz_a[j];
         const sg_bf16x8 h = *reinterpret_cast<const sg_bf16x8*>(x.hi + src), l = *reinterpret_cast<const sg_bf16x8*>(x.lo + src);
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = fmaf(a, (float)h[e] + (float)l[e], acc[e]);
@@ -182,10 +198,11 @@ __global__ void k_sg_agg_small(SgPl x, SgPl z, const int* __restrict__ nz_ptr, c
     }
 }
 
-// zero the pad frames (4 behind every sequence) and the guard rows (at both ends of every plane block) of padded planes with `cb` channel blocks
-__global__ void k_sg_zero(SgPl g, int NM, int T, int V, int cb, int guard) {
-    const int Tp = T + SG_PAD;
-    const size_t npad = (size_t)NM * SG_PAD * V, per = npad + 2 * (size_t)guard;
+// zero the pad frames and the guard rows of padded planes with `cb` channel blocks: sequences of Tr real + (Tp - Tr) pad frames starting at row
+// `base` of every plane block, `lead` / `trail` guard rows in front of / behind the NM sequences (0: that side borders another region)
+__global__ void k_sg_zero(SgPl g, long long base, int NM, int Tr, int Tp, int V, int cb, int lead, int trail) {
+    const int npf = Tp - Tr;
+    const size_t npad = (size_t)NM * npf * V, per = npad + (size_t)lead + (size_t)trail;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= per * cb * 4) return;
     const int q = (int)(idx & 3);
@@ -193,40 +210,45 @@ __global__ void k_sg_zero(SgPl g, int NM, int T, int V, int cb, int guard) {
     const int b = (int)((idx >> 2) / per);
     long long row;
     if (e < npad) {
-        const int nm = (int)(e / ((size_t)SG_PAD * V));
-        const int r = (int)(e % ((size_t)SG_PAD * V));
-        const int f = r / V;
-        const int tp = T + f;                             // frames T .. T+3
-        row = ((long long)nm * Tp + tp) * V + (r % V);
+        const int nm = (int)(e / ((size_t)npf * V));
+        const int r = (int)(e % ((size_t)npf * V));
+        row = ((long long)nm * Tp + Tr + r / V) * V + (r % V);
     } else {
         const long long j = (long long)(e - npad);
-        row = j < guard ? j - guard : (long long)NM * Tp * V + (j - guard);
+        row = j < lead ? j - lead : (long long)NM * Tp * V + (j - lead);
     }
     sg_bf16x8 zero;
 #pragma unroll
     for (int j = 0; j < 8; ++j) zero[j] = (__bf16)0.f;
-    const long long o = ((long long)b * g.R + row) * 32 + 8 * q;
+    const long long o = ((long long)b * g.R + base + row) * 32 + 8 * q;
     *reinterpret_cast<sg_bf16x8*>(g.hi + o) = zero;
     *reinterpret_cast<sg_bf16x8*>(g.lo + o) = zero;
 }
 
-// x'[nm][t'][v][co] = relu(conv[nm][s t'][v][co] + b2[co] + res) as planes, pads of x' zero
-//   res: none | identity x[nm][t'][v][co] (planes) | rfull[nm][s t'][v][co] + br[co] (1x1 conv + BN computed at full rate)
+// x'[nm][t'][v][co] = relu(conv[nm][t'][v][co] + b2[co] + res) as planes, pads of x' zero. conv / rfull rows run (nm, frame < Tpi, v): the block's own
+// rate (a stride-2 block computes its convolution at the OUTPUT rate from polyphase planes: nothing is subsampled here).
+//   res: none | identity x[nm][t'][v][co] (planes, same geometry) | rfull[nm][t'][v][co] + br[co] (the strided 1x1 convolution + BN)
+// Output geometry: sequences of To real + 4 pad frames - or, when the NEXT block has stride 2 (opoly), polyphase: the even frames of all sequences as one
+// region (Te = ceil(To / 2) real frames + 4 pads each), the odd frames as a second region of the SAME geometry (floor(To / 2) real frames, the rest pads)
 // one thread per (output row, run of 8 channels)
 __global__ void k_sg_post(const float* __restrict__ conv, const float* __restrict__ b2, SgPl xin, int res_id, const float* __restrict__ rfull,
-                          const float* __restrict__ br, SgPl xout, int NM, int T, int To, int stride, int V, int C) {
-    const int Tp = T + SG_PAD, Tpo = To + SG_PAD, c8n = C / 8;
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (size_t)NM * Tpo * V * c8n) return;
-    const int c8 = (int)(gid % c8n);
-    const size_t orow = gid / c8n;
-    const int v = (int)(orow % V);
-    const int tpo = (int)((orow / V) % Tpo);
-    const int nm = (int)(orow / ((size_t)V * Tpo));
-    const int to = tpo;
+                          const float* __restrict__ br, SgPl xout, int NM, int Tpi, int To, int opoly, int V, int C) {
+    const int Te = (To + 1) >> 1, Tpo = opoly ? Te + SG_PAD : To + SG_PAD;
+    const unsigned region = (unsigned)NM * Tpo * V, orows = opoly ? 2 * region : region;       // (32-bit index arithmetic: rows < 2^26)
+    const unsigned gx = blockIdx.x * 256u + threadIdx.x, orow = gx >> 2;                       // lanes along (quarter of a plane row, row): contiguous 1 KiB plane stores per wave
+    if (orow >= orows) return;
+    const int c8 = blockIdx.y * 4 + (int)(gx & 3);                                             // grid y = channel block
+    const unsigned rr = orow >= region ? orow - region : orow;
+    const int odd = orow >= region ? 1 : 0;
+    const unsigned fr = rr / (unsigned)V;
+    const int v = (int)(rr - fr * (unsigned)V);
+    const int nm = (int)(fr / (unsigned)Tpo);
+    const int tpo = (int)(fr - (unsigned)nm * (unsigned)Tpo);
+    const int to = opoly ? 2 * tpo + odd : tpo;               // the frame this output row holds (pads: beyond the real frames of its region)
+    const bool real = opoly ? (tpo < (odd ? (To >> 1) : Te)) : (tpo < To);
     float val[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (to >= 0 && to < To) {
-        const size_t srow = ((size_t)nm * Tp + (size_t)stride * to) * V + v;
+    if (real) {
+        const size_t srow = ((size_t)nm * Tpi + (size_t)to) * V + v;
         const float4 c0 = *reinterpret_cast<const float4*>(conv + srow * C + 8 * c8), c1 = *reinterpret_cast<const float4*>(conv + srow * C + 8 * c8 + 4);
         const float4 bb0 = *reinterpret_cast<const float4*>(b2 + 8 * c8), bb1 = *reinterpret_cast<const float4*>(b2 + 8 * c8 + 4);
         val[0] = c0.x + bb0.x; val[1] = c0.y + bb0.y; val[2] = c0.z + bb0.z; val[3] = c0.w + bb0.w;
@@ -236,7 +258,7 @@ __global__ void k_sg_post(const float* __restrict__ conv, const float* __restric
             const float4 q0 = *reinterpret_cast<const float4*>(br + 8 * c8), q1 = *reinterpret_cast<const float4*>(br + 8 * c8 + 4);
             val[0] += r0.x + q0.x; val[1] += r0.y + q0.y; val[2] += r0.z + q0.z; val[3] += r0.w + q0.w;
             val[4] += r1.x + q1.x; val[5] += r1.y + q1.y; val[6] += r1.z + q1.z; val[7] += r1.w + q1.w;
-        } else if (res_id) {                       // identity residual: stride 1, same channel count
+        } else if (res_id) {                       // identity residual: stride 1, same channel count, same geometry as conv
             const size_t o = ((size_t)(c8 >> 2) * xin.R + srow) * 32 + 8 * (c8 & 3);
             const sg_bf16x8 h = *reinterpret_cast<const sg_bf16x8*>(xin.hi + o), l = *reinterpret_cast<const sg_bf16x8*>(xin.lo + o);
 #pragma unroll
@@ -252,18 +274,30 @@ __global__ void k_sg_post(const float* __restrict__ conv, const float* __restric
     *reinterpret_cast<sg_bf16x8*>(xout.lo + o) = l;
 }
 
-// global average pool over (t, v) and mean over the M persons (stgcn.py:113-114): pooled[n][c]
-__global__ void k_sg_pool(SgPl x, float* __restrict__ pooled, int M, int T, int V, int C) {
-    const int n = blockIdx.x, Tp = T + SG_PAD;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float acc = 0.f;
+// global average pool over (t, v) and mean over the M persons (stgcn.py:113-114): pooled[n][c]. One workgroup per motion: thread = (run of 8 channels,
+// slice of the rows), 16-byte plane loads, the slices summed through LDS
+__global__ __launch_bounds__(256) void k_sg_pool(SgPl x, float* __restrict__ pooled, int M, int T, int V, int C) {
+    __shared__ float part[8][256];
+    const int n = blockIdx.x, Tp = T + SG_PAD, c8n = C / 8;                      // C <= 256: c8n <= 32
+    const int c8 = threadIdx.x % 32, sl = threadIdx.x / 32;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c8 < c8n)
         for (int m = 0; m < M; ++m) {
-            float a = 0.f;
-            const size_t o = ((size_t)(c >> 5) * x.R + ((size_t)(n * M + m) * Tp) * V) * 32 + (c & 31);
-            for (int i = 0; i < T * V; ++i) a += (float)x.hi[o + (size_t)i * 32] + (float)x.lo[o + (size_t)i * 32];
-            acc += a / (float)(T * V);
+            const size_t o = ((size_t)(c8 >> 2) * x.R + ((size_t)(n * M + m) * Tp) * V) * 32 + 8 * (c8 & 3);
+            for (int i = sl; i < T * V; i += 8) {
+                const sg_bf16x8 h = *reinterpret_cast<const sg_bf16x8*>(x.hi + o + (size_t)i * 32), l = *reinterpret_cast<const sg_bf16x8*>(x.lo + o + (size_t)i * 32);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)h[e] + (float)l[e];
+            }
         }
-        pooled[(size_t)n * C + c] = acc / (float)M;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[sl][(8 * c8 + e) & 255] = acc[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a += part[q][c];
+        pooled[(size_t)n * C + c] = a / (float)(T * V) / (float)M;
     }
 }
 
@@ -558,17 +592,21 @@ int rgn_stgcn_finalize(rgn_stgcn_handle h) {
         c->guard = (size_t)SG_PAD * V;
         size_t xmax = 0, zmax = 0, gmax = 0, cmax = 0;     // elements per plane / fp32 tensor
         {
+            // physical rows of a block's input: sequences of T + 4 frames - or, for a stride-2 block, the polyphase form: two regions (even / odd frames)
+            // of ceil(T / 2) + 4 frames per sequence each, so that its temporal convolution runs at the OUTPUT rate
+            auto phys = [&](int T, bool poly) { return (size_t)c->cfg.max_batch * M * (poly ? 2 * ((size_t)(T + 1) / 2 + SG_PAD) : (size_t)T + SG_PAD) * V; };
             int T = c->cfg.num_frames;
             for (int i = 0; i < 10; ++i) {
                 const SgBlock& b = c->blocks[i];
-                const size_t rows = (size_t)c->cfg.max_batch * M * ((size_t)T + SG_PAD) * V, R = rows + 2 * c->guard;
+                const size_t rows = phys(T, b.stride == 2), R = rows + 2 * c->guard;
                 if (rows >= ((size_t)1 << 26)) return c->fail(RGN_ERR_UNSUPPORTED, "rgn_stgcn_finalize: max_batch x persons x frames x nodes beyond 2^26 rows");
+                if (b.stride != 1 && b.stride != 2) return c->fail(RGN_ERR_UNSUPPORTED, "rgn_stgcn_finalize: temporal stride other than 1 or 2");
                 xmax = std::max(xmax, up32((size_t)b.ci) * R);
                 zmax = std::max(zmax, (size_t)b.kp1 * R);
                 gmax = std::max(gmax, (size_t)b.co * R);
-                cmax = std::max(cmax, rows * b.co);                        // conv / rfull live at the block's INPUT rate
+                cmax = std::max(cmax, rows * b.co);
                 T = (T + b.stride - 1) / b.stride;
-                const size_t rows_o = (size_t)c->cfg.max_batch * M * ((size_t)T + SG_PAD) * V;
+                const size_t rows_o = phys(T, i + 1 < 10 && c->blocks[i + 1].stride == 2);
                 xmax = std::max(xmax, (size_t)b.co * (rows_o + 2 * c->guard));
             }
         }
@@ -608,36 +646,52 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
             hipLaunchKernelGGL(k_sg_in, blocks1d(rows), dim3(256), 0, s, output, planes(c->xa, rows), c->bn_s, c->bn_t, N, V, M, c->C0, T);
         }
         __bf16 *(*x)[2] = &c->xa, *(*xn)[2] = &c->xb;
+        auto phys = [&](int Tf, bool poly) { return (size_t)NM * (poly ? 2 * ((size_t)(Tf + 1) / 2 + SG_PAD) : (size_t)Tf + SG_PAD) * V; };
         for (int i = 0; i < 10; ++i) {
             const SgBlock& b = c->blocks[i];
-            const int Tp = T + SG_PAD, To = (T + b.stride - 1) / b.stride;   // Conv2d(9x1, pad 4, stride s): ceil(T / s) frames
-            const size_t rows = (size_t)NM * Tp * V, rows_o = (size_t)NM * (To + SG_PAD) * V;
+            // a stride-2 block reads POLYPHASE planes (written so by the block in front of it): region E = the even frames of every sequence, region O = the odd
+            // ones, Te + 4 frames per sequence in both - its 9-tap stride-2 convolution is then five row-shifted taps on E and four on O at the OUTPUT rate
+            const bool ipoly = b.stride == 2, opoly = i + 1 < 10 && c->blocks[i + 1].stride == 2;
+            const int To = (T + b.stride - 1) / b.stride, Te = (T + 1) / 2;   // Conv2d(9x1, pad 4, stride s): ceil(T / s) frames
+            const int Tpi = ipoly ? Te + SG_PAD : T + SG_PAD;                 // frames per sequence of the rows the convolution is computed on
+            const size_t rows = phys(T, ipoly), rows_c = (size_t)NM * Tpi * V, rows_o = phys(To, opoly);
             const SgPl xp = planes(*x, rows), zp = planes(c->z, rows), gp = planes(c->g, rows), xo = planes(*xn, rows_o);
-            // graph aggregation on the input channels (sparse A'), then the 1x1 convolution over K C_in (+ folded BN, vertex bias, ReLU)
-            if (b.ci % 32 == 0) hipLaunchKernelGGL(k_sg_agg, blocks1d(rows * K * (b.ci / 8)), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
+            // graph aggregation on the input channels (sparse A'), then the 1x1 convolution over K C_in (+ folded BN, vertex bias, ReLU): frame-local, any row order
+            if (b.ci % 32 == 0) hipLaunchKernelGGL(k_sg_agg, dim3((unsigned)((rows * 4 + 255) / 256), (unsigned)(K * (b.ci / 32))), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
             else hipLaunchKernelGGL(k_sg_agg_small, blocks1d(rows), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
             GemmX3Args g1 = sg_gemm_x3(zp, b.W1h, b.W1l, (int)rows, b.co, b.kp1);
             g1.add = b.b1; g1.ldadd = b.co; g1.add_mod = V; g1.act = 3;                          // + b1'[row % V], ReLU
             g1.Chi = gp.hi; g1.Clo = gp.lo; g1.c_rows = (int)gp.R;
             SG_HIP(c, launch_gemm_x3_sg(g1, s));
-            {   // pad frames and guard rows of g back to zero: what the temporal taps read beyond a sequence
-                const size_t n = ((size_t)NM * SG_PAD * V + 2 * (size_t)guard) * (b.co / 32) * 4;
-                hipLaunchKernelGGL(k_sg_zero, blocks1d(n), dim3(256), 0, s, gp, NM, T, V, b.co / 32, guard);
+            // pad frames and guard rows of g back to zero: what the temporal taps read beyond a sequence
+            auto zero = [&](long long base, int Tr, int Tp, int lead, int trail) {
+                const size_t n = ((size_t)NM * (Tp - Tr) * V + (size_t)lead + (size_t)trail) * (b.co / 32) * 4;
+                hipLaunchKernelGGL(k_sg_zero, blocks1d(n), dim3(256), 0, s, gp, base, NM, Tr, Tp, V, b.co / 32, lead, trail);
+            };
+            if (!ipoly) zero(0, T, T + SG_PAD, guard, guard);
+            else {
+                zero(0, Te, Te + SG_PAD, guard, 0);
+                zero((long long)rows_c, T / 2, Te + SG_PAD, 0, guard);
             }
-            // 9x1 temporal convolution: ONE GEMM over K = 9 C_out, k-block (dt, channel block) reads g with its rows shifted by (dt - 4) V
-            GemmX3Args g2 = sg_gemm_x3(gp, b.W2h, b.W2l, (int)rows, b.co, 9 * b.co);
+            // 9x1 temporal convolution: ONE GEMM over K = 9 C_out; tap dt of k-block (dt, channel block) is a byte offset into g
+            GemmX3Args g2 = sg_gemm_x3(gp, b.W2h, b.W2l, (int)rows_c, b.co, 9 * b.co);
             int klog = 0;
             while ((1 << klog) < b.co / 32) ++klog;
-            g2.a_klog = klog; g2.a_kshift = V; g2.a_kbias = SG_PAD;
+            g2.a_klog = klog;
+            for (int dt = 0; dt < 9; ++dt) {
+                if (!ipoly) g2.a_tap[dt] = (long long)(dt - 4) * V * 64;                                  // frame t + dt - 4
+                else if ((dt & 1) == 0) g2.a_tap[dt] = (long long)((dt - 4) / 2) * V * 64;                  // frame 2 t' + dt - 4 = even frame t' + (dt - 4) / 2
+                else g2.a_tap[dt] = ((long long)rows_c + (long long)((dt - 5) / 2) * V) * 64;               // ... = odd frame t' + (dt - 5) / 2
+            }
             g2.C = c->conv; g2.ldc = b.co;
             SG_HIP(c, launch_gemm_x3_sg(g2, s));
-            if (b.res_conv) {
-                GemmX3Args gr = sg_gemm_x3(xp, b.Wrh, b.Wrl, (int)rows, b.co, b.kpr);
+            if (b.res_conv) {   // strided 1x1 convolution of the block input: the even frames = region E of the polyphase planes (all rows for a stride-1 block)
+                GemmX3Args gr = sg_gemm_x3(xp, b.Wrh, b.Wrl, (int)rows_c, b.co, b.kpr);
                 gr.C = c->rfull; gr.ldc = b.co;
                 SG_HIP(c, launch_gemm_x3_sg(gr, s));
             }
-            hipLaunchKernelGGL(k_sg_post, blocks1d(rows_o * (b.co / 8)), dim3(256), 0, s, c->conv, b.b2, xp, b.res_id ? 1 : 0, b.res_conv ? c->rfull : nullptr, b.br,
-                               xo, NM, T, To, b.stride, V, b.co);
+            hipLaunchKernelGGL(k_sg_post, dim3((unsigned)((rows_o * 4 + 255) / 256), (unsigned)(b.co / 32)), dim3(256), 0, s, c->conv, b.b2, xp, b.res_id ? 1 : 0, b.res_conv ? c->rfull : nullptr, b.br,
+                               xo, NM, Tpi, To, opoly ? 1 : 0, V, b.co);
             std::swap(x, xn);
             T = To;
         }
