@@ -468,6 +468,38 @@ hipError_t configure_gemm_x3_sg() {
     return e != hipSuccess ? e : sg_launch<128, 2>(g, nullptr, true);
 }
 
+// variant 0 = 128x128 / 4 waves (two workgroups per CU): the default. variant 1 = 256x256 / 8 waves / interleaved DMA (one
+// workgroup per CU): its loop is ~1.45x faster per output but it needs several tiles per CU to hide its 256 KiB-per-tile
+// epilogue, so the engine picks it only for launches of >= 7000 rows per chain (rgn_api.cpp). tools/gemm_bench builds
+// with RGN_GEMM_TOOLS and can also time 2 = 256x256 with the two-barrier loop, 3 = 128x128 with the interleaved loop,
+// 4 / 5 = 128x256 / 256x128 interleaved.
+hipError_t launch_gemm_x3(const GemmX3Args& g, bool x3, int variant, hipStream_t s) {
+    if (variant == 1) return x3_launch<256, 256, 4, 2, true>(g, x3, s, false);
+#ifdef RGN_GEMM_TOOLS
+    if (variant == 2) return x3_launch<256, 256, 4, 2, false>(g, x3, s, false);
+    if (variant == 3) return x3_launch<128, 128, 2, 2, true>(g, x3, s, false);
+    if (variant == 4) return x3_launch<128, 256, 2, 4, true>(g, x3, s, false);
+    if (variant == 5) return x3_launch<256, 128, 4, 2, true>(g, x3, s, false);
+#endif
+    return x3_launch<128, 128, 2, 2, false>(g, x3, s, false);
+}
+hipError_t configure_gemm_x3() {
+    GemmX3Args g{};
+    hipError_t e = x3_launch<128, 128, 2, 2, false>(g, true, nullptr, true);
+    if (e != hipSuccess) return e;
+#ifdef RGN_GEMM_TOOLS
+    e = x3_launch<256, 256, 4, 2, false>(g, true, nullptr, true);
+    if (e != hipSuccess) return e;
+    e = x3_launch<128, 128, 2, 2, true>(g, true, nullptr, true);
+    if (e != hipSuccess) return e;
+    e = x3_launch<128, 256, 2, 4, true>(g, true, nullptr, true);
+    if (e != hipSuccess) return e;
+    e = x3_launch<256, 128, 4, 2, true>(g, true, nullptr, true);
+#endif
+    if (e != hipSuccess) return e;
+    return x3_launch<256, 256, 4, 2, true>(g, true, nullptr, true);
+}
+
 #ifdef RGN_GEMM_PROF
 void gemm_prof_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(long long) * 1024); }
 #endif
