@@ -352,11 +352,14 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         //      what it wrote), the unconditional evaluation's input (written to the planes by the previous step boundary / the up-front
         //      embedding; sc1: past this CU's L1, which may still hold last step's lines) takes its place in X
         f32x16 accp[2][2];
-        int wave_p = wave;
-        asm volatile("" : "+s"(wave_p));
+        // (ids made opaque per pass: the park / reload addresses below are invariant across the step loop - hoisted out of it they stay live across the
+        //  whole layer loop and are spilled)
+        int wave_p = wave, lane_p = lane, b_p = b;
+        asm volatile("" : "+s"(wave_p), "+s"(b_p));
+        asm volatile("" : "+v"(lane_p));
         out_proj(accp, wave_p);
         if (wave_p < 6) {
-            float* pk = g.park + ((size_t)b * 6 + wave_p) * 4096 + lane * 4;
+            float* pk = g.park + ((size_t)b_p * 6 + wave_p) * 4096 + lane_p * 4;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -367,12 +370,13 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         }
         __builtin_amdgcn_s_barrier();                                     // every wave is done reading the image
         {
-            const int r16 = lane >> 2, c = lane & 3;
+            const int r16 = lane_p >> 2, c = lane_p & 3;
+            const size_t row0_p = (size_t)b_p * Tq;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int p = wave + 8 * j, kb = p >> 2, r = (p & 3) * 16 + r16;
+                const int p = wave_p + 8 * j, kb = p >> 2, r = (p & 3) * 16 + r16;
                 const int rr = r < Tq ? r : Tq - 1;
-                const size_t src = ((size_t)kb * g.rows + g.half + row0 + rr) * 32 + ((c ^ ((r >> 2) & 3)) << 3);
+                const size_t src = ((size_t)kb * g.rows + g.half + row0_p + rr) * 32 + ((c ^ ((r >> 2) & 3)) << 3);
                 __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(g.h + src), (RGN_AS3 void*)(smem + LY_X + p * 1024), 16, 0, 16);
             }
         }
@@ -599,7 +603,8 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         vec[V_BO + lane] = bo_r;                                 // (wave-private; the exchange it lies in is dead: every wave passed the barrier behind the last round)
 #pragma unroll
         for (int s = 0; s < LY_RDM - 1; ++s) load_g(p_wo, s, s);
-        const int cw = 64 * wave + lane;
+        int cw = 64 * wave + lane;
+        asm volatile("" : "+v"(cw));                             // (per layer: the per-column vector addresses are step-loop invariants - hoisted, they are spilled in the guided form)
         float vv[12];
         {
             const float* src[9] = {w.bo, w.g1, w.g2, w.b2, w.bf1, w.bf1 + 512, w.bf2, w.g3, w.b3};
