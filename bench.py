@@ -115,6 +115,63 @@ def bench_stgcn(a):
                       "roofline": lines[0]["roofline"], "per_length": lines}), flush=True)
 
 
+def bench_eval_pipeline(a):
+    """`--config eval_pipeline`: one evaluation batch of eval/eval_cmdm.py's hot loop on the device (eval/a2m/stgcn_eval.py:61-81 + evaluate.py:55-124): sample
+    B action-conditioned NTU motions with the reference's shipped schedule (`ddim5` through p_sample_loop), concatenate with the actor motion, run the
+    recogniser, keep the features; FID / accuracy statistics once at the end. A step = one batch; the stages are bracketed with HIP events."""
+    from regennet_amd import synth
+    from regennet_amd.eval import STGCN
+    from regennet_amd.eval.fid import calculate_activation_statistics, calculate_fid
+    dev = torch.device("cuda:0")
+    cfg = synth.get_config("ntu_action")
+    model, diffusion = synth.build_model(cfg, synth.make_state_dict(cfg, seed=0), resp="ddim5", precision=a.precision, device=str(dev))
+    V, K = 56, 3
+    A = np.zeros((K, V, V), np.float32)
+    A[0] = np.eye(V)
+    for v in range(1, V):
+        A[1, v, v - 1] = 0.5
+        A[2, v - 1, v] = 0.5
+    rec = STGCN(in_channels=12, num_class=26, num_person=2, graph_args={"layout": "smplx", "strategy": "spatial"}, device=str(dev))
+    rec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_stgcn_state_dict(A, num_class=26, seed=0).items()}, strict=True)
+    rec.to(dev).eval()
+    B = a.batch
+    y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1)).to(dev), "action": torch.from_numpy(synth.make_actions(cfg, B, seed=2)).to(dev)}
+    shape = (B, 56, 6, 60)
+
+    def batch(seed, ev=None):
+        if ev:
+            ev[0].record()
+        sample = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y}, seed=seed)
+        if ev:
+            ev[1].record()
+        out = rec({"output": torch.cat((y["cmotion"], sample), dim=2)})     # stgcn_eval.py:71
+        if ev:
+            ev[2].record()
+        return out["features"].reshape(B, 256), out["yhat"]
+
+    for w in range(max(a.warmup, 1)):
+        batch(10 + w)
+    torch.cuda.synchronize()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
+    feats = []
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        feats.append(batch(100 + k, evs[k])[0])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    stats = calculate_activation_statistics(torch.cat(feats))
+    fid_self = float(calculate_fid(stats, stats))
+    torch.cuda.synchronize()
+    t_fid = time.perf_counter() - t1
+    ms_s = float(np.mean([e[0].elapsed_time(e[1]) for e in evs])), float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+    print(json.dumps({"metric": "evaluation batches of eval_cmdm's hot loop (sample ddim5 + ST-GCN features)", "value": round(a.steps * B / dt, 1), "unit": "motions/s", "n_gpus": 1,
+                      "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "sampler: bf16 / split-bf16 schedule; recogniser: split-bf16", "data": "synthetic",
+                      "config": {"workload": f"ntu_action B={B}: p_sample_loop(ddim5) -> cat(cmotion, sample) -> STGCN features; FID statistics over {a.steps * B} motions once"},
+                      "stage_ms": {"sample_ddim5": round(ms_s[0], 3), "recogniser": round(ms_s[1], 3), "fid_statistics_once": round(1e3 * t_fid, 2)}, "fid_self_numerical_floor": fid_self}), flush=True)
+
+
 def cpu_baseline(cfg, sd, steps_total, seconds_budget=20.0):
     """Oracle (CPU port of the reference path) on this host: B=8 motions, a bounded number of the S steps.
     torch's intra-op pool oversubscribes badly on many-core hosts for these small GEMMs, so the thread count
@@ -215,6 +272,8 @@ def main(argv=None):
         sys.exit(self_launch(a.gpus, argv))
     if a.config == "stgcn":
         return bench_stgcn(a)
+    if a.config == "eval_pipeline":
+        return bench_eval_pipeline(a)
 
     from regennet_amd import synth
     from regennet_amd._lib import default_x3_tail
