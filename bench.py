@@ -461,7 +461,12 @@ def main(argv=None):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 with open(pmc) as fh:
-                    rec = json.load(fh).get(key, {}).get(dom["kernel"], {})
+                    per = json.load(fh).get(key, {})
+                # the PMC summary names kernel CLASSES (tools/summarize_pmc.py), the plan names instantiations
+                alias = next((name for sub, name in (("k_layers<true", "k_layers<steps>"), ("k_layers", "k_layers"), ("k_step", "k_step"), ("k_mlp", "k_mlp"),
+                                                     ("k_qkv_attn_long", "k_qkv_attn_long"), ("k_qkv_attn", "k_qkv_attn"), ("k_sb_gemm", "k_sb_gemm"),
+                                                     ("k_gemm_x3", "k_gemm_x3")) if sub in dom["kernel"]), dom["kernel"])
+                rec = per.get(dom["kernel"]) or per.get(alias) or {}
                 if rec.get("hbm_bytes_per_launch"):
                     roof["traffic"] = rec["hbm_bytes_per_launch"]
                     counted = "counted on a launch of the same step count"
@@ -470,7 +475,7 @@ def main(argv=None):
                         if rec["steps_per_launch"] != dom["steps_per_launch"]:   # counted on a launch of another length: scale to the timed launch's step count
                             roof["traffic"] = round(rec["hbm_bytes_per_launch"] / rec["steps_per_launch"] * dom["steps_per_launch"])
                             counted = f"counted on a {rec['steps_per_launch']}-step launch and scaled to {dom['steps_per_launch']} steps"
-                    roof["traffic_source"] = (f"profiles/{name} [{key}][{dom['kernel']}]: FETCH_SIZE x 2 (gfx950) + WRITE_SIZE from separate "
+                    roof["traffic_source"] = (f"profiles/{name} [{key}][{alias}]: FETCH_SIZE x 2 (gfx950) + WRITE_SIZE from separate "
                                               f"rocprofv3 --pmc passes of a committed earlier run of this command ({counted}); not measured in this run")
                     roof["mfma_util_pmc"] = rec.get("mfma_util")
                     break
