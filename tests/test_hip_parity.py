@@ -1234,6 +1234,53 @@ def test_per_handle_kernel_switches():
     eng2.close()
 
 
+@pytest.mark.parametrize("cfg_name,B,guided,opts", [("ntu", 64, False, {}), ("ntu", 64, False, {"LAYERS_STEPS": 0}), ("ntu", 64, False, {"LAYERS": 0}),
+                                                  ("ntu_action", 64, True, {}), ("chi3d", 8, False, {}), ("ntu", 4, False, {})])
+def test_the_reported_plan_is_what_the_engine_launches(cfg_name, B, guided, opts):
+    """rgn_plan_query (what bench.py prices) against rgn_profile_query (what was launched): one eager, profiled, plain-bf16 sampling step per
+    configuration - the kernel classes with launches and their launch counts per evaluation must agree with the plan, for the one-kernel stack, its
+    per-step form, the kernel-per-stage chain, guidance, 150 frames and the small-batch engine."""
+    from regennet_amd import synth
+    cfg = synth.get_config(cfg_name)
+    sd = synth.make_state_dict(cfg, seed=0)
+    model, diffusion = build_hip(cfg, sd, resp="8", precision="bf16_x3tail", x3_tail=0)
+    model.engine_options = dict(opts, STREAMS=1)
+    eng, dev = model._get_engine(B)
+    y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1)).cuda()}
+    if cfg["cond_mode"] == "action":
+        y["action"] = torch.from_numpy(synth.make_actions(cfg, B, seed=2)).cuda()
+    if guided:
+        y["scale"] = torch.full((B,), 2.5, device="cuda")
+    fm = _wrap(model, guided)
+    shape = (B, cfg["njoints"], cfg["nfeats"], cfg["num_frames"])
+    fn = diffusion.ddim_sample_loop if guided else diffusion.p_sample_loop
+    fn(fm, shape, clip_denoised=False, model_kwargs={"y": y}, seed=3)                 # binds schedule + condition, warms the kernels
+    plan = eng.plan_query(B, guided, split_phase=False)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.empty(shape, device="cuda")
+    eng.randn(x, B, 3, 0, st)
+    eng.profile_enable(True)
+    steps = 3
+    eng.sample_range("ddim" if guided else "ddpm", guided, 0.0, x, None, 3, 0, 7, steps, None, False, False, st)
+    torch.cuda.synchronize()
+    prof = {k: n for k, (ms, n) in eng.profile_query().items() if n > 0}
+    eng.profile_enable(False)
+    launched = {k: n for k, n in prof.items() if k not in ("embed", "misc")}             # (once-per-call work in front of the first fused step)
+    for cls, rec in plan.items():
+        if cls == "steps_fused":
+            assert launched.get(cls) == 1, (cls, launched, plan)                         # ONE launch for the whole run of steps
+        elif rec["launches_per_eval"] > 0:
+            want = rec["launches_per_eval"] * steps
+            got = launched.get(cls, 0)
+            if cls in ("gemm_mfma", "update", "sb_gemm"):    # + once per call: the state pack (k_pack_x) / the up-front embedding in front of the first step
+                assert want <= got <= want + 1, (cls, got, want, launched, plan)
+            else:
+                assert got == want, (cls, got, want, launched, plan)
+    for cls, n in launched.items():
+        assert cls in plan or (cls in ("gemm_mfma", "update") and n == 1), (cls, launched, plan)
+    model._engine.close()
+
+
 def test_exceptions_do_not_cross_the_c_boundary():
     """include/regennet_hip.h: "no exceptions cross the boundary". A positional table of 2^40 rows (its first dimension is free) makes the
     host-side copy throw std::length_error / std::bad_alloc inside rgn_load_weight: it must come back as RGN_ERR_INTERNAL with the text in
