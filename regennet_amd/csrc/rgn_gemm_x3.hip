@@ -27,6 +27,7 @@
 // barrier per step and the DMA issued between MFMA groups (ILV = true, tools only) halves the bytes per MFMA and its
 // loop runs at ~80 % MFMA occupancy, but at M = 15360 it leaves only 120-240 tiles for 256 CUs and nothing to hide its
 // 256 KiB-per-tile epilogue behind: end to end it only ties (70 vs 72 us on linear1), so it is not shipped.
+#include <cstdlib>
 #include "rgn_internal.h"
 
 #include <hip/hip_runtime.h>
@@ -254,7 +255,10 @@ __global__ __launch_bounds__(64 * WM * WN, (2 * 2 * (BM + BN) * 64 <= 80 * 1024)
     auto piece = [&](int idx, int kt, char* sb) {
         ptrdiff_t ka = (ptrdiff_t)kt * g.a_rows * 64;
         if constexpr (EPI == 2) {   // temporal convolution as one GEMM: k-block -> (tap, channel block), the tap shifts the rows
-            if (g.a_klog >= 0) ka = (ptrdiff_t)(kt & ((1 << g.a_klog) - 1)) * g.a_rows * 64 + (ptrdiff_t)g.a_tap[kt >> g.a_klog];
+            if (g.a_taps > 0) {
+                const int cb = kt / g.a_taps;
+                ka = (ptrdiff_t)cb * g.a_rows * 64 + (ptrdiff_t)g.a_tap[kt - cb * g.a_taps];
+            }
         }
         const size_t kw = (size_t)kt * g.N * 64;
         if (idx < NPL * A_IT) {
@@ -466,6 +470,160 @@ hipError_t configure_gemm_x3_sg() {
     GemmX3Args g{};
     hipError_t e = sg_launch<64, 1>(g, nullptr, true);
     return e != hipSuccess ? e : sg_launch<128, 2>(g, nullptr, true);
+}
+
+// ---- the 9 x 1 temporal convolution of a stride-1 ST-GCN block with the activation WINDOW resident in LDS (rgn_stgcn.hip) ---------------------
+// As a row-shifted GEMM (above) every tap DMAs its own 256-row slice of the activation - 9 x 32 KB per channel block through the ~20 B/clk L2 -> LDS
+// path beside 9 x 16 KB of weights: 48 KB per k-step against 2304 cycles of MFMA (PMC: matrix pipe 0.35 busy, and NOT because of the fabric - with the
+// taps innermost the L2 hit rate rose 0.61 -> 0.76 and the HBM fetch halved while the kernel got 4 % slower). Here the 256 + 8 V rows a tile needs of
+// one channel block sit in LDS ONCE ([row][64 B] x {hi, lo}, 88 KiB at V = 56) and the nine taps read their fragments V rows apart: per k-step the
+// path carries the weight tile + V rows of the NEXT channel block's window (7 KB), which overwrite the V rows the finished tap no longer needs -
+// tap dt reads window rows [dt V, dt V + 256), so after it only rows >= (dt + 1) V are live; the top 256 rows of a window are fetched during its
+// own taps 0-3 (first needed by tap 4). K order: k-block kt = (channel block kt / 9, tap kt % 9).
+template <int BN>
+__global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int nby, int V) {
+    constexpr int BM = 256, NT = 512, TAPS = 9;
+    constexpr int WN = BN >= 128 ? 2 : 1, WM = 8 / WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int W_BYTES = BN * 64, W_STAGE = 2 * W_BYTES;      // one plane tile; a stage = hi | lo
+    constexpr int W_IT = BN * 8 / NT;                            // DMA instructions per thread per weight tile (hi + lo): 1 / 2 / 4
+    static_assert(TM >= 1 && TN >= 1 && BN * 8 % NT == 0 && (BN * 4) % 64 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int nwg = nbx * nby, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int m0 = (vid / nbx) * BM, n0 = (vid % nbx) * BN;
+    const int WR = BM + 8 * V, A_PLANE = WR * 64;                // window rows (a multiple of 16: V even)
+    char* const wst = smem + 2 * A_PLANE;                        // weight stages behind the two window planes
+    const int ncb = g.Kp / (32 * TAPS), nk = ncb * TAPS;
+    const long long row_lo = -4LL * V, row_hi = (long long)g.M + 4LL * V - 1;   // the planes' zero guard rows bound what a window may touch
+    const char* const a_pl[2] = {reinterpret_cast<const char*>(g.Ahi), reinterpret_cast<const char*>(g.Alo)};
+    const char* const w_pl[2] = {reinterpret_cast<const char*>(g.Whi), reinterpret_cast<const char*>(g.Wlo)};
+
+    // one 16-row piece (1 KiB per plane) of channel block cb's window, rows [r0, r0 + 16) limited to rows < rend, into its place in plane pl
+    auto a_piece = [&](int cb, int pl, int r0, int rend) {
+        const int r = r0 + (lane >> 2);
+        if (r < rend) {
+            long long gr = (long long)m0 - 4LL * V + r;
+            gr = gr < row_lo ? row_lo : (gr > row_hi ? row_hi : gr);
+            const char* src = a_pl[pl] + ((long long)cb * g.a_rows + gr) * 64 + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)src, (RGN_AS3 void*)(smem + pl * A_PLANE + r0 * 64), 16, 0, 0);
+        }
+    };
+    unsigned w_src[W_IT];
+    int w_dst[W_IT];
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int q = it * NT + tid, pl = q / (BN * 4), qq = q - pl * (BN * 4), r = qq >> 2, c = (qq & 3) ^ ((r >> 2) & 3);
+        int n = n0 + r;
+        n = n < g.N ? n : g.N - 1;
+        w_src[it] = (unsigned)n * 64u + c * 16u;
+        w_dst[it] = pl * W_BYTES + (it * NT + (tid & ~63)) * 16 - pl * (BN * 4) * 16;       // wave-uniform: this wave's 1 KiB of the stage
+    }
+    auto w_piece = [&](int it, int kt, char* stage) {
+        const int pl = (it * NT + (tid & ~63)) / (BN * 4);
+        __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(w_pl[pl] + (size_t)kt * g.N * 64 + w_src[it]), (RGN_AS3 void*)(stage + w_dst[it]), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    int w_off[TN][2];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int rr = wn * (BN / WN) + t * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w_off[t][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
+    }
+    const int arow0 = wm * (BM / WM) + l31;
+    auto mma3 = [&](f32x16& c, const bf16x8& a_h, const bf16x8& a_l, const bf16x8& w_h, const bf16x8& w_l) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, w_h, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_l, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_h, c, 0, 0, 0);
+    };
+
+    // prologue: rows [0, 8 V) of channel block 0's window (its top 256 rows follow under taps 0-3 like every window's) and the first weight tile
+    {
+        const int np = 8 * V / 16;                               // pieces per plane
+        for (int q = wave; q < 2 * np; q += 8) a_piece(0, q / np, (q % np) * 16, 8 * V);
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) w_piece(it, 0, wst);
+    }
+    for (int cb = 0; cb < ncb; ++cb) {
+#pragma unroll
+        for (int dt = 0; dt < TAPS; ++dt) {
+            const int kt = cb * TAPS + dt;
+            wait_vmcnt<0>();                                     // everything this thread requested up to the last k-step has landed ...
+            __builtin_amdgcn_s_barrier();                        // ... everyone's has, and everyone is done reading k-step kt - 1
+            const char* wsb = wst + (kt & 1) * W_STAGE;
+            // fragments: the tap's rows start dt V further down the window (the 16-byte chunk swizzle follows the LDS row)
+            bf16x8 ah[2][TM], al[2][TM], wh[2], wl[2];
+            auto fetch = [&](int grp) {                          // grp = ks * TN + tb
+                const int ks = grp / TN, tb = grp % TN;
+                if (tb == 0) {
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) {
+                        const int rr = arow0 + t * 32 + dt * V;
+                        const int o = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
+                        ah[ks][t] = *reinterpret_cast<const bf16x8*>(smem + o);
+                        al[ks][t] = *reinterpret_cast<const bf16x8*>(smem + A_PLANE + o);
+                    }
+                }
+                wh[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + w_off[tb][ks]);
+                wl[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + W_BYTES + w_off[tb][ks]);
+            };
+            fetch(0);
+#pragma unroll
+            for (int grp = 0; grp < 2 * TN; ++grp) {
+                if (grp + 1 < 2 * TN) fetch(grp + 1);
+#pragma unroll
+                for (int ta = 0; ta < TM; ++ta) mma3(acc[ta][grp % TN], ah[grp / TN][ta], al[grp / TN][ta], wh[grp & 1], wl[grp & 1]);
+                if (grp == 0) {
+                    // the path's load for this k-step, behind the first MFMA group: next weight tile, the dead strip's successor, the window's top quarter
+                    if (kt + 1 < nk) {
+#pragma unroll
+                        for (int it = 0; it < W_IT; ++it) w_piece(it, kt + 1, wst + ((kt + 1) & 1) * W_STAGE);
+                    }
+                    if (dt >= 1 && cb + 1 < ncb) a_piece(cb + 1, wave >> 2, (dt - 1) * V + 16 * (wave & 3), dt * V);   // V <= 64 rows: four pieces per plane
+                    if (dt < 4) a_piece(cb, wave >> 2, 8 * V + 64 * dt + 16 * (wave & 3), WR);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+    if (interior) x3_epilogue<TM, TN, 2, false>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+    else x3_epilogue<TM, TN, 2, true>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+}
+template <int BN>
+static hipError_t tconv_launch(const GemmX3Args& g, int V, hipStream_t s, bool configure_only) {
+    const int lds = 2 * (256 + 8 * 64) * 64 + 2 * 2 * BN * 64;      // (sized for V <= 64)
+    if (configure_only) return hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_tconv<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int nbx = (g.N + BN - 1) / BN, nby = (g.M + 255) / 256;
+    hipLaunchKernelGGL((k_sg_tconv<BN>), dim3(nbx * nby), dim3(512), 2 * (256 + 8 * V) * 64 + 2 * 2 * BN * 64, s, g, nbx, nby, V);
+    return hipGetLastError();
+}
+bool sg_tconv_supported(int N, int Kp, int V) { return (N == 64 || N == 128 || N == 256) && Kp == 9 * N && V % 4 == 0 && V >= 16 && V <= 64; }
+hipError_t launch_sg_tconv(const GemmX3Args& g, int V, hipStream_t s) {
+    if (g.N == 64) return tconv_launch<64>(g, V, s, false);
+    static const bool wide = getenv("REGENNET_SG_TCONV_256") != nullptr;
+    if (g.N == 128 || !wide) return tconv_launch<128>(g, V, s, false);
+    return tconv_launch<256>(g, V, s, false);
+}
+hipError_t configure_sg_tconv() {
+    GemmX3Args g{};
+    hipError_t e = tconv_launch<64>(g, 0, nullptr, true);
+    if (e != hipSuccess) return e;
+    e = tconv_launch<128>(g, 0, nullptr, true);
+    return e != hipSuccess ? e : tconv_launch<256>(g, 0, nullptr, true);
 }
 
 // variant 0 = 128x128 / 4 waves (two workgroups per CU): the default. variant 1 = 256x256 / 8 waves / interleaved DMA (one

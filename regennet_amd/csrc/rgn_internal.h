@@ -86,11 +86,13 @@ struct GemmX3Args {
     int d, H, dh, Tq, Tqp;
     unsigned tq_magic;                               // floor(2^32 / Tq) + 1: m / Tq == umulhi(m, tq_magic) for m * Tq < 2^32
     float qscale;
-    // launch_gemm_x3_sg only (rgn_stgcn.hip): a temporal convolution as ONE GEMM over K = taps x channels - k-block kt reads plane block
-    // kt & (2^a_klog - 1) at the byte offset a_tap[kt >> a_klog] of tap kt >> a_klog (a row shift for a stride-1 convolution; for stride 2 the
-    // even- / odd-frame region of a polyphase plane plus a row shift; a_klog < 0: plain addressing; the planes carry zero pad frames and guard
-    // rows for the taps' reach); the addend row is (row % add_mod) when add_mod > 0; act 3 = ReLU
-    int a_klog, add_mod;
+    // launch_gemm_x3_sg only (rgn_stgcn.hip): a temporal convolution as ONE GEMM over K = channel blocks x taps - k-block kt reads plane block
+    // kt / a_taps at the byte offset a_tap[kt % a_taps] of its tap (a row shift for a stride-1 convolution; for stride 2 the even- / odd-frame
+    // region of a polyphase plane plus a row shift; a_taps = 0: plain addressing; the planes carry zero pad frames and guard rows for the taps'
+    // reach). TAPS INNERMOST: consecutive k-steps re-read the same channel block 56 rows further on, so the shifted windows hit L2 - with the
+    // taps outermost every tap swept all channel blocks (256 KB per tile, 8 MB per XCD) before the next one touched the same lines again, and
+    // the 256-channel blocks fetched 32 GB per forward over the fabric (L2 hit rate 0.61). The addend row is (row % add_mod) when add_mod > 0; act 3 = ReLU
+    int a_taps, add_mod;
     long long a_tap[9];
 };
 
@@ -316,6 +318,10 @@ hipError_t configure_gemm_x3();
 // A addressing for the 9 x 1 temporal convolution, (row % V) addend, ReLU
 hipError_t launch_gemm_x3_sg(const GemmX3Args& g, hipStream_t s);
 hipError_t configure_gemm_x3_sg();
+// ... and the stride-1 9 x 1 temporal convolution with the activation window resident in LDS (K order: channel block, tap): V = rows per frame
+bool sg_tconv_supported(int N, int Kp, int V);
+hipError_t launch_sg_tconv(const GemmX3Args& g, int V, hipStream_t s);
+hipError_t configure_sg_tconv();
 hipError_t configure_attention(int Tq, int dh);
 struct AttnX3Args {
     const __bf16 *Qhi, *Qlo, *Khi, *Klo, *Vthi, *Vtlo;   // layouts above

@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -369,7 +370,6 @@ GemmX3Args sg_gemm_x3(const SgPl& A, const __bf16* Wh, const __bf16* Wl, int M, 
     g.Ahi = A.hi; g.Alo = A.lo; g.a_rows = (int)A.R;
     g.Whi = Wh; g.Wlo = Wl;
     g.M = M; g.N = N; g.Kp = Kp;
-    g.a_klog = -1;
     return g;
 }
 
@@ -554,11 +554,13 @@ int rgn_stgcn_finalize(rgn_stgcn_handle h) {
                     }
                     b1[(size_t)w * co + o] = (float)(s1[o] * acc + t1[o]);
                 }
-            // W2'[co][(dt, ci)] = s2[co] * Wt[co][ci][dt] (K = 9 co: tap-major, the order the shifted-row GEMM walks);  b2' = s2 * bt + t2
+            // W2'[co][(channel block, dt, channel in block)] = s2[co] * Wt[co][ci][dt] (K = 9 co in the order the shifted-row GEMM walks: taps innermost
+            // per 32-channel block, so that consecutive k-steps re-read one channel block of the activation 56 rows further on);  b2' = s2 * bt + t2
             std::vector<float> W2((size_t)co * 9 * co, 0.f), b2(co);
             for (int dt = 0; dt < 9; ++dt)
                 for (int o = 0; o < co; ++o)
-                    for (int q = 0; q < co; ++q) W2[(size_t)o * 9 * co + (size_t)dt * co + q] = (float)(s2[o] * (double)wt[((size_t)o * co + q) * 9 + dt]);
+                    for (int q = 0; q < co; ++q)
+                        W2[(size_t)o * 9 * co + ((size_t)(q / 32) * 9 + dt) * 32 + q % 32] = (float)(s2[o] * (double)wt[((size_t)o * co + q) * 9 + dt]);
             for (int o = 0; o < co; ++o) b2[o] = (float)(s2[o] * (double)bt[o] + t2[o]);
             if ((rc = sg_upload_ints(c, &b.nz_ptr, nzp)) || (rc = sg_upload_ints(c, &b.nz_v, nzv)) || (rc = sg_upload(c, &b.nz_a, nza)) ||
                 (rc = sg_upload_planes(c, W1, co, b.kp1, &b.W1h, &b.W1l)) || (rc = sg_upload(c, &b.b1, b1)) ||
@@ -617,6 +619,7 @@ int rgn_stgcn_finalize(rgn_stgcn_handle h) {
         if ((rc = sg_alloc(c, &c->rfull, cmax))) return rc;
         if ((rc = sg_alloc(c, &c->pooled, (size_t)c->cfg.max_batch * 256))) return rc;
         SG_HIP(c, configure_gemm_x3_sg());
+        SG_HIP(c, configure_sg_tconv());
         SG_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         SG_HIP(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
         SG_HIP(c, hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
@@ -675,16 +678,16 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
             }
             // 9x1 temporal convolution: ONE GEMM over K = 9 C_out; tap dt of k-block (dt, channel block) is a byte offset into g
             GemmX3Args g2 = sg_gemm_x3(gp, b.W2h, b.W2l, (int)rows_c, b.co, 9 * b.co);
-            int klog = 0;
-            while ((1 << klog) < b.co / 32) ++klog;
-            g2.a_klog = klog;
+            g2.a_taps = 9;
             for (int dt = 0; dt < 9; ++dt) {
                 if (!ipoly) g2.a_tap[dt] = (long long)(dt - 4) * V * 64;                                  // frame t + dt - 4
                 else if ((dt & 1) == 0) g2.a_tap[dt] = (long long)((dt - 4) / 2) * V * 64;                  // frame 2 t' + dt - 4 = even frame t' + (dt - 4) / 2
                 else g2.a_tap[dt] = ((long long)rows_c + (long long)((dt - 5) / 2) * V) * 64;               // ... = odd frame t' + (dt - 5) / 2
             }
             g2.C = c->conv; g2.ldc = b.co;
-            SG_HIP(c, launch_gemm_x3_sg(g2, s));
+            static const bool no_window = getenv("REGENNET_SG_NO_WINDOW") != nullptr;            // (tools: the row-shifted GEMM for every block)
+            if (!ipoly && !no_window && sg_tconv_supported(b.co, 9 * b.co, V)) SG_HIP(c, launch_sg_tconv(g2, V, s));   // activation window resident in LDS
+            else SG_HIP(c, launch_gemm_x3_sg(g2, s));
             if (b.res_conv) {   // strided 1x1 convolution of the block input: the even frames = region E of the polyphase planes (all rows for a stride-1 block)
                 GemmX3Args gr = sg_gemm_x3(xp, b.Wrh, b.Wrl, (int)rows_c, b.co, b.kpr);
                 gr.C = c->rfull; gr.ldc = b.co;
