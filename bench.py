@@ -59,6 +59,14 @@ def row_check(cfg, sd, a, dev, y, out, seed, lo, plan, fn_name, rows):
     return worst
 
 
+def _recogniser_graph(K, V):
+    """The reference recogniser's own normalised adjacency (3 x 56 x 56, 166 nonzeros; longest lists 1 / 6 / 1 per partition): the `A` buffer of the
+    reference model as committed with the golden vectors (tests/golden/stgcn.npz, written by tests/golden/make_golden.py)."""
+    A = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "stgcn.npz"))["A"].astype(np.float32)
+    assert A.shape == (K, V, V), A.shape
+    return A
+
+
 def bench_stgcn(a):
     """`--config stgcn`: the evaluation harness's recogniser (rgn_stgcn_forward; eval/a2m/recognition/models/stgcn.py:76-123) on N = --batch
     two-person motions of 60 and 150 frames, timed with the same barrier / synchronize bracket, HIP events around every forward, against the
@@ -70,11 +78,7 @@ def bench_stgcn(a):
     dev = torch.device("cuda:0")
     V, K, M, C = 56, 3, 2, 6
     rng = np.random.default_rng(0)
-    A = np.zeros((K, V, V), np.float32)                       # a chain skeleton: self, inward and outward partitions (stgcnutils/graph.py 'spatial')
-    A[0] = np.eye(V)
-    for v in range(1, V):
-        A[1, v, v - 1] = 0.5
-        A[2, v - 1, v] = 0.5
+    A = _recogniser_graph(K, V)
     sd = synth.make_stgcn_state_dict(A, num_class=26, seed=0)
     model = STGCN(in_channels=M * C, num_class=26, num_person=M, graph_args={"layout": "smplx", "strategy": "spatial"}, device=str(dev))
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
@@ -126,11 +130,7 @@ def bench_eval_pipeline(a):
     cfg = synth.get_config("ntu_action")
     model, diffusion = synth.build_model(cfg, synth.make_state_dict(cfg, seed=0), resp="ddim5", precision=a.precision, device=str(dev))
     V, K = 56, 3
-    A = np.zeros((K, V, V), np.float32)
-    A[0] = np.eye(V)
-    for v in range(1, V):
-        A[1, v, v - 1] = 0.5
-        A[2, v - 1, v] = 0.5
+    A = _recogniser_graph(K, V)
     rec = STGCN(in_channels=12, num_class=26, num_person=2, graph_args={"layout": "smplx", "strategy": "spatial"}, device=str(dev))
     rec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_stgcn_state_dict(A, num_class=26, seed=0).items()}, strict=True)
     rec.to(dev).eval()

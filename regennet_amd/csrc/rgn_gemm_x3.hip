@@ -27,6 +27,7 @@
 // barrier per step and the DMA issued between MFMA groups (ILV = true, tools only) halves the bytes per MFMA and its
 // loop runs at ~80 % MFMA occupancy, but at M = 15360 it leaves only 120-240 tiles for 256 CUs and nothing to hide its
 // 256 KiB-per-tile epilogue behind: end to end it only ties (70 vs 72 us on linear1), so it is not shipped.
+#include <algorithm>
 #include <cstdlib>
 #include "rgn_internal.h"
 
@@ -614,16 +615,285 @@ static hipError_t tconv_launch(const GemmX3Args& g, int V, hipStream_t s, bool c
 bool sg_tconv_supported(int N, int Kp, int V) { return (N == 64 || N == 128 || N == 256) && Kp == 9 * N && V % 4 == 0 && V >= 16 && V <= 64; }
 hipError_t launch_sg_tconv(const GemmX3Args& g, int V, hipStream_t s) {
     if (g.N == 64) return tconv_launch<64>(g, V, s, false);
-    static const bool wide = getenv("REGENNET_SG_TCONV_256") != nullptr;
-    if (g.N == 128 || !wide) return tconv_launch<128>(g, V, s, false);
-    return tconv_launch<256>(g, V, s, false);
+    return tconv_launch<128>(g, V, s, false);      // 256 channels: two 128-wide tiles (a 256-wide one needs 254 VGPRs + scratch: measured 1.5x slower)
 }
 hipError_t configure_sg_tconv() {
     GemmX3Args g{};
     hipError_t e = tconv_launch<64>(g, 0, nullptr, true);
     if (e != hipSuccess) return e;
-    e = tconv_launch<128>(g, 0, nullptr, true);
-    return e != hipSuccess ? e : tconv_launch<256>(g, 0, nullptr, true);
+    return tconv_launch<128>(g, 0, nullptr, true);
+}
+
+// ---- the ST-GCN kernels' epilogue: out = act(acc + bias[n] + addend), as fp32 [M, ldc] and / or split planes. The addend (a per-vertex bias row
+// (row % add_mod), or a full [M, ldadd] matrix) of the NEXT 32 x 32 tile is requested before this tile's stores are issued: vmcnt retires in order, so
+// a load queued behind stores would wait for their acknowledgements - 2 TN round trips to memory per workgroup tile in x3_epilogue's order.
+enum { SGE_VERTEX_BIAS = 1, SGE_RELU = 2, SGE_PLANES = 4 };   // addend row = row % add_mod | ReLU | output: split planes (else fp32 [M, ldc])
+template <int TM, int TN, bool CHECK, int MODE>
+__device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[TM][TN], int mw, int nw, int lane) {
+    const int l31 = lane & 31, kh = lane >> 5;
+    auto fetch = [&](int idx, float (&r)[16]) {
+        const int tb = idx / TM, ta = idx - tb * TM;
+        const int n = nw + tb * 32 + l31, mb = mw + ta * 32 + 4 * kh;
+        const bool n_ok = !CHECK || n < g.N;
+        if constexpr ((MODE & SGE_VERTEX_BIAS) != 0) {
+            const int base = (int)((unsigned)mb % (unsigned)g.add_mod);
+            const float* ap = g.add + n;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int rr = base + (i & 3) + 8 * (i >> 2);
+                rr = rr >= g.add_mod ? rr - g.add_mod : rr;
+                r[i] = n_ok ? ap[rr * g.ldadd] : 0.f;
+            }
+        } else {
+            const float b = n_ok ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) r[i] = b;
+        }
+    };
+    float nxt[16];
+    fetch(0, nxt);
+#pragma unroll
+    for (int idx = 0; idx < TM * TN; ++idx) {
+        const int tb = idx / TM, ta = idx - tb * TM;
+        const int n = nw + tb * 32 + l31, mb = mw + ta * 32 + 4 * kh;
+        const bool n_ok = !CHECK || n < g.N;
+        float r[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r[i] = nxt[i];
+        if (idx + 1 < TM * TN) fetch(idx + 1, nxt);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = acc[ta][tb][i] + r[i];
+            r[i] = (MODE & SGE_RELU) ? fmaxf(v, 0.f) : v;
+        }
+        if constexpr ((MODE & SGE_PLANES) == 0) {
+            float* cp = g.C + (size_t)mb * g.ldc + n;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ro = (i & 3) + 8 * (i >> 2);
+                if (!CHECK || (n_ok && mb + ro < g.M)) cp[(size_t)ro * g.ldc] = r[i];
+            }
+        } else if constexpr (!CHECK) {   // K32-blocked planes [N/32][c_rows][32]: a 32-column tile is one contiguous run of rows
+            // adjacent columns paired across lane ^ 1 -> packed bf16x2 stores: even lanes rows of registers 0..7, odd lanes those of registers 8..15
+            const size_t o = ((size_t)(n >> 5) * g.c_rows + mb) * 32 + (n & 30);
+            const bool odd = lane & 1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float mine = odd ? r[i + 8] : r[i], give = odd ? r[i] : r[i + 8];
+                const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+                const float c0 = odd ? got : mine, c1 = odd ? mine : got;
+                const int ii = odd ? i + 8 : i, ro = (ii & 3) + 8 * (ii >> 2);
+                const __bf16 h0 = (__bf16)c0, h1 = (__bf16)c1;
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                bf16x2 hv = {h0, h1}, lv = {(__bf16)(c0 - (float)h0), (__bf16)(c1 - (float)h1)};
+                *reinterpret_cast<bf16x2*>(g.Chi + o + ro * 32) = hv;
+                *reinterpret_cast<bf16x2*>(g.Clo + o + ro * 32) = lv;
+            }
+        } else {
+            const size_t o = ((size_t)(n >> 5) * g.c_rows + mb) * 32 + (n & 31);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ro = (i & 3) + 8 * (i >> 2);
+                if (n_ok && mb + ro < g.M) {
+                    const __bf16 h = (__bf16)r[i];
+                    g.Chi[o + ro * 32] = h;
+                    g.Clo[o + ro * 32] = (__bf16)(r[i] - (float)h);
+                }
+            }
+        }
+    }
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_any() {   // (the six-bit counter saturates at 63)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : N) : "memory");
+}
+
+// ---- graph aggregation + 1 x 1 convolution of an ST-GCN block as ONE kernel (rgn_stgcn.hip) -------------------------------------------------------
+// z[(frame, w), (k, ci)] = sum_v A'_k[v, w] x[(frame, v), ci] followed by z . W1'^T was two launches with z (3 x the activation) written and read back:
+// 24 of the 52 bytes per activation element a block moved, both kernels fabric-bound (the 64-channel GEMM kept its matrix pipe 13 % busy). Here a
+// workgroup holds the rows [m0 - V, m0 + 256 + V) of ONE 32-channel block of x in LDS (every frame a tile row belongs to lies inside) and each wave
+// builds the operand fragments of its own 32 rows in registers, in the fragment layout itself: lane (row, k half) sums a_j x[frame base + v_j] over
+// the nonzeros of A'_k[:, w(row)] for its 8 channels in fp32, splits the sum into bf16 hi / lo and feeds three MFMAs per weight fragment - the
+// arithmetic of k_sg_agg + k_gemm_x3 to the bit, z never exists. K order: (channel block, k); the weight k-block of (cb, k) is k C/32 + cb. Eight waves
+// of 32 rows x BN columns (no wave repeats another's aggregation); the next channel block's window arrives a third per k-step beside the weight tile.
+// PERSISTENT: a workgroup walks tiles blockIdx, + gridDim, ... as one k-step stream - the next tile's first window and weight tile are in flight under
+// the last k-steps of this one, and its first wait leaves this tile's stores outstanding (a tile is only 6 - 24 k-steps: as one workgroup per tile,
+// launch + first window + store acknowledgements were 25 - 45 % of the kernel with the matrix pipe and the fabric taking turns idling).
+template <int BN>
+__global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int ntiles, int V, int KP, unsigned slot_k, const int* __restrict__ sl_v, const float* __restrict__ sl_a) {
+    constexpr int BM = 256, NT = 512, TN = BN / 32, NS = 8;
+    constexpr int W_BYTES = BN * 64, W_STAGE = 2 * W_BYTES;
+    constexpr int W_IT = BN * 8 / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int WRX = BM + 2 * V, XP = WRX * 64, XW = 2 * XP;      // window rows, bytes per plane, bytes per window (hi | lo)
+    char* const wst = smem + 2 * XW;
+    int* const t_v = reinterpret_cast<int*>(wst + 2 * W_STAGE);   // the slot tables [V][8]
+    float* const t_a = reinterpret_cast<float*>(t_v + V * NS);
+    for (int i = tid; i < V * NS; i += NT) {
+        t_v[i] = sl_v[i];
+        t_a[i] = sl_a[i];
+    }
+    __syncthreads();
+    const int ncb = g.Kp / (32 * KP);
+    const long long row_hi = (long long)g.M + 4LL * V - 1;       // (the planes carry 4 V guard rows at both ends)
+    const char* const a_pl[2] = {reinterpret_cast<const char*>(g.Ahi), reinterpret_cast<const char*>(g.Alo)};
+    const char* const w_pl[2] = {reinterpret_cast<const char*>(g.Whi), reinterpret_cast<const char*>(g.Wlo)};
+    const int npc = (WRX + 15) / 16, npieces = 2 * npc;          // 16-row pieces of a window: hi plane, then lo plane
+    const int ppk = (npieces + 8 * KP - 1) / (8 * KP);           // pieces per wave per k-step
+    auto x_piece = [&](int m0t, int cb, int p, int buf) {        // piece p of the window of (tile rows m0t, channel block cb) into window buffer buf
+        const int pl = p >= npc ? 1 : 0, r0 = (p - pl * npc) * 16, r = r0 + (lane >> 2);
+        if (r < WRX) {
+            long long gr = (long long)m0t - V + r;
+            gr = gr > row_hi ? row_hi : gr;
+            const char* src = a_pl[pl] + ((long long)cb * g.a_rows + gr) * 64 + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)src, (RGN_AS3 void*)(smem + buf * XW + pl * XP + r0 * 64), 16, 0, 0);
+        }
+    };
+    auto w_tile = [&](int n0t, int kb, char* stage) {
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int q = it * NT + tid, pl = (it * NT + (tid & ~63)) / (BN * 4), qq = q - pl * (BN * 4), r = qq >> 2, c = (qq & 3) ^ ((r >> 2) & 3);
+            int n = n0t + r;
+            n = n < g.N ? n : g.N - 1;
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(w_pl[pl] + ((size_t)kb * g.N + n) * 64 + c * 16),
+                                             (RGN_AS3 void*)(stage + pl * W_BYTES + (it * NT + (tid & ~63) - pl * (BN * 4)) * 16), 16, 0, 0);
+        }
+    };
+    int w_off[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int rr = t * 32 + l31;
+        w_off[t] = rr * 64 + ((kh ^ ((rr >> 2) & 3)) << 4);      // k half ks = 0; ks = 1 is the chunk two further on: offset ^ 32
+    }
+    const int r = wave * 32 + l31;
+
+    int tile = blockIdx.x;
+    int m0 = (tile / nbx) * BM, n0 = (tile % nbx) * BN;
+    for (int p = wave; p < npieces; p += 8) x_piece(m0, 0, p, 0);
+    w_tile(n0, 0, wst);
+    unsigned gstep = 0, widx = 0;                                // k-steps / windows consumed so far: stage gstep & 1, window buffer widx & 1
+    bool stores_behind = false;                                  // the previous tile's stores were issued after everything the next wait is for
+    while (true) {
+        // This lane's row keeps its vertex w for the whole tile, so its lists do too: NS slots of (source row in the window, coefficient), slot s serving
+        // partition (slot_k >> 4 s) & 15 - a partition owns as many slots as its longest list; shorter lists are padded with (own row, 0).
+        const int wv = (int)((unsigned)(m0 + r) % (unsigned)V);
+        const int fbase = V + r - wv;                            // window row of vertex 0 of this row's frame
+        int so[NS];
+        float sa[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int src = fbase + t_v[wv * NS + s];
+            so[s] = src * 64 + ((kh ^ ((src >> 2) & 3)) << 4);
+            sa[s] = t_a[wv * NS + s];
+        }
+        unsigned live = 0;                                       // slots that carry a coefficient for at least one row of this wave (a hub vertex's long list
+#pragma unroll                                                   //  pads everyone else's: most waves skip most of its slots)
+        for (int s = 0; s < NS; ++s) live |= (__builtin_amdgcn_ballot_w64(sa[s] != 0.f) != 0ull ? 1u : 0u) << s;
+        const int tnext = tile + (int)gridDim.x;
+        const bool more = tnext < ntiles;
+        const int m0n = (tnext / nbx) * BM, n0n = (tnext % nbx) * BN;
+        f32x16 acc[1][TN];
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[0][b][i] = 0.f;
+
+        for (int cb = 0; cb < ncb; ++cb, ++widx) {
+            const char* xw = smem + (widx & 1) * XW;
+            const bool wlast = cb + 1 == ncb;
+            for (int k = 0; k < KP; ++k, ++gstep) {
+                if (stores_behind) wait_vmcnt_any<16 * TN>();    // the DMA of this k-step is older than the 16 TN stores of the tile just written
+                else wait_vmcnt<0>();
+                stores_behind = false;
+                __builtin_amdgcn_s_barrier();                    // the tile of this k-step (and, at k = 0, the window) is in LDS; the previous k-step is read out
+                {
+                    const bool klast = k + 1 == KP;
+                    if (!(klast && wlast)) w_tile(n0, klast ? cb + 1 : (k + 1) * ncb + cb, wst + ((gstep + 1) & 1) * W_STAGE);
+                    else if (more) w_tile(n0n, 0, wst + ((gstep + 1) & 1) * W_STAGE);
+                }
+                if (!wlast || more)
+                    for (int i = 0; i < ppk; ++i) {
+                        const int p = (k * ppk + i) * 8 + wave;
+                        if (p < npieces) x_piece(wlast ? m0n : m0, wlast ? 0 : cb + 1, p, (widx + 1) & 1);
+                    }
+                const char* wsb = wst + (gstep & 1) * W_STAGE;
+                float z[2][8];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) z[ks][e] = 0.f;
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    if ((int)((slot_k >> (4 * s)) & 15u) == k && ((live >> s) & 1u)) {     // (uniform)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const int o = so[s] ^ (32 * ks);
+                            const bf16x8 h = *reinterpret_cast<const bf16x8*>(xw + o), l = *reinterpret_cast<const bf16x8*>(xw + XP + o);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) z[ks][e] = fmaf(sa[s], (float)h[e] + (float)l[e], z[ks][e]);
+                        }
+                    }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 ah, al;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        ah[e] = (__bf16)z[ks][e];
+                        al[e] = (__bf16)(z[ks][e] - (float)ah[e]);
+                    }
+#pragma unroll
+                    for (int tb = 0; tb < TN; ++tb) {
+                        const int o = w_off[tb] ^ (32 * ks);
+                        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wsb + o), wl = *reinterpret_cast<const bf16x8*>(wsb + W_BYTES + o);
+                        acc[0][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[0][tb], 0, 0, 0);
+                        acc[0][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[0][tb], 0, 0, 0);
+                        acc[0][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[0][tb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+        if (interior) {
+            sg_epilogue<1, TN, false, SGE_VERTEX_BIAS | SGE_RELU | SGE_PLANES>(g, acc, m0 + wave * 32, n0, lane);
+            stores_behind = true;                                // (exactly 16 TN stores, all issued after the next k-step's DMA)
+        } else sg_epilogue<1, TN, true, SGE_VERTEX_BIAS | SGE_RELU | SGE_PLANES>(g, acc, m0 + wave * 32, n0, lane);
+        if (!more) break;
+        tile = tnext; m0 = m0n; n0 = n0n;
+    }
+}
+static int gcn_lds_bytes(int BN, int V) { return 2 * 2 * (256 + 2 * V) * 64 + 2 * 2 * BN * 64 + 2 * 4 * 8 * V; }
+bool sg_gcn_supported(int N, int Kp, int V, int KP) {
+    return (N == 64 || N == 128 || N == 256) && KP >= 1 && KP <= 8 && Kp % (32 * KP) == 0 && V % 4 == 0 && V >= 16 && V <= 64 && gcn_lds_bytes(64, V) <= 160 * 1024;
+}
+static int sg_cu_count() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus;
+    }();
+    return n;
+}
+template <int BN>
+static hipError_t gcn_launch(const GemmX3Args& g, int V, int KP, unsigned slot_k, const int* sl_v, const float* sl_a, hipStream_t s) {
+    const int nbx = (g.N + BN - 1) / BN, ntiles = nbx * ((g.M + 255) / 256);
+    hipLaunchKernelGGL((k_sg_gcn<BN>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), gcn_lds_bytes(BN, V), s, g, nbx, ntiles, V, KP, slot_k, sl_v, sl_a);
+    return hipGetLastError();
+}
+hipError_t launch_sg_gcn(const GemmX3Args& g, int V, int KP, unsigned slot_k, const int* sl_v, const float* sl_a, hipStream_t s) {
+    static const char* narrow = getenv("REGENNET_SG_GCN_BN");    // (tools: cap the tile width)
+    const int cap = narrow ? atoi(narrow) : 256;
+    if (g.N >= 256 && cap >= 256 && gcn_lds_bytes(256, V) <= 160 * 1024) return gcn_launch<256>(g, V, KP, slot_k, sl_v, sl_a, s);
+    if (g.N >= 128 && cap >= 128 && gcn_lds_bytes(128, V) <= 160 * 1024) return gcn_launch<128>(g, V, KP, slot_k, sl_v, sl_a, s);
+    return gcn_launch<64>(g, V, KP, slot_k, sl_v, sl_a, s);
+}
+hipError_t configure_sg_gcn() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 // variant 0 = 128x128 / 4 waves (two workgroups per CU): the default. variant 1 = 256x256 / 8 waves / interleaved DMA (one

@@ -322,6 +322,12 @@ hipError_t configure_gemm_x3_sg();
 bool sg_tconv_supported(int N, int Kp, int V);
 hipError_t launch_sg_tconv(const GemmX3Args& g, int V, hipStream_t s);
 hipError_t configure_sg_tconv();
+// ... and graph aggregation + 1 x 1 convolution as one kernel: A = the block's INPUT planes, Kp = KP x C_in. The nonzero lists of A'_k[:, w] come as 8
+// slots per vertex, sl_v / sl_a [V][8] (source vertex, coefficient); slot s serves partition (slot_k >> 4 s) & 15 (15: unused) and a list shorter than
+// its partition's slot count is padded with (w, 0)
+bool sg_gcn_supported(int N, int Kp, int V, int KP);
+hipError_t launch_sg_gcn(const GemmX3Args& g, int V, int KP, unsigned slot_k, const int* sl_v, const float* sl_a, hipStream_t s);
+hipError_t configure_sg_gcn();
 hipError_t configure_attention(int Tq, int dh);
 struct AttnX3Args {
     const __bf16 *Qhi, *Qlo, *Khi, *Klo, *Vthi, *Vtlo;   // layouts above

@@ -42,6 +42,9 @@ struct SgBlockDef { int ci, co, stride; bool res_conv, res_id; };
 
 struct SgBlock {
     int ci = 0, co = 0, stride = 1, kp1 = 0, kpr = 0;
+    unsigned slot_k = 0;                             // the same lists as 8 slots per vertex for k_sg_gcn (rgn_internal.h); sl_v == nullptr: they do not fit
+    int* sl_v = nullptr;
+    float* sl_a = nullptr;
     bool res_conv = false, res_id = false;
     int *nz_ptr = nullptr, *nz_v = nullptr;          // nonzeros of A'_k[:, w]: list (k V + w) = [nz_ptr[k V + w], nz_ptr[k V + w + 1])
     float* nz_a = nullptr;
@@ -562,6 +565,32 @@ int rgn_stgcn_finalize(rgn_stgcn_handle h) {
                     for (int q = 0; q < co; ++q)
                         W2[(size_t)o * 9 * co + ((size_t)(q / 32) * 9 + dt) * 32 + q % 32] = (float)(s2[o] * (double)wt[((size_t)o * co + q) * 9 + dt]);
             for (int o = 0; o < co; ++o) b2[o] = (float)(s2[o] * (double)bt[o] + t2[o]);
+            {   // slot form of the lists: partition k owns as many slots as its longest list
+                std::vector<int> cnt(K, 0);
+                int total = 0;
+                for (int k = 0; k < K; ++k) {
+                    for (int w = 0; w < V; ++w) cnt[k] = std::max(cnt[k], nzp[(size_t)k * V + w + 1] - nzp[(size_t)k * V + w]);
+                    total += cnt[k];
+                }
+                if (total <= 8 && K <= 8) {
+                    std::vector<int> sv((size_t)V * 8);
+                    std::vector<float> sa((size_t)V * 8, 0.f);
+                    b.slot_k = 0xFFFFFFFFu;
+                    for (int w = 0; w < V; ++w) {
+                        int sidx = 0;
+                        for (int k = 0; k < K; ++k)
+                            for (int i = 0; i < cnt[k]; ++i, ++sidx) {
+                                const int j = nzp[(size_t)k * V + w] + i;
+                                const bool real = j < nzp[(size_t)k * V + w + 1];
+                                sv[(size_t)w * 8 + sidx] = real ? nzv[j] : w;
+                                sa[(size_t)w * 8 + sidx] = real ? nza[j] : 0.f;
+                                b.slot_k = (b.slot_k & ~(15u << (4 * sidx))) | ((unsigned)k << (4 * sidx));
+                            }
+                        for (; sidx < 8; ++sidx) sv[(size_t)w * 8 + sidx] = w;
+                    }
+                    if ((rc = sg_upload_ints(c, &b.sl_v, sv)) || (rc = sg_upload(c, &b.sl_a, sa))) return rc;
+                }
+            }
             if ((rc = sg_upload_ints(c, &b.nz_ptr, nzp)) || (rc = sg_upload_ints(c, &b.nz_v, nzv)) || (rc = sg_upload(c, &b.nz_a, nza)) ||
                 (rc = sg_upload_planes(c, W1, co, b.kp1, &b.W1h, &b.W1l)) || (rc = sg_upload(c, &b.b1, b1)) ||
                 (rc = sg_upload_planes(c, W2, co, 9 * co, &b.W2h, &b.W2l)) || (rc = sg_upload(c, &b.b2, b2)))
@@ -620,6 +649,7 @@ int rgn_stgcn_finalize(rgn_stgcn_handle h) {
         if ((rc = sg_alloc(c, &c->pooled, (size_t)c->cfg.max_batch * 256))) return rc;
         SG_HIP(c, configure_gemm_x3_sg());
         SG_HIP(c, configure_sg_tconv());
+        SG_HIP(c, configure_sg_gcn());
         SG_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         SG_HIP(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
         SG_HIP(c, hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
@@ -660,12 +690,17 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
             const size_t rows = phys(T, ipoly), rows_c = (size_t)NM * Tpi * V, rows_o = phys(To, opoly);
             const SgPl xp = planes(*x, rows), zp = planes(c->z, rows), gp = planes(c->g, rows), xo = planes(*xn, rows_o);
             // graph aggregation on the input channels (sparse A'), then the 1x1 convolution over K C_in (+ folded BN, vertex bias, ReLU): frame-local, any row order
-            if (b.ci % 32 == 0) hipLaunchKernelGGL(k_sg_agg, dim3((unsigned)((rows * 4 + 255) / 256), (unsigned)(K * (b.ci / 32))), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
-            else hipLaunchKernelGGL(k_sg_agg_small, blocks1d(rows), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
-            GemmX3Args g1 = sg_gemm_x3(zp, b.W1h, b.W1l, (int)rows, b.co, b.kp1);
+            static const bool no_fuse = getenv("REGENNET_SG_NO_GCN_FUSE") != nullptr;             // (tools: aggregation and GEMM as two launches for every block)
+            const bool fused = !no_fuse && b.sl_v && b.ci % 32 == 0 && b.kp1 == K * b.ci && sg_gcn_supported(b.co, b.kp1, V, K);
+            GemmX3Args g1 = sg_gemm_x3(fused ? xp : zp, b.W1h, b.W1l, (int)rows, b.co, b.kp1);
             g1.add = b.b1; g1.ldadd = b.co; g1.add_mod = V; g1.act = 3;                          // + b1'[row % V], ReLU
             g1.Chi = gp.hi; g1.Clo = gp.lo; g1.c_rows = (int)gp.R;
-            SG_HIP(c, launch_gemm_x3_sg(g1, s));
+            if (fused) SG_HIP(c, launch_sg_gcn(g1, V, K, b.slot_k, b.sl_v, b.sl_a, s));   // z is formed in registers, fragment by fragment
+            else {
+                if (b.ci % 32 == 0) hipLaunchKernelGGL(k_sg_agg, dim3((unsigned)((rows * 4 + 255) / 256), (unsigned)(K * (b.ci / 32))), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
+                else hipLaunchKernelGGL(k_sg_agg_small, blocks1d(rows), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
+                SG_HIP(c, launch_gemm_x3_sg(g1, s));
+            }
             // pad frames and guard rows of g back to zero: what the temporal taps read beyond a sequence
             auto zero = [&](long long base, int Tr, int Tp, int lead, int trail) {
                 const size_t n = ((size_t)NM * (Tp - Tr) * V + (size_t)lead + (size_t)trail) * (b.co / 32) * 4;
