@@ -473,165 +473,19 @@ hipError_t configure_gemm_x3_sg() {
     return e != hipSuccess ? e : sg_launch<128, 2>(g, nullptr, true);
 }
 
-// ---- the 9 x 1 temporal convolution of a stride-1 ST-GCN block with the activation WINDOW resident in LDS (rgn_stgcn.hip) ---------------------
-// As a row-shifted GEMM (above) every tap DMAs its own 256-row slice of the activation - 9 x 32 KB per channel block through the ~20 B/clk L2 -> LDS
-// path beside 9 x 16 KB of weights: 48 KB per k-step against 2304 cycles of MFMA (PMC: matrix pipe 0.35 busy, and NOT because of the fabric - with the
-// taps innermost the L2 hit rate rose 0.61 -> 0.76 and the HBM fetch halved while the kernel got 4 % slower). Here the 256 + 8 V rows a tile needs of
-// one channel block sit in LDS ONCE ([row][64 B] x {hi, lo}, 88 KiB at V = 56) and the nine taps read their fragments V rows apart: per k-step the
-// path carries the weight tile + V rows of the NEXT channel block's window (7 KB), which overwrite the V rows the finished tap no longer needs -
-// tap dt reads window rows [dt V, dt V + 256), so after it only rows >= (dt + 1) V are live; the top 256 rows of a window are fetched during its
-// own taps 0-3 (first needed by tap 4). K order: k-block kt = (channel block kt / 9, tap kt % 9).
-template <int BN>
-__global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int nby, int V) {
-    constexpr int BM = 256, NT = 512, TAPS = 9;
-    constexpr int WN = BN >= 128 ? 2 : 1, WM = 8 / WN;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int W_BYTES = BN * 64, W_STAGE = 2 * W_BYTES;      // one plane tile; a stage = hi | lo
-    constexpr int W_IT = BN * 8 / NT;                            // DMA instructions per thread per weight tile (hi + lo): 1 / 2 / 4
-    static_assert(TM >= 1 && TN >= 1 && BN * 8 % NT == 0 && (BN * 4) % 64 == 0, "tile shape");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, kh = lane >> 5;
-    const int nwg = nbx * nby, bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-    const int vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int m0 = (vid / nbx) * BM, n0 = (vid % nbx) * BN;
-    const int WR = BM + 8 * V, A_PLANE = WR * 64;                // window rows (a multiple of 16: V even)
-    char* const wst = smem + 2 * A_PLANE;                        // weight stages behind the two window planes
-    const int ncb = g.Kp / (32 * TAPS), nk = ncb * TAPS;
-    const long long row_lo = -4LL * V, row_hi = (long long)g.M + 4LL * V - 1;   // the planes' zero guard rows bound what a window may touch
-    const char* const a_pl[2] = {reinterpret_cast<const char*>(g.Ahi), reinterpret_cast<const char*>(g.Alo)};
-    const char* const w_pl[2] = {reinterpret_cast<const char*>(g.Whi), reinterpret_cast<const char*>(g.Wlo)};
-
-    // one 16-row piece (1 KiB per plane) of channel block cb's window, rows [r0, r0 + 16) limited to rows < rend, into its place in plane pl
-    auto a_piece = [&](int cb, int pl, int r0, int rend) {
-        const int r = r0 + (lane >> 2);
-        if (r < rend) {
-            long long gr = (long long)m0 - 4LL * V + r;
-            gr = gr < row_lo ? row_lo : (gr > row_hi ? row_hi : gr);
-            const char* src = a_pl[pl] + ((long long)cb * g.a_rows + gr) * 64 + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
-            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)src, (RGN_AS3 void*)(smem + pl * A_PLANE + r0 * 64), 16, 0, 0);
-        }
-    };
-    unsigned w_src[W_IT];
-    int w_dst[W_IT];
-#pragma unroll
-    for (int it = 0; it < W_IT; ++it) {
-        const int q = it * NT + tid, pl = q / (BN * 4), qq = q - pl * (BN * 4), r = qq >> 2, c = (qq & 3) ^ ((r >> 2) & 3);
-        int n = n0 + r;
-        n = n < g.N ? n : g.N - 1;
-        w_src[it] = (unsigned)n * 64u + c * 16u;
-        w_dst[it] = pl * W_BYTES + (it * NT + (tid & ~63)) * 16 - pl * (BN * 4) * 16;       // wave-uniform: this wave's 1 KiB of the stage
-    }
-    auto w_piece = [&](int it, int kt, char* stage) {
-        const int pl = (it * NT + (tid & ~63)) / (BN * 4);
-        __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(w_pl[pl] + (size_t)kt * g.N * 64 + w_src[it]), (RGN_AS3 void*)(stage + w_dst[it]), 16, 0, 0);
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-    int w_off[TN][2];
-#pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        const int rr = wn * (BN / WN) + t * 32 + l31;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) w_off[t][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
-    }
-    const int arow0 = wm * (BM / WM) + l31;
-    auto mma3 = [&](f32x16& c, const bf16x8& a_h, const bf16x8& a_l, const bf16x8& w_h, const bf16x8& w_l) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, w_h, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_l, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_h, c, 0, 0, 0);
-    };
-
-    // prologue: rows [0, 8 V) of channel block 0's window (its top 256 rows follow under taps 0-3 like every window's) and the first weight tile
-    {
-        const int np = 8 * V / 16;                               // pieces per plane
-        for (int q = wave; q < 2 * np; q += 8) a_piece(0, q / np, (q % np) * 16, 8 * V);
-#pragma unroll
-        for (int it = 0; it < W_IT; ++it) w_piece(it, 0, wst);
-    }
-    for (int cb = 0; cb < ncb; ++cb) {
-#pragma unroll
-        for (int dt = 0; dt < TAPS; ++dt) {
-            const int kt = cb * TAPS + dt;
-            wait_vmcnt<0>();                                     // everything this thread requested up to the last k-step has landed ...
-            __builtin_amdgcn_s_barrier();                        // ... everyone's has, and everyone is done reading k-step kt - 1
-            const char* wsb = wst + (kt & 1) * W_STAGE;
-            // fragments: the tap's rows start dt V further down the window (the 16-byte chunk swizzle follows the LDS row)
-            bf16x8 ah[2][TM], al[2][TM], wh[2], wl[2];
-            auto fetch = [&](int grp) {                          // grp = ks * TN + tb
-                const int ks = grp / TN, tb = grp % TN;
-                if (tb == 0) {
-#pragma unroll
-                    for (int t = 0; t < TM; ++t) {
-                        const int rr = arow0 + t * 32 + dt * V;
-                        const int o = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
-                        ah[ks][t] = *reinterpret_cast<const bf16x8*>(smem + o);
-                        al[ks][t] = *reinterpret_cast<const bf16x8*>(smem + A_PLANE + o);
-                    }
-                }
-                wh[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + w_off[tb][ks]);
-                wl[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + W_BYTES + w_off[tb][ks]);
-            };
-            fetch(0);
-#pragma unroll
-            for (int grp = 0; grp < 2 * TN; ++grp) {
-                if (grp + 1 < 2 * TN) fetch(grp + 1);
-#pragma unroll
-                for (int ta = 0; ta < TM; ++ta) mma3(acc[ta][grp % TN], ah[grp / TN][ta], al[grp / TN][ta], wh[grp & 1], wl[grp & 1]);
-                if (grp == 0) {
-                    // the path's load for this k-step, behind the first MFMA group: next weight tile, the dead strip's successor, the window's top quarter
-                    if (kt + 1 < nk) {
-#pragma unroll
-                        for (int it = 0; it < W_IT; ++it) w_piece(it, kt + 1, wst + ((kt + 1) & 1) * W_STAGE);
-                    }
-                    if (dt >= 1 && cb + 1 < ncb) a_piece(cb + 1, wave >> 2, (dt - 1) * V + 16 * (wave & 3), dt * V);   // V <= 64 rows: four pieces per plane
-                    if (dt < 4) a_piece(cb, wave >> 2, 8 * V + 64 * dt + 16 * (wave & 3), WR);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
-    if (interior) x3_epilogue<TM, TN, 2, false>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
-    else x3_epilogue<TM, TN, 2, true>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
-}
-template <int BN>
-static hipError_t tconv_launch(const GemmX3Args& g, int V, hipStream_t s, bool configure_only) {
-    const int lds = 2 * (256 + 8 * 64) * 64 + 2 * 2 * BN * 64;      // (sized for V <= 64)
-    if (configure_only) return hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_tconv<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    const int nbx = (g.N + BN - 1) / BN, nby = (g.M + 255) / 256;
-    hipLaunchKernelGGL((k_sg_tconv<BN>), dim3(nbx * nby), dim3(512), 2 * (256 + 8 * V) * 64 + 2 * 2 * BN * 64, s, g, nbx, nby, V);
-    return hipGetLastError();
-}
-bool sg_tconv_supported(int N, int Kp, int V) { return (N == 64 || N == 128 || N == 256) && Kp == 9 * N && V % 4 == 0 && V >= 16 && V <= 64; }
-hipError_t launch_sg_tconv(const GemmX3Args& g, int V, hipStream_t s) {
-    if (g.N == 64) return tconv_launch<64>(g, V, s, false);
-    return tconv_launch<128>(g, V, s, false);      // 256 channels: two 128-wide tiles (a 256-wide one needs 254 VGPRs + scratch: measured 1.5x slower)
-}
-hipError_t configure_sg_tconv() {
-    GemmX3Args g{};
-    hipError_t e = tconv_launch<64>(g, 0, nullptr, true);
-    if (e != hipSuccess) return e;
-    return tconv_launch<128>(g, 0, nullptr, true);
-}
-
-// ---- the ST-GCN kernels' epilogue: out = act(acc + bias[n] + addend), as fp32 [M, ldc] and / or split planes. The addend (a per-vertex bias row
-// (row % add_mod), or a full [M, ldadd] matrix) of the NEXT 32 x 32 tile is requested before this tile's stores are issued: vmcnt retires in order, so
-// a load queued behind stores would wait for their acknowledgements - 2 TN round trips to memory per workgroup tile in x3_epilogue's order.
-enum { SGE_VERTEX_BIAS = 1, SGE_RELU = 2, SGE_PLANES = 4 };   // addend row = row % add_mod | ReLU | output: split planes (else fp32 [M, ldc])
+// ---- the ST-GCN kernels' epilogue: out = act(acc + bias + addend), as fp32 [M, ldc] or as split planes. MODE (compile time):
+//   SGE_VERTEX_BIAS  the bias is a per-vertex row add[(row % add_mod)][n] (the graph convolution's, rgn_stgcn.hip); else bias[n]
+//   SGE_RES_PLANES   + the residual Rhi + Rlo (split planes [N/32][r_rows][32], the block's input: identity shortcut)
+//   SGE_RELU | SGE_PLANES (output as split planes, else fp32)
+// What a 32 x 32 tile needs from memory is requested one tile AHEAD of its use: vmcnt retires in order, so a load queued behind the previous tile's
+// stores would wait for their acknowledgements - 2 TM TN round trips to memory per workgroup tile in x3_epilogue's order.
+enum { SGE_VERTEX_BIAS = 1, SGE_RELU = 2, SGE_PLANES = 4, SGE_RES_PLANES = 8 };
 template <int TM, int TN, bool CHECK, int MODE>
 __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[TM][TN], int mw, int nw, int lane) {
     const int l31 = lane & 31, kh = lane >> 5;
-    auto fetch = [&](int idx, float (&r)[16]) {
+    const bool odd = lane & 1;
+    constexpr int NF = (MODE & (SGE_VERTEX_BIAS | SGE_RES_PLANES)) ? 16 : 1;
+    auto fetch = [&](int idx, unsigned (&f)[NF]) {
         const int tb = idx / TM, ta = idx - tb * TM;
         const int n = nw + tb * 32 + l31, mb = mw + ta * 32 + 4 * kh;
         const bool n_ok = !CHECK || n < g.N;
@@ -642,15 +496,23 @@ __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
             for (int i = 0; i < 16; ++i) {
                 int rr = base + (i & 3) + 8 * (i >> 2);
                 rr = rr >= g.add_mod ? rr - g.add_mod : rr;
-                r[i] = n_ok ? ap[rr * g.ldadd] : 0.f;
+                f[i] = n_ok ? __builtin_bit_cast(unsigned, ap[rr * g.ldadd]) : 0u;
+            }
+        } else if constexpr ((MODE & SGE_RES_PLANES) != 0) {
+            // column pairs (n & ~1, + 1) as one 4-byte load: even lanes the rows of registers 0..7, odd lanes those of registers 8..15; f[0..7] hi, f[8..15] lo
+            const size_t o = ((size_t)(n >> 5) * g.r_rows + mb) * 32 + (n & 30);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ii = odd ? i + 8 : i, ro = (ii & 3) + 8 * (ii >> 2);
+                const bool ok = !CHECK || (n_ok && mb + ro < g.M);
+                f[i] = ok ? *reinterpret_cast<const unsigned*>(g.Rhi + o + ro * 32) : 0u;
+                f[8 + i] = ok ? *reinterpret_cast<const unsigned*>(g.Rlo + o + ro * 32) : 0u;
             }
         } else {
-            const float b = n_ok ? g.bias[n] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) r[i] = b;
+            f[0] = (g.bias && n_ok) ? __builtin_bit_cast(unsigned, g.bias[n]) : 0u;
         }
     };
-    float nxt[16];
+    unsigned nxt[NF];
     fetch(0, nxt);
 #pragma unroll
     for (int idx = 0; idx < TM * TN; ++idx) {
@@ -658,13 +520,32 @@ __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
         const int n = nw + tb * 32 + l31, mb = mw + ta * 32 + 4 * kh;
         const bool n_ok = !CHECK || n < g.N;
         float r[16];
+        if constexpr ((MODE & SGE_VERTEX_BIAS) != 0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) r[i] = nxt[i];
+            for (int i = 0; i < 16; ++i) r[i] = acc[ta][tb][i] + __builtin_bit_cast(float, nxt[i]);
+        } else if constexpr ((MODE & SGE_RES_PLANES) != 0) {
+            const float b = (g.bias && n_ok) ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                // the partner lane (lane ^ 1) holds this column's values for the other eight rows
+                const unsigned ph = nxt[i], pl = nxt[8 + i];
+                const unsigned qh = (unsigned)__builtin_amdgcn_mov_dpp((int)ph, 0xB1, 0xf, 0xf, true), ql = (unsigned)__builtin_amdgcn_mov_dpp((int)pl, 0xB1, 0xf, 0xf, true);
+                const unsigned mh = odd ? (ph & 0xffff0000u) : (ph << 16), ml = odd ? (pl & 0xffff0000u) : (pl << 16);   // own rows: register ii = odd ? i + 8 : i
+                const unsigned oh = odd ? (qh & 0xffff0000u) : (qh << 16), ol = odd ? (ql & 0xffff0000u) : (ql << 16);   // the partner's rows
+                const float mine = __builtin_bit_cast(float, mh) + __builtin_bit_cast(float, ml), other = __builtin_bit_cast(float, oh) + __builtin_bit_cast(float, ol);
+                const int im = odd ? i + 8 : i, io = odd ? i : i + 8;
+                r[im] = (acc[ta][tb][im] + b) + mine;
+                r[io] = (acc[ta][tb][io] + b) + other;
+            }
+        } else {
+            const float b = __builtin_bit_cast(float, nxt[0]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) r[i] = acc[ta][tb][i] + b;
+        }
         if (idx + 1 < TM * TN) fetch(idx + 1, nxt);
+        if constexpr ((MODE & SGE_RELU) != 0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float v = acc[ta][tb][i] + r[i];
-            r[i] = (MODE & SGE_RELU) ? fmaxf(v, 0.f) : v;
+            for (int i = 0; i < 16; ++i) r[i] = fmaxf(r[i], 0.f);
         }
         if constexpr ((MODE & SGE_PLANES) == 0) {
             float* cp = g.C + (size_t)mb * g.ldc + n;
@@ -676,7 +557,6 @@ __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
         } else if constexpr (!CHECK) {   // K32-blocked planes [N/32][c_rows][32]: a 32-column tile is one contiguous run of rows
             // adjacent columns paired across lane ^ 1 -> packed bf16x2 stores: even lanes rows of registers 0..7, odd lanes those of registers 8..15
             const size_t o = ((size_t)(n >> 5) * g.c_rows + mb) * 32 + (n & 30);
-            const bool odd = lane & 1;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float mine = odd ? r[i + 8] : r[i], give = odd ? r[i] : r[i + 8];
@@ -706,6 +586,191 @@ __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_any() {   // (the six-bit counter saturates at 63)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : N) : "memory");
+}
+static int sg_cu_count() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus;
+    }();
+    return n;
+}
+
+// ---- the 9 x 1 temporal convolution of a stride-1 ST-GCN block with the activation WINDOW resident in LDS (rgn_stgcn.hip) ---------------------
+// As a row-shifted GEMM (above) every tap DMAs its own 256-row slice of the activation - 9 x 32 KB per channel block through the ~20 B/clk L2 -> LDS
+// path beside 9 x 16 KB of weights: 48 KB per k-step against 2304 cycles of MFMA (PMC: matrix pipe 0.35 busy, and NOT because of the fabric - with the
+// taps innermost the L2 hit rate rose 0.61 -> 0.76 and the HBM fetch halved while the kernel got 4 % slower). Here the 256 + 8 V rows a tile needs of
+// one channel block sit in LDS ONCE ([row][64 B] x {hi, lo}, 88 KiB at V = 56) and the nine taps read their fragments V rows apart: per k-step the
+// path carries the weight tile + V rows of the NEXT window (the next channel block's - or the next tile's first), which overwrite the V rows the
+// finished tap no longer needs - tap dt reads window rows [dt V, dt V + 256), so after it only rows >= (dt + 1) V are live; the top 256 rows of a
+// window are fetched during its own taps 0-3 (first needed by tap 4). K order: k-block kt = (channel block kt / 9, tap kt % 9).
+// PERSISTENT over tiles (slot, + gridDim, ...) like k_sg_gcn: no launch / first-window / store-acknowledgement gap between tiles. The epilogue (MODE,
+// sg_epilogue) writes the fp32 convolution, or - the block's whole tail in place - relu(conv + b2' [+ identity residual]) as the next block's planes.
+template <int BN, int MODE>
+__global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int ntiles, int V) {
+    constexpr int BM = 256, NT = 512, TAPS = 9;
+    constexpr int WN = BN >= 128 ? 2 : 1, WM = 8 / WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int W_BYTES = BN * 64, W_STAGE = 2 * W_BYTES;      // one plane tile; a stage = hi | lo
+    constexpr int W_IT = BN * 8 / NT;                            // DMA instructions per thread per weight tile (hi + lo): 1 / 2 / 4
+    static_assert(TM >= 1 && TN >= 1 && BN * 8 % NT == 0 && (BN * 4) % 64 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int q8 = G >> 3, r8 = G & 7, xcd = bid & 7;
+    const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);   // workgroups of one XCD take neighbouring tiles (they share windows)
+    const int WR = BM + 8 * V, A_PLANE = WR * 64;                // window rows (a multiple of 16: V even)
+    char* const wst = smem + 2 * A_PLANE;                        // weight stages behind the two window planes
+    const int ncb = g.Kp / (32 * TAPS);
+    const long long row_lo = -4LL * V, row_hi = (long long)g.M + 4LL * V - 1;   // the planes' zero guard rows bound what a window may touch
+    const char* const a_pl[2] = {reinterpret_cast<const char*>(g.Ahi), reinterpret_cast<const char*>(g.Alo)};
+    const char* const w_pl[2] = {reinterpret_cast<const char*>(g.Whi), reinterpret_cast<const char*>(g.Wlo)};
+
+    // one 16-row piece (1 KiB per plane) of the window of (tile rows m0t, channel block cb), rows [r0, r0 + 16) limited to rows < rend, into its place in plane pl
+    auto a_piece = [&](int m0t, int cb, int pl, int r0, int rend) {
+        const int r = r0 + (lane >> 2);
+        if (r < rend) {
+            long long gr = (long long)m0t - 4LL * V + r;
+            gr = gr < row_lo ? row_lo : (gr > row_hi ? row_hi : gr);
+            const char* src = a_pl[pl] + ((long long)cb * g.a_rows + gr) * 64 + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)src, (RGN_AS3 void*)(smem + pl * A_PLANE + r0 * 64), 16, 0, 0);
+        }
+    };
+    unsigned w_lane[W_IT];                                       // this thread's 16 bytes of a weight tile (N is a multiple of BN: no column clamp)
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int q = it * NT + tid, pl = (it * NT + (tid & ~63)) / (BN * 4), qq = q - pl * (BN * 4), r = qq >> 2, c = (qq & 3) ^ ((r >> 2) & 3);
+        w_lane[it] = (unsigned)r * 64u + c * 16u;
+    }
+    auto w_tile = [&](int n0t, int kt, char* stage) {
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int pl = (it * NT + (tid & ~63)) / (BN * 4);
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(w_pl[pl] + ((size_t)kt * g.N + n0t) * 64 + w_lane[it]),
+                                             (RGN_AS3 void*)(stage + pl * W_BYTES + (it * NT + (tid & ~63) - pl * (BN * 4)) * 16), 16, 0, 0);
+        }
+    };
+    int w_off[TN][2];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int rr = wn * (BN / WN) + t * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w_off[t][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
+    }
+    const int arow0 = wm * (BM / WM) + l31;
+    auto mma3 = [&](f32x16& c, const bf16x8& a_h, const bf16x8& a_l, const bf16x8& w_h, const bf16x8& w_l) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, w_h, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_l, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_h, c, 0, 0, 0);
+    };
+
+    int tile = slot;
+    int m0 = (tile / nbx) * BM, n0 = (tile % nbx) * BN;
+    // prologue: rows [0, 8 V) of the first window (its top 256 rows follow under taps 0-3 like every window's) and the first weight tile
+    {
+        const int np = 8 * V / 16;                               // pieces per plane
+        for (int q = wave; q < 2 * np; q += 8) a_piece(m0, 0, q / np, (q % np) * 16, 8 * V);
+        w_tile(n0, 0, wst);
+    }
+    unsigned gstep = 0;                                          // k-steps done: weight stage gstep & 1
+    bool stores_behind = false;
+    while (true) {
+        const int tnext = tile + G;
+        const bool more = tnext < ntiles;
+        const int m0n = (tnext / nbx) * BM, n0n = (tnext % nbx) * BN;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+        for (int cb = 0; cb < ncb; ++cb) {
+            const bool wlast = cb + 1 == ncb;
+#pragma unroll 1
+            for (int dt = 0; dt < TAPS; ++dt, ++gstep) {
+                if (stores_behind) wait_vmcnt_any<16 * TM * TN>();   // this k-step's DMA is older than the 16 TM TN stores of the tile just written
+                else wait_vmcnt<0>();                            // everything this thread requested up to the last k-step has landed ...
+                stores_behind = false;
+                __builtin_amdgcn_s_barrier();                    // ... everyone's has, and everyone is done reading the previous k-step
+                const char* wsb = wst + (gstep & 1) * W_STAGE;
+                // fragments: the tap's rows start dt V further down the window (the 16-byte chunk swizzle follows the LDS row)
+                bf16x8 ah[2][TM], al[2][TM], wh[2], wl[2];
+                auto fetch = [&](int grp) {                      // grp = ks * TN + tb
+                    const int ks = grp / TN, tb = grp % TN;
+                    if (tb == 0) {
+#pragma unroll
+                        for (int t = 0; t < TM; ++t) {
+                            const int rr = arow0 + t * 32 + dt * V;
+                            const int o = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
+                            ah[ks][t] = *reinterpret_cast<const bf16x8*>(smem + o);
+                            al[ks][t] = *reinterpret_cast<const bf16x8*>(smem + A_PLANE + o);
+                        }
+                    }
+                    wh[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + w_off[tb][ks]);
+                    wl[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + W_BYTES + w_off[tb][ks]);
+                };
+                fetch(0);
+#pragma unroll
+                for (int grp = 0; grp < 2 * TN; ++grp) {
+                    if (grp + 1 < 2 * TN) fetch(grp + 1);
+#pragma unroll
+                    for (int ta = 0; ta < TM; ++ta) mma3(acc[ta][grp % TN], ah[grp / TN][ta], al[grp / TN][ta], wh[grp & 1], wl[grp & 1]);
+                    if (grp == 0) {
+                        // the path's load for this k-step, behind the first MFMA group: next weight tile, the dead strip's successor, the window's top quarter
+                        const bool klast = wlast && dt == TAPS - 1;
+                        if (!klast) w_tile(n0, cb * TAPS + dt + 1, wst + ((gstep + 1) & 1) * W_STAGE);
+                        else if (more) w_tile(n0n, 0, wst + ((gstep + 1) & 1) * W_STAGE);
+                        if (dt >= 1 && (!wlast || more))
+                            a_piece(wlast ? m0n : m0, wlast ? 0 : cb + 1, wave >> 2, (dt - 1) * V + 16 * (wave & 3), dt * V);   // V <= 64 rows: four pieces per plane
+                        if (dt < 4) a_piece(m0, cb, wave >> 2, 8 * V + 64 * dt + 16 * (wave & 3), WR);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+        if (interior) {
+            sg_epilogue<TM, TN, false, MODE>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+            stores_behind = true;
+        } else sg_epilogue<TM, TN, true, MODE>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+        if (!more) break;
+        tile = tnext; m0 = m0n; n0 = n0n;
+    }
+}
+template <int BN, int MODE>
+static hipError_t tconv_launch(const GemmX3Args& g, int V, hipStream_t s, bool configure_only) {
+    const int lds = 2 * (256 + 8 * 64) * 64 + 2 * 2 * BN * 64;      // (sized for V <= 64)
+    if (configure_only) return hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_tconv<BN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int nbx = (g.N + BN - 1) / BN, ntiles = nbx * ((g.M + 255) / 256);
+    hipLaunchKernelGGL((k_sg_tconv<BN, MODE>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), 2 * (256 + 8 * V) * 64 + 2 * 2 * BN * 64, s, g, nbx, ntiles, V);
+    return hipGetLastError();
+}
+bool sg_tconv_supported(int N, int Kp, int V) { return (N == 64 || N == 128 || N == 256) && Kp == 9 * N && V % 4 == 0 && V >= 16 && V <= 64; }
+// tail 0: C = conv + bias (fp32);  1: planes relu(conv + bias);  2: planes relu(conv + bias + (Rhi + Rlo))
+template <int BN>
+static hipError_t tconv_dispatch(const GemmX3Args& g, int V, int tail, hipStream_t s, bool configure_only) {
+    if (configure_only) {
+        hipError_t e = tconv_launch<BN, 0>(g, V, s, true);
+        if (e != hipSuccess) return e;
+        e = tconv_launch<BN, SGE_RELU | SGE_PLANES>(g, V, s, true);
+        return e != hipSuccess ? e : tconv_launch<BN, SGE_RELU | SGE_PLANES | SGE_RES_PLANES>(g, V, s, true);
+    }
+    if (tail == 0) return tconv_launch<BN, 0>(g, V, s, false);
+    if (tail == 1) return tconv_launch<BN, SGE_RELU | SGE_PLANES>(g, V, s, false);
+    return tconv_launch<BN, SGE_RELU | SGE_PLANES | SGE_RES_PLANES>(g, V, s, false);
+}
+hipError_t launch_sg_tconv(const GemmX3Args& g, int V, int tail, hipStream_t s) {
+    if (g.N == 64) return tconv_dispatch<64>(g, V, tail, s, false);
+    return tconv_dispatch<128>(g, V, tail, s, false);      // 256 channels: two 128-wide tiles (a 256-wide one needs 254 VGPRs + scratch: measured 1.5x slower)
+}
+hipError_t configure_sg_tconv() {
+    GemmX3Args g{};
+    hipError_t e = tconv_dispatch<64>(g, 0, 0, nullptr, true);
+    return e != hipSuccess ? e : tconv_dispatch<128>(g, 0, 0, nullptr, true);
 }
 
 // ---- graph aggregation + 1 x 1 convolution of an ST-GCN block as ONE kernel (rgn_stgcn.hip) -------------------------------------------------------
@@ -867,14 +932,6 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
 static int gcn_lds_bytes(int BN, int V) { return 2 * 2 * (256 + 2 * V) * 64 + 2 * 2 * BN * 64 + 2 * 4 * 8 * V; }
 bool sg_gcn_supported(int N, int Kp, int V, int KP) {
     return (N == 64 || N == 128 || N == 256) && KP >= 1 && KP <= 8 && Kp % (32 * KP) == 0 && V % 4 == 0 && V >= 16 && V <= 64 && gcn_lds_bytes(64, V) <= 160 * 1024;
-}
-static int sg_cu_count() {
-    static const int n = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        return cus;
-    }();
-    return n;
 }
 template <int BN>
 static hipError_t gcn_launch(const GemmX3Args& g, int V, int KP, unsigned slot_k, const int* sl_v, const float* sl_a, hipStream_t s) {

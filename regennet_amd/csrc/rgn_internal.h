@@ -77,6 +77,7 @@ struct GemmX3Args {
     const float* add; int ldadd;                        // optional fp32 addend [M, ldadd]
     float* C; int ldc;                                  // optional fp32 output [M, ldc]
     __bf16* Chi; __bf16* Clo; int c_rows;               // optional split output planes [ceil(N/32)][c_rows][32]
+    const __bf16* Rhi; const __bf16* Rlo; int r_rows;   // launch_sg_tconv tail 2 only: residual planes [N/32][r_rows][32], added as (hi + lo)
     int M, N, Kp;
     int act;
     // Optional "attention-ready" output of the packed in_proj GEMM (N = 3*d): instead of C / Chi the epilogue
@@ -320,7 +321,7 @@ hipError_t launch_gemm_x3_sg(const GemmX3Args& g, hipStream_t s);
 hipError_t configure_gemm_x3_sg();
 // ... and the stride-1 9 x 1 temporal convolution with the activation window resident in LDS (K order: channel block, tap): V = rows per frame
 bool sg_tconv_supported(int N, int Kp, int V);
-hipError_t launch_sg_tconv(const GemmX3Args& g, int V, hipStream_t s);
+hipError_t launch_sg_tconv(const GemmX3Args& g, int V, int tail, hipStream_t s);   // tail 0: C = conv + bias (fp32) | 1: planes relu(conv + bias) | 2: planes relu(conv + bias + R)
 hipError_t configure_sg_tconv();
 // ... and graph aggregation + 1 x 1 convolution as one kernel: A = the block's INPUT planes, Kp = KP x C_in. The nonzero lists of A'_k[:, w] come as 8
 // slots per vertex, sl_v / sl_a [V][8] (source vertex, coefficient); slot s serves partition (slot_k >> 4 s) & 15 (15: unused) and a list shorter than

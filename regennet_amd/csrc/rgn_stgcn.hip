@@ -701,17 +701,17 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
                 else hipLaunchKernelGGL(k_sg_agg_small, blocks1d(rows), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
                 SG_HIP(c, launch_gemm_x3_sg(g1, s));
             }
-            // pad frames and guard rows of g back to zero: what the temporal taps read beyond a sequence
-            auto zero = [&](long long base, int Tr, int Tp, int lead, int trail) {
+            // pad frames and guard rows back to zero: what the temporal taps read beyond a sequence
+            auto zero = [&](const SgPl& pl, long long base, int Tr, int Tp, int lead, int trail) {
                 const size_t n = ((size_t)NM * (Tp - Tr) * V + (size_t)lead + (size_t)trail) * (b.co / 32) * 4;
-                hipLaunchKernelGGL(k_sg_zero, blocks1d(n), dim3(256), 0, s, gp, base, NM, Tr, Tp, V, b.co / 32, lead, trail);
+                hipLaunchKernelGGL(k_sg_zero, blocks1d(n), dim3(256), 0, s, pl, base, NM, Tr, Tp, V, b.co / 32, lead, trail);
             };
-            if (!ipoly) zero(0, T, T + SG_PAD, guard, guard);
+            if (!ipoly) zero(gp, 0, T, T + SG_PAD, guard, guard);
             else {
-                zero(0, Te, Te + SG_PAD, guard, 0);
-                zero((long long)rows_c, T / 2, Te + SG_PAD, 0, guard);
+                zero(gp, 0, Te, Te + SG_PAD, guard, 0);
+                zero(gp, (long long)rows_c, T / 2, Te + SG_PAD, 0, guard);
             }
-            // 9x1 temporal convolution: ONE GEMM over K = 9 C_out; tap dt of k-block (dt, channel block) is a byte offset into g
+            // 9x1 temporal convolution: ONE GEMM over K = 9 C_out; tap dt of k-block (channel block, dt) is a byte offset into g
             GemmX3Args g2 = sg_gemm_x3(gp, b.W2h, b.W2l, (int)rows_c, b.co, 9 * b.co);
             g2.a_taps = 9;
             for (int dt = 0; dt < 9; ++dt) {
@@ -719,17 +719,28 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
                 else if ((dt & 1) == 0) g2.a_tap[dt] = (long long)((dt - 4) / 2) * V * 64;                  // frame 2 t' + dt - 4 = even frame t' + (dt - 4) / 2
                 else g2.a_tap[dt] = ((long long)rows_c + (long long)((dt - 5) / 2) * V) * 64;               // ... = odd frame t' + (dt - 5) / 2
             }
-            g2.C = c->conv; g2.ldc = b.co;
             static const bool no_window = getenv("REGENNET_SG_NO_WINDOW") != nullptr;            // (tools: the row-shifted GEMM for every block)
-            if (!ipoly && !no_window && sg_tconv_supported(b.co, 9 * b.co, V)) SG_HIP(c, launch_sg_tconv(g2, V, s));   // activation window resident in LDS
-            else SG_HIP(c, launch_gemm_x3_sg(g2, s));
-            if (b.res_conv) {   // strided 1x1 convolution of the block input: the even frames = region E of the polyphase planes (all rows for a stride-1 block)
-                GemmX3Args gr = sg_gemm_x3(xp, b.Wrh, b.Wrl, (int)rows_c, b.co, b.kpr);
-                gr.C = c->rfull; gr.ldc = b.co;
-                SG_HIP(c, launch_gemm_x3_sg(gr, s));
+            static const bool no_tail = getenv("REGENNET_SG_NO_TAIL_FUSE") != nullptr;            // (tools: k_sg_post for every block)
+            const bool window = !ipoly && !no_window && sg_tconv_supported(b.co, 9 * b.co, V);     // activation window resident in LDS
+            if (window && !opoly && !b.res_conv && !no_tail) {
+                // the block's tail in the convolution's epilogue: x' = relu(conv + b2' [+ x]) straight into the next block's planes (same row geometry)
+                g2.bias = b.b2;
+                g2.Chi = xo.hi; g2.Clo = xo.lo; g2.c_rows = (int)xo.R;
+                g2.Rhi = xp.hi; g2.Rlo = xp.lo; g2.r_rows = (int)xp.R;
+                SG_HIP(c, launch_sg_tconv(g2, V, b.res_id ? 2 : 1, s));
+                zero(xo, 0, To, To + SG_PAD, guard, guard);
+            } else {
+                g2.C = c->conv; g2.ldc = b.co;
+                if (window) SG_HIP(c, launch_sg_tconv(g2, V, 0, s));
+                else SG_HIP(c, launch_gemm_x3_sg(g2, s));
+                if (b.res_conv) {   // strided 1x1 convolution of the block input: the even frames = region E of the polyphase planes (all rows for a stride-1 block)
+                    GemmX3Args gr = sg_gemm_x3(xp, b.Wrh, b.Wrl, (int)rows_c, b.co, b.kpr);
+                    gr.C = c->rfull; gr.ldc = b.co;
+                    SG_HIP(c, launch_gemm_x3_sg(gr, s));
+                }
+                hipLaunchKernelGGL(k_sg_post, dim3((unsigned)((rows_o * 4 + 255) / 256), (unsigned)(b.co / 32)), dim3(256), 0, s, c->conv, b.b2, xp, b.res_id ? 1 : 0, b.res_conv ? c->rfull : nullptr, b.br,
+                                   xo, NM, Tpi, To, opoly ? 1 : 0, V, b.co);
             }
-            hipLaunchKernelGGL(k_sg_post, dim3((unsigned)((rows_o * 4 + 255) / 256), (unsigned)(b.co / 32)), dim3(256), 0, s, c->conv, b.b2, xp, b.res_id ? 1 : 0, b.res_conv ? c->rfull : nullptr, b.br,
-                               xo, NM, Tpi, To, opoly ? 1 : 0, V, b.co);
             std::swap(x, xn);
             T = To;
         }
