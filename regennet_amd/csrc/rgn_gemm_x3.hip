@@ -533,9 +533,8 @@ __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
                 const unsigned mh = odd ? (ph & 0xffff0000u) : (ph << 16), ml = odd ? (pl & 0xffff0000u) : (pl << 16);   // own rows: register ii = odd ? i + 8 : i
                 const unsigned oh = odd ? (qh & 0xffff0000u) : (qh << 16), ol = odd ? (ql & 0xffff0000u) : (ql << 16);   // the partner's rows
                 const float mine = __builtin_bit_cast(float, mh) + __builtin_bit_cast(float, ml), other = __builtin_bit_cast(float, oh) + __builtin_bit_cast(float, ol);
-                const int im = odd ? i + 8 : i, io = odd ? i : i + 8;
-                r[im] = (acc[ta][tb][im] + b) + mine;
-                r[io] = (acc[ta][tb][io] + b) + other;
+                r[i] = (acc[ta][tb][i] + b) + (odd ? other : mine);          // (static register indices: a lane-dependent index is a 16-way select chain)
+                r[i + 8] = (acc[ta][tb][i + 8] + b) + (odd ? mine : other);
             }
         } else {
             const float b = __builtin_bit_cast(float, nxt[0]);
@@ -606,14 +605,14 @@ static int sg_cu_count() {
 // window are fetched during its own taps 0-3 (first needed by tap 4). K order: k-block kt = (channel block kt / 9, tap kt % 9).
 // PERSISTENT over tiles (slot, + gridDim, ...) like k_sg_gcn: no launch / first-window / store-acknowledgement gap between tiles. The epilogue (MODE,
 // sg_epilogue) writes the fp32 convolution, or - the block's whole tail in place - relu(conv + b2' [+ identity residual]) as the next block's planes.
-template <int BN, int MODE>
+template <int BM, int BN, int WM, int MODE>
 __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int ntiles, int V) {
-    constexpr int BM = 256, NT = 512, TAPS = 9;
-    constexpr int WN = BN >= 128 ? 2 : 1, WM = 8 / WN;
+    constexpr int NT = 512, TAPS = 9;
+    constexpr int WN = 8 / WM;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int W_BYTES = BN * 64, W_STAGE = 2 * W_BYTES;      // one plane tile; a stage = hi | lo
     constexpr int W_IT = BN * 8 / NT;                            // DMA instructions per thread per weight tile (hi + lo): 1 / 2 / 4
-    static_assert(TM >= 1 && TN >= 1 && BN * 8 % NT == 0 && (BN * 4) % 64 == 0, "tile shape");
+    static_assert(TM >= 1 && TN >= 1 && BN * 8 % NT == 0 && (BN * 4) % 64 == 0 && BM % (32 * WM) == 0 && BM % 64 == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -726,7 +725,14 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
                         else if (more) w_tile(n0n, 0, wst + ((gstep + 1) & 1) * W_STAGE);
                         if (dt >= 1 && (!wlast || more))
                             a_piece(wlast ? m0n : m0, wlast ? 0 : cb + 1, wave >> 2, (dt - 1) * V + 16 * (wave & 3), dt * V);   // V <= 64 rows: four pieces per plane
-                        if (dt < 4) a_piece(m0, cb, wave >> 2, 8 * V + 64 * dt + 16 * (wave & 3), WR);
+                        if (dt < 4) {
+                            constexpr int PPT = BM / 64;                 // 16-row pieces per plane per tap: a quarter of the window top
+#pragma unroll
+                            for (int j = 0; j < (2 * PPT + 7) / 8; ++j) {
+                                const int p = wave + 8 * j;
+                                if (p < 2 * PPT) a_piece(m0, cb, p / PPT, 8 * V + (BM / 4) * dt + 16 * (p % PPT), WR);
+                            }
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -741,36 +747,47 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
         tile = tnext; m0 = m0n; n0 = n0n;
     }
 }
-template <int BN, int MODE>
+static int tconv_lds_bytes(int BM, int BN, int V) { return 2 * (BM + 8 * V) * 64 + 2 * 2 * BN * 64; }
+template <int BM, int BN, int WM, int MODE>
 static hipError_t tconv_launch(const GemmX3Args& g, int V, hipStream_t s, bool configure_only) {
-    const int lds = 2 * (256 + 8 * 64) * 64 + 2 * 2 * BN * 64;      // (sized for V <= 64)
-    if (configure_only) return hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_tconv<BN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    const int nbx = (g.N + BN - 1) / BN, ntiles = nbx * ((g.M + 255) / 256);
-    hipLaunchKernelGGL((k_sg_tconv<BN, MODE>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), 2 * (256 + 8 * V) * 64 + 2 * 2 * BN * 64, s, g, nbx, ntiles, V);
+    if (configure_only)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_tconv<BM, BN, WM, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, std::min(160 * 1024, tconv_lds_bytes(BM, BN, 64)));
+    const int nbx = (g.N + BN - 1) / BN, ntiles = nbx * ((g.M + BM - 1) / BM);
+    hipLaunchKernelGGL((k_sg_tconv<BM, BN, WM, MODE>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), tconv_lds_bytes(BM, BN, V), s, g, nbx, ntiles, V);
     return hipGetLastError();
 }
 bool sg_tconv_supported(int N, int Kp, int V) { return (N == 64 || N == 128 || N == 256) && Kp == 9 * N && V % 4 == 0 && V >= 16 && V <= 64; }
 // tail 0: C = conv + bias (fp32);  1: planes relu(conv + bias);  2: planes relu(conv + bias + (Rhi + Rlo))
-template <int BN>
+template <int BM, int BN, int WM>
 static hipError_t tconv_dispatch(const GemmX3Args& g, int V, int tail, hipStream_t s, bool configure_only) {
     if (configure_only) {
-        hipError_t e = tconv_launch<BN, 0>(g, V, s, true);
+        hipError_t e = tconv_launch<BM, BN, WM, 0>(g, V, s, true);
         if (e != hipSuccess) return e;
-        e = tconv_launch<BN, SGE_RELU | SGE_PLANES>(g, V, s, true);
-        return e != hipSuccess ? e : tconv_launch<BN, SGE_RELU | SGE_PLANES | SGE_RES_PLANES>(g, V, s, true);
+        e = tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES>(g, V, s, true);
+        return e != hipSuccess ? e : tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES | SGE_RES_PLANES>(g, V, s, true);
     }
-    if (tail == 0) return tconv_launch<BN, 0>(g, V, s, false);
-    if (tail == 1) return tconv_launch<BN, SGE_RELU | SGE_PLANES>(g, V, s, false);
-    return tconv_launch<BN, SGE_RELU | SGE_PLANES | SGE_RES_PLANES>(g, V, s, false);
+    if (tail == 0) return tconv_launch<BM, BN, WM, 0>(g, V, s, false);
+    if (tail == 1) return tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES>(g, V, s, false);
+    return tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES | SGE_RES_PLANES>(g, V, s, false);
 }
+// Tile shapes. Per k-step the L2 -> LDS path (~20 B/clk) carries the weight tile + V rows + (taps 0-3) a quarter of the window top against
+// TM TN x 6 MFMAs per wave: 256 x 64 tiles (768 MFMA cycles per SIMD, 21 KB) and 256 x 128 (1536, 29 KB) sit at or past the path's rate; a 256-wide tile
+// for the 256-channel blocks halves the window bytes per MFMA. Taller tiles would halve the weight bytes, but a tile taller than 8 V rows needs its rows
+// [8 V, BM) at tap 0 of a window while the previous window's tap 8 still reads them (512 rows, run without regard for that: -16 ... -24 % on the 64- and
+// 128-channel kernels), and 384-row tiles (4 x 2 waves of 96 rows) measured 5 - 15 % SLOWER than 256 (profiles/r05/stgcn_tconv_shapes.txt).
 hipError_t launch_sg_tconv(const GemmX3Args& g, int V, int tail, hipStream_t s) {
-    if (g.N == 64) return tconv_dispatch<64>(g, V, tail, s, false);
-    return tconv_dispatch<128>(g, V, tail, s, false);      // 256 channels: two 128-wide tiles (a 256-wide one needs 254 VGPRs + scratch: measured 1.5x slower)
+    static const char* shape = getenv("REGENNET_SG_TCONV_SHAPE");   // (tools) "small": no 256-wide tiles
+    const bool small = shape && shape[0] == 's';
+    if (g.N == 64) return tconv_dispatch<256, 64, 8>(g, V, tail, s, false);
+    if (g.N == 256 && !small && tconv_lds_bytes(256, 256, V) <= 160 * 1024) return tconv_dispatch<256, 256, 8>(g, V, tail, s, false);
+    return tconv_dispatch<256, 128, 4>(g, V, tail, s, false);
 }
 hipError_t configure_sg_tconv() {
     GemmX3Args g{};
-    hipError_t e = tconv_dispatch<64>(g, 0, 0, nullptr, true);
-    return e != hipSuccess ? e : tconv_dispatch<128>(g, 0, 0, nullptr, true);
+    hipError_t e = tconv_dispatch<256, 64, 8>(g, 0, 0, nullptr, true);
+    if (e == hipSuccess) e = tconv_dispatch<256, 128, 4>(g, 0, 0, nullptr, true);
+    if (e == hipSuccess) e = tconv_dispatch<256, 256, 8>(g, 0, 0, nullptr, true);
+    return e;
 }
 
 // ---- graph aggregation + 1 x 1 convolution of an ST-GCN block as ONE kernel (rgn_stgcn.hip) -------------------------------------------------------
