@@ -756,7 +756,8 @@ static hipError_t tconv_launch(const GemmX3Args& g, int V, hipStream_t s, bool c
     hipLaunchKernelGGL((k_sg_tconv<BM, BN, WM, MODE>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), tconv_lds_bytes(BM, BN, V), s, g, nbx, ntiles, V);
     return hipGetLastError();
 }
-bool sg_tconv_supported(int N, int Kp, int V) { return (N == 64 || N == 128 || N == 256) && Kp == 9 * N && V % 4 == 0 && V >= 16 && V <= 64; }
+// (8 V >= 256: tap 0 reads window rows [0, 256), and only the first 8 V rows of a window are in place before its own taps run)
+bool sg_tconv_supported(int N, int Kp, int V) { return (N == 64 || N == 128 || N == 256) && Kp == 9 * N && V % 4 == 0 && V >= 32 && V <= 64; }
 // tail 0: C = conv + bias (fp32);  1: planes relu(conv + bias);  2: planes relu(conv + bias + (Rhi + Rlo))
 template <int BM, int BN, int WM>
 static hipError_t tconv_dispatch(const GemmX3Args& g, int V, int tail, hipStream_t s, bool configure_only) {

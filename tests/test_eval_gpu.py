@@ -37,6 +37,49 @@ def test_stgcn_features_and_logits_match_reference(golden, tag):
     assert torch.equal(batch["yhat"].max(dim=1).indices.cpu(), torch.from_numpy(ref_y).max(dim=1).indices)
 
 
+def _tree_graph(V, hub_children, rng):
+    """A random skeleton in the reference's 'spatial' partition form (stgcnutils/graph.py): A[0] self loops, A[1] the edge to the parent, A[2]
+    the edges to the children, column-normalised; vertex 0 is a hub with `hub_children` children."""
+    parent = np.zeros(V, np.int64)
+    for v in range(1, V):
+        parent[v] = 0 if v <= hub_children else rng.integers(1, v)
+    adj = np.eye(V)
+    for v in range(1, V):
+        adj[v, parent[v]] = adj[parent[v], v] = 1.0
+    dn = adj / adj.sum(0, keepdims=True)
+    A = np.zeros((3, V, V), np.float32)
+    for v in range(V):
+        for w in range(V):
+            if adj[v, w] == 0:
+                continue
+            k = 0 if v == w else (1 if parent[w] == v else 2)      # the source is w's parent (closer to the root) | one of its children
+            A[k, v, w] = dn[v, w]
+    return A
+
+
+@pytest.mark.parametrize("V,hub,T,N", [(56, 5, 24, 3), (32, 3, 24, 2), (40, 6, 30, 2), (64, 4, 20, 2), (28, 3, 24, 2), (30, 4, 24, 2), (56, 12, 24, 2), (36, 2, 150, 1)])
+def test_stgcn_other_skeletons_match_the_oracle(V, hub, T, N):
+    """Graphs the golden vectors do not hold, against the CPU oracle: vertex counts on both sides of what the LDS-window kernels take (V % 4 == 0,
+    32 <= V <= 64; others run the row-shifted GEMMs; the engine takes V >= 28), a hub whose child list exceeds the 8 register slots of the fused aggregation (two-launch form),
+    frame counts that leave ragged last tiles, 150 frames."""
+    from oracle import stgcn_oracle
+    from regennet_amd.eval import STGCN
+    rng = np.random.Generator(np.random.PCG64(1000 + V + hub))
+    A = _tree_graph(V, hub, rng)
+    sd = synth.make_stgcn_state_dict(A, num_class=13, seed=V)
+    model = STGCN(in_channels=12, num_class=13, num_person=2, num_nodes=V, device="cuda:0")
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model = model.to("cuda:0").eval()
+    x = rng.standard_normal((N, V, 12, T)).astype(np.float32)
+    batch = model({"output": torch.from_numpy(x).cuda()})
+    ref_f, ref_y = stgcn_oracle.stgcn_forward(sd, x)
+    feats = batch["features"].reshape(N, -1).cpu().numpy()
+    err_f, err_y = np.abs(feats - ref_f.numpy()).max(), np.abs(batch["yhat"].cpu().numpy() - ref_y.numpy()).max()
+    print(f"\n[stgcn V={V} hub={hub} T={T}] max |features - oracle| = {err_f:.2e} (|ref| max {ref_f.abs().max():.2f}), logits {err_y:.2e}")
+    assert err_f < 1e-4 * max(1.0, float(ref_f.abs().max())), err_f
+    assert err_y < 1e-4 * max(1.0, float(ref_y.abs().max())), err_y
+
+
 def test_stgcn_batching_and_errors(golden):
     """A batch evaluated at once equals its samples evaluated one by one (rows are independent); a checkpoint with a
     missing key is refused with the key named."""
