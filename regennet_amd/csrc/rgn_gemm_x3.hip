@@ -621,7 +621,13 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
     const int G = gridDim.x, bid = blockIdx.x;
     const int q8 = G >> 3, r8 = G & 7, xcd = bid & 7;
     const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);   // workgroups of one XCD take neighbouring tiles (they share windows)
-    const int WR = BM + 8 * V, A_PLANE = WR * 64;                // window rows (a multiple of 16: V even)
+    // BM = 256: the window is BM + 8 V rows in place. BM = 512 (> 8 V): CIRCULAR - a window needs its rows [0, BM) at tap 0 while the previous window's
+    // tap 8 still reads its rows [8 V, 8 V + BM), so the buffer holds 2 BM = 1024 rows and every window starts SP = BM - 8 V rows in front of the last:
+    // its first SP rows land in rows nobody uses, rows [SP, BM) follow the previous window's dying strips, the top 8 V rows come under its own taps 0-3.
+    constexpr bool CIRC = BM > 256;
+    constexpr int RMASK = 2 * BM - 1;
+    const int WR = BM + 8 * V, A_PLANE = (CIRC ? 2 * BM : WR) * 64;   // window rows (a multiple of 16: V even); bytes per plane
+    const int SP = CIRC ? BM - 8 * V : 0;
     char* const wst = smem + 2 * A_PLANE;                        // weight stages behind the two window planes
     const int ncb = g.Kp / (32 * TAPS);
     const long long row_lo = -4LL * V, row_hi = (long long)g.M + 4LL * V - 1;   // the planes' zero guard rows bound what a window may touch
@@ -629,13 +635,15 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
     const char* const w_pl[2] = {reinterpret_cast<const char*>(g.Whi), reinterpret_cast<const char*>(g.Wlo)};
 
     // one 16-row piece (1 KiB per plane) of the window of (tile rows m0t, channel block cb), rows [r0, r0 + 16) limited to rows < rend, into its place in plane pl
-    auto a_piece = [&](int m0t, int cb, int pl, int r0, int rend) {
+    // ws = the window's first physical row (0 unless CIRC)
+    auto a_piece = [&](int m0t, int cb, int pl, int r0, int rend, int ws) {
         const int r = r0 + (lane >> 2);
         if (r < rend) {
             long long gr = (long long)m0t - 4LL * V + r;
             gr = gr < row_lo ? row_lo : (gr > row_hi ? row_hi : gr);
-            const char* src = a_pl[pl] + ((long long)cb * g.a_rows + gr) * 64 + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
-            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)src, (RGN_AS3 void*)(smem + pl * A_PLANE + r0 * 64), 16, 0, 0);
+            const int p0 = CIRC ? ((ws + r0) & RMASK) : r0, pr = p0 + (lane >> 2);   // (pieces start on multiples of 16: they never wrap)
+            const char* src = a_pl[pl] + ((long long)cb * g.a_rows + gr) * 64 + (((lane & 3) ^ ((pr >> 2) & 3)) << 4);
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)src, (RGN_AS3 void*)(smem + pl * A_PLANE + p0 * 64), 16, 0, 0);
         }
     };
     unsigned w_lane[W_IT];                                       // this thread's 16 bytes of a weight tile (N is a multiple of BN: no column clamp)
@@ -668,13 +676,14 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
 
     int tile = slot;
     int m0 = (tile / nbx) * BM, n0 = (tile % nbx) * BN;
-    // prologue: rows [0, 8 V) of the first window (its top 256 rows follow under taps 0-3 like every window's) and the first weight tile
+    // prologue: rows [0, 8 V + SP) of the first window (its top rows follow under taps 0-3 like every window's) and the first weight tile
     {
-        const int np = 8 * V / 16;                               // pieces per plane
-        for (int q = wave; q < 2 * np; q += 8) a_piece(m0, 0, q / np, (q % np) * 16, 8 * V);
+        const int np = (8 * V + SP) / 16;                        // pieces per plane
+        for (int q = wave; q < 2 * np; q += 8) a_piece(m0, 0, q / np, (q % np) * 16, 8 * V + SP, 0);
         w_tile(n0, 0, wst);
     }
     unsigned gstep = 0;                                          // k-steps done: weight stage gstep & 1
+    int ws = 0;                                                  // first physical row of the current window
     bool stores_behind = false;
     while (true) {
         const int tnext = tile + G;
@@ -703,7 +712,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
                     if (tb == 0) {
 #pragma unroll
                         for (int t = 0; t < TM; ++t) {
-                            const int rr = arow0 + t * 32 + dt * V;
+                            const int rl = arow0 + t * 32 + dt * V, rr = CIRC ? ((ws + rl) & RMASK) : rl;
                             const int o = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
                             ah[ks][t] = *reinterpret_cast<const bf16x8*>(smem + o);
                             al[ks][t] = *reinterpret_cast<const bf16x8*>(smem + A_PLANE + o);
@@ -723,20 +732,34 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
                         const bool klast = wlast && dt == TAPS - 1;
                         if (!klast) w_tile(n0, cb * TAPS + dt + 1, wst + ((gstep + 1) & 1) * W_STAGE);
                         else if (more) w_tile(n0n, 0, wst + ((gstep + 1) & 1) * W_STAGE);
-                        if (dt >= 1 && (!wlast || more))
-                            a_piece(wlast ? m0n : m0, wlast ? 0 : cb + 1, wave >> 2, (dt - 1) * V + 16 * (wave & 3), dt * V);   // V <= 64 rows: four pieces per plane
+                        if (!wlast || more) {
+                            const int m0w = wlast ? m0n : m0, cbw = wlast ? 0 : cb + 1;
+                            if constexpr (!CIRC) {
+                                if (dt >= 1) a_piece(m0w, cbw, wave >> 2, (dt - 1) * V + 16 * (wave & 3), dt * V, 0);   // V <= 64 rows: four pieces per plane
+                            } else {
+                                // the next window's piece p (rows [16 p, 16 p + 16)) lies on this window's rows [16 p - SP, ...): free once tap dt has passed them
+                                const int c0 = dt == 0 ? 0 : ((dt - 1) * V + SP) >> 4, c1 = (dt * V + SP) >> 4;
+                                for (int p = c0 + (wave & 3); p < c1; p += 4) a_piece(m0w, cbw, wave >> 2, 16 * p, BM, (ws - SP) & RMASK);
+                            }
+                        }
                         if (dt < 4) {
-                            constexpr int PPT = BM / 64;                 // 16-row pieces per plane per tap: a quarter of the window top
+                            if constexpr (!CIRC) {
+                                constexpr int PPT = BM / 64;             // 16-row pieces per plane per tap: a quarter of the window top
 #pragma unroll
-                            for (int j = 0; j < (2 * PPT + 7) / 8; ++j) {
-                                const int p = wave + 8 * j;
-                                if (p < 2 * PPT) a_piece(m0, cb, p / PPT, 8 * V + (BM / 4) * dt + 16 * (p % PPT), WR);
+                                for (int j = 0; j < (2 * PPT + 7) / 8; ++j) {
+                                    const int p = wave + 8 * j;
+                                    if (p < 2 * PPT) a_piece(m0, cb, p / PPT, 8 * V + (BM / 4) * dt + 16 * (p % PPT), WR, 0);
+                                }
+                            } else {
+                                // the top 8 V rows, 2 V per tap (tap dt + 1 reads rows below (dt + 1) V + BM <= BM + 2 V (dt + 1))
+                                for (int p = wave & 3; 16 * p < 2 * V; p += 4) a_piece(m0, cb, wave >> 2, BM + 2 * V * dt + 16 * p, BM + 2 * V * (dt + 1), ws);
                             }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if constexpr (CIRC) ws = (ws - SP) & RMASK;
         }
         const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
         if (interior) {
@@ -747,7 +770,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
         tile = tnext; m0 = m0n; n0 = n0n;
     }
 }
-static int tconv_lds_bytes(int BM, int BN, int V) { return 2 * (BM + 8 * V) * 64 + 2 * 2 * BN * 64; }
+static int tconv_lds_bytes(int BM, int BN, int V) { return 2 * (BM > 256 ? 2 * BM : BM + 8 * V) * 64 + 2 * 2 * BN * 64; }
 template <int BM, int BN, int WM, int MODE>
 static hipError_t tconv_launch(const GemmX3Args& g, int V, hipStream_t s, bool configure_only) {
     if (configure_only)
@@ -777,9 +800,11 @@ static hipError_t tconv_dispatch(const GemmX3Args& g, int V, int tail, hipStream
 // [8 V, BM) at tap 0 of a window while the previous window's tap 8 still reads them (512 rows, run without regard for that: -16 ... -24 % on the 64- and
 // 128-channel kernels), and 384-row tiles (4 x 2 waves of 96 rows) measured 5 - 15 % SLOWER than 256 (profiles/r05/stgcn_tconv_shapes.txt).
 hipError_t launch_sg_tconv(const GemmX3Args& g, int V, int tail, hipStream_t s) {
-    static const char* shape = getenv("REGENNET_SG_TCONV_SHAPE");   // (tools) "small": no 256-wide tiles
+    static const char* shape = getenv("REGENNET_SG_TCONV_SHAPE");   // (tools) "small": 256-row tiles, <= 128 wide
     const bool small = shape && shape[0] == 's';
-    if (g.N == 64) return tconv_dispatch<256, 64, 8>(g, V, tail, s, false);
+    const bool tall = !small && V % 8 == 0 && 8 * V <= 512;         // (the circular window: 2 V-row pieces, SP = 512 - 8 V >= 0)
+    if (g.N == 64) return tall ? tconv_dispatch<512, 64, 8>(g, V, tail, s, false) : tconv_dispatch<256, 64, 8>(g, V, tail, s, false);
+    if (g.N == 128 && tall) return tconv_dispatch<512, 128, 8>(g, V, tail, s, false);
     if (g.N == 256 && !small && tconv_lds_bytes(256, 256, V) <= 160 * 1024) return tconv_dispatch<256, 256, 8>(g, V, tail, s, false);
     return tconv_dispatch<256, 128, 4>(g, V, tail, s, false);
 }
@@ -788,6 +813,8 @@ hipError_t configure_sg_tconv() {
     hipError_t e = tconv_dispatch<256, 64, 8>(g, 0, 0, nullptr, true);
     if (e == hipSuccess) e = tconv_dispatch<256, 128, 4>(g, 0, 0, nullptr, true);
     if (e == hipSuccess) e = tconv_dispatch<256, 256, 8>(g, 0, 0, nullptr, true);
+    if (e == hipSuccess) e = tconv_dispatch<512, 64, 8>(g, 0, 0, nullptr, true);
+    if (e == hipSuccess) e = tconv_dispatch<512, 128, 8>(g, 0, 0, nullptr, true);
     return e;
 }
 
