@@ -808,6 +808,8 @@ hipError_t launch_sg_tconv(const GemmX3Args& g, int V, int tail, hipStream_t s) 
     if (g.N == 256 && !small && tconv_lds_bytes(256, 256, V) <= 160 * 1024) return tconv_dispatch<256, 256, 8>(g, V, tail, s, false);
     return tconv_dispatch<256, 128, 4>(g, V, tail, s, false);
 }
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, int ntiles, int V, long long o_rows);
 hipError_t configure_sg_tconv() {
     GemmX3Args g{};
     hipError_t e = tconv_dispatch<256, 64, 8>(g, 0, 0, nullptr, true);
@@ -815,7 +817,199 @@ hipError_t configure_sg_tconv() {
     if (e == hipSuccess) e = tconv_dispatch<256, 256, 8>(g, 0, 0, nullptr, true);
     if (e == hipSuccess) e = tconv_dispatch<512, 64, 8>(g, 0, 0, nullptr, true);
     if (e == hipSuccess) e = tconv_dispatch<512, 128, 8>(g, 0, 0, nullptr, true);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_tconv_s2<SGE_RELU | SGE_PLANES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;
+}
+
+// ---- the 9 x 1 temporal convolution of a STRIDE-2 block, at the output rate, on polyphase planes (region E: even frames, region O: odd frames, same
+// geometry, O starts o_rows rows behind E) + the block's convolved shortcut + its tail. Output row m = sum over the even taps dt = 2 j of
+// g_E[m + (j - 2) V] W_dt + over the odd taps dt = 2 j + 1 of g_O[m + (j - 2) V] W_dt: two resident windows per channel block, E (256 + 4 V rows,
+// taps j = 0..4) and O (256 + 3 V rows, j = 0..3), walked E first. Each window's top 256 rows arrive while the OTHER window is being read (E top
+// of the next channel block under the O taps, O top under the E taps), its low rows strip by strip behind the taps that are done with them - per
+// k-step the L2 -> LDS path carries the weight tile + V rows + 64 rows (31 KB; 48 KB as a row-shifted GEMM). The strided 1 x 1 shortcut (BN folded)
+// is k2 more k-steps on the same accumulators: its operand fragments come straight from the block's input planes (region E = the even frames)
+// into registers, requested one k-step ahead. Epilogue: planes relu(acc + bias), bias = b2' + br'. Persistent over tiles like k_sg_tconv.
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, int ntiles, int V, long long o_rows) {
+    constexpr int BM = 256, BN = 128, NT = 512, WM = 4, WN = 2, TM = 2, TN = 2;
+    constexpr int W_BYTES = BN * 64, W_STAGE = 2 * W_BYTES, W_IT = BN * 8 / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int q8 = G >> 3, r8 = G & 7, xcd = bid & 7;
+    const int slot = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int WE = BM + 4 * V, WO = BM + 3 * V, EP = WE * 64, OP = WO * 64;   // window rows, bytes per plane
+    char* const ebuf = smem;                                     // E hi | E lo
+    char* const obuf = smem + 2 * EP;                            // O hi | O lo
+    char* const wst = obuf + 2 * OP;
+    const int ncb = g.Kp / (32 * 9);
+    const long long row_lo = -4LL * V, row_hi = o_rows + (long long)g.M + 4LL * V - 1;   // guard rows in front of E and behind O
+    const char* const a_pl[2] = {reinterpret_cast<const char*>(g.Ahi), reinterpret_cast<const char*>(g.Alo)};
+    // one 16-row piece of a window: `first` = the global row of window row 0, rows [r0, r0 + 16) below rend, plane pl of the buffer at `buf` (`pb` bytes per plane)
+    auto a_piece = [&](long long first, int cb, int pl, int r0, int rend, char* buf, int pb) {
+        const int r = r0 + (lane >> 2);
+        if (r < rend) {
+            long long gr = first + r;
+            gr = gr < row_lo ? row_lo : (gr > row_hi ? row_hi : gr);
+            const char* src = a_pl[pl] + ((long long)cb * g.a_rows + gr) * 64 + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)src, (RGN_AS3 void*)(buf + pl * pb + r0 * 64), 16, 0, 0);
+        }
+    };
+    unsigned w_lane[W_IT];
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int q = it * NT + tid, pl = (it * NT + (tid & ~63)) / (BN * 4), qq = q - pl * (BN * 4), r = qq >> 2, c = (qq & 3) ^ ((r >> 2) & 3);
+        w_lane[it] = (unsigned)r * 64u + c * 16u;
+    }
+    auto w_tile = [&](const __bf16* whi, const __bf16* wlo, int n0t, int kt, char* stage) {
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int pl = (it * NT + (tid & ~63)) / (BN * 4);
+            const char* base = reinterpret_cast<const char*>(pl ? wlo : whi);
+            __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(base + ((size_t)kt * g.N + n0t) * 64 + w_lane[it]),
+                                             (RGN_AS3 void*)(stage + pl * W_BYTES + (it * NT + (tid & ~63) - pl * (BN * 4)) * 16), 16, 0, 0);
+        }
+    };
+    int w_off[TN][2];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int rr = wn * (BN / WN) + t * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w_off[t][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
+    }
+    const int arow0 = wm * (BM / WM) + l31;
+    auto mma3 = [&](f32x16& c, const bf16x8& a_h, const bf16x8& a_l, const bf16x8& w_h, const bf16x8& w_l) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, w_h, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_l, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_h, c, 0, 0, 0);
+    };
+    // the shortcut's operand fragments of this lane's rows, k-block cr (straight from the input planes, region E)
+    bf16x8 sh[2][TM], sl[2][TM];
+    auto shortcut_fetch = [&](int m0t, int cr) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            long long row = (long long)m0t + arow0 + t * 32;
+            row = row > row_hi ? row_hi : row;
+            const size_t o = ((size_t)cr * g.a2_rows + (size_t)row) * 32 + 8 * kh;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                sh[ks][t] = *reinterpret_cast<const bf16x8*>(g.A2hi + o + 16 * ks);
+                sl[ks][t] = *reinterpret_cast<const bf16x8*>(g.A2lo + o + 16 * ks);
+            }
+        }
+    };
+
+    int tile = slot;
+    int m0 = (tile / nbx) * BM, n0 = (tile % nbx) * BN;
+    {   // prologue: all of E and the low 3 V rows of O of the first window (O's top follows under the E taps like every window's), the first weight tile
+        const int ne = (WE + 15) / 16, no = (3 * V + 15) / 16;
+        for (int q = wave; q < 2 * ne; q += 8) a_piece((long long)m0 - 2 * V, 0, q / ne, (q % ne) * 16, WE, ebuf, EP);
+        for (int q = wave; q < 2 * no; q += 8) a_piece(o_rows + m0 - 2 * V, 0, q / no, (q % no) * 16, 3 * V, obuf, OP);
+        w_tile(g.Whi, g.Wlo, n0, 0, wst);
+    }
+    unsigned gstep = 0;
+    bool stores_behind = false;
+    while (true) {
+        const int tnext = tile + G;
+        const bool more = tnext < ntiles;
+        const int m0n = (tnext / nbx) * BM, n0n = (tnext % nbx) * BN;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+        const int nsteps = ncb * 9 + g.k2;
+        for (int st = 0; st < nsteps; ++st, ++gstep) {
+            const bool shortcut = st >= ncb * 9;
+            const int cb = shortcut ? ncb - 1 : st / 9, i9 = shortcut ? 9 : st - cb * 9;      // i9: 0..4 E taps, 5..8 O taps
+            const bool isE = i9 < 5;
+            const int j = isE ? i9 : i9 - 5;
+            if (stores_behind) wait_vmcnt_any<16 * TM * TN>();
+            else wait_vmcnt<0>();
+            stores_behind = false;
+            __builtin_amdgcn_s_barrier();
+            const char* wsb = wst + (gstep & 1) * W_STAGE;
+            const char* abuf = isE ? ebuf : obuf;
+            const int apl = isE ? EP : OP;
+            bf16x8 ah[2][TM], al[2][TM], wh[2], wl[2];
+            if (shortcut) {                                      // (both k halves now: the next k-block's fragments are requested into sh / sl under this step)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) {
+                        ah[ks][t] = sh[ks][t];
+                        al[ks][t] = sl[ks][t];
+                    }
+            }
+            auto fetch = [&](int grp) {                          // grp = ks * TN + tb
+                const int ks = grp / TN, tb = grp % TN;
+                if (tb == 0 && !shortcut) {
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) {
+                        const int rr = arow0 + t * 32 + j * V;
+                        const int o = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
+                        ah[ks][t] = *reinterpret_cast<const bf16x8*>(abuf + o);
+                        al[ks][t] = *reinterpret_cast<const bf16x8*>(abuf + apl + o);
+                    }
+                }
+                wh[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + w_off[tb][ks]);
+                wl[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + W_BYTES + w_off[tb][ks]);
+            };
+            fetch(0);
+#pragma unroll
+            for (int grp = 0; grp < 2 * TN; ++grp) {
+                if (grp + 1 < 2 * TN) fetch(grp + 1);
+#pragma unroll
+                for (int ta = 0; ta < TM; ++ta) mma3(acc[ta][grp % TN], ah[grp / TN][ta], al[grp / TN][ta], wh[grp & 1], wl[grp & 1]);
+                if (grp == 0) {
+                    char* nstage = wst + ((gstep + 1) & 1) * W_STAGE;
+                    // the next k-step's weight tile (tap order E 0, 2, 4, 6, 8 then O 1, 3, 5, 7: step i of a channel block is tap i < 5 ? 2 i : 2 (i - 5) + 1)
+                    if (st + 1 < nsteps) {
+                        const int s1 = st + 1;
+                        if (s1 < ncb * 9) {
+                            const int c1 = s1 / 9, i1 = s1 - c1 * 9;
+                            w_tile(g.Whi, g.Wlo, n0, c1 * 9 + (i1 < 5 ? 2 * i1 : 2 * (i1 - 5) + 1), nstage);
+                        } else w_tile(g.W2hi, g.W2lo, n0, s1 - ncb * 9, nstage);
+                    } else if (more) w_tile(g.Whi, g.Wlo, n0n, 0, nstage);
+                    if (!shortcut) {
+                        const bool wlast = cb + 1 == ncb;
+                        const bool nextw = !wlast || more;       // a next pair of windows exists: (this tile, cb + 1) or (next tile, 0)
+                        const long long firstn = (long long)(wlast ? m0n : m0) - 2 * V;
+                        const int cbn = wlast ? 0 : cb + 1;
+                        if (isE) {
+                            if (j >= 1 && nextw) a_piece(firstn, cbn, wave >> 2, (j - 1) * V + 16 * (wave & 3), j * V, ebuf, EP);       // E strip of the next window
+                            if (j < 4) a_piece(o_rows + m0 - 2 * V, cb, wave >> 2, 3 * V + 64 * j + 16 * (wave & 3), WO, obuf, OP);       // this window's O top
+                        } else {
+                            if (j >= 1 && nextw) a_piece(o_rows + firstn, cbn, wave >> 2, (j - 1) * V + 16 * (wave & 3), j * V, obuf, OP);   // O strip of the next window
+                            if (nextw) a_piece(firstn, cbn, wave >> 2, 4 * V + 64 * j + 16 * (wave & 3), WE, ebuf, EP);                  // the next window's E top
+                        }
+                    }
+                    // the shortcut's fragments for the next k-step
+                    if (st + 1 >= ncb * 9 && st + 1 < nsteps) shortcut_fetch(m0, st + 1 - ncb * 9);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+        if (interior) {
+            sg_epilogue<TM, TN, false, MODE>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+            stores_behind = true;
+        } else sg_epilogue<TM, TN, true, MODE>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+        if (!more) break;
+        tile = tnext; m0 = m0n; n0 = n0n;
+    }
+}
+static int tconv_s2_lds_bytes(int V) { return 2 * (256 + 4 * V) * 64 + 2 * (256 + 3 * V) * 64 + 2 * 2 * 128 * 64; }
+bool sg_tconv_s2_supported(int N, int Kp, int V) { return (N == 128 || N == 256) && Kp == 9 * N && V % 4 == 0 && V >= 16 && V <= 64 && tconv_s2_lds_bytes(V) <= 160 * 1024; }
+hipError_t launch_sg_tconv_s2(const GemmX3Args& g, int V, long long o_rows, hipStream_t s) {
+    const int nbx = g.N / 128, ntiles = nbx * ((g.M + 255) / 256);
+    hipLaunchKernelGGL((k_sg_tconv_s2<SGE_RELU | SGE_PLANES>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), tconv_s2_lds_bytes(V), s, g, nbx, ntiles, V, o_rows);
+    return hipGetLastError();
 }
 
 // ---- graph aggregation + 1 x 1 convolution of an ST-GCN block as ONE kernel (rgn_stgcn.hip) -------------------------------------------------------

@@ -78,6 +78,9 @@ struct GemmX3Args {
     float* C; int ldc;                                  // optional fp32 output [M, ldc]
     __bf16* Chi; __bf16* Clo; int c_rows;               // optional split output planes [ceil(N/32)][c_rows][32]
     const __bf16* Rhi; const __bf16* Rlo; int r_rows;   // launch_sg_tconv tail 2 only: residual planes [N/32][r_rows][32], added as (hi + lo)
+    // launch_sg_tconv_s2 only: a second product accumulated into the same tile, A2 [k2][a2_rows][32] (rows as the output's) x W2 [k2][N][32] - the
+    // block's convolved shortcut
+    const __bf16* A2hi; const __bf16* A2lo; int a2_rows; const __bf16* W2hi; const __bf16* W2lo; int k2;
     int M, N, Kp;
     int act;
     // Optional "attention-ready" output of the packed in_proj GEMM (N = 3*d): instead of C / Chi the epilogue
@@ -323,6 +326,10 @@ hipError_t configure_gemm_x3_sg();
 bool sg_tconv_supported(int N, int Kp, int V);
 hipError_t launch_sg_tconv(const GemmX3Args& g, int V, int tail, hipStream_t s);   // tail 0: C = conv + bias (fp32) | 1: planes relu(conv + bias) | 2: planes relu(conv + bias + R)
 hipError_t configure_sg_tconv();
+// ... the stride-2 form on polyphase planes (region O starts o_rows rows behind region E; M = rows of one region = output rows), + the convolved shortcut;
+// output: planes relu(conv + shortcut + bias)
+bool sg_tconv_s2_supported(int N, int Kp, int V);
+hipError_t launch_sg_tconv_s2(const GemmX3Args& g, int V, long long o_rows, hipStream_t s);
 // ... and graph aggregation + 1 x 1 convolution as one kernel: A = the block's INPUT planes, Kp = KP x C_in. The nonzero lists of A'_k[:, w] come as 8
 // slots per vertex, sl_v / sl_a [V][8] (source vertex, coefficient); slot s serves partition (slot_k >> 4 s) & 15 (15: unused) and a list shorter than
 // its partition's slot count is padded with (w, 0)

@@ -49,7 +49,7 @@ struct SgBlock {
     int *nz_ptr = nullptr, *nz_v = nullptr;          // nonzeros of A'_k[:, w]: list (k V + w) = [nz_ptr[k V + w], nz_ptr[k V + w + 1])
     float* nz_a = nullptr;
     __bf16 *W1h = nullptr, *W1l = nullptr, *W2h = nullptr, *W2l = nullptr, *Wrh = nullptr, *Wrl = nullptr;   // K32-blocked weight planes [Kp/32][co][32]
-    float *b1 = nullptr, *b2 = nullptr, *br = nullptr;
+    float *b1 = nullptr, *b2 = nullptr, *br = nullptr, *b2r = nullptr;   // b2r = b2' + br' (the stride-2 kernel adds the shortcut into the same accumulators)
 };
 
 // split-bf16 activation planes [C/32][R][32]; hi / lo point at row 0 (behind the leading guard rows), R = block stride in rows
@@ -602,7 +602,9 @@ int rgn_stgcn_finalize(rgn_stgcn_handle h) {
                     for (int q = 0; q < ci; ++q) Wr[(size_t)o * b.kpr + q] = (float)(sr[o] * (double)wr[(size_t)o * ci + q]);
                     br[o] = (float)(sr[o] * (double)brs[o] + tr[o]);
                 }
-                if ((rc = sg_upload_planes(c, Wr, co, b.kpr, &b.Wrh, &b.Wrl)) || (rc = sg_upload(c, &b.br, br))) return rc;
+                std::vector<float> b2r(co);
+                for (int o = 0; o < co; ++o) b2r[o] = b2[o] + br[o];
+                if ((rc = sg_upload_planes(c, Wr, co, b.kpr, &b.Wrh, &b.Wrl)) || (rc = sg_upload(c, &b.br, br)) || (rc = sg_upload(c, &b.b2r, b2r))) return rc;
             }
         }
         {
@@ -722,7 +724,16 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
             static const bool no_window = getenv("REGENNET_SG_NO_WINDOW") != nullptr;            // (tools: the row-shifted GEMM for every block)
             static const bool no_tail = getenv("REGENNET_SG_NO_TAIL_FUSE") != nullptr;            // (tools: k_sg_post for every block)
             const bool window = !ipoly && !no_window && sg_tconv_supported(b.co, 9 * b.co, V);     // activation window resident in LDS
-            if (window && !opoly && !b.res_conv && !no_tail) {
+            static const bool no_s2 = getenv("REGENNET_SG_NO_S2_WINDOW") != nullptr;             // (tools: the row-shifted GEMM + shortcut GEMM + k_sg_post for the stride-2 blocks)
+            if (ipoly && !opoly && b.res_conv && !no_s2 && !no_window && b.kpr == b.ci && sg_tconv_s2_supported(b.co, 9 * b.co, V)) {
+                // stride-2 block: two resident windows (even / odd frames), the convolved shortcut as extra k-steps, the tail in the epilogue
+                g2.bias = b.b2r;
+                g2.Chi = xo.hi; g2.Clo = xo.lo; g2.c_rows = (int)xo.R;
+                g2.A2hi = xp.hi; g2.A2lo = xp.lo; g2.a2_rows = (int)xp.R;
+                g2.W2hi = b.Wrh; g2.W2lo = b.Wrl; g2.k2 = b.kpr / 32;
+                SG_HIP(c, launch_sg_tconv_s2(g2, V, (long long)rows_c, s));
+                zero(xo, 0, To, To + SG_PAD, guard, guard);
+            } else if (window && !opoly && !b.res_conv && !no_tail) {
                 // the block's tail in the convolution's epilogue: x' = relu(conv + b2' [+ x]) straight into the next block's planes (same row geometry)
                 g2.bias = b.b2;
                 g2.Chi = xo.hi; g2.Clo = xo.lo; g2.c_rows = (int)xo.R;
