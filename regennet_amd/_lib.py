@@ -79,6 +79,7 @@ SYMBOLS.update({
     "rgn_stgcn_last_error": (C.c_char_p, [_vp]),
     "rgn_stgcn_load_weight": (C.c_int, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i32]),
     "rgn_stgcn_finalize": (C.c_int, [_vp]),
+    "rgn_stgcn_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
     "rgn_stgcn_forward": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp]),
 })
 
@@ -278,7 +279,7 @@ class Engine:
 class StgcnEngine:
     """Owns one rgn_stgcn_handle (the ST-GCN evaluator, include/regennet_hip.h)."""
 
-    def __init__(self, in_channels, num_class, num_person, num_nodes, num_frames, max_batch, device_index):
+    def __init__(self, in_channels, num_class, num_person, num_nodes, num_frames, max_batch, device_index, options=None):
         self.lib = load()
         self.shape = (int(num_nodes), int(in_channels), int(num_frames))
         self.num_class, self.max_batch = int(num_class), int(max_batch)
@@ -289,6 +290,8 @@ class StgcnEngine:
         if code != RGN_OK:
             raise RgnError(code, (self.lib.rgn_stgcn_last_error(None) or b"").decode())
         self.h = h
+        for k, v in (options or {}).items():         # kernel-selection switches of this handle (rgn_stgcn_set_option)
+            self.set_option(k, v)
 
     def _ck(self, code):
         if code != RGN_OK:
@@ -312,6 +315,9 @@ class StgcnEngine:
 
     def finalize(self):
         self._ck(self.lib.rgn_stgcn_finalize(self.h))
+
+    def set_option(self, key, value):
+        self._ck(self.lib.rgn_stgcn_set_option(self.h, key.encode(), int(value)))
 
     def forward(self, N, output, features, yhat, stream):
         self._ck(self.lib.rgn_stgcn_forward(self.h, int(N), _ptr(output), _ptr(features), _ptr(yhat), C.c_void_p(stream)))

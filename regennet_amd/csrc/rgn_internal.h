@@ -324,7 +324,7 @@ hipError_t launch_gemm_x3_sg(const GemmX3Args& g, hipStream_t s);
 hipError_t configure_gemm_x3_sg();
 // ... and the stride-1 9 x 1 temporal convolution with the activation window resident in LDS (K order: channel block, tap): V = rows per frame
 bool sg_tconv_supported(int N, int Kp, int V);
-hipError_t launch_sg_tconv(const GemmX3Args& g, int V, int tail, hipStream_t s);   // tail 0: C = conv + bias (fp32) | 1: planes relu(conv + bias) | 2: planes relu(conv + bias + R)
+hipError_t launch_sg_tconv(const GemmX3Args& g, int V, int tail, bool small_tiles, hipStream_t s);   // tail 0: C = conv + bias (fp32) | 1: planes relu(conv + bias) | 2: planes relu(conv + bias + R)
 hipError_t configure_sg_tconv();
 // ... the stride-2 form on polyphase planes (region O starts o_rows rows behind region E; M = rows of one region = output rows), + the convolved shortcut;
 // output: planes relu(conv + shortcut + bias)
@@ -334,7 +334,7 @@ hipError_t launch_sg_tconv_s2(const GemmX3Args& g, int V, long long o_rows, hipS
 // slots per vertex, sl_v / sl_a [V][8] (source vertex, coefficient); slot s serves partition (slot_k >> 4 s) & 15 (15: unused) and a list shorter than
 // its partition's slot count is padded with (w, 0)
 bool sg_gcn_supported(int N, int Kp, int V, int KP);
-hipError_t launch_sg_gcn(const GemmX3Args& g, int V, int KP, unsigned slot_k, const int* sl_v, const float* sl_a, hipStream_t s);
+hipError_t launch_sg_gcn(const GemmX3Args& g, int V, int KP, unsigned slot_k, const int* sl_v, const float* sl_a, int widest_tile, hipStream_t s);
 hipError_t configure_sg_gcn();
 hipError_t configure_attention(int Tq, int dh);
 struct AttnX3Args {

@@ -348,9 +348,7 @@ static hipError_t tconv_dispatch(const GemmX3Args& g, int V, int tail, hipStream
 // for the 256-channel blocks halves the window bytes per MFMA. Taller tiles would halve the weight bytes, but a tile taller than 8 V rows needs its rows
 // [8 V, BM) at tap 0 of a window while the previous window's tap 8 still reads them (512 rows, run without regard for that: -16 ... -24 % on the 64- and
 // 128-channel kernels), and 384-row tiles (4 x 2 waves of 96 rows) measured 5 - 15 % SLOWER than 256 (profiles/r05/stgcn_tconv_shapes.txt).
-hipError_t launch_sg_tconv(const GemmX3Args& g, int V, int tail, hipStream_t s) {
-    static const char* shape = getenv("REGENNET_SG_TCONV_SHAPE");   // (tools) "small": 256-row tiles, <= 128 wide
-    const bool small = shape && shape[0] == 's';
+hipError_t launch_sg_tconv(const GemmX3Args& g, int V, int tail, bool small, hipStream_t s) {   // small: 256-row tiles, <= 128 wide (tools / tests)
     const bool tall = !small && V % 8 == 0 && 8 * V <= 512;         // (the circular window: 2 V-row pieces, SP = 512 - 8 V >= 0)
     if (g.N == 64) return tall ? tconv_dispatch<512, 64, 8>(g, V, tail, s, false) : tconv_dispatch<256, 64, 8>(g, V, tail, s, false);
     if (g.N == 128 && tall) return tconv_dispatch<512, 128, 8>(g, V, tail, s, false);
@@ -727,9 +725,7 @@ static hipError_t gcn_launch(const GemmX3Args& g, int V, int KP, unsigned slot_k
     hipLaunchKernelGGL((k_sg_gcn<BN>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), gcn_lds_bytes(BN, V), s, g, nbx, ntiles, V, KP, slot_k, sl_v, sl_a);
     return hipGetLastError();
 }
-hipError_t launch_sg_gcn(const GemmX3Args& g, int V, int KP, unsigned slot_k, const int* sl_v, const float* sl_a, hipStream_t s) {
-    static const char* narrow = getenv("REGENNET_SG_GCN_BN");    // (tools: cap the tile width)
-    const int cap = narrow ? atoi(narrow) : 256;
+hipError_t launch_sg_gcn(const GemmX3Args& g, int V, int KP, unsigned slot_k, const int* sl_v, const float* sl_a, int cap, hipStream_t s) {   // cap: widest tile (tools / tests)
     if (g.N >= 256 && cap >= 256 && gcn_lds_bytes(256, V) <= 160 * 1024) return gcn_launch<256>(g, V, KP, slot_k, sl_v, sl_a, s);
     if (g.N >= 128 && cap >= 128 && gcn_lds_bytes(128, V) <= 160 * 1024) return gcn_launch<128>(g, V, KP, slot_k, sl_v, sl_a, s);
     return gcn_launch<64>(g, V, KP, slot_k, sl_v, sl_a, s);

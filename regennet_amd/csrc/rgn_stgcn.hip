@@ -67,6 +67,7 @@ struct rgn_stgcn_ctx {
     std::map<std::string, std::vector<float>> sd;
     std::map<std::string, std::vector<int64_t>> shapes;
     bool finalized = false;
+    std::map<std::string, int> opts;             // rgn_stgcn_set_option: kernel-selection switches of this handle (they take precedence over REGENNET_<KEY>)
     int V = 0, K = 0, C0 = 0;
     std::vector<SgBlock> blocks;
     float *bn_s = nullptr, *bn_t = nullptr, *Wf = nullptr, *bf = nullptr;
@@ -91,6 +92,17 @@ thread_local std::string g_sg_create_error;
         hipError_t _e = (expr);                                                                         \
         if (_e != hipSuccess) return (h)->fail(RGN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
+
+// The kernel-selection switches (rgn_stgcn_set_option; every selectable form meets the same parity bound - tests/test_eval_gpu.py runs them all):
+const char* const kSgOptions[] = {"SG_NO_WINDOW", "SG_NO_GCN_FUSE", "SG_NO_TAIL_FUSE", "SG_NO_S2_WINDOW", "SG_TCONV_SMALL", "SG_GCN_BN"};
+// value of a switch: the handle's option if given, else the environment variable REGENNET_<KEY>, else `dflt`
+int sg_opt(const rgn_stgcn_ctx* c, const char* key, int dflt) {
+    auto it = c->opts.find(key);
+    if (it != c->opts.end()) return it->second;
+    const std::string env = std::string("REGENNET_") + key;
+    if (const char* e = getenv(env.c_str())) return atoi(e);
+    return dflt;
+}
 
 typedef __bf16 sg_bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -660,6 +672,19 @@ int rgn_stgcn_finalize(rgn_stgcn_handle h) {
     });
 }
 
+int rgn_stgcn_set_option(rgn_stgcn_handle h, const char* key, int32_t value) {
+    return sg_guard(h, "rgn_stgcn_set_option", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        if (!key) return h->fail(RGN_ERR_INVALID_ARG, "rgn_stgcn_set_option: null key");
+        for (const char* k : kSgOptions)
+            if (!strcmp(k, key)) {
+                h->opts[key] = value;
+                return RGN_OK;
+            }
+        return h->fail(RGN_ERR_BAD_KEY, std::string("rgn_stgcn_set_option: unknown switch '") + key + "'");
+    });
+}
+
 int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float* features, float* yhat, void* stream) {
     return sg_guard(h, "rgn_stgcn_forward", [&]() -> int {
         if (!h) return RGN_ERR_INVALID_ARG;
@@ -680,6 +705,13 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
             const size_t rows = (size_t)NM * (T + SG_PAD) * V;
             hipLaunchKernelGGL(k_sg_in, blocks1d(rows), dim3(256), 0, s, output, planes(c->xa, rows), c->bn_s, c->bn_t, N, V, M, c->C0, T);
         }
+        // kernel forms (defaults: everything fused; the switches exist for tools and for the tests that run every form against the goldens)
+        const bool no_window = sg_opt(c, "SG_NO_WINDOW", 0) != 0;        // the row-shifted GEMM for every temporal convolution
+        const bool no_fuse = sg_opt(c, "SG_NO_GCN_FUSE", 0) != 0;        // aggregation and 1x1 GEMM as two launches
+        const bool no_tail = sg_opt(c, "SG_NO_TAIL_FUSE", 0) != 0;       // k_sg_post for every block
+        const bool no_s2 = sg_opt(c, "SG_NO_S2_WINDOW", 0) != 0;         // row-shifted GEMM + shortcut GEMM + k_sg_post for the stride-2 blocks
+        const bool small_tiles = sg_opt(c, "SG_TCONV_SMALL", 0) != 0;    // 256-row, <= 128-wide temporal-convolution tiles
+        const int gcn_bn = sg_opt(c, "SG_GCN_BN", 256);                  // widest k_sg_gcn tile
         __bf16 *(*x)[2] = &c->xa, *(*xn)[2] = &c->xb;
         auto phys = [&](int Tf, bool poly) { return (size_t)NM * (poly ? 2 * ((size_t)(Tf + 1) / 2 + SG_PAD) : (size_t)Tf + SG_PAD) * V; };
         for (int i = 0; i < 10; ++i) {
@@ -692,12 +724,11 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
             const size_t rows = phys(T, ipoly), rows_c = (size_t)NM * Tpi * V, rows_o = phys(To, opoly);
             const SgPl xp = planes(*x, rows), zp = planes(c->z, rows), gp = planes(c->g, rows), xo = planes(*xn, rows_o);
             // graph aggregation on the input channels (sparse A'), then the 1x1 convolution over K C_in (+ folded BN, vertex bias, ReLU): frame-local, any row order
-            static const bool no_fuse = getenv("REGENNET_SG_NO_GCN_FUSE") != nullptr;             // (tools: aggregation and GEMM as two launches for every block)
             const bool fused = !no_fuse && b.sl_v && b.ci % 32 == 0 && b.kp1 == K * b.ci && sg_gcn_supported(b.co, b.kp1, V, K);
             GemmX3Args g1 = sg_gemm_x3(fused ? xp : zp, b.W1h, b.W1l, (int)rows, b.co, b.kp1);
             g1.add = b.b1; g1.ldadd = b.co; g1.add_mod = V; g1.act = 3;                          // + b1'[row % V], ReLU
             g1.Chi = gp.hi; g1.Clo = gp.lo; g1.c_rows = (int)gp.R;
-            if (fused) SG_HIP(c, launch_sg_gcn(g1, V, K, b.slot_k, b.sl_v, b.sl_a, s));   // z is formed in registers, fragment by fragment
+            if (fused) SG_HIP(c, launch_sg_gcn(g1, V, K, b.slot_k, b.sl_v, b.sl_a, gcn_bn, s));   // z is formed in registers, fragment by fragment
             else {
                 if (b.ci % 32 == 0) hipLaunchKernelGGL(k_sg_agg, dim3((unsigned)((rows * 4 + 255) / 256), (unsigned)(K * (b.ci / 32))), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
                 else hipLaunchKernelGGL(k_sg_agg_small, blocks1d(rows), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
@@ -721,10 +752,7 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
                 else if ((dt & 1) == 0) g2.a_tap[dt] = (long long)((dt - 4) / 2) * V * 64;                  // frame 2 t' + dt - 4 = even frame t' + (dt - 4) / 2
                 else g2.a_tap[dt] = ((long long)rows_c + (long long)((dt - 5) / 2) * V) * 64;               // ... = odd frame t' + (dt - 5) / 2
             }
-            static const bool no_window = getenv("REGENNET_SG_NO_WINDOW") != nullptr;            // (tools: the row-shifted GEMM for every block)
-            static const bool no_tail = getenv("REGENNET_SG_NO_TAIL_FUSE") != nullptr;            // (tools: k_sg_post for every block)
             const bool window = !ipoly && !no_window && sg_tconv_supported(b.co, 9 * b.co, V);     // activation window resident in LDS
-            static const bool no_s2 = getenv("REGENNET_SG_NO_S2_WINDOW") != nullptr;             // (tools: the row-shifted GEMM + shortcut GEMM + k_sg_post for the stride-2 blocks)
             if (ipoly && !opoly && b.res_conv && !no_s2 && !no_window && b.kpr == b.ci && sg_tconv_s2_supported(b.co, 9 * b.co, V)) {
                 // stride-2 block: two resident windows (even / odd frames), the convolved shortcut as extra k-steps, the tail in the epilogue
                 g2.bias = b.b2r;
@@ -738,11 +766,11 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
                 g2.bias = b.b2;
                 g2.Chi = xo.hi; g2.Clo = xo.lo; g2.c_rows = (int)xo.R;
                 g2.Rhi = xp.hi; g2.Rlo = xp.lo; g2.r_rows = (int)xp.R;
-                SG_HIP(c, launch_sg_tconv(g2, V, b.res_id ? 2 : 1, s));
+                SG_HIP(c, launch_sg_tconv(g2, V, b.res_id ? 2 : 1, small_tiles, s));
                 zero(xo, 0, To, To + SG_PAD, guard, guard);
             } else {
                 g2.C = c->conv; g2.ldc = b.co;
-                if (window) SG_HIP(c, launch_sg_tconv(g2, V, 0, s));
+                if (window) SG_HIP(c, launch_sg_tconv(g2, V, 0, small_tiles, s));
                 else SG_HIP(c, launch_gemm_x3_sg(g2, s));
                 if (b.res_conv) {   // strided 1x1 convolution of the block input: the even frames = region E of the polyphase planes (all rows for a stride-1 block)
                     GemmX3Args gr = sg_gemm_x3(xp, b.Wrh, b.Wrl, (int)rows_c, b.co, b.kpr);

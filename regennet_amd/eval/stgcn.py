@@ -52,6 +52,7 @@ class STGCN(nn.Module):
         self.edge_importance = nn.ParameterList([nn.Parameter(torch.ones(K, V, V)) for _ in _BLOCKS])
         self.fcn = nn.Conv2d(256, num_class, kernel_size=1)
         self._engine, self._stale = None, True
+        self.engine_options = {}                  # kernel-selection switches for this model's engine (rgn_stgcn_set_option; tools and tests)
         for p in self.parameters():
             p.requires_grad_(False)
 
@@ -74,7 +75,7 @@ class STGCN(nn.Module):
                 torch.cuda.synchronize(dev)
                 eng.close()
             eng = _lib.StgcnEngine(self.in_channels, self.num_class, self.num_person, V, T, max(N, eng.max_batch if eng and eng.shape == (V, self.in_channels, T) else 0),
-                                   dev.index or 0)
+                                   dev.index or 0, options=self.engine_options)
             for k, v in self.state_dict().items():
                 if k.endswith("num_batches_tracked"):
                     continue

@@ -80,6 +80,27 @@ def test_stgcn_other_skeletons_match_the_oracle(V, hub, T, N):
     assert err_y < 1e-4 * max(1.0, float(ref_y.abs().max())), err_y
 
 
+@pytest.mark.parametrize("opts", [{"SG_NO_WINDOW": 1}, {"SG_NO_GCN_FUSE": 1}, {"SG_NO_TAIL_FUSE": 1}, {"SG_NO_S2_WINDOW": 1}, {"SG_TCONV_SMALL": 1},
+                                  {"SG_GCN_BN": 64}, {"SG_NO_WINDOW": 1, "SG_NO_GCN_FUSE": 1, "SG_NO_TAIL_FUSE": 1}])
+def test_stgcn_every_kernel_form_matches_reference(golden, opts):
+    """rgn_stgcn_set_option: each selectable kernel form (the fused kernels one at a time switched back to the form they replaced, the narrow / small
+    tiles, and the first split-bf16 build as a whole) against the reference's outputs, per handle and without touching the environment."""
+    from regennet_amd import _lib
+    g = golden("stgcn")
+    model, _ = _model(g)
+    model.engine_options = dict(opts)
+    for tag in ("ntu", "chi3d"):
+        x = torch.from_numpy(g[f"x_{tag}"]).cuda()
+        batch = model({"output": x})
+        feats = batch["features"].reshape(x.shape[0], -1).cpu().numpy()
+        ref_f, ref_y = g[f"features_{tag}"], g[f"yhat_{tag}"]
+        assert np.abs(feats - ref_f).max() < 1e-4 * max(1.0, np.abs(ref_f).max()), (opts, tag, np.abs(feats - ref_f).max())
+        assert np.abs(batch["yhat"].cpu().numpy() - ref_y).max() < 1e-4 * max(1.0, np.abs(ref_y).max()), (opts, tag)
+    with pytest.raises(_lib.RgnError) as e:
+        model._engine.set_option("SG_NO_SUCH_SWITCH", 1)
+    assert e.value.code == -2
+
+
 def test_stgcn_batching_and_errors(golden):
     """A batch evaluated at once equals its samples evaluated one by one (rows are independent); a checkpoint with a
     missing key is refused with the key named."""

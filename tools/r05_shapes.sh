@@ -5,10 +5,10 @@ timeout 900 python -m pytest tests/test_eval_gpu.py -x -q > gpurun_out/r05g/eval
 tail -5 gpurun_out/r05g/eval_tests.log
 for rep in 1 2; do
   echo "big:"; timeout 300 python bench.py --config stgcn --steps 10 --warmup 2 2>/dev/null | tee gpurun_out/r05g/bench_big_$rep.json | cut -c1-200
-  echo "small:"; REGENNET_SG_TCONV_SHAPE=small timeout 300 python bench.py --config stgcn --steps 10 --warmup 2 2>/dev/null | tee gpurun_out/r05g/bench_small_$rep.json | cut -c1-200
+  echo "small:"; REGENNET_SG_TCONV_SMALL=1 timeout 300 python bench.py --config stgcn --steps 10 --warmup 2 2>/dev/null | tee gpurun_out/r05g/bench_small_$rep.json | cut -c1-200
 done
 for v in big small; do
-if [ $v = small ]; then export REGENNET_SG_TCONV_SHAPE=small; fi
+if [ $v = small ]; then export REGENNET_SG_TCONV_SMALL=1; fi
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r05g/prof -o stgcn -- python $GRAFT_REPO_ROOT/bench.py --config stgcn --steps 3 --warmup 1 > $GRAFT_REPO_ROOT/gpurun_out/r05g/stgcn_prof.log 2>&1)
 find gpurun_out/r05g/prof -name "*kernel_stats.csv" -exec cp {} gpurun_out/r05g/stgcn_kernel_stats_$v.csv \;
 rm -rf gpurun_out/r05g/prof
