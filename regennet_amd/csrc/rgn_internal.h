@@ -78,6 +78,7 @@ struct GemmX3Args {
     float* C; int ldc;                                  // optional fp32 output [M, ldc]
     __bf16* Chi; __bf16* Clo; int c_rows;               // optional split output planes [ceil(N/32)][c_rows][32]
     const __bf16* Rhi; const __bf16* Rlo; int r_rows;   // launch_sg_tconv tail 2 only: residual planes [N/32][r_rows][32], added as (hi + lo)
+    int poly_T, poly_V, poly_region;                    // launch_sg_tconv tail 3 only: frames per sequence of the rows (+ 4 pads), vertices, rows per output region
     // launch_sg_tconv_s2 only: a second product accumulated into the same tile, A2 [k2][a2_rows][32] (rows as the output's) x W2 [k2][N][32] - the
     // block's convolved shortcut
     const __bf16* A2hi; const __bf16* A2lo; int a2_rows; const __bf16* W2hi; const __bf16* W2lo; int k2;
@@ -324,7 +325,7 @@ hipError_t launch_gemm_x3_sg(const GemmX3Args& g, hipStream_t s);
 hipError_t configure_gemm_x3_sg();
 // ... and the stride-1 9 x 1 temporal convolution with the activation window resident in LDS (K order: channel block, tap): V = rows per frame
 bool sg_tconv_supported(int N, int Kp, int V);
-hipError_t launch_sg_tconv(const GemmX3Args& g, int V, int tail, bool small_tiles, hipStream_t s);   // tail 0: C = conv + bias (fp32) | 1: planes relu(conv + bias) | 2: planes relu(conv + bias + R)
+hipError_t launch_sg_tconv(const GemmX3Args& g, int V, int tail, bool small_tiles, hipStream_t s);   // tail 0: C = conv + bias (fp32) | 1: planes relu(conv + bias) | 2: planes relu(conv + bias + R) | 3: as 2, polyphase
 hipError_t configure_sg_tconv();
 // ... the stride-2 form on polyphase planes (region O starts o_rows rows behind region E; M = rows of one region = output rows), + the convolved shortcut;
 // output: planes relu(conv + shortcut + bias)

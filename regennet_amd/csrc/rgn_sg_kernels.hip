@@ -30,9 +30,11 @@ __device__ __forceinline__ void wait_vmcnt() {   // at most N vector-memory oper
 //   SGE_VERTEX_BIAS  the bias is a per-vertex row add[(row % add_mod)][n] (the graph convolution's, rgn_stgcn.hip); else bias[n]
 //   SGE_RES_PLANES   + the residual Rhi + Rlo (split planes [N/32][r_rows][32], the block's input: identity shortcut)
 //   SGE_RELU | SGE_PLANES (output as split planes, else fp32)
+//   SGE_POLY         the planes are written POLYPHASE for a stride-2 consumer: input row (sequence, frame t < T of T + 4, vertex) -> region t & 1 (poly_region
+//                    rows each), frame t >> 1 of ceil(T / 2) + 4; the input's pad frames are not written (the consumer's pads are zeroed by the host's k_sg_zero)
 // What a 32 x 32 tile needs from memory is requested one tile AHEAD of its use: vmcnt retires in order, so a load queued behind the previous tile's
 // stores would wait for their acknowledgements - 2 TM TN round trips to memory per workgroup tile in x3_epilogue's order.
-enum { SGE_VERTEX_BIAS = 1, SGE_RELU = 2, SGE_PLANES = 4, SGE_RES_PLANES = 8 };
+enum { SGE_VERTEX_BIAS = 1, SGE_RELU = 2, SGE_PLANES = 4, SGE_RES_PLANES = 8, SGE_POLY = 16 };
 template <int TM, int TN, bool CHECK, int MODE>
 __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[TM][TN], int mw, int nw, int lane) {
     const int l31 = lane & 31, kh = lane >> 5;
@@ -105,6 +107,30 @@ __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
             for (int i = 0; i < 16; ++i) {
                 const int ro = (i & 3) + 8 * (i >> 2);
                 if (!CHECK || (n_ok && mb + ro < g.M)) cp[(size_t)ro * g.ldc] = r[i];
+            }
+        } else if constexpr ((MODE & SGE_POLY) != 0) {
+            // rows mb + ro, ro < 32 <= V: at most one step into the next frame, which may be the next sequence's first
+            const int Vv = g.poly_V, Tr = g.poly_T, Tp = Tr + 4, Tpo = ((Tr + 1) >> 1) + 4;
+            const unsigned f0 = (unsigned)mb / (unsigned)Vv, nm0 = f0 / (unsigned)Tp;
+            const int v0 = mb - (int)f0 * Vv, t0 = (int)(f0 - nm0 * (unsigned)Tp);
+            const size_t cb = (size_t)(n >> 5) * g.c_rows;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float mine = odd ? r[i + 8] : r[i], give = odd ? r[i] : r[i + 8];
+                const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+                const float c0 = odd ? got : mine, c1 = odd ? mine : got;
+                const int ii = odd ? i + 8 : i, ro = (ii & 3) + 8 * (ii >> 2);
+                int v = v0 + ro, t = t0, nm = (int)nm0;
+                if (v >= Vv) { v -= Vv; ++t; }
+                if (t >= Tp) { t -= Tp; ++nm; }
+                if (t < Tr && (!CHECK || mb + ro < g.M)) {
+                    const size_t o = (cb + (size_t)(t & 1) * g.poly_region + ((size_t)nm * Tpo + (t >> 1)) * Vv + v) * 32 + (n & 30);
+                    const __bf16 h0 = (__bf16)c0, h1 = (__bf16)c1;
+                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                    bf16x2 hv = {h0, h1}, lv = {(__bf16)(c0 - (float)h0), (__bf16)(c1 - (float)h1)};
+                    *reinterpret_cast<bf16x2*>(g.Chi + o) = hv;
+                    *reinterpret_cast<bf16x2*>(g.Clo + o) = lv;
+                }
             }
         } else if constexpr (!CHECK) {   // K32-blocked planes [N/32][c_rows][32]: a 32-column tile is one contiguous run of rows
             // adjacent columns paired across lane ^ 1 -> packed bf16x2 stores: even lanes rows of registers 0..7, odd lanes those of registers 8..15
@@ -330,18 +356,20 @@ static hipError_t tconv_launch(const GemmX3Args& g, int V, hipStream_t s, bool c
 }
 // (8 V >= 256: tap 0 reads window rows [0, 256), and only the first 8 V rows of a window are in place before its own taps run)
 bool sg_tconv_supported(int N, int Kp, int V) { return (N == 64 || N == 128 || N == 256) && Kp == 9 * N && V % 4 == 0 && V >= 32 && V <= 64; }
-// tail 0: C = conv + bias (fp32);  1: planes relu(conv + bias);  2: planes relu(conv + bias + (Rhi + Rlo))
+// tail 0: C = conv + bias (fp32);  1: planes relu(conv + bias);  2: planes relu(conv + bias + (Rhi + Rlo));  3: as 2, written polyphase (poly_*)
 template <int BM, int BN, int WM>
 static hipError_t tconv_dispatch(const GemmX3Args& g, int V, int tail, hipStream_t s, bool configure_only) {
     if (configure_only) {
         hipError_t e = tconv_launch<BM, BN, WM, 0>(g, V, s, true);
         if (e != hipSuccess) return e;
         e = tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES>(g, V, s, true);
-        return e != hipSuccess ? e : tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES | SGE_RES_PLANES>(g, V, s, true);
+        if (e == hipSuccess) e = tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES | SGE_RES_PLANES>(g, V, s, true);
+        return e != hipSuccess ? e : tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES | SGE_RES_PLANES | SGE_POLY>(g, V, s, true);
     }
     if (tail == 0) return tconv_launch<BM, BN, WM, 0>(g, V, s, false);
     if (tail == 1) return tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES>(g, V, s, false);
-    return tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES | SGE_RES_PLANES>(g, V, s, false);
+    if (tail == 2) return tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES | SGE_RES_PLANES>(g, V, s, false);
+    return tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES | SGE_RES_PLANES | SGE_POLY>(g, V, s, false);
 }
 // Tile shapes. Per k-step the L2 -> LDS path (~20 B/clk) carries the weight tile + V rows + (taps 0-3) a quarter of the window top against
 // TM TN x 6 MFMAs per wave: 256 x 64 tiles (768 MFMA cycles per SIMD, 21 KB) and 256 x 128 (1536, 29 KB) sit at or past the path's rate; a 256-wide tile

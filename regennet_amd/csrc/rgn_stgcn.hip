@@ -94,7 +94,7 @@ thread_local std::string g_sg_create_error;
     } while (0)
 
 // The kernel-selection switches (rgn_stgcn_set_option; every selectable form meets the same parity bound - tests/test_eval_gpu.py runs them all):
-const char* const kSgOptions[] = {"SG_NO_WINDOW", "SG_NO_GCN_FUSE", "SG_NO_TAIL_FUSE", "SG_NO_S2_WINDOW", "SG_TCONV_SMALL", "SG_GCN_BN"};
+const char* const kSgOptions[] = {"SG_NO_WINDOW", "SG_NO_GCN_FUSE", "SG_NO_TAIL_FUSE", "SG_NO_POLY_TAIL", "SG_NO_S2_WINDOW", "SG_TCONV_SMALL", "SG_GCN_BN"};
 // value of a switch: the handle's option if given, else the environment variable REGENNET_<KEY>, else `dflt`
 int sg_opt(const rgn_stgcn_ctx* c, const char* key, int dflt) {
     auto it = c->opts.find(key);
@@ -709,6 +709,7 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
         const bool no_window = sg_opt(c, "SG_NO_WINDOW", 0) != 0;        // the row-shifted GEMM for every temporal convolution
         const bool no_fuse = sg_opt(c, "SG_NO_GCN_FUSE", 0) != 0;        // aggregation and 1x1 GEMM as two launches
         const bool no_tail = sg_opt(c, "SG_NO_TAIL_FUSE", 0) != 0;       // k_sg_post for every block
+        const bool no_poly = sg_opt(c, "SG_NO_POLY_TAIL", 0) != 0;       // ... only for the blocks whose output is polyphase
         const bool no_s2 = sg_opt(c, "SG_NO_S2_WINDOW", 0) != 0;         // row-shifted GEMM + shortcut GEMM + k_sg_post for the stride-2 blocks
         const bool small_tiles = sg_opt(c, "SG_TCONV_SMALL", 0) != 0;    // 256-row, <= 128-wide temporal-convolution tiles
         const int gcn_bn = sg_opt(c, "SG_GCN_BN", 256);                  // widest k_sg_gcn tile
@@ -761,6 +762,16 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
                 g2.W2hi = b.Wrh; g2.W2lo = b.Wrl; g2.k2 = b.kpr / 32;
                 SG_HIP(c, launch_sg_tconv_s2(g2, V, (long long)rows_c, s));
                 zero(xo, 0, To, To + SG_PAD, guard, guard);
+            } else if (window && opoly && b.res_id && !no_tail && !no_poly) {
+                // ... and for the block in front of a stride-2 block the same tail, written polyphase (even frames | odd frames)
+                g2.bias = b.b2;
+                g2.Chi = xo.hi; g2.Clo = xo.lo; g2.c_rows = (int)xo.R;
+                g2.Rhi = xp.hi; g2.Rlo = xp.lo; g2.r_rows = (int)xp.R;
+                const int Teo = (To + 1) / 2;
+                g2.poly_T = T; g2.poly_V = V; g2.poly_region = (int)((size_t)NM * (Teo + SG_PAD) * V);
+                SG_HIP(c, launch_sg_tconv(g2, V, 3, small_tiles, s));
+                zero(xo, 0, Teo, Teo + SG_PAD, guard, 0);
+                zero(xo, (long long)g2.poly_region, To / 2, Teo + SG_PAD, 0, guard);
             } else if (window && !opoly && !b.res_conv && !no_tail) {
                 // the block's tail in the convolution's epilogue: x' = relu(conv + b2' [+ x]) straight into the next block's planes (same row geometry)
                 g2.bias = b.b2;
