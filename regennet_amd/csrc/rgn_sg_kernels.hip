@@ -161,6 +161,13 @@ __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
         }
     }
 }
+#ifdef RGN_SG_PROF
+// tools only (tools/r05_tconv_stamps.sh, tools/sg_stamps.py): cycle stamps of workgroup 0's first 64 k-steps in k_sg_tconv<256, 256>: [step][wave][5]
+__device__ long long g_sg_prof[64 * 8 * 5];
+#define SG_STAMP(i) if (PROF && blockIdx.x == 0 && lane == 0 && gstep < 64) g_sg_prof[(gstep * 8 + wave) * 5 + (i)] = __builtin_readcyclecounter();
+#else
+#define SG_STAMP(i)
+#endif
 static int sg_cu_count() {
     static const int n = [] {
         int dev = 0, cus = 0;
@@ -183,6 +190,7 @@ static int sg_cu_count() {
 template <int BM, int BN, int WM, int MODE>
 __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int ntiles, int V) {
     constexpr int NT = 512, TAPS = 9;
+    [[maybe_unused]] constexpr bool PROF = BM == 256 && BN == 256 && MODE == (SGE_RELU | SGE_PLANES | SGE_RES_PLANES);   // (tools: SG_STAMP)
     constexpr int WN = 8 / WM;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int W_BYTES = BN * 64, W_STAGE = 2 * W_BYTES;      // one plane tile; a stage = hi | lo
@@ -275,10 +283,13 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
             const bool wlast = cb + 1 == ncb;
 #pragma unroll 1
             for (int dt = 0; dt < TAPS; ++dt, ++gstep) {
+                SG_STAMP(0)
                 if (stores_behind) wait_vmcnt<16 * TM * TN>();   // this k-step's DMA is older than the 16 TM TN stores of the tile just written
                 else wait_vmcnt<0>();                            // everything this thread requested up to the last k-step has landed ...
                 stores_behind = false;
+                SG_STAMP(1)
                 __builtin_amdgcn_s_barrier();                    // ... everyone's has, and everyone is done reading the previous k-step
+                SG_STAMP(2)
                 const char* wsb = wst + (gstep & 1) * W_STAGE;
                 // fragments: the tap's rows start dt V further down the window (the 16-byte chunk swizzle follows the LDS row)
                 bf16x8 ah[2][TM], al[2][TM], wh[2], wl[2];
@@ -317,6 +328,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
                                 for (int p = c0 + (wave & 3); p < c1; p += 4) a_piece(m0w, cbw, wave >> 2, 16 * p, BM, (ws - SP) & RMASK);
                             }
                         }
+                        SG_STAMP(3)
                         if (dt < 4) {
                             if constexpr (!CIRC) {
                                 constexpr int PPT = BM / 64;             // 16-row pieces per plane per tap: a quarter of the window top
@@ -333,6 +345,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                SG_STAMP(4)
             }
             if constexpr (CIRC) ws = (ws - SP) & RMASK;
         }
@@ -766,3 +779,8 @@ hipError_t configure_sg_gcn() {
 }
 
 }  // namespace rgn
+#ifdef RGN_SG_PROF
+extern "C" __attribute__((visibility("default"))) int rgn_debug_sg_prof(long long* out) {   // (tools build only: not part of the C-ABI)
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(rgn::g_sg_prof), sizeof(long long) * 64 * 8 * 5);
+}
+#endif
