@@ -112,7 +112,7 @@ def bench_stgcn(a):
                       "motions_per_s": round(N / (ms * 1e-3), 1), "algo_gflop_per_forward": round(flops / 1e9, 2),
                       "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS["bf16x3"], "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS["bf16x3"], 4),
                                    "traffic": None, "note": "algorithmic FLOPs of one forward (all its launches) / its duration; split-bf16 GEMMs: three MFMAs per product, "
-                                                            "ceiling for algorithmic FLOPs = peak / 3; the 4 + 4 zero pad frames per sequence are computed too"}})
+                                                            "ceiling for algorithmic FLOPs = peak / 3; the 4 shared zero pad frames per sequence are computed too (not counted)"}})
     print(json.dumps({"metric": "ST-GCN recogniser forward (evaluation harness, SURVEY 8f next-4)", "value": lines[0]["motions_per_s"], "unit": "motions/s",
                       "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": lines[0]["ms_per_forward"], "higher_is_better": True,
                       "scaling": "weak", "vs_baseline": None, "dtype": "split-bf16 (x3) MFMA, fp32 accumulate", "data": "synthetic", "config": {"workload": f"stgcn: N={a.batch} x [56, 12, 60 | 150]"},
