@@ -101,6 +101,32 @@ def test_stgcn_every_kernel_form_matches_reference(golden, opts):
     assert e.value.code == -2
 
 
+@pytest.mark.parametrize("T,N", [(60, 48), (150, 20)])
+def test_stgcn_many_tiles_per_workgroup(golden, T, N):
+    """The fused kernels are persistent: a workgroup walks tiles slot, slot + #CU, ... with the next tile's first window in flight under the last k-steps of
+    the current one. The golden batches are smaller than one tile per CU, so this runs a batch of several hundred to a thousand tiles and compares it (a)
+    with the same motions evaluated four at a time (one tile per workgroup: the same arithmetic per row, so bit for bit) and (b) with the CPU oracle on
+    the first, a middle and the last motion."""
+    from oracle import stgcn_oracle
+    g = golden("stgcn")
+    model, sd = _model(g)
+    rng = np.random.Generator(np.random.PCG64(4242 + T))
+    x = rng.standard_normal((N, 56, 12, T)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    big = model({"output": xd})
+    feats, yhat = big["features"].clone(), big["yhat"].clone()
+    for i in range(0, N, 4):
+        part = model({"output": xd[i:i + 4]})
+        assert torch.equal(part["features"], feats[i:i + 4]), (i, (part["features"] - feats[i:i + 4]).abs().max().item())
+        assert torch.equal(part["yhat"], yhat[i:i + 4]), i
+    sel = [0, N // 2, N - 1]
+    ref_f, ref_y = stgcn_oracle.stgcn_forward(sd, x[sel])
+    err = (feats[sel].cpu() - ref_f).abs().max().item()
+    print(f"\n[stgcn many tiles T={T} N={N}] max |features - oracle| = {err:.2e} (|ref| max {ref_f.abs().max():.2f})")
+    assert err < 1e-4 * max(1.0, float(ref_f.abs().max())), err
+    assert (yhat[sel].cpu() - ref_y).abs().max().item() < 1e-4 * max(1.0, float(ref_y.abs().max()))
+
+
 def test_stgcn_batching_and_errors(golden):
     """A batch evaluated at once equals its samples evaluated one by one (rows are independent); a checkpoint with a
     missing key is refused with the key named."""
