@@ -163,13 +163,18 @@ def bench_eval_pipeline(a):
     stats = calculate_activation_statistics(torch.cat(feats))
     fid_self = float(calculate_fid(stats, stats))
     torch.cuda.synchronize()
-    t_fid = time.perf_counter() - t1
+    t_fid = time.perf_counter() - t1                          # first call of the process: loads the fp64 solver library
+    t2 = time.perf_counter()
+    stats = calculate_activation_statistics(torch.cat(feats))
+    fid_self = float(calculate_fid(stats, stats))
+    torch.cuda.synchronize()
+    t_fid2 = time.perf_counter() - t2
     ms_s = float(np.mean([e[0].elapsed_time(e[1]) for e in evs])), float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
     print(json.dumps({"metric": "evaluation batches of eval_cmdm's hot loop (sample ddim5 + ST-GCN features)", "value": round(a.steps * B / dt, 1), "unit": "motions/s", "n_gpus": 1,
                       "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                       "dtype": "sampler: bf16 / split-bf16 schedule; recogniser: split-bf16", "data": "synthetic",
                       "config": {"workload": f"ntu_action B={B}: p_sample_loop(ddim5) -> cat(cmotion, sample) -> STGCN features; FID statistics over {a.steps * B} motions once"},
-                      "stage_ms": {"sample_ddim5": round(ms_s[0], 3), "recogniser": round(ms_s[1], 3), "fid_statistics_once": round(1e3 * t_fid, 2)}, "fid_self_numerical_floor": fid_self}), flush=True)
+                      "stage_ms": {"sample_ddim5": round(ms_s[0], 3), "recogniser": round(ms_s[1], 3), "fid_statistics_first_call": round(1e3 * t_fid, 2), "fid_statistics_again": round(1e3 * t_fid2, 2)}, "fid_self_numerical_floor": fid_self}), flush=True)
 
 
 def cpu_baseline(cfg, sd, steps_total, seconds_budget=20.0):

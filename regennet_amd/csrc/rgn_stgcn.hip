@@ -3,15 +3,19 @@
 // Replaces eval/a2m/recognition/models/stgcn.py:76-123 (STGCN.forward, eval mode) with its ten st_gcn blocks (:145-228)
 // and ConvTemporalGraphical (stgcnutils/tgcn.py:61-71). What runs per block, all BatchNorms folded at load time (fp64):
 //
-//   z[(n,t,w),(k,ci)] = sum_v A'_k[v,w] x[(n,t,v),ci]                       k_sg_agg      (graph aggregation first: the 1x1 conv and the
-//                                                                            vertex mixing commute; A' = A * edge_importance keeps the
-//                                                                            skeleton's sparsity - 166 of 3 x 56 x 56 entries for SMPL-X -
-//                                                                            so the kernel walks per-(k, w) nonzero lists)
-//   g = relu(z . W1'^T + b1'[w])                                            split-bf16 MFMA GEMM, K = 3 C_in
-//   c = sum_dt g[t + dt - 4] . W2'_dt^T                                     ONE split-bf16 MFMA GEMM over K = 9 C_out: k-block (dt, channel
-//                                                                            block) reads the time-PADDED activation with its rows
-//                                                                            shifted by (dt - 4) V (no im2col buffer, no read-modify-write)
-//   x' = relu(c[s t'] + b2' + residual)                                     k_sg_post     (stride s subsampling here)
+//   g  = relu((sum_v A'_k[v,w] x[(n,t,v),ci]) . W1'^T + b1'[w])            k_sg_gcn      graph aggregation first (the 1x1 conv and the vertex mixing
+//                                                                            commute; A' = A * edge_importance keeps the skeleton's sparsity -
+//                                                                            166 of 3 x 56 x 56 entries for SMPL-X), formed in registers in MFMA
+//                                                                            fragment layout, then ONE split-bf16 GEMM over K = 3 C_in
+//   x' = relu(sum_dt g[t + dt - 4] . W2'_dt^T + b2' + residual)             k_sg_tconv    ONE split-bf16 GEMM over K = 9 C_out on an LDS-resident window
+//                                                                            of the time-PADDED activation (tap dt = rows shifted by (dt - 4) V:
+//                                                                            no im2col buffer), the block's tail in the epilogue; output as the
+//                                                                            next block's planes - polyphase (even | odd frames) in front of a
+//   (stride 2: taps on the even / odd frame regions, + the 1x1 shortcut)    k_sg_tconv_s2 stride-2 block, which then runs at the output rate
+//
+// The kernels live in rgn_sg_kernels.hip; this file holds the load-time folding, the plane geometry and the block loop, plus the small kernels around
+// them (input layout + data_bn, pad zeroing, pooling) and the forms the fused kernels replaced (k_sg_agg + row-shifted k_gemm_x3 + k_sg_post), which
+// still serve graphs and shapes the fused kernels do not take and can be selected per handle (rgn_stgcn_set_option; every form is tested).
 //
 // Activations are split-bf16 operand planes (hi = rne(x), lo = rne(x - hi)) in the K32-blocked layout of rgn_gemm_x3.hip,
 // [C/32][R][32] with rows (n m, frame, vertex): 4 zero pad frames behind every sequence (= in front of the next one) and 4 V zero guard rows
