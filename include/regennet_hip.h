@@ -240,7 +240,7 @@ RGN_API int rgn_stgcn_finalize(rgn_stgcn_handle h);
 /* Kernel-selection switches of ONE recogniser handle (like rgn_set_option; any time before a forward): "SG_NO_WINDOW" (row-shifted GEMMs instead of the
  * LDS-window temporal convolutions), "SG_NO_GCN_FUSE" (aggregation and 1x1 convolution as two launches), "SG_NO_TAIL_FUSE" (k_sg_post for every block), "SG_NO_POLY_TAIL" (... for the two blocks with polyphase output),
  * "SG_NO_S2_WINDOW" (stride-2 blocks as row-shifted GEMM + shortcut GEMM), "SG_TCONV_SMALL" (256-row tiles), "SG_GCN_BN" (widest aggregation tile: 64 |
- * 128 | 256). A handle's option takes precedence over REGENNET_<KEY> in the environment; unknown names are RGN_ERR_BAD_KEY. Every form meets the same
+ * 128 | 256), "SG_GCN_STEP32" (64-wide aggregation tiles: one barrier per 32-deep k-block). A handle's option takes precedence over REGENNET_<KEY> in the environment; unknown names are RGN_ERR_BAD_KEY. Every form meets the same
  * parity bound (tests/test_eval_gpu.py runs each against the reference's outputs). */
 RGN_API int rgn_stgcn_set_option(rgn_stgcn_handle h, const char* key, int32_t value);
 /* STGCN.forward (stgcn.py:76-123): output_dev fp32 [N, num_nodes, in_channels, T] (batch['output']) ->

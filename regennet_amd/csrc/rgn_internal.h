@@ -335,7 +335,7 @@ hipError_t launch_sg_tconv_s2(const GemmX3Args& g, int V, long long o_rows, hipS
 // slots per vertex, sl_v / sl_a [V][8] (source vertex, coefficient); slot s serves partition (slot_k >> 4 s) & 15 (15: unused) and a list shorter than
 // its partition's slot count is padded with (w, 0)
 bool sg_gcn_supported(int N, int Kp, int V, int KP);
-hipError_t launch_sg_gcn(const GemmX3Args& g, int V, int KP, unsigned slot_k, const int* sl_v, const float* sl_a, int widest_tile, hipStream_t s);
+hipError_t launch_sg_gcn(const GemmX3Args& g, int V, int KP, unsigned slot_k, const int* sl_v, const float* sl_a, int widest_tile, bool per_block_barrier, hipStream_t s);
 hipError_t configure_sg_gcn();
 hipError_t configure_attention(int Tq, int dh);
 struct AttnX3Args {

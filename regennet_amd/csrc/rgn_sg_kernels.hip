@@ -611,10 +611,12 @@ hipError_t launch_sg_tconv_s2(const GemmX3Args& g, int V, long long o_rows, hipS
 // PERSISTENT: a workgroup walks tiles blockIdx, + gridDim, ... as one k-step stream - the next tile's first window and weight tile are in flight under
 // the last k-steps of this one, and its first wait leaves this tile's stores outstanding (a tile is only 6 - 24 k-steps: as one workgroup per tile,
 // launch + first window + store acknowledgements were 25 - 45 % of the kernel with the matrix pipe and the fabric taking turns idling).
-template <int BN>
+// ALLK: one barrier per CHANNEL BLOCK - a weight stage holds the tiles of all KP <= 4 partitions (narrow tiles only: 3 x 8 KB at BN = 64): the k-step's fixed
+// costs (DMA wait, barrier, DMA issue; ~1950 cycles in k_sg_tconv's stamps) are paid once per 96-deep step instead of once per 32.
+template <int BN, bool ALLK>
 __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int ntiles, int V, int KP, unsigned slot_k, const int* __restrict__ sl_v, const float* __restrict__ sl_a) {
     constexpr int BM = 256, NT = 512, TN = BN / 32, NS = 8;
-    constexpr int W_BYTES = BN * 64, W_STAGE = 2 * W_BYTES;
+    constexpr int W_BYTES = BN * 64, W_STAGE = 2 * W_BYTES * (ALLK ? 4 : 1);
     constexpr int W_IT = BN * 8 / NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -665,7 +667,9 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
     int tile = blockIdx.x;
     int m0 = (tile / nbx) * BM, n0 = (tile % nbx) * BN;
     for (int p = wave; p < npieces; p += 8) x_piece(m0, 0, p, 0);
-    w_tile(n0, 0, wst);
+    if constexpr (ALLK) {
+        for (int kk = 0; kk < KP; ++kk) w_tile(n0, kk * ncb, wst + kk * 2 * W_BYTES);
+    } else w_tile(n0, 0, wst);
     unsigned gstep = 0, widx = 0;                                // k-steps / windows consumed so far: stage gstep & 1, window buffer widx & 1
     bool stores_behind = false;                                  // the previous tile's stores were issued after everything the next wait is for
     while (true) {
@@ -696,22 +700,27 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
         for (int cb = 0; cb < ncb; ++cb, ++widx) {
             const char* xw = smem + (widx & 1) * XW;
             const bool wlast = cb + 1 == ncb;
-            for (int k = 0; k < KP; ++k, ++gstep) {
-                if (stores_behind) wait_vmcnt<16 * TN>();    // the DMA of this k-step is older than the 16 TN stores of the tile just written
-                else wait_vmcnt<0>();
-                stores_behind = false;
-                __builtin_amdgcn_s_barrier();                    // the tile of this k-step (and, at k = 0, the window) is in LDS; the previous k-step is read out
-                {
-                    const bool klast = k + 1 == KP;
-                    if (!(klast && wlast)) w_tile(n0, klast ? cb + 1 : (k + 1) * ncb + cb, wst + ((gstep + 1) & 1) * W_STAGE);
-                    else if (more) w_tile(n0n, 0, wst + ((gstep + 1) & 1) * W_STAGE);
-                }
-                if (!wlast || more)
-                    for (int i = 0; i < ppk; ++i) {
-                        const int p = (k * ppk + i) * 8 + wave;
-                        if (p < npieces) x_piece(wlast ? m0n : m0, wlast ? 0 : cb + 1, p, (widx + 1) & 1);
+            for (int k = 0; k < KP; ++k) {
+                if (!ALLK || k == 0) {
+                    if (stores_behind) wait_vmcnt<16 * TN>();    // the DMA of this step is older than the 16 TN stores of the tile just written
+                    else wait_vmcnt<0>();
+                    stores_behind = false;
+                    __builtin_amdgcn_s_barrier();                // the tile(s) of this step (and, at k = 0, the window) are in LDS; the previous step is read out
+                    if constexpr (!ALLK) {
+                        const bool klast = k + 1 == KP;
+                        if (!(klast && wlast)) w_tile(n0, klast ? cb + 1 : (k + 1) * ncb + cb, wst + ((gstep + 1) & 1) * W_STAGE);
+                        else if (more) w_tile(n0n, 0, wst + ((gstep + 1) & 1) * W_STAGE);
+                        if (!wlast || more)
+                            for (int i = 0; i < ppk; ++i) {
+                                const int p = (k * ppk + i) * 8 + wave;
+                                if (p < npieces) x_piece(wlast ? m0n : m0, wlast ? 0 : cb + 1, p, (widx + 1) & 1);
+                            }
+                    } else if (!wlast || more) {                 // every partition's tile of the next channel block, and its whole window
+                        for (int kk = 0; kk < KP; ++kk) w_tile(wlast ? n0n : n0, kk * ncb + (wlast ? 0 : cb + 1), wst + ((gstep + 1) & 1) * W_STAGE + kk * 2 * W_BYTES);
+                        for (int p = wave; p < npieces; p += 8) x_piece(wlast ? m0n : m0, wlast ? 0 : cb + 1, p, (widx + 1) & 1);
                     }
-                const char* wsb = wst + (gstep & 1) * W_STAGE;
+                }
+                const char* wsb = wst + (gstep & 1) * W_STAGE + (ALLK ? k * 2 * W_BYTES : 0);
                 float z[2][8];
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
@@ -745,6 +754,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
                         acc[0][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[0][tb], 0, 0, 0);
                     }
                 }
+                if (!ALLK || k + 1 == KP) ++gstep;
             }
         }
         const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
@@ -756,26 +766,28 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
         tile = tnext; m0 = m0n; n0 = n0n;
     }
 }
-static int gcn_lds_bytes(int BN, int V) { return 2 * 2 * (256 + 2 * V) * 64 + 2 * 2 * BN * 64 + 2 * 4 * 8 * V; }
+static int gcn_lds_bytes(int BN, int V, bool allk = false) { return 2 * 2 * (256 + 2 * V) * 64 + 2 * 2 * BN * 64 * (allk ? 4 : 1) + 2 * 4 * 8 * V; }
 bool sg_gcn_supported(int N, int Kp, int V, int KP) {
     return (N == 64 || N == 128 || N == 256) && KP >= 1 && KP <= 8 && Kp % (32 * KP) == 0 && V % 4 == 0 && V >= 16 && V <= 64 && gcn_lds_bytes(64, V) <= 160 * 1024;
 }
-template <int BN>
+template <int BN, bool ALLK>
 static hipError_t gcn_launch(const GemmX3Args& g, int V, int KP, unsigned slot_k, const int* sl_v, const float* sl_a, hipStream_t s) {
     const int nbx = (g.N + BN - 1) / BN, ntiles = nbx * ((g.M + 255) / 256);
-    hipLaunchKernelGGL((k_sg_gcn<BN>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), gcn_lds_bytes(BN, V), s, g, nbx, ntiles, V, KP, slot_k, sl_v, sl_a);
+    hipLaunchKernelGGL((k_sg_gcn<BN, ALLK>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), gcn_lds_bytes(BN, V, ALLK), s, g, nbx, ntiles, V, KP, slot_k, sl_v, sl_a);
     return hipGetLastError();
 }
-hipError_t launch_sg_gcn(const GemmX3Args& g, int V, int KP, unsigned slot_k, const int* sl_v, const float* sl_a, int cap, hipStream_t s) {   // cap: widest tile (tools / tests)
-    if (g.N >= 256 && cap >= 256 && gcn_lds_bytes(256, V) <= 160 * 1024) return gcn_launch<256>(g, V, KP, slot_k, sl_v, sl_a, s);
-    if (g.N >= 128 && cap >= 128 && gcn_lds_bytes(128, V) <= 160 * 1024) return gcn_launch<128>(g, V, KP, slot_k, sl_v, sl_a, s);
-    return gcn_launch<64>(g, V, KP, slot_k, sl_v, sl_a, s);
+hipError_t launch_sg_gcn(const GemmX3Args& g, int V, int KP, unsigned slot_k, const int* sl_v, const float* sl_a, int cap, bool per_block_barrier, hipStream_t s) {   // cap: widest tile (tools / tests)
+    if (g.N >= 256 && cap >= 256 && gcn_lds_bytes(256, V) <= 160 * 1024) return gcn_launch<256, false>(g, V, KP, slot_k, sl_v, sl_a, s);
+    if (g.N >= 128 && cap >= 128 && gcn_lds_bytes(128, V) <= 160 * 1024) return gcn_launch<128, false>(g, V, KP, slot_k, sl_v, sl_a, s);
+    if (!per_block_barrier && KP <= 4 && gcn_lds_bytes(64, V, true) <= 160 * 1024) return gcn_launch<64, true>(g, V, KP, slot_k, sl_v, sl_a, s);
+    return gcn_launch<64, false>(g, V, KP, slot_k, sl_v, sl_a, s);
 }
 hipError_t configure_sg_gcn() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e;
 }
 
 }  // namespace rgn

@@ -98,7 +98,7 @@ thread_local std::string g_sg_create_error;
     } while (0)
 
 // The kernel-selection switches (rgn_stgcn_set_option; every selectable form meets the same parity bound - tests/test_eval_gpu.py runs them all):
-const char* const kSgOptions[] = {"SG_NO_WINDOW", "SG_NO_GCN_FUSE", "SG_NO_TAIL_FUSE", "SG_NO_POLY_TAIL", "SG_NO_S2_WINDOW", "SG_TCONV_SMALL", "SG_GCN_BN"};
+const char* const kSgOptions[] = {"SG_NO_WINDOW", "SG_NO_GCN_FUSE", "SG_NO_TAIL_FUSE", "SG_NO_POLY_TAIL", "SG_NO_S2_WINDOW", "SG_TCONV_SMALL", "SG_GCN_BN", "SG_GCN_STEP32"};
 // value of a switch: the handle's option if given, else the environment variable REGENNET_<KEY>, else `dflt`
 int sg_opt(const rgn_stgcn_ctx* c, const char* key, int dflt) {
     auto it = c->opts.find(key);
@@ -717,6 +717,7 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
         const bool no_s2 = sg_opt(c, "SG_NO_S2_WINDOW", 0) != 0;         // row-shifted GEMM + shortcut GEMM + k_sg_post for the stride-2 blocks
         const bool small_tiles = sg_opt(c, "SG_TCONV_SMALL", 0) != 0;    // 256-row, <= 128-wide temporal-convolution tiles
         const int gcn_bn = sg_opt(c, "SG_GCN_BN", 256);                  // widest k_sg_gcn tile
+        const bool gcn_step32 = sg_opt(c, "SG_GCN_STEP32", 0) != 0;      // 64-wide k_sg_gcn: one barrier per 32-deep k-block (default: per channel block)
         __bf16 *(*x)[2] = &c->xa, *(*xn)[2] = &c->xb;
         auto phys = [&](int Tf, bool poly) { return (size_t)NM * (poly ? 2 * ((size_t)(Tf + 1) / 2 + SG_PAD) : (size_t)Tf + SG_PAD) * V; };
         for (int i = 0; i < 10; ++i) {
@@ -733,7 +734,7 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
             GemmX3Args g1 = sg_gemm_x3(fused ? xp : zp, b.W1h, b.W1l, (int)rows, b.co, b.kp1);
             g1.add = b.b1; g1.ldadd = b.co; g1.add_mod = V; g1.act = 3;                          // + b1'[row % V], ReLU
             g1.Chi = gp.hi; g1.Clo = gp.lo; g1.c_rows = (int)gp.R;
-            if (fused) SG_HIP(c, launch_sg_gcn(g1, V, K, b.slot_k, b.sl_v, b.sl_a, gcn_bn, s));   // z is formed in registers, fragment by fragment
+            if (fused) SG_HIP(c, launch_sg_gcn(g1, V, K, b.slot_k, b.sl_v, b.sl_a, gcn_bn, gcn_step32, s));   // z is formed in registers, fragment by fragment
             else {
                 if (b.ci % 32 == 0) hipLaunchKernelGGL(k_sg_agg, dim3((unsigned)((rows * 4 + 255) / 256), (unsigned)(K * (b.ci / 32))), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
                 else hipLaunchKernelGGL(k_sg_agg_small, blocks1d(rows), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);

@@ -81,7 +81,7 @@ def test_stgcn_other_skeletons_match_the_oracle(V, hub, T, N):
 
 
 @pytest.mark.parametrize("opts", [{"SG_NO_WINDOW": 1}, {"SG_NO_GCN_FUSE": 1}, {"SG_NO_TAIL_FUSE": 1}, {"SG_NO_POLY_TAIL": 1}, {"SG_NO_S2_WINDOW": 1}, {"SG_TCONV_SMALL": 1},
-                                  {"SG_GCN_BN": 64}, {"SG_NO_WINDOW": 1, "SG_NO_GCN_FUSE": 1, "SG_NO_TAIL_FUSE": 1}])
+                                  {"SG_GCN_BN": 64}, {"SG_GCN_BN": 64, "SG_GCN_STEP32": 1}, {"SG_NO_WINDOW": 1, "SG_NO_GCN_FUSE": 1, "SG_NO_TAIL_FUSE": 1}])
 def test_stgcn_every_kernel_form_matches_reference(golden, opts):
     """rgn_stgcn_set_option: each selectable kernel form (the fused kernels one at a time switched back to the form they replaced, the narrow / small
     tiles, and the first split-bf16 build as a whole) against the reference's outputs, per handle and without touching the environment."""
