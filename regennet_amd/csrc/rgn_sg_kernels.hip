@@ -41,7 +41,7 @@ __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
     const bool odd = lane & 1;
     constexpr int NF = (MODE & (SGE_VERTEX_BIAS | SGE_RES_PLANES)) ? 16 : 1;
     auto fetch = [&](int idx, unsigned (&f)[NF]) {
-        const int tb = idx / TM, ta = idx - tb * TM;
+        const int ta = idx / TN, tb = idx - ta * TN;                   // (row tile outermost: what depends on the rows only is shared by its TN column tiles)
         const int n = nw + tb * 32 + l31, mb = mw + ta * 32 + 4 * kh;
         const bool n_ok = !CHECK || n < g.N;
         if constexpr ((MODE & SGE_VERTEX_BIAS) != 0) {
@@ -71,7 +71,7 @@ __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
     fetch(0, nxt);
 #pragma unroll
     for (int idx = 0; idx < TM * TN; ++idx) {
-        const int tb = idx / TM, ta = idx - tb * TM;
+        const int ta = idx / TN, tb = idx - ta * TN;                   // (row tile outermost: what depends on the rows only is shared by its TN column tiles)
         const int n = nw + tb * 32 + l31, mb = mw + ta * 32 + 4 * kh;
         const bool n_ok = !CHECK || n < g.N;
         float r[16];
