@@ -664,7 +664,9 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
     }
     const int r = wave * 32 + l31;
 
-    int tile = blockIdx.x;
+    // workgroups of one XCD take neighbouring tiles: a tile's window overlaps its neighbours' by V rows on either side, which then come from that XCD's L2
+    const int G = gridDim.x, q8 = G >> 3, r8 = G & 7, xcd = blockIdx.x & 7;
+    int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
     int m0 = (tile / nbx) * BM, n0 = (tile % nbx) * BN;
     for (int p = wave; p < npieces; p += 8) x_piece(m0, 0, p, 0);
     if constexpr (ALLK) {
