@@ -42,7 +42,8 @@ def row_check(cfg, sd, a, dev, y, out, seed, lo, plan, fn_name, rows):
     headline number rests on - 256 workgroups x 995 steps - is checked at its real shape on every bench run, not only for isfinite."""
     from regennet_amd import synth
     from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
-    model1, diffusion1 = synth.build_model(cfg, sd, resp=a.respacing, precision=a.precision, device=str(dev), x3_tail=a.x3_tail)
+    model1, diffusion1 = synth.build_model(cfg, sd, resp=a.respacing, precision=a.precision, device=str(dev), x3_tail=a.x3_tail,
+                                           engine_options={} if a.bulk_f16 is None else {"BULK_F16": a.bulk_f16})
     if "sb_gemm" not in plan:                       # (a batch the small-batch engine ran is bit-exact under batch composition by itself)
         model1.small_batch_rows = 0
     if any(k in plan for k in ("layers", "steps_fused")):
@@ -263,6 +264,8 @@ def main(argv=None):
     ap.add_argument("--precision", default=os.environ.get("REGENNET_PRECISION", "bf16_x3tail"),
                     choices=["f32", "bf16x3", "bf16", "bf16_x3tail"])
     ap.add_argument("--x3-tail", type=int, default=None, help="precision schedule: split-bf16 for the last N loop indices")
+    ap.add_argument("--bulk-f16", type=int, default=None, choices=[0, 1],
+                    help="plain phase of the precision schedule on fp16 (1) / bf16 (0) MFMA operands where the one-kernel decoder stack runs it (default: the engine's)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", default=bool(os.environ.get("REGENNET_FORCE_DIST")),
@@ -310,7 +313,8 @@ def main(argv=None):
     B = a.batch
     # rank 0 owns the checkpoint; other ranks start from a different seed and receive the packed blob via RCCL
     sd = synth.make_state_dict(cfg, seed=0 if rank == 0 else 1000 + rank)
-    model, diffusion = synth.build_model(cfg, sd, resp=a.respacing, precision=a.precision, device=str(dev), x3_tail=a.x3_tail)
+    eopts = {} if a.bulk_f16 is None else {"BULK_F16": a.bulk_f16}
+    model, diffusion = synth.build_model(cfg, sd, resp=a.respacing, precision=a.precision, device=str(dev), x3_tail=a.x3_tail, engine_options=eopts)
     # Engine build = host-side repack of the checkpoint into the device blob (fp32 -> bf16 planes in three layouts) + upload; timed and
     # reported ("engine_build_s": ~2 s of one host core at N = 1). N ranks repack concurrently by default; REGENNET_SERIAL_ENGINE_BUILD=1
     # makes them take turns (a host whose memory bandwidth 8 concurrent repacks would saturate), the broadcast follows either way.

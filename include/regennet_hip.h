@@ -153,6 +153,18 @@ RGN_API int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, floa
  * (gaussian_diffusion.py:265-276; 0.0016 at t=999, -> 1 at t=0), so early-step rounding is contracted away. */
 RGN_API int rgn_set_x3_tail(rgn_handle h, int32_t tail_steps);
 
+/* RGN_PREC_BF16_X3TAIL only, and only where the plain phase runs as the one-kernel decoder stack (k_layers<true>: <= 64 tokens, d = 512, >= 64
+ * motions per call): the `steps` plain loop indices right in front of the split-bf16 tail (tail <= i < tail + steps) use IEEE fp16 MFMA operands
+ * (11 mantissa bits) instead of bf16 (8) - weights, activation images, q / k / v / p; accumulation, LayerNorm, softmax and the sampler update stay
+ * fp32. -1 restores the default (8, or REGENNET_F16_STEPS); 0 = no fp16 phase (then the default split-bf16 tail is the bf16 rule's again). With an
+ * fp16 phase the default tail is 2 steps instead of 5 (3 for schedules of <= 10 steps): rgn_set_x3_tail overrides either. fp16 has a 5-bit exponent:
+ * rgn_finalize_weights refuses (RGN_ERR_UNSUPPORTED, key named) a checkpoint with a weight of magnitude >= 6e4 unless the "BULK_F16" option is 0.
+ * Reference: diffusion/gaussian_diffusion.py:508-560 (why only the last steps' arithmetic reaches the output), model/cmdm.py:227. */
+RGN_API int rgn_set_f16_steps(rgn_handle h, int32_t steps);
+/* The precision plan rgn_sample_range will follow for B motions on the bound schedule (rgn_set_schedule): loop indices i < *x3_tail run split-bf16,
+ * x3_tail <= i < x3_tail + *f16_steps plain fp16 operands, the rest plain bf16 (RGN_PREC_BF16X3: x3_tail = S; other modes: 0 / 0). */
+RGN_API int rgn_precision_plan(rgn_handle h, int32_t B, int32_t guided, int32_t* f16_steps, int32_t* x3_tail);
+
 /* const_noise of p_sample (gaussian_diffusion.py:544-547): every motion of the batch receives the per-step draw of the
  * batch's motion 0 (tape entry [k, 0] / the Philox stream of sample_offset + 0); x_T is not affected (:706). Holds for the
  * following rgn_sample_range calls until cleared. */
@@ -169,7 +181,8 @@ RGN_API int rgn_set_small_batch_rows(rgn_handle h, int32_t rows);
 /* Kernel-selection switches of ONE handle, set between rgn_create and rgn_finalize_weights (afterwards: RGN_ERR_STATE): the names of the
  * REGENNET_<KEY> environment variables without the prefix - "LAYERS" (0: kernel per stage instead of the one-kernel decoder stack), "LAYERS_STEPS",
  * "LAYERS_GUIDED", "LAYERS_MIN_B", "LAYERS_MIN_TQ", "NO_STEP_FUSION", "NO_MLP", "MLP_X3", "NO_ROWGEMM", "NO_FUSED_QKV", "NO_QKV_RS", "NO_QKV_LONG",
- * "SB_ROWS", "SB_FUSED_ATTN", "SB_GRAPH", "STREAMS", "GRAPH_STEPS", "BIG_TILE_ROWS", "BULK_RESID_LO", "STEP_NO_QUADS"; an unknown name is
+ * "SB_ROWS", "SB_FUSED_ATTN", "SB_GRAPH", "STREAMS", "GRAPH_STEPS", "BIG_TILE_ROWS", "BULK_RESID_LO", "STEP_NO_QUADS", "BULK_F16" (0: no fp16
+ * weight planes, no fp16 phase), "F16_STEPS"; an unknown name is
  * RGN_ERR_BAD_KEY. A handle's option takes precedence over the environment, which remains the process-wide default (tools, A/B runs): tests and
  * library users address one engine without touching global state. Every selectable form meets the same parity bound. */
 RGN_API int rgn_set_option(rgn_handle h, const char* key, int32_t value);

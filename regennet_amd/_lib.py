@@ -54,6 +54,8 @@ SYMBOLS = {
     "rgn_denoise": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "rgn_sample_range": (C.c_int, [_vp, _i32, _i32, _f32, _vp, _vp, _u64, _u64, _i32, _i32, _vp, _i32, _i32, _vp]),
     "rgn_set_x3_tail": (C.c_int, [_vp, _i32]),
+    "rgn_set_f16_steps": (C.c_int, [_vp, _i32]),
+    "rgn_precision_plan": (C.c_int, [_vp, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "rgn_set_small_batch_rows": (C.c_int, [_vp, _i32]),
     "rgn_set_const_noise": (C.c_int, [_vp, _i32]),
     "rgn_set_option": (C.c_int, [_vp, C.c_char_p, _i32]),
@@ -87,9 +89,9 @@ _lib = None
 
 
 def default_x3_tail(S, layers=8, etd=False):
-    """The engine's default precision-schedule switch point (rgn_api.cpp default_tail(), rgn_set_x3_tail(-1)): how many of
-    the last loop indices run split-bf16. Host-side mirror for reporting (bench.py's dtype string) and as the calibration's
-    starting point; the engine applies its own copy."""
+    """The engine's default split-bf16 tail where the plain phase has NO fp16 sub-phase (rgn_api.cpp default_tail(): kernel-per-stage forms,
+    150-frame models, batches below 64, "BULK_F16": 0): how many of the last loop indices run split-bf16. Host-side mirror for tests; what an
+    engine will actually do for a batch on its bound schedule is Engine.precision_plan()."""
     if etd:
         return S
     if layers >= 8:
@@ -217,6 +219,17 @@ class Engine:
     def set_x3_tail(self, tail_steps):
         """Precision schedule ('bf16_x3tail'): split-bf16 for the last `tail_steps` loop indices (-1: default)."""
         self._ck(self.lib.rgn_set_x3_tail(self.h, int(tail_steps)))
+
+    def set_f16_steps(self, steps):
+        """Precision schedule: the `steps` plain loop indices in front of the split-bf16 tail run on fp16 MFMA operands (-1: default 8; 0: none)."""
+        self._ck(self.lib.rgn_set_f16_steps(self.h, int(steps)))
+
+    def precision_plan(self, B, guided=False):
+        """(f16_steps, x3_tail) rgn_sample_range will use for B motions on the bound schedule: loop indices < x3_tail split-bf16, the next f16_steps
+        plain fp16, the rest plain bf16."""
+        n16, tail = _i32(), _i32()
+        self._ck(self.lib.rgn_precision_plan(self.h, int(B), int(bool(guided)), C.byref(n16), C.byref(tail)))
+        return n16.value, tail.value
 
     def set_const_noise(self, on):
         """p_sample's const_noise (gaussian_diffusion.py:544-547) for the following sample_range calls."""

@@ -34,6 +34,7 @@ struct Lin {  // one packed nn.Linear: offsets (bytes) into the weight blob
     size_t w = 0, hi = 0, lo = 0, b = 0;   // fp32 [N,Kp]; bf16 hi/lo planes (row-major [N,Kp] or K32-blocked)
     size_t fr = 0;                         // bf16 hi plane in MFMA-fragment order (operand of k_rowgemm), optional
     size_t fr_lo = 0;                      // bf16 lo plane in the same order (operand of k_mlp_x3), optional
+    size_t fr16 = 0;                       // IEEE fp16 plane in the same order (operand of k_layers<.., F16>: rgn_set_option "BULK_F16"), optional
     int N = 0, K = 0, Kp = 0;
     bool has_bias = false;
     bool blocked = false;                  // hi/lo are K32-blocked [Kp/32][N][32] (operands of k_gemm_x3)
@@ -58,6 +59,24 @@ inline uint16_t f2bf(float f) {
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
+}
+// round-to-nearest-even fp32 -> IEEE fp16 bits (subnormals kept, overflow -> inf: the caller has checked the range)
+inline uint16_t f2h(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    const uint32_t a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((a > 0x7f800000u) ? 0x200u : 0u));
+    if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);            // >= 65520 rounds to inf
+    if (a < 0x33000001u) return sign;                                   // <= 2^-25: rounds to zero
+    int e = (int)(a >> 23) - 127;
+    uint32_t m = (a & 0x7fffffu) | 0x800000u;                           // 24-bit significand
+    int shift = e < -14 ? (13 + (-14 - e)) : 13;                        // bits dropped (subnormal: more)
+    const uint32_t halfway = 1u << (shift - 1), rem = m & ((1u << shift) - 1);
+    uint32_t q = m >> shift;
+    if (rem > halfway || (rem == halfway && (q & 1u))) ++q;
+    const uint32_t bits = e < -14 ? q : (uint32_t)((e + 15 - 1) << 10) + q;   // (q carries the implicit one: + (e + 14) << 10)
+    return (uint16_t)(sign | bits);
 }
 inline float bf2f(uint16_t h) {
     uint32_t u = (uint32_t)h << 16;
@@ -90,6 +109,8 @@ struct rgn_ctx {
           *ffn = nullptr, *x0tok = nullptr, *pe_rows = nullptr, *emb1 = nullptr, *emb = nullptr, *call = nullptr,
           *condemb = nullptr, *scale = nullptr, *te_all = nullptr, *call_time = nullptr, *call_cond = nullptr, *sched_tmp = nullptr;
     __bf16* c0h = nullptr;             // bf16 copy of c0 for the fused step boundary (k_step)
+    _Float16* c0h16 = nullptr;         // fp16 copy of c0 (bulk_f16)
+    bool bulk_f16 = false;             // plain phase of the precision schedule on fp16 operands where k_layers<true> runs it (rgn_set_option "BULK_F16" / REGENNET_BULK_F16)
     __bf16 *xin_hi = nullptr, *xin_lo = nullptr, *h_hi = nullptr, *h_lo = nullptr, *att_hi = nullptr, *att_lo = nullptr,
            *ffn_hi = nullptr, *ffn_lo = nullptr;   // K32-blocked split planes (bf16 precision modes)
     __bf16 *q_hi = nullptr, *q_lo = nullptr, *k_hi = nullptr, *k_lo = nullptr, *vt_hi = nullptr, *vt_lo = nullptr;   // attention-ready planes
@@ -131,6 +152,7 @@ struct rgn_ctx {
     // phase_x3 is the phase of the evaluation being enqueued / captured.
     bool phase_x3 = true;
     int x3_tail = -1;                  // -1: default_tail(S)
+    int f16_steps = -1;                // rgn_set_f16_steps: plain-phase steps right in front of the split-bf16 tail that run on fp16 operands (-1: default)
     int const_noise = 0;               // rgn_set_const_noise
     bool bulk_resid_lo = false;        // bulk phase: residual stream as the hi plane only (REGENNET_BULK_RESID_LO=1: hi + lo; the switch-point
                                        // sweeps measure the same final error either way, hi-only is ~6 % faster)
@@ -260,7 +282,7 @@ size_t blob_put(rgn_ctx* c, const void* src, size_t bytes) {
 }
 
 // Pack W[N,K] (row-major fp32) into fp32 [N,Kp] plus bf16 hi/lo planes; bias optional.
-Lin pack_linear(rgn_ctx* c, const float* W, const float* bias, int N, int K, bool blocked = false, bool frag = false, bool frag_lo = false) {
+Lin pack_linear(rgn_ctx* c, const float* W, const float* bias, int N, int K, bool blocked = false, bool frag = false, bool frag_lo = false, bool frag16 = false) {
     Lin L;
     L.blocked = blocked;
     L.N = N;
@@ -301,6 +323,15 @@ Lin pack_linear(rgn_ctx* c, const float* W, const float* bias, int N, int K, boo
                     fl[(((kt * nb_all + n / 32) * 2 + ks) * 64 + lane) * 8 + k % 8] = f2bf(v - bf2f(f2bf(v)));
                 }
             L.fr_lo = blob_put(c, fl.data(), fl.size() * 2);
+        }
+        if (frag16) {    // the same plane as IEEE fp16 (k_layers' fp16-operand form)
+            std::vector<uint16_t> fh(Np * L.Kp, 0);
+            for (int n = 0; n < N; ++n)
+                for (int k = 0; k < K; ++k) {
+                    const size_t kt = k / 32, ks = (k % 32) / 16, lane = 32 * ((k % 16) / 8) + n % 32;
+                    fh[(((kt * nb_all + n / 32) * 2 + ks) * 64 + lane) * 8 + k % 8] = f2h(W[(size_t)n * K + k]);
+                }
+            L.fr16 = blob_put(c, fh.data(), fh.size() * 2);
         }
     }
     if (bias) {
@@ -515,6 +546,29 @@ EvalPlan plan_eval(const rgn_ctx* c, const Dims& dm, bool guided, bool x3, bool 
     return p;
 }
 
+// ---- the precision plan of a sampling loop over the bound schedule: loop indices [0, tail) run split-bf16, [tail, tail + n16) plain
+//      fp16 operands, the rest plain bf16. Why three phases: v_mfma_f32_32x32x16_f16 has the bf16 instruction's nominal rate and 8x less operand
+//      rounding, but the chip is power-managed under a matrix load and a pure f16 MFMA loop sustains 7.5 - 8 % less than the bf16 one
+//      (tools/experiments/mfma_sustained.hip: 1690 vs 1830 TFLOP/s) - k_layers measures -6 % end to end on fp16 operands. The sampler contracts
+//      what early steps get wrong, so fp16 is spent where rounding still reaches the output: the last plain steps. With them on fp16
+//      the split-bf16 tail, at 3.7x the cost of a plain step, shrinks from 5 (3 for schedules of <= 10 steps) to F16_TAIL steps at the same
+//      error on every golden (tools/f16_sweep.py, tests: test_three_phase_precision_schedule_sweep).
+constexpr int F16_STEPS_DEFAULT = 8, F16_TAIL = 2;
+struct PrecPlan { int tail = 0, n16 = 0; };
+PrecPlan prec_plan(const rgn_ctx* c, const Dims& dm, bool guided) {
+    PrecPlan pp;
+    if (c->cfg.precision != RGN_PREC_BF16_X3TAIL) return pp;
+    const EvalPlan plain = plan_eval(c, dm, guided, false, true);
+    const bool f16_ok = c->bulk_f16 && plain.steps;          // (only the multi-step one-kernel form has the fp16 instantiation)
+    pp.n16 = !f16_ok ? 0 : (c->f16_steps >= 0 ? c->f16_steps : F16_STEPS_DEFAULT);
+    if (c->x3_tail >= 0) pp.tail = c->x3_tail;
+    else if (pp.n16 > 0 && c->L >= 8 && !c->etd) pp.tail = F16_TAIL < c->S ? F16_TAIL : c->S;
+    else pp.tail = default_tail(c->S, c->L, c->etd != 0);
+    if (pp.tail > c->S) pp.tail = c->S;
+    if (pp.n16 > c->S - pp.tail) pp.n16 = c->S - pp.tail;
+    return pp;
+}
+
 int run_layers_sb(rgn_ctx* c, const Dims& dm, bool sampling, const float* cond_rows, const float* ccond_rows, hipStream_t s) {
     const int d = c->d, Ld = c->L * c->d, M = dm.Bm * dm.Tq;
     const bool x3 = eval_x3(c);
@@ -598,13 +652,14 @@ int run_layers_sb(rgn_ctx* c, const Dims& dm, bool sampling, const float* cond_r
 // Embedding GEMM + the L decoder layers + output projection for samples [s0, s0+ns) of the evaluation's sample list
 // (row range [s0*Tq, (s0+ns)*Tq)), enqueued on stream s. F32 mode is always called with the full range.
 // Arguments of k_layers that do not depend on the launch's sample range but for the per-sample vector base (rgn_layers.hip)
-void fill_layers_args(rgn_ctx* c, LayersArgs& g, const Dims& dm, bool sampling, const float* ccond_rows, int s0) {
+void fill_layers_args(rgn_ctx* c, LayersArgs& g, const Dims& dm, bool sampling, const float* ccond_rows, int s0, bool f16 = false) {
     const int Ld = c->L * c->d;
     g.Tq = dm.Tq; g.L = c->L;
     for (int l = 0; l < c->L; ++l) {
         const LayerW& w = c->layers[l];
         LayerWts& t = g.lw[l];
-        t.Wqkv = c->dp<__bf16>(w.qkv.fr); t.Wo = c->dp<__bf16>(w.out.fr); t.W1 = c->dp<__bf16>(w.ff1.fr); t.W2 = c->dp<__bf16>(w.ff2.fr);
+        t.Wqkv = c->dp<__bf16>(f16 ? w.qkv.fr16 : w.qkv.fr); t.Wo = c->dp<__bf16>(f16 ? w.out.fr16 : w.out.fr);
+        t.W1 = c->dp<__bf16>(f16 ? w.ff1.fr16 : w.ff1.fr); t.W2 = c->dp<__bf16>(f16 ? w.ff2.fr16 : w.ff2.fr);
         t.bqkv = c->dp<float>(w.qkv.b); t.bo = c->dp<float>(w.out.b); t.bf1 = c->dp<float>(w.ff1.b); t.bf2 = c->dp<float>(w.ff2.b);
         t.g1 = c->dp<float>(w.ln[0]); t.b1 = c->dp<float>(w.ln[1]); t.g2 = c->dp<float>(w.ln[2]); t.b2 = c->dp<float>(w.ln[3]);
         t.g3 = c->dp<float>(w.ln[4]); t.b3 = c->dp<float>(w.ln[5]);
@@ -1131,6 +1186,20 @@ int rgn_finalize_weights(rgn_handle h) {
         RGN_HIP(c, hipSetDevice(c->cfg.device));
         auto W = [&](const std::string& k) -> const float* { return c->sd[k].v.data(); };
         const int d = c->d, F = c->F, ff = c->ff;
+        // fp16 operands for the plain phase of the precision schedule (k_layers<.., F16>): same MFMA rate and bytes as bf16, 2^-12 instead of
+        // 2^-9 operand rounding - but a 5-bit exponent: a weight at or beyond fp16's range would become inf, so such a checkpoint is refused
+        // here, with the key named (activations are LayerNorm outputs, probabilities and GELU values: O(1) by construction)
+        { int v = 1; (void)opt_get(c, "BULK_F16", &v); c->bulk_f16 = c->cfg.precision == RGN_PREC_BF16_X3TAIL && v != 0; }
+        { int v; if (opt_get(c, "F16_STEPS", &v)) c->f16_steps = v < 0 ? -1 : v; }
+        auto f16_range = [&](const std::string& key, const float* w, size_t n) -> bool {
+            for (size_t i = 0; i < n; ++i)
+                if (!(std::fabs(w[i]) < 6.0e4f)) {
+                    c->hblob.clear();   // (nothing packed so far survives a refused load)
+                    c->err = "BULK_F16: |" + key + "| reaches " + std::to_string(w[i]) + " - outside fp16's range (6e4); load this checkpoint without the BULK_F16 option";
+                    return false;
+                }
+            return true;
+        };
 
         // --- positional table: the buffer both modules alias; load order makes the embed_timestep key win
         const HostTensor& pe = c->sd["embed_timestep.sequence_pos_encoder.pe"];
@@ -1171,7 +1240,8 @@ int rgn_finalize_weights(rgn_handle h) {
                 memcpy(wcf.data(), wcm, wcf.size() * 4);
                 for (int n = 0; n < d; ++n) bconst[n] = (float)((double)bin[n] + (double)bcm[n]);
             }
-            c->lin_x = pack_linear(c, wxf.data(), nullptr, d, F, true, c->cfg.precision == RGN_PREC_BF16_X3TAIL);   // fragment order: k_step
+            if (c->bulk_f16 && !f16_range("fuse_process.weight x input_process.poseEmbedding.weight (folded)", wxf.data(), wxf.size())) return RGN_ERR_UNSUPPORTED;
+            c->lin_x = pack_linear(c, wxf.data(), nullptr, d, F, true, c->cfg.precision == RGN_PREC_BF16_X3TAIL, false, c->bulk_f16);   // fragment order: k_step
             c->lin_c = pack_linear(c, wcf.data(), bconst.data(), d, F);
         }
         c->lin_t0 = pack_linear(c, W("embed_timestep.time_embed.0.weight"), W("embed_timestep.time_embed.0.bias"), d, d);
@@ -1183,14 +1253,17 @@ int rgn_finalize_weights(rgn_handle h) {
         for (int l = 0; l < c->L; ++l) {
             const std::string p = "seqTransDecoder.layers." + std::to_string(l) + ".";
             LayerW& lw = c->layers[l];
+            if (c->bulk_f16)
+                for (const char* nm : {"self_attn.in_proj_weight", "self_attn.out_proj.weight", "linear1.weight", "linear2.weight"})
+                    if (!f16_range(p + nm, W(p + nm), c->sd[p + nm].v.size())) return RGN_ERR_UNSUPPORTED;
             lw.qkv = pack_linear(c, W(p + "self_attn.in_proj_weight"), W(p + "self_attn.in_proj_bias"), 3 * d, d, true,
-                                 c->cfg.precision == RGN_PREC_BF16_X3TAIL);   // fragment order: k_rowgemm (long sequences) / k_qkv_attn_rs
+                                 c->cfg.precision == RGN_PREC_BF16_X3TAIL, false, c->bulk_f16);   // fragment order: k_rowgemm (long sequences) / k_qkv_attn_rs
             const bool fr = c->cfg.precision == RGN_PREC_BF16_X3TAIL;   // k_rowgemm operands (plain-bf16 phase)
             // (+ lo fragment planes: the operand pairs of k_mlp_x3, the split-bf16 layer tail, in every mode that has a split-bf16 phase)
             const bool frx = c->cfg.precision == RGN_PREC_BF16_X3TAIL || c->cfg.precision == RGN_PREC_BF16X3;
-            lw.out = pack_linear(c, W(p + "self_attn.out_proj.weight"), W(p + "self_attn.out_proj.bias"), d, d, true, fr || frx, frx);
-            lw.ff1 = pack_linear(c, W(p + "linear1.weight"), W(p + "linear1.bias"), ff, d, true, fr || frx, frx);
-            lw.ff2 = pack_linear(c, W(p + "linear2.weight"), W(p + "linear2.bias"), d, ff, true, fr || frx, frx);
+            lw.out = pack_linear(c, W(p + "self_attn.out_proj.weight"), W(p + "self_attn.out_proj.bias"), d, d, true, fr || frx, frx, c->bulk_f16);
+            lw.ff1 = pack_linear(c, W(p + "linear1.weight"), W(p + "linear1.bias"), ff, d, true, fr || frx, frx, c->bulk_f16);
+            lw.ff2 = pack_linear(c, W(p + "linear2.weight"), W(p + "linear2.bias"), d, ff, true, fr || frx, frx, c->bulk_f16);
             const char* names[6] = {"norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "norm3.weight", "norm3.bias"};
             for (int i = 0; i < 6; ++i) lw.ln[i] = blob_put(c, W(p + names[i]), (size_t)d * 4);
             const float* wv = W(p + "multihead_attn.in_proj_weight") + (size_t)2 * d * d;
@@ -1207,8 +1280,9 @@ int rgn_finalize_weights(rgn_handle h) {
             }
         }
         c->lin_g = pack_linear(c, gall.data(), gb.data(), c->L * d, d);
+        if (c->bulk_f16 && !f16_range("output_process.poseFinal.weight", W("output_process.poseFinal.weight"), (size_t)F * d)) return RGN_ERR_UNSUPPORTED;
         c->lin_out = pack_linear(c, W("output_process.poseFinal.weight"), W("output_process.poseFinal.bias"), F, d, true,
-                                 c->cfg.precision == RGN_PREC_BF16_X3TAIL);   // fragment order: k_step
+                                 c->cfg.precision == RGN_PREC_BF16_X3TAIL, false, c->bulk_f16);   // fragment order: k_step
         if (c->cfg.cond_mode == RGN_COND_TEXT) {
             c->lin_text = pack_linear(c, W("embed_text.weight"), W("embed_text.bias"), d, c->cfg.clip_dim);
             c->off_bt = c->lin_text.b;
@@ -1252,6 +1326,7 @@ int rgn_finalize_weights(rgn_handle h) {
             if ((rc = ws_alloc(c, &c->xin_hi, M * Fp))) return rc;
             if ((rc = ws_alloc(c, &c->xin_lo, M * Fp))) return rc;
             if ((rc = ws_alloc(c, &c->c0h, M * d))) return rc;
+            if (c->bulk_f16 && (rc = ws_alloc(c, &c->c0h16, M * d))) return rc;
             if ((rc = ws_alloc(c, &c->h_hi, M * d))) return rc;
             if ((rc = ws_alloc(c, &c->h_lo, M * d))) return rc;
             if ((rc = ws_alloc(c, &c->att_hi, M * d))) return rc;
@@ -1308,6 +1383,7 @@ int rgn_finalize_weights(rgn_handle h) {
             c->layers_steps = c->layers_fused && c->step_fused && layers_steps_supported(d, F, c->lin_x.Kp) &&
                               ly_steps != 0;
             c->step_no_quads = opt_flag(c, "STEP_NO_QUADS");
+            c->bulk_f16 = c->bulk_f16 && c->layers_steps;     // (only the multi-step form of k_layers has the fp16 instantiation)
             c->qkv_long = c->cfg.precision == RGN_PREC_BF16_X3TAIL && qkv_attn_long_supported(c->Tq, d / c->H, d) && !opt_flag(c, "NO_QKV_LONG");
             if (c->qkv_long) RGN_HIP(c, configure_qkv_attn_long());
             c->sb = c->attn_x3 && sb_supported(d, ff, d / c->H);
@@ -1422,6 +1498,7 @@ int rgn_set_condition(rgn_handle h, int32_t B, const float* cmotion, const int64
         if (!c->cfg.wo_pos_emb) RGN_LAUNCH(c, KC_EMBED, s, launch_add_pe(c->c0, c->dp<float>(c->off_pe), dm, s));
         RGN_HIP(c, hipMemcpyAsync(c->c0 + (size_t)B * dm.Tq * d, c->c0, (size_t)B * dm.Tq * d * sizeof(float), hipMemcpyDeviceToDevice, s));   // uncond half
         if (c->c0h) RGN_LAUNCH(c, KC_EMBED, s, launch_cvt_bf16(c->c0, c->c0h, (size_t)2 * B * dm.Tq * d, s));   // k_step's copy (plain-bf16 phase only)
+        if (c->c0h16) RGN_LAUNCH(c, KC_EMBED, s, launch_cvt_f16(c->c0, c->c0h16, (size_t)2 * B * dm.Tq * d, s));  // ... and the fp16-operand form's
         // condition embedding rows: [0,B) conditional, [B,2B) what mask_cond(force_mask=True) leaves
         if (c->cfg.cond_mode == RGN_COND_ACTION) {
             RGN_LAUNCH(c, KC_EMBED, s, launch_cond_rows(c->dp<float>(c->off_action), action, c->condemb, B, d, c->cfg.num_actions, s));
@@ -1516,7 +1593,8 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
         // Precision schedule: loop indices >= tail run the plain-bf16 phase, the last `tail` indices the split-bf16 one.
         // One captured step graph per phase; everything t-dependent is read on the device, so each serves all its steps.
         const bool sched = c->cfg.precision == RGN_PREC_BF16_X3TAIL;
-        const int tail = !sched ? 0 : (c->x3_tail >= 0 ? c->x3_tail : default_tail(c->S, c->L, c->etd != 0));
+        const PrecPlan pp = prec_plan(c, dm, guided != 0);
+        const int tail = pp.tail, n16 = pp.n16;
         // A graph holds `steps` consecutive loop iterations (evaluation + sampler update + counter decrement each): the loop
         // index lives on the device, so one instantiated graph serves any starting index. Long ranges replay the multi-step
         // graph (graph_steps iterations per host launch; a 4-branch launch costs the host ~1 ms, as much as the GPU needs for
@@ -1560,14 +1638,23 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
         // Fused step boundaries (k_step) hand the next evaluation's input embedding over in the residual-stream planes and no
         // longer write the token-major x planes: the first fused step of the call needs the embedding made once up front, and
         // the first un-fused step behind fused ones (the split-bf16 tail) needs the planes re-made from the sampler state.
-        bool prev_fused = false;
+        bool prev_fused = false, planes_f16 = false;
         while (k < count) {
             const int i = first_index - k;                       // loop index of the next step
             const bool x3 = !sched || i < tail;
-            const int phase_left = x3 ? (count - k) : ((i - tail + 1) < (count - k) ? (i - tail + 1) : (count - k));   // steps left in this phase
+            const bool f16 = !x3 && i < tail + n16;              // (n16 > 0 only where the plain phase is k_layers<true>)
+            const int phase_end = x3 ? 0 : (f16 ? tail : tail + n16);            // first loop index behind this phase
+            const int phase_left = (i - phase_end + 1) < (count - k) ? (i - phase_end + 1) : (count - k);              // steps left in this phase
             const EvalPlan pl = plan_eval(c, dm, guided != 0, x3, true);
             const bool fused_now = pl.step_fused;
-            if (fused_now && !prev_fused && (rc = embed_all(c, dm, s))) return rc;
+            if (fused_now && !prev_fused) {
+                if ((rc = embed_all(c, dm, s))) return rc;
+                planes_f16 = false;
+            }
+            if (f16 && pl.steps && !planes_f16) {   // the fp16-operand form reads (and rewrites) the residual-stream planes as fp16: what the embedding or the bf16 launch left there is re-encoded
+                RGN_LAUNCH(c, KC_EMBED, s, launch_bf16_to_f16(c->h_hi, (size_t)dm.Bm * dm.Tq * c->d, s));
+                planes_f16 = true;
+            }
             if (!fused_now && prev_fused && (rc = pack_state(c, x, dm, guided != 0, s))) return rc;
             prev_fused = fused_now;
             if (pl.steps) {
@@ -1579,15 +1666,16 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
                     const bool has_cond = c->cfg.cond_mode != RGN_COND_NONE;
                     LayersArgs g{};
                     g.h = c->h_hi; g.out = c->h_hi; g.rows = M; g.Bm = dm.B;   // one workgroup per MOTION (guided: its two evaluations back to back)
-                    fill_layers_args(c, g, dm, true, has_cond ? c->call_cond : nullptr, 0);
+                    fill_layers_args(c, g, dm, true, has_cond ? c->call_cond : nullptr, 0, f16);
                     g.steps = phase_left;
+                    g.f16 = f16 ? 1 : 0;
                     if (guided) {
                         g.scale = c->scale; g.half = dm.B * dm.Tq;
                         g.park = reinterpret_cast<float*>(c->ffn_hi);           // (the hidden-tensor planes are idle on this path: 2B * T * ff * 2 bytes >= B * 96 KiB)
                     }
-                    g.Wout = c->dp<__bf16>(c->lin_out.fr); g.bout = c->dp<float>(c->lin_out.b); g.F = c->F; g.nb_out = (c->F + 31) / 32;
-                    g.Wx = c->dp<__bf16>(c->lin_x.fr);
-                    g.c0 = c->c0h;
+                    g.Wout = c->dp<__bf16>(f16 ? c->lin_out.fr16 : c->lin_out.fr); g.bout = c->dp<float>(c->lin_out.b); g.F = c->F; g.nb_out = (c->F + 31) / 32;
+                    g.Wx = c->dp<__bf16>(f16 ? c->lin_x.fr16 : c->lin_x.fr);
+                    g.c0 = f16 ? reinterpret_cast<const __bf16*>(c->c0h16) : c->c0h;
                     g.tab = c->d_tab; g.d_stepw = c->d_step; g.sp = c->d_sp;
                     g.B = dm.B; g.s0 = 0; g.no_quads = c->step_no_quads;
                     RGN_LAUNCH(c, KC_STEPS, s, launch_layers(g, s));
@@ -1622,6 +1710,29 @@ int rgn_set_x3_tail(rgn_handle h, int32_t tail_steps) {
     });
 }
 
+int rgn_set_f16_steps(rgn_handle h, int32_t steps) {
+    return rgn_guard(h, "rgn_set_f16_steps", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        if (steps < -1) return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_f16_steps: steps < -1");
+        h->f16_steps = steps;
+        return RGN_OK;
+    });
+}
+
+int rgn_precision_plan(rgn_handle h, int32_t B, int32_t guided, int32_t* f16_steps, int32_t* x3_tail) {
+    return rgn_guard(h, "rgn_precision_plan", [&]() -> int {
+        if (!h) return RGN_ERR_INVALID_ARG;
+        if (!f16_steps || !x3_tail) return h->fail(RGN_ERR_INVALID_ARG, "rgn_precision_plan: null output");
+        if (!h->finalized) return h->fail(RGN_ERR_STATE, "rgn_precision_plan: weights not finalized");
+        if (!h->have_sched) return h->fail(RGN_ERR_STATE, "rgn_precision_plan: no schedule (rgn_set_schedule)");
+        if (B <= 0 || B > h->cfg.max_batch) return h->fail(RGN_ERR_INVALID_ARG, "rgn_precision_plan: B outside (0, max_batch]");
+        const PrecPlan pp = prec_plan(h, make_dims(h, B, guided != 0), guided != 0);
+        *f16_steps = pp.n16;
+        *x3_tail = h->cfg.precision == RGN_PREC_BF16X3 ? h->S : pp.tail;
+        return RGN_OK;
+    });
+}
+
 int rgn_set_const_noise(rgn_handle h, int32_t on) {
     return rgn_guard(h, "rgn_set_const_noise", [&]() -> int {
         if (!h) return RGN_ERR_INVALID_ARG;
@@ -1651,7 +1762,8 @@ int rgn_set_option(rgn_handle h, const char* key, int32_t value) {
         if (!key || !*key) return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_option: empty key");
         if (h->finalized) return h->fail(RGN_ERR_STATE, "rgn_set_option: the switches select kernels when the weights are packed - set them before rgn_finalize_weights");
         static const char* known[] = {"NO_FUSED_QKV", "BIG_TILE_ROWS", "NO_ROWGEMM", "NO_MLP", "MLP_X3", "NO_QKV_RS", "NO_STEP_FUSION", "LAYERS_MIN_TQ", "LAYERS", "LAYERS_STEPS",
-                                      "LAYERS_MIN_B", "LAYERS_GUIDED", "STEP_NO_QUADS", "NO_QKV_LONG", "SB_FUSED_ATTN", "SB_ROWS", "BULK_RESID_LO", "GRAPH_STEPS", "STREAMS", "SB_GRAPH"};
+                                      "LAYERS_MIN_B", "LAYERS_GUIDED", "STEP_NO_QUADS", "NO_QKV_LONG", "SB_FUSED_ATTN", "SB_ROWS", "BULK_RESID_LO", "GRAPH_STEPS", "STREAMS", "SB_GRAPH",
+                                      "BULK_F16", "F16_STEPS"};
         bool ok = false;
         for (const char* k : known) ok = ok || strcmp(k, key) == 0;
         if (!ok) return h->fail(RGN_ERR_BAD_KEY, std::string("rgn_set_option: unknown switch '") + key + "'");
@@ -1707,7 +1819,11 @@ int rgn_plan_query(rgn_handle h, int32_t B, int32_t guided, int32_t split_phase,
             const char* gemm = f32 ? "k_gemm_f32" : "k_gemm_x3";
             kn[KC_GEMM] = gemm;
             if (pl.steps) {
-                mac[KC_STEPS] = qkv + attn + tail + embed; kn[KC_STEPS] = guided ? "k_layers<true, true>" : "k_layers<true>";
+                mac[KC_STEPS] = qkv + attn + tail + embed; {
+                    const PrecPlan pp = c->have_sched ? prec_plan(c, dm, guided != 0) : PrecPlan{};
+                    const bool all16 = c->have_sched && pp.n16 > 0 && pp.n16 >= c->S - pp.tail;   // every plain step of the bound schedule runs on fp16 operands
+                    kn[KC_STEPS] = all16 ? (guided ? "k_layers<true, true, f16>" : "k_layers<true, false, f16>") : (guided ? "k_layers<true, true>" : "k_layers<true>");
+                }
                 n[KC_STEPS] = 0;   // ONE launch per run of steps (rgn_sample_range), not per evaluation
                 const double passes = guided ? 2 : 1;
                 l2[KC_STEPS] = (double)dm.B * (passes * (wl + Fp * d) + Fp * d) * 2.0;

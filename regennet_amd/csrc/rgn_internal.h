@@ -220,6 +220,10 @@ struct LayersArgs {
     //      evaluation (planes rows of sample b) and its unconditional one (rows of sample B + b) run back to back in the same workgroup, the
     //      conditional x0 parked in `park` meanwhile; Bm = B motions; pervec / c0 / h hold both halves, `half` = row distance B * T
     const float* scale; int half; float* park;                // scale[B]; park: >= B * 6 * 4096 floats of scratch
+    // ---- f16 != 0 (steps > 0 only): every 16-bit operand is IEEE fp16 instead of bf16 - the weight planes (same fragment order), c0, and the
+    //      residual-stream planes h / out (same K32-blocked layout): v_mfma_f32_32x32x16_f16 runs at the bf16 instruction's rate with 2^-12
+    //      operand rounding instead of 2^-9 (rgn_set_option "BULK_F16")
+    int f16;
 };
 bool layers_supported(int d, int ff, int H, int Tq, int L);
 bool layers_steps_supported(int d, int F, int Kpx);
@@ -366,6 +370,8 @@ hipError_t launch_advance(int* d_step, hipStream_t s);
 hipError_t launch_cond_rows(const float* table, const int64_t* action, float* out, int B, int d, int num_actions, hipStream_t s);
 hipError_t launch_fill_rows(float* out, const float* row, int rows, int d, hipStream_t s);
 hipError_t launch_cvt_bf16(const float* in, __bf16* out, size_t n, hipStream_t s);
+hipError_t launch_cvt_f16(const float* in, _Float16* out, size_t n, hipStream_t s);          // fp32 -> fp16 (rne)
+hipError_t launch_bf16_to_f16(__bf16* inout, size_t n, hipStream_t s);                       // in place: a bf16 buffer re-encoded as fp16 (n % 8 == 0)
 hipError_t launch_randn(float* x, int B, int FT, int T, unsigned long long seed, unsigned long long sample_offset,
                         uint32_t noise_stream, hipStream_t s);
 hipError_t launch_rot6d(const float* d6, float* mat, long long n, hipStream_t s);

@@ -991,6 +991,42 @@ hipError_t launch_cvt_bf16(const float* in, __bf16* out, size_t n, hipStream_t s
     hipLaunchKernelGGL(k_cvt_bf16, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, in, out, n8);
     return hipGetLastError();
 }
+// fp32 -> fp16 (rne) and bf16 -> fp16 in place: the fp16-operand form of k_layers (rgn_layers.hip, LayersArgs::f16) reads its condition rows and
+// the residual-stream planes the up-front embedding wrote in that format (a bf16 value inside fp16's normal range converts exactly)
+__global__ void k_cvt_f16(const float* __restrict__ in, _Float16* __restrict__ out, long long n8) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    const f32x4 a = reinterpret_cast<const f32x4*>(in)[2 * i], b = reinterpret_cast<const f32x4*>(in)[2 * i + 1];
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = (_Float16)a[e]; o[4 + e] = (_Float16)b[e]; }
+    reinterpret_cast<f16x8*>(out)[i] = o;
+}
+__global__ void k_bf16_to_f16(__bf16* __restrict__ io, long long n8) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    const bf16x8 a = reinterpret_cast<const bf16x8*>(io)[i];
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)(float)a[e];
+    reinterpret_cast<f16x8*>(io)[i] = o;
+}
+hipError_t launch_cvt_f16(const float* in, _Float16* out, size_t n, hipStream_t s) {   // n % 8 == 0
+    if (n == 0) return hipSuccess;
+    const long long n8 = (long long)(n / 8);
+    hipLaunchKernelGGL(k_cvt_f16, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, in, out, n8);
+    return hipGetLastError();
+}
+hipError_t launch_bf16_to_f16(__bf16* inout, size_t n, hipStream_t s) {   // n % 8 == 0
+    if (n == 0) return hipSuccess;
+    const long long n8 = (long long)(n / 8);
+    hipLaunchKernelGGL(k_bf16_to_f16, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, inout, n8);
+    return hipGetLastError();
+}
 hipError_t launch_fill_rows(float* out, const float* row, int rows, int d, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_fill_rows, dim3(rows), dim3(256), 0, s, out, row, rows, d);

@@ -46,6 +46,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// The 16-bit operand format of the MFMAs (weights, activation images, q / k / v / p): bf16 (8 mantissa bits) or fp16 (11). Both instructions are
+// 8 passes of 4 cycles per 32 x 32 x 16 tile and take 16 bytes per lane and operand, so the kernel's structure - rings, images, waits - is the
+// same; what changes is the rounding of every operand (2^-9 -> 2^-12 relative) and the range (fp16: 6.1e-5 .. 65504 normal; activations behind
+// a LayerNorm, softmax probabilities and weights of a trained transformer sit well inside, the engine refuses a checkpoint that does not).
+// Accumulation, LayerNorm statistics, softmax and the sampler update are fp32 either way.
+template <bool F16> struct LyOp;
+template <> struct LyOp<false> {
+    typedef __bf16 t; typedef bf16x8 v8; typedef bf16x4 v4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct LyOp<true> {
+    typedef _Float16 t; typedef f16x8 v8; typedef f16x4 v4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 
 #define RGN_AS1 __attribute__((address_space(1)))
 #define RGN_AS3 __attribute__((address_space(3)))
@@ -104,9 +121,13 @@ __device__ __forceinline__ void ly_static_for_seq(std::integer_sequence<int, Is.
 template <int N, class F>
 __device__ __forceinline__ void ly_static_for(F&& f) { ly_static_for_seq(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
 
-template <bool STEPS, bool GUIDED = false>
+template <bool STEPS, bool GUIDED = false, bool F16 = false>
 __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
     static_assert(STEPS || !GUIDED, "guidance inside the launch needs the step boundary");
+    using OP = LyOp<F16>;
+    using op_t = typename OP::t;
+    using op8 = typename OP::v8;
+    using op4 = typename OP::v4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -153,30 +174,30 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
     const float qs2 = g.qscale * 1.44269504088896340736f;        // 1 / sqrt(dh) in log2 units, applied INSIDE the softmax's exponent: exp2(qs2 s - qs2 max), one FMA where the subtraction was
 
     struct Pass { __amdgpu_buffer_rsrc_t rs; int kstride, hs0; };
-    bf16x8 wf[LY_RDM][2];
+    op8 wf[LY_RDM][2];
     auto load_g = [&](const Pass& ps, int hs_rel, int slot) {
         const int hs = ps.hs0 + hs_rel;
         int soff;
         asm volatile("s_mov_b32 %0, %1" : "=s"(soff) : "i"((hs >> 1) * ps.kstride + (hs & 1) * 1024));
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-            wf[slot][nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ps.rs, lane16, soff + nt * 2048, 0));
+            wf[slot][nt] = __builtin_bit_cast(op8, __builtin_amdgcn_raw_buffer_load_b128(ps.rs, lane16, soff + nt * 2048, 0));
     };
     // one GEMM pass over K = 512 from the image at byte offsets aoff (see rgn_mlp2.hip): the ring never drains between passes
     auto gemm_n = [&](f32x16 (&acc)[2][2], const int (&aoff)[2], const Pass& cur, const Pass& nxt, auto chain, auto extra, auto ngran) {
         constexpr int EX = decltype(extra)::value, AH = LY_RDM - 1, NG = decltype(ngran)::value;   // NG granules = NG / 2 k-blocks
         constexpr bool CH = decltype(chain)::value;
         __builtin_amdgcn_sched_barrier(0);
-        bf16x8 af[2];
+        op8 af[2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(smem + aoff[0] + mt * 2048);
+        for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const op8*>(smem + aoff[0] + mt * 2048);
 #pragma unroll
         for (int hs = 0; hs < NG; ++hs) {
-            bf16x8 afn[2];
+            op8 afn[2];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 afn[mt] = af[mt];
-                if (hs + 1 < NG) afn[mt] = *reinterpret_cast<const bf16x8*>(smem + ((hs + 1) >> 1) * LY_KB + aoff[(hs + 1) & 1] + mt * 2048);
+                if (hs + 1 < NG) afn[mt] = *reinterpret_cast<const op8*>(smem + ((hs + 1) >> 1) * LY_KB + aoff[(hs + 1) & 1] + mt * 2048);
             }
             if (hs + AH < NG) load_g(cur, hs + AH, (hs + AH) % LY_RDM);
             else if (CH) load_g(nxt, hs + AH - NG, (hs + AH) % LY_RDM);
@@ -187,7 +208,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[hs % LY_RDM][nt], af[mt], acc[nt][mt], 0, 0, 0);
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = OP::mfma(wf[hs % LY_RDM][nt], af[mt], acc[nt][mt]);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) af[mt] = afn[mt];
         }
@@ -280,21 +301,21 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
             for (int i4 = 0; i4 < 4; ++i4)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    bf16x4 hh;
+                    op4 hh;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) hh[e] = (__bf16)acc[nt][mt][4 * i4 + e];
-                    *reinterpret_cast<bf16x4*>(smem + img + img_off(nt, i4, mt)) = hh;
+                    for (int e = 0; e < 4; ++e) hh[e] = (op_t)acc[nt][mt][4 * i4 + e];
+                    *reinterpret_cast<op4*>(smem + img + img_off(nt, i4, mt)) = hh;
                 }
     };
     // acc += bf16 residual from the image X (this wave's own columns)
     auto add_resid = [&](f32x16 (&acc)[2][2]) {
-        bf16x4 rr[2][2][4];
+        op4 rr[2][2][4];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int i4 = 0; i4 < 4; ++i4) rr[nt][mt][i4] = *reinterpret_cast<const bf16x4*>(smem + LY_X + img_off(nt, i4, mt));
+                for (int i4 = 0; i4 < 4; ++i4) rr[nt][mt][i4] = *reinterpret_cast<const op4*>(smem + LY_X + img_off(nt, i4, mt));
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -387,7 +408,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
         const LayerWts& w = g.lw[l];
         RGN_LYT(0)
         // ========================= self-attention: in_proj + causal softmax + p . v, two heads at a time ===================
-        bf16x4 attk[2][2][4];                                    // [round][query tile][run of 4 dh]: this wave's O^T tiles as bf16
+        op4 attk[2][2][4];                                    // [round][query tile][run of 4 dh]: this wave's O^T tiles as bf16
         float bo_r = 0.f;
         {
             struct PassA { __amdgpu_buffer_rsrc_t rs; };
@@ -396,7 +417,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                 return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(w.Wqkv) + (size_t)blk * 1024, 0, 3 * 512 * 512 * 2 - blk * 2048, 0x00020000);
             };
             const PassA pa[2] = {{qrs(0)}, {qrs(1)}};
-            bf16x8 wq[LY_RDA][3];
+            op8 wq[LY_RDA][3];
             // granule hs = 2 kt + ks of the plane [16 k-blocks][48 column blocks][2][64][8]: the q, k, v fragments sit 16 column blocks apart
             auto load_ga = [&](const PassA& ps, int hs, int slot) {
                 // (the granule offset is materialised by a volatile s_mov right here: as plain literals the ~300 offsets of a layer are hoisted
@@ -405,7 +426,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                 asm volatile("s_mov_b32 %0, %1" : "=s"(soff) : "i"((hs >> 1) * (48 * 2048) + (hs & 1) * 1024));
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
-                    wq[slot][t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ps.rs, lane16, soff + t * (16 * 2048), 0));
+                    wq[slot][t] = __builtin_bit_cast(op8, __builtin_amdgcn_raw_buffer_load_b128(ps.rs, lane16, soff + t * (16 * 2048), 0));
             };
             constexpr int AH = LY_RDA - 1;
 #pragma unroll
@@ -428,16 +449,16 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                 // ---- in_proj: [64 tokens] x [q | k | v of this wave's 32 dh columns] over K = 512, from the resident image X
                 __builtin_amdgcn_sched_barrier(0);
                 {
-                    bf16x8 af[2];
+                    op8 af[2];
 #pragma unroll
-                    for (int ta = 0; ta < 2; ++ta) af[ta] = *reinterpret_cast<const bf16x8*>(smem + a_off[0] + ta * 2048);
+                    for (int ta = 0; ta < 2; ++ta) af[ta] = *reinterpret_cast<const op8*>(smem + a_off[0] + ta * 2048);
 #pragma unroll
                     for (int hs = 0; hs < 32; ++hs) {
-                        bf16x8 afn[2];
+                        op8 afn[2];
 #pragma unroll
                         for (int ta = 0; ta < 2; ++ta) {
                             afn[ta] = af[ta];
-                            if (hs + 1 < 32) afn[ta] = *reinterpret_cast<const bf16x8*>(smem + ((hs + 1) >> 1) * LY_KB + a_off[(hs + 1) & 1] + ta * 2048);
+                            if (hs + 1 < 32) afn[ta] = *reinterpret_cast<const op8*>(smem + ((hs + 1) >> 1) * LY_KB + a_off[(hs + 1) & 1] + ta * 2048);
                         }
                         if (hs + AH < 32) load_ga(pa[r], hs + AH, (32 * r + hs + AH) % LY_RDA);
                         else if (r == 0) load_ga(pa[1], hs + AH - 32, (32 * r + hs + AH) % LY_RDA);
@@ -450,8 +471,8 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                         for (int t = 0; t < 3; ++t)
 #pragma unroll
                             for (int ta = 0; ta < 2; ++ta) {
-                                if (t < 2) acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[slot][t], af[ta], acc[ta][t], 0, 0, 0);
-                                else acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ta], wq[slot][t], acc[ta][t], 0, 0, 0);
+                                if (t < 2) acc[ta][t] = OP::mfma(wq[slot][t], af[ta], acc[ta][t]);
+                                else acc[ta][t] = OP::mfma(af[ta], wq[slot][t], acc[ta][t]);
                             }
 #pragma unroll
                         for (int ta = 0; ta < 2; ++ta) af[ta] = afn[ta];
@@ -460,7 +481,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                 __builtin_amdgcn_sched_barrier(0);
                 RGN_LYT(1 + 3 * r)
                 // ---- attention straight from the accumulators (rgn_qkv_attn.hip qa_attention, plain-bf16 form)
-                bf16x8 qh[2][2], kf[2][2], vh[2][2];             // [token tile][16-slice of the register index]
+                op8 qh[2][2], kf[2][2], vh[2][2];             // [token tile][16-slice of the register index]
 #pragma unroll
                 for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
@@ -468,9 +489,9 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const int i = 8 * sl + j;
-                            qh[ta][sl][j] = (__bf16)acc[ta][0][i];
-                            kf[ta][sl][j] = (__bf16)acc[ta][1][i];
-                            vh[ta][sl][j] = (__bf16)acc[ta][2][i];
+                            qh[ta][sl][j] = (op_t)acc[ta][0][i];
+                            kf[ta][sl][j] = (op_t)acc[ta][1][i];
+                            vh[ta][sl][j] = (op_t)acc[ta][2][i];
                         }
                 if (r == 0) load_qbias(w.bqkv, 1);                // (the accumulators are dead: round 1's start value lands under this round's softmax)
                 else bo_r = w.bo[64 * wave + lane];              // out_proj's bias = its accumulators' start value: lands under round 1's softmax
@@ -482,7 +503,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) st[tl][i] = 0.f;
 #pragma unroll
-                    for (int sl = 0; sl < 2; ++sl) st[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kj][sl], qh[qtile][sl], st[tl], 0, 0, 0);
+                    for (int sl = 0; sl < 2; ++sl) st[tl] = OP::mfma(kf[kj][sl], qh[qtile][sl], st[tl]);
                 }
                 // sum the partials of the four dh tiles: [head of the pair][tile][wave wn][i / 4][lane] float4
                 f32x4* sred = reinterpret_cast<f32x4*>(smem + LY_EXCH);
@@ -551,13 +572,13 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                     if (live) {
 #pragma unroll
                         for (int h2 = 0; h2 < 2; ++h2) {
-                            bf16x8 pp;
+                            op8 pp;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                pp[e] = (__bf16)(sv[h2][e] * inv);
-                                pp[4 + e] = (__bf16)(sv[2 + h2][e] * inv);
+                                pp[e] = (op_t)(sv[h2][e] * inv);
+                                pp[4 + e] = (op_t)(sv[2 + h2][e] * inv);
                             }
-                            *reinterpret_cast<bf16x8*>(smem + LY_EXCH + (((hg * 3 + tl) * 4 + 0) * 4 + sl) * 1024 + (h2 * 32 + ql) * 16) = pp;
+                            *reinterpret_cast<op8*>(smem + LY_EXCH + (((hg * 3 + tl) * 4 + 0) * 4 + sl) * 1024 + (h2 * 32 + ql) * 16) = pp;
                         }
                     }
                 }
@@ -576,15 +597,15 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                         const int kj = tl >> 1;
 #pragma unroll
                         for (int sl = 0; sl < 2; ++sl) {
-                            const bf16x8 ph = *reinterpret_cast<const bf16x8*>(smem + LY_EXCH + (((hg * 3 + tl) * 4 + 0) * 4 + sl) * 1024 + lane * 16);
-                            oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[kj][sl], ph, oa, 0, 0, 0);
+                            const op8 ph = *reinterpret_cast<const op8*>(smem + LY_EXCH + (((hg * 3 + tl) * 4 + 0) * 4 + sl) * 1024 + lane * 16);
+                            oa = OP::mfma(vh[kj][sl], ph, oa);
                         }
                     }
                     // O^T tile: lane = query, registers = 16 dh indices -> 4 runs of 4 consecutive dh
 #pragma unroll
                     for (int i4 = 0; i4 < 4; ++i4)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) attk[r][qtile][i4][e] = (__bf16)oa[4 * i4 + e];
+                        for (int e = 0; e < 4; ++e) attk[r][qtile][i4][e] = (op_t)oa[4 * i4 + e];
                 }
                 RGN_LYT(2 + 3 * r)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -621,7 +642,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
             for (int qtile = 0; qtile < 2; ++qtile)
 #pragma unroll
                 for (int i4 = 0; i4 < 4; ++i4)
-                    *reinterpret_cast<bf16x4*>(smem + LY_Y + ((2 * r + hg) * 4 + wn) * LY_KB + (32 * qtile + l31) * 64 + ((i4 ^ swz) << 4) + 8 * kh) = attk[r][qtile][i4];
+                    *reinterpret_cast<op4*>(smem + LY_Y + ((2 * r + hg) * 4 + wn) * LY_KB + (32 * qtile + l31) * 64 + ((i4 ^ swz) << 4) + 8 * kh) = attk[r][qtile][i4];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         f32x16 acc[2][2];
@@ -678,7 +699,10 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                 const unsigned pf_lds = (unsigned)(size_t)((RGN_AS3 char*)(smem + LY_PF)) + (unsigned)wave * 256u;
                 for (int ln = sl + nsl * tid; ln < n_all; ln += nsl * LY_NTH) {
                     const char* pp = ln < n_out ? reinterpret_cast<const char*>(g.Wout) + (size_t)ln * 128 : reinterpret_cast<const char*>(g.Wx) + (size_t)(ln - n_out) * 128;
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(pp), "s"(pf_lds) : "memory", "m0");
+                    // (m0 - the LDS base of a direct-to-LDS load - is the compiler's too: it keeps the base of its own global_load_lds builtins there and does not
+                    //  honour a clobber of a reserved register, so the asm saves and restores it; tools/check_m0.py reads the ISA)
+                    int m0_keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(m0_keep) : "v"(pp), "s"(pf_lds) : "memory");
                 }
             }
         }
@@ -742,7 +766,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
 #pragma unroll
         for (int s2 = 0; s2 < LY_RDM - 1; ++s2) load_g(p_wx, s2, s2);   // the embedding's first fragments fly under the update phase
         // the condition rows the embedding adds, in the accumulator layout (requested now, used behind the GEMM)
-        bf16x4 c0v[2][2][4];
+        op4 c0v[2][2][4];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int r = 32 * mt + l31_s, rr = r < T ? r : T - 1;
@@ -750,9 +774,9 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int i4 = 0; i4 < 4; ++i4)
-                    c0v[nt][mt][i4] = *reinterpret_cast<const bf16x4*>(g.c0 + (row0_s + rr) * 512 + 64 * wave_s + col4s(nt, i4));
+                    c0v[nt][mt][i4] = *reinterpret_cast<const op4*>(g.c0 + (row0_s + rr) * 512 + 64 * wave_s + col4s(nt, i4));
         }
-        bf16x4 c0u[GUIDED ? 2 : 1][2][4];                                 // guided: the unconditional evaluation's condition rows
+        op4 c0u[GUIDED ? 2 : 1][2][4];                                 // guided: the unconditional evaluation's condition rows
         if constexpr (GUIDED) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
@@ -761,7 +785,7 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int i4 = 0; i4 < 4; ++i4)
-                        c0u[nt][mt][i4] = *reinterpret_cast<const bf16x4*>(g.c0 + ((size_t)g.half + row0_s + rr) * 512 + 64 * wave_s + col4s(nt, i4));
+                        c0u[nt][mt][i4] = *reinterpret_cast<const op4*>(g.c0 + ((size_t)g.half + row0_s + rr) * 512 + 64 * wave_s + col4s(nt, i4));
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -790,9 +814,9 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
             // the bf16 x' run (feature 32 i2 + 4 wave + j sits in k-block i2, 16-byte chunk wave >> 1, bytes 8 (wave & 1) + 2 j of its row)
             const int ximg_lane = lane_s * 64 + ((((wave_s >> 1) ^ ((lane_s >> 2) & 3)) << 4) + 8 * (wave_s & 1));
             auto update4 = [&](int i2, int fg, const float (&eps_in)[4], const float (&xv)[4]) {
-                bf16x4 nvb;
+                op4 nvb;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) nvb[j] = (__bf16)0.f;
+                for (int j = 0; j < 4; ++j) nvb[j] = (op_t)0.f;
                 if (valid && 4 * fg < g.F) {                              // (F % 4 == 0: whole groups)
                     const f32x4 x04 = *reinterpret_cast<const f32x4*>(tile + lane_s * LY_XLD + 4 * fg);
 #pragma unroll
@@ -817,11 +841,11 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                             nv = __fadd_rn(mean, __fmul_rn(k.sig_ddim, eps));
                         }
                         sp.x[o] = nv;
-                        nvb[j] = (__bf16)nv;
+                        nvb[j] = (op_t)nv;
                     }
                 }
                 // x' (0 in the K padding columns and the surplus rows) -> the K32-blocked image of the embedding's A operand
-                *reinterpret_cast<bf16x4*>(ximg + i2 * 4096 + ximg_lane) = nvb;
+                *reinterpret_cast<op4*>(ximg + i2 * 4096 + ximg_lane) = nvb;
             };
             ly_static_for<LY_NKX>([&](auto IT) __attribute__((always_inline)) {   // groups of 4 features
                 constexpr int i2 = decltype(IT)::value;
@@ -876,10 +900,10 @@ __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
                 for (int i4 = 0; i4 < 4; ++i4)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        bf16x4 hh;
+                        op4 hh;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) hh[e] = (__bf16)(acc[nt][mt][4 * i4 + e] + (float)c0u[nt][mt][i4][e]);
-                        *reinterpret_cast<bf16x4*>(smem + LY_Y + img_off(nt, i4, mt)) = hh;
+                        for (int e = 0; e < 4; ++e) hh[e] = (op_t)(acc[nt][mt][4 * i4 + e] + (float)c0u[nt][mt][i4][e]);
+                        *reinterpret_cast<op4*>(smem + LY_Y + img_off(nt, i4, mt)) = hh;
                     }
         }
 #pragma unroll
@@ -940,16 +964,25 @@ void ly_stamps_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(
 
 bool layers_supported(int d, int ff, int H, int Tq, int L) { return d == 512 && ff == 1024 && H == 4 && Tq >= 1 && Tq <= 64 && L >= 1 && L <= LY_MAXL; }
 bool layers_steps_supported(int d, int F, int Kpx) { return d == 512 && F % 4 == 0 && F <= 352 && Kpx == 32 * LY_NKX; }
+template <class K>
+static hipError_t ly_lds(K kern) { return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LY_LDS); }
 hipError_t configure_layers() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_layers<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LY_LDS);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_layers<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LY_LDS);
-    return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(k_layers<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LY_LDS);
+    hipError_t e = ly_lds(k_layers<false>);
+    if (e == hipSuccess) e = ly_lds(k_layers<true>);
+    if (e == hipSuccess) e = ly_lds(k_layers<true, true>);
+    if (e == hipSuccess) e = ly_lds(k_layers<true, false, true>);
+    if (e == hipSuccess) e = ly_lds(k_layers<true, true, true>);
+    return e;
 }
 hipError_t launch_layers(const LayersArgs& g, hipStream_t s) {
-    if (g.steps > 0 && g.scale) hipLaunchKernelGGL((k_layers<true, true>), dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
-    else if (g.steps > 0) hipLaunchKernelGGL(k_layers<true>, dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
-    else hipLaunchKernelGGL(k_layers<false>, dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
+    if (g.f16 && g.steps <= 0) return hipErrorInvalidValue;      // fp16 operands: the multi-step forms only (the engine never asks for anything else)
+    if (g.steps > 0 && g.scale) {
+        if (g.f16) hipLaunchKernelGGL((k_layers<true, true, true>), dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
+        else hipLaunchKernelGGL((k_layers<true, true>), dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
+    } else if (g.steps > 0) {
+        if (g.f16) hipLaunchKernelGGL((k_layers<true, false, true>), dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
+        else hipLaunchKernelGGL(k_layers<true>, dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
+    } else hipLaunchKernelGGL(k_layers<false>, dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
     return hipGetLastError();
 }
 

@@ -319,7 +319,7 @@ class GaussianDiffusion:
         print(f"[regennet_amd] precision schedule calibrated on this checkpoint: split-bf16 for the last {tail} of "
               f"{self.num_timesteps} {sampler} steps{' (guided)' if inner is not model else ''}, T={T}"
               f"{' (agreed across the ranks: MAX)' if agreed else ''} "
-              f"(max |dev| vs uniform split-bf16 on {nb} motions: {dev:.1e}; one full {self.num_timesteps}-step run plus the candidates, "
+              f"(max |dev| vs the fp32 run of {nb} motions: {dev:.1e}; one full {self.num_timesteps}-step run plus the candidates, "
               f"once per schedule; override: x3_tail= / REGENNET_X3_TAIL)",
               file=sys.stderr, flush=True)
 
@@ -348,12 +348,18 @@ class GaussianDiffusion:
         self._log_tail(inner, model, sampler, tail, int(shape[3]), nb, agreed=dist_util.collectives_active())
         return tail
 
-    def calibrate_x3_tail(self, model, shape, model_kwargs, sampler="ddpm", eta=0.0, tol=2.5e-4, max_batch=4, seed=1234, verbose=False):
+    def calibrate_x3_tail(self, model, shape, model_kwargs, sampler="ddpm", eta=0.0, tol=2.5e-4, max_batch=4, seed=1234, verbose=False, anchor=True):
         """How many split-bf16 steps THIS checkpoint needs at the end of THIS schedule: the precision schedule's validity
         depends on how strongly the model damps early-step rounding, so it can be measured instead of assumed.
         Samples the first min(B, max_batch) motions of the given condition with the uniform split-bf16 arithmetic (tail = S)
-        and with growing tails (engine default, x2, x4, ...), all from the same Philox noise, and returns the smallest tail
-        whose result stays within `tol` (max abs) of the uniform run. Cost: a few small sampling runs, once."""
+        and with growing tails (the engine's default for this batch - with its fp16 sub-phase where the engine has one - x2, x4, ...),
+        all from the same Philox noise, and returns the smallest tail whose result stays within `tol` (max abs) of the reference run.
+        The reference is an fp32 run (exact-product MFMA, `precision="f32"`) of the same motions (`anchor`; without it the uniform split-bf16
+        run): how far 16-bit operands may go is a property of the checkpoint - on the i.i.d.-Gaussian synthetic family uniform split-bf16 sits
+        5e-5 from fp32 and two split steps suffice, on a checkpoint with LayerNorm outlier channels (synth.make_state_dict_family) plain 16-bit
+        steps cost 0.1 and uniform split-bf16 itself 6e-4. When even uniform split-bf16 is beyond `tol` of fp32 the schedule stays split-bf16
+        throughout (the most accurate 16-bit arithmetic the engine has) and one warning names `precision="f32"` as the remedy.
+        Cost: a few small sampling runs + one fp32 run, once."""
         inner = getattr(model, "model", model)
         y = model_kwargs["y"]
         B, nb, S = int(shape[0]), min(int(shape[0]), max_batch), self.num_timesteps
@@ -362,15 +368,16 @@ class GaussianDiffusion:
         saved, self._calibrating, self._last_calibration_dev = (inner.x3_tail, inner._auto_tail, inner.small_batch_rows, getattr(inner, "layers_min_b", None)), True, 0.0
         # calibrate on the kernels the CALLER's batch will run: the small-batch engine takes evaluations of at most sb token rows
         # (motions x tokens, doubled under guidance; rgn_set_small_batch_rows: the model's setting, else REGENNET_SB_ROWS, else 640)
-        sb = inner.small_batch_rows if inner.small_batch_rows is not None else int(os.environ.get("REGENNET_SB_ROWS", "640"))
+        eo = getattr(inner, "engine_options", None) or {}      # (a handle's option takes precedence over the environment inside the engine: opt_get)
+        sb = inner.small_batch_rows if inner.small_batch_rows is not None else int(eo.get("SB_ROWS", os.environ.get("REGENNET_SB_ROWS", "640")))
         Tq = int(shape[3]) + (1 if getattr(inner, "emb_trans_dec", False) else 0)
         if B * Tq * (2 if inner is not model else 1) > int(sb):
             inner.small_batch_rows = 0      # the 4 calibration motions alone would fall under the threshold: force the throughput engine
         # ... and in the caller's kernel FORM: evaluations of >= layers_min_b samples (64 by default; motions doubled under guidance) run the
         # one-kernel decoder stack (k_layers), smaller ones the kernel-per-stage chain, and the two differ by bf16 roundings in the
         # plain-bf16 phase - the 4 calibration motions take the form the caller's batch gets (rgn_set_layers_min_b)
-        lmb = inner.layers_min_b if getattr(inner, "layers_min_b", None) is not None else int(os.environ.get("REGENNET_LAYERS_MIN_B", "64"))
-        if B * (2 if inner is not model else 1) >= lmb:
+        lmb = inner.layers_min_b if getattr(inner, "layers_min_b", None) is not None else int(eo.get("LAYERS_MIN_B", os.environ.get("REGENNET_LAYERS_MIN_B", "64")))
+        if int(eo.get("LAYERS", os.environ.get("REGENNET_LAYERS", "1"))) != 0 and B * (2 if inner is not model else 1) >= lmb:
             inner.layers_min_b = 1
         fn = self.p_sample_loop if sampler == "ddpm" else self.ddim_sample_loop
         kw = dict(clip_denoised=False, model_kwargs={"y": ys}, seed=seed)
@@ -383,14 +390,26 @@ class GaussianDiffusion:
 
         try:
             ref = run(S)
-            L = max(1, int(getattr(inner, "num_layers", 8)))
-            from .. import _lib
-            t = _lib.default_x3_tail(S, L, bool(getattr(inner, 'emb_trans_dec', False)))
+            if anchor:
+                ref32 = self._f32_run(inner, run, S)
+                dev32 = float((ref - ref32).abs().max())
+                ref = ref32                                   # the candidates are measured against fp32, not against split-bf16
+                if dev32 > tol:
+                    self._last_calibration_dev = 0.0
+                    if not getattr(inner, "_warned_anchor", False):
+                        inner._warned_anchor = True
+                        print(f"[regennet_amd] precision schedule: on this checkpoint uniform split-bf16 arithmetic itself differs from fp32 by {dev32:.1e} "
+                              f"(> {tol:.1e}) - the schedule stays split-bf16 throughout; build the model with precision='f32' for exact-product MFMA",
+                              file=sys.stderr, flush=True)
+                    return S
+            # start from the engine's own default for this batch on this schedule (2 behind an fp16 sub-phase, else the bf16 rule's 5 / 3 / ...)
+            inner._engine.set_x3_tail(-1)
+            t = max(1, int(inner._engine.precision_plan(nb, inner is not model)[1]))
             chosen = S
             while t < S:
                 dev = float((run(t) - ref).abs().max())
                 if verbose:
-                    print(f"[calibrate_x3_tail] tail {t} of {S}: max |dev| vs uniform split-bf16 = {dev:.2e}")
+                    print(f"[calibrate_x3_tail] tail {t} of {S}: max |dev| vs the reference run = {dev:.2e}")
                 self._last_calibration_dev = dev
                 if dev <= tol:
                     chosen = t
@@ -402,6 +421,18 @@ class GaussianDiffusion:
             inner.x3_tail, inner._auto_tail, inner.small_batch_rows, inner.layers_min_b = saved
             self._calibrating = False
         return chosen
+
+    def _f32_run(self, inner, run, S):
+        """The calibration motions sampled in the engine's fp32 mode. The fp32 engine is built beside the model's engine cache (own cache, no
+        weight broadcast: every rank holds the checkpoint it loaded) and closed again."""
+        saved = (inner._engines, inner._engine, inner.precision, inner.weights_src, inner._ever_synced, inner._cond_key, inner._keep)
+        inner._engines, inner._engine, inner.precision, inner.weights_src, inner._ever_synced = {}, None, "f32", None, False
+        try:
+            return run(S)
+        finally:
+            for e in inner._engines.values():
+                e.close()
+            inner._engines, inner._engine, inner.precision, inner.weights_src, inner._ever_synced, inner._cond_key, inner._keep = saved
 
     @staticmethod
     def _keyed_normal(eng, shape, seed, sample_offset, loop_index, dev):

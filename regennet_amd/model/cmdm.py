@@ -139,6 +139,9 @@ class CMDM(nn.Module):
         # A model that loads a checkpoint (load_state_dict) without an explicit x3_tail switches to "auto": the default rule was
         # derived from synthetic weights, so on weights nobody validated the switch point is measured (a few small runs, once).
         self.x3_tail = kargs.get("x3_tail", None)
+        # ... and fp16 MFMA operands for the f16_steps plain steps in front of that tail (None: engine default 8 where the one-kernel decoder stack runs
+        # the plain phase; 0: none - the default tail is then the bf16 rule's)
+        self.f16_steps = kargs.get("f16_steps", None)
         # evaluations of at most this many token rows run the small-batch engine (None: engine default, 0: never)
         self.small_batch_rows = kargs.get("small_batch_rows", None)
         # evaluations of at least this many samples run the one-kernel decoder stack (k_layers; None: engine default 64, 1: always)
@@ -165,7 +168,7 @@ class CMDM(nn.Module):
 
     def load_state_dict(self, state_dict, strict=True):
         self._engine_stale = True
-        self._auto_tail, self._auto_tails = None, {}
+        self._auto_tail, self._auto_tails, self._warned_anchor = None, {}, False
         if self.x3_tail is None and "REGENNET_X3_TAIL" not in os.environ:
             self.x3_tail = "auto"                   # measured at the first sampling call per (schedule, sampler, guidance, T)
         return super().load_state_dict(state_dict, strict=strict)
@@ -224,12 +227,22 @@ class CMDM(nn.Module):
                     outgoing = victim
                 else:
                     victim.close()
-            eng = _lib.Engine(self.engine_config(T), B, dev.index or 0, self.precision, **({"options": self.engine_options} if self.engine_options else {}))
-            for k, v in self.state_dict().items():
-                if k.startswith("clip_model."):
-                    continue
-                eng.load_weight(k, v.detach().float().cpu().numpy())
-            eng.finalize()
+            eng = None
+            try:
+                eng = _lib.Engine(self.engine_config(T), B, dev.index or 0, self.precision, **({"options": self.engine_options} if self.engine_options else {}))
+                for k, v in self.state_dict().items():
+                    if k.startswith("clip_model."):
+                        continue
+                    eng.load_weight(k, v.detach().float().cpu().numpy())
+                eng.finalize()
+            except BaseException:
+                # (out of memory, a refused checkpoint ...): nothing may leak and the engine this one was to replace - possibly this rank's only
+                # holder of the synchronised weight blob - goes back into the cache
+                if eng is not None:
+                    eng.close()
+                if outgoing is not None:
+                    self._engines[int(outgoing.cfg["num_frames"])] = outgoing
+                raise
             if self.weights_src is not None:
                 # The RCCL broadcast is a collective: it may only run where EVERY rank builds an engine - the first one (the callers
                 # build it at start-up, whatever their shard size). Engines built later by one rank alone (a new sequence length, a
@@ -245,7 +258,8 @@ class CMDM(nn.Module):
                             outgoing.close()
                         eng.close()
                         raise RuntimeError("regennet_amd: this rank needs a new engine after start-up and holds no engine with the synchronised weight "
-                                           "blob to copy from (blob layouts differ?) - build every engine the run needs at start-up, where all ranks "
+                                           "blob to copy from (a blob's layout depends on the precision mode and the engine options: an engine rebuilt because "
+                                           "model.precision changed cannot take the old one's) - build every engine the run needs at start-up, where all ranks "
                                            "take part in the RCCL broadcast (model._get_engine(B, T) on every rank)")
                     dist_util.broadcast_engine_weights(eng, dev, int(self.weights_src))
                 eng._blob_synced = True
@@ -259,6 +273,7 @@ class CMDM(nn.Module):
         if tail == "auto":                                    # filled in per (schedule, sampler, guidance, T) by calibrate_x3_tail
             tail = self._auto_tail
         eng.set_x3_tail(-1 if tail is None else int(tail))
+        eng.set_f16_steps(-1 if self.f16_steps is None else int(self.f16_steps))
         eng.set_small_batch_rows(-1 if self.small_batch_rows is None else int(self.small_batch_rows))
         eng.set_layers_min_b(-1 if self.layers_min_b is None else int(self.layers_min_b))
         return eng, dev

@@ -64,13 +64,13 @@ def autoreg_inputs(g):
 
 
 # ---- HIP-side construction (GPU tests) --------------------------------------------------------------
-def build_hip(cfg, sd, resp="", precision="f32", device="cuda:0", noise_schedule="cosine", sigma_small=True, x3_tail=None):
+def build_hip(cfg, sd, resp="", precision="f32", device="cuda:0", noise_schedule="cosine", sigma_small=True, x3_tail=None, engine_options=None, f16_steps=None):
     """(model, diffusion) from regennet_amd for a synth config + synthetic checkpoint.
     precision "<mode>/throughput": the same mode with the small-batch engine (rgn_sb.hip) switched off, so a test-sized
     batch runs the kernels a full-size batch gets."""
     mode, _, engine = precision.partition("/")
     model, diffusion = synth.build_model(cfg, sd, resp=resp, precision=mode, device=device, noise_schedule=noise_schedule,
-                                         sigma_small=sigma_small, x3_tail=x3_tail)
+                                         sigma_small=sigma_small, x3_tail=x3_tail, engine_options=engine_options, f16_steps=f16_steps)
     if engine == "throughput":
         model.small_batch_rows = 0
     return model, diffusion

@@ -45,6 +45,17 @@ def test_the_c_abi_is_the_only_dynamic_symbol_set():
     assert all(r[-2] == "T" for r in rows), [r for r in rows if r[-2] != "T"]
 
 
+def test_direct_to_lds_loads_find_their_m0_in_the_isa():
+    """rgn_layers.hip issues direct-to-LDS loads both through the compiler's builtin and from inline asm (the step boundary's L2 prefetch); m0 - their LDS
+    base - is a register the compiler manages and does not preserve across an asm that names it as a clobber. tools/check_m0.py compiles the source to
+    ISA and checks every such load for an m0 write inside its own basic block, the asm's save / restore pairing, and a warning-free compile."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_m0.py"), "rgn_layers.hip"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "60 direct-to-LDS loads checked, 0 problem(s)" in r.stdout, r.stdout
+
+
 def test_null_and_bad_arguments_return_status_codes():
     from regennet_amd import _lib
     lib = _lib.load()
@@ -53,6 +64,8 @@ def test_null_and_bad_arguments_return_status_codes():
     assert lib.rgn_destroy(None) == -1
     assert lib.rgn_finalize_weights(None) == -1
     assert lib.rgn_set_layers_min_b(None, 1) == -1
+    assert lib.rgn_set_f16_steps(None, 1) == -1
+    assert lib.rgn_precision_plan(None, 1, 0, None, None) == -1
     assert lib.rgn_plan_query(None, 1, 0, 0, 0, None, None, None, None, None) == -1
     cfg = _lib.RgnConfig(njoints=56, nfeats=6, num_frames=60, latent_dim=500, ff_size=1024, num_heads=4, num_layers=8,
                          cm_mode=1, cond_mode=0, num_actions=1, clip_dim=512, emb_trans_dec=0, wo_pos_emb=0, max_batch=1,

@@ -99,11 +99,18 @@ class FakeEngine:
     def set_layers_min_b(self, n):
         self.knobs = dict(getattr(self, "knobs", {}), layers_min_b=int(n))
 
+    def set_f16_steps(self, n):
+        self.knobs = dict(getattr(self, "knobs", {}), f16_steps=int(n))
+
     def set_const_noise(self, on):
         self.const_noise = bool(on)
 
+    def precision_plan(self, B, guided=False):
+        from regennet_amd._lib import default_x3_tail
+        return 0, default_x3_tail(self.S, self.cfg["layers"], bool(self.cfg.get("emb_trans_dec", False)))
+
     def set_schedule(self, tmap, tables, sched_id=None):
-        self.schedule_id = sched_id
+        self.schedule_id, self.S = sched_id, len(tmap)
         self.calls.append("schedule")
 
     def set_condition(self, B, cm, action, text, scale, stream):
@@ -223,10 +230,10 @@ def test_model_knobs_reach_the_engine(monkeypatch):
     cfg = synth.get_config("tiny")
     model, _ = synth.build_model(cfg, synth.make_state_dict(cfg, seed=0), precision="bf16_x3tail", device="cpu")
     eng, _dev = model._get_engine(2)
-    assert eng.knobs == {"x3_tail": -1, "small_batch_rows": -1, "layers_min_b": -1}
-    model.x3_tail, model.small_batch_rows, model.layers_min_b = 5, 0, 1
+    assert eng.knobs == {"x3_tail": -1, "f16_steps": -1, "small_batch_rows": -1, "layers_min_b": -1}
+    model.x3_tail, model.f16_steps, model.small_batch_rows, model.layers_min_b = 5, 4, 0, 1
     eng2, _dev = model._get_engine(2)
-    assert eng2 is eng and eng.knobs == {"x3_tail": 5, "small_batch_rows": 0, "layers_min_b": 1}
+    assert eng2 is eng and eng.knobs == {"x3_tail": 5, "f16_steps": 4, "small_batch_rows": 0, "layers_min_b": 1}
 
 
 # ---- bench.py launches its own ranks (the counterpart of the reference's rank bootstrap, utils/dist_util.py:20-42) ---------------
