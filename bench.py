@@ -42,8 +42,7 @@ def row_check(cfg, sd, a, dev, y, out, seed, lo, plan, fn_name, rows):
     headline number rests on - 256 workgroups x 995 steps - is checked at its real shape on every bench run, not only for isfinite."""
     from regennet_amd import synth
     from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
-    model1, diffusion1 = synth.build_model(cfg, sd, resp=a.respacing, precision=a.precision, device=str(dev), x3_tail=a.x3_tail,
-                                           engine_options={} if a.bulk_f16 is None else {"BULK_F16": a.bulk_f16})
+    model1, diffusion1 = synth.build_model(cfg, sd, resp=a.respacing, precision=a.precision, device=str(dev), x3_tail=a.x3_tail, f16_steps=a.f16_steps)
     if "sb_gemm" not in plan:                       # (a batch the small-batch engine ran is bit-exact under batch composition by itself)
         model1.small_batch_rows = 0
     if any(k in plan for k in ("layers", "steps_fused")):
@@ -264,8 +263,9 @@ def main(argv=None):
     ap.add_argument("--precision", default=os.environ.get("REGENNET_PRECISION", "bf16_x3tail"),
                     choices=["f32", "bf16x3", "bf16", "bf16_x3tail"])
     ap.add_argument("--x3-tail", type=int, default=None, help="precision schedule: split-bf16 for the last N loop indices")
-    ap.add_argument("--bulk-f16", type=int, default=None, choices=[0, 1],
-                    help="plain phase of the precision schedule on fp16 (1) / bf16 (0) MFMA operands where the one-kernel decoder stack runs it (default: the engine's)")
+    ap.add_argument("--f16-steps", type=int, default=None,
+                    help="precision schedule: fp16 MFMA operands for the N plain steps in front of the split-bf16 tail (default: the engine's 8 where the one-kernel "
+                         "decoder stack runs the plain phase; 0: none, and the bf16 rule's tail)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", default=bool(os.environ.get("REGENNET_FORCE_DIST")),
@@ -284,7 +284,6 @@ def main(argv=None):
         return bench_eval_pipeline(a)
 
     from regennet_amd import synth
-    from regennet_amd._lib import default_x3_tail
     from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
     from regennet_amd.utils import dist_util
 
@@ -311,25 +310,21 @@ def main(argv=None):
 
     cfg = synth.get_config(a.config)
     B = a.batch
-    # rank 0 owns the checkpoint; other ranks start from a different seed and receive the packed blob via RCCL
+    # rank 0 owns the checkpoint; other ranks start from a different seed and receive rank 0's parameters via RCCL (dist_util.sync_model_weights)
     sd = synth.make_state_dict(cfg, seed=0 if rank == 0 else 1000 + rank)
-    eopts = {} if a.bulk_f16 is None else {"BULK_F16": a.bulk_f16}
-    model, diffusion = synth.build_model(cfg, sd, resp=a.respacing, precision=a.precision, device=str(dev), x3_tail=a.x3_tail, engine_options=eopts)
+    model, diffusion = synth.build_model(cfg, sd, resp=a.respacing, precision=a.precision, device=str(dev), x3_tail=a.x3_tail, f16_steps=a.f16_steps)
     # Engine build = host-side repack of the checkpoint into the device blob (fp32 -> bf16 planes in three layouts) + upload; timed and
     # reported ("engine_build_s": ~2 s of one host core at N = 1). N ranks repack concurrently by default; REGENNET_SERIAL_ENGINE_BUILD=1
     # makes them take turns (a host whose memory bandwidth 8 concurrent repacks would saturate), the broadcast follows either way.
     t_build = time.perf_counter()
+    synced_bytes = dist_util.sync_model_weights(model, 0) if multi else 0   # ONE collective over xGMI: rank 0's checkpoint as a flat fp32 buffer
     if multi and a.serial_engine_build:
         eng = None
         for r in range(world):
             if r == rank:
                 eng, _ = model._get_engine(B)
             dist.barrier()
-        dist_util.broadcast_engine_weights(eng, dev, 0)     # ONE collective over xGMI: rank 0's packed blob
-        eng._blob_synced = True
-        model.weights_src = 0
     else:
-        model.weights_src = 0 if multi else None        # ONE collective over xGMI for the engine every rank builds here (none at N = 1)
         eng, _ = model._get_engine(B)
     sync()
     build_s = time.perf_counter() - t_build
@@ -375,6 +370,8 @@ def main(argv=None):
 
     # ---- the timed launch at its real shape: motions 0 and B-1 of the LAST timed call against single-motion runs of the same kernel form
     plan = {} if a.engine_stub else eng.plan_query(B, a.guided, split_phase=False)
+    # the precision plan the timed calls followed (rgn_precision_plan: the engine's own answer for this batch on this schedule)
+    n16, tail = (0, 0) if a.engine_stub else eng.precision_plan(B, a.guided)
     row_dev = None
     if rank == 0 and not a.engine_stub and not a.no_row_check and a.steps > 0:
         row_dev = row_check(cfg, synth.make_state_dict(cfg, seed=0), a, dev, y, out, 100 + a.steps - 1, lo, plan,
@@ -399,8 +396,8 @@ def main(argv=None):
         if fl.get("steps_fused", 0.0) > 0:
             # the timed region's dominant launch covers the WHOLE plain-bf16 phase of a call: profile exactly that launch (every
             # k_layers<steps> launch of this command then has the same step count, and rocprofv3's average duration is comparable)
-            tail = a.x3_tail if a.x3_tail is not None else default_x3_tail(S, cfg['layers'], bool(cfg.get('emb_trans_dec', False)))
-            run_steps = n_eval = max(S - min(tail, S), 1)
+            bulk = S - tail - n16                               # plain-bf16 steps of a call; 0: the schedule's plain steps all run on fp16 operands
+            run_steps = n_eval = max(bulk if bulk > 0 else n16, 1)
             eng.randn(x, B, 5, lo, st)
             eng.sample_range(a.sampler, a.guided, 0.0, x, None, 5, lo, first, run_steps, None, False, False, st)
         else:
@@ -446,7 +443,7 @@ def main(argv=None):
         dom = next(e for e in per_kernel if "frac" in e)     # the class with the largest share of the step that does MFMA work
         phase = ""
         if a.precision == "bf16_x3tail":
-            phase = " (plain-bf16 phase of the precision schedule: single-plane operands, one MFMA per product)"
+            phase = " (plain phase of the precision schedule: single-plane operands, one MFMA per product)"
         roof = {"bound": "mfma", "kernel": dom["kernel"] + phase, "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s",
                 "frac": dom["frac"], "traffic": None,
                 "avg_launch_us": dom["avg_us"], "launches_per_eval": dom["launches_per_eval"], "steps_per_launch": dom.get("steps_per_launch"),
@@ -495,14 +492,14 @@ def main(argv=None):
         value = a.steps * B * world / dt
         dtype = a.precision
         if a.precision == "bf16_x3tail":
-            tail = a.x3_tail if a.x3_tail is not None else default_x3_tail(S, cfg['layers'], bool(cfg.get('emb_trans_dec', False)))
-            dtype = f"bf16 MFMA, fp32 accumulate/LayerNorm/softmax; split-bf16 (x3) for the last {min(tail, S)} of {S} steps"
+            dtype = (f"bf16 MFMA operands, fp32 accumulate/LayerNorm/softmax, for {S - tail - n16} of {S} steps; " +
+                     (f"fp16 MFMA operands for the next {n16}; " if n16 else "") + f"split-bf16 (x3) for the last {tail}")
         line = {
             "metric": "sampled motions/sec", "value": round(value, 3), "unit": "motions/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic" if not a.engine_stub else f"STUB ENGINE {a.engine_stub}: launcher test, nothing measured",
-            "engine_build_s": round(build_s, 2),
+            "engine_build_s": round(build_s, 2), "weights_broadcast_bytes": synced_bytes,
             "headline_row_check_max_abs": row_dev,
             "headline_row_check": None if row_dev is None else f"motions 0 and {B - 1} of the last timed call vs B = 1 runs of the same kernel form "
                                                                f"with the motion's global Philox key (bit-exact in the plain-bf16 phase; <= 2e-5 behind the split-bf16 tail)",

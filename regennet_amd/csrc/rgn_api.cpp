@@ -151,6 +151,7 @@ struct rgn_ctx {
     // product, hi planes only as GEMM operands), the last x3_tail indices and every rgn_denoise call the split-bf16 ones.
     // phase_x3 is the phase of the evaluation being enqueued / captured.
     bool phase_x3 = true;
+    bool phase_f16 = false;            // ... and, for a plain evaluation: fp16 operands (the fp16 sub-phase of the schedule, rgn_set_f16_steps)
     int x3_tail = -1;                  // -1: default_tail(S)
     int f16_steps = -1;                // rgn_set_f16_steps: plain-phase steps right in front of the split-bf16 tail that run on fp16 operands (-1: default)
     int const_noise = 0;               // rgn_set_const_noise
@@ -559,7 +560,9 @@ PrecPlan prec_plan(const rgn_ctx* c, const Dims& dm, bool guided) {
     PrecPlan pp;
     if (c->cfg.precision != RGN_PREC_BF16_X3TAIL) return pp;
     const EvalPlan plain = plan_eval(c, dm, guided, false, true);
-    const bool f16_ok = c->bulk_f16 && plain.steps;          // (only the multi-step one-kernel form has the fp16 instantiation)
+    // (the forms with an fp16 instantiation: the multi-step one-kernel stack, and the kernel-per-stage chain of 150-frame models -
+    //  k_qkv_attn_long + k_mlp2 + k_step, whose planes hand the residual stream from step to step)
+    const bool f16_ok = c->bulk_f16 && (plain.steps || (plain.step_fused && !plain.layers && plain.attn == AF_QKV_LONG && plain.tail == TF_MLP));
     pp.n16 = !f16_ok ? 0 : (c->f16_steps >= 0 ? c->f16_steps : F16_STEPS_DEFAULT);
     if (c->x3_tail >= 0) pp.tail = c->x3_tail;
     else if (pp.n16 > 0 && c->L >= 8 && !c->etd) pp.tail = F16_TAIL < c->S ? F16_TAIL : c->S;
@@ -679,6 +682,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
     const bool fast = prec != RGN_PREC_F32, x3 = eval_x3(c);
     const EvalPlan pl = plan_eval(c, dmf, guided, x3, sampling);
     if (pl.sb) return run_layers_sb(c, dmf, sampling, cond_rows, ccond_rows, s);   // (called with the full range)
+    const bool f16 = !x3 && sampling && c->phase_f16;      // the schedule's fp16 sub-phase (rgn_sample_range sets it only where prec_plan allows)
     Dims dm = dmf;
     dm.Bm = ns;
     // ---- the big GEMMs: F32 mode keeps fp32 activations (k_gemm_f32); the bf16 modes chain pre-split
@@ -775,10 +779,11 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             // plain-bf16 phase, long sequence: in_proj + attention of one (sample, head) per workgroup, q / k / v stay in LDS
             QkvAttnArgs g{};
             g.Ahi = h_p.hi; g.a_rows = h_p.rows;
-            g.Wfr = c->dp<__bf16>(w.qkv.fr); g.bias = c->dp<float>(w.qkv.b);
+            g.Wfr = c->dp<__bf16>(f16 ? w.qkv.fr16 : w.qkv.fr); g.bias = c->dp<float>(w.qkv.b);
             g.out = att_p;
             g.Bm = ns; g.Kp = w.qkv.Kp; g.d = d; g.H = c->H; g.Tq = dm.Tq;
             g.qscale = 1.0f / sqrtf((float)dm.dh);
+            g.f16 = f16 ? 1 : 0;
             RGN_LAUNCH(c, KC_QKV, s, launch_qkv_attn_long(g, s));
         } else if (pl.attn == AF_ROWGEMM_ATTN) {
             // plain-bf16 phase, long sequence: packed in_proj as a row-complete GEMM that scatters q (pre-scaled), k, v as
@@ -842,7 +847,8 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             // linear1 + GELU + linear2 + norm3) as ONE row-persistent kernel; residual stream updated in place (hi plane)
             MlpArgs g{};
             g.att = att_p.hi; g.h = h_p.hi; g.out = h_p.hi; g.rows = h_p.rows; g.M = M;
-            g.Wo = c->dp<__bf16>(w.out.fr); g.W1 = c->dp<__bf16>(w.ff1.fr); g.W2 = c->dp<__bf16>(w.ff2.fr);
+            g.Wo = c->dp<__bf16>(f16 ? w.out.fr16 : w.out.fr); g.W1 = c->dp<__bf16>(f16 ? w.ff1.fr16 : w.ff1.fr); g.W2 = c->dp<__bf16>(f16 ? w.ff2.fr16 : w.ff2.fr);
+            g.f16 = f16 ? 1 : 0;
             g.bo = c->dp<float>(w.out.b); g.bf1 = c->dp<float>(w.ff1.b); g.bf2 = c->dp<float>(w.ff2.b);
             g.g1 = c->dp<float>(w.ln[0]); g.b1 = c->dp<float>(w.ln[1]); g.g2 = c->dp<float>(w.ln[2]); g.b2 = c->dp<float>(w.ln[3]);
             g.g3 = c->dp<float>(w.ln[4]); g.b3 = c->dp<float>(w.ln[5]);
@@ -976,9 +982,11 @@ int run_eval(rgn_ctx* c, int B, bool guided, bool uncond, bool sampling, hipStre
             StepArgs g{};
             const size_t row0 = (size_t)s_first * dm.Tq;
             g.h = c->h_hi + row0 * 32; g.hout = c->h_hi + row0 * 32; g.rows = M; g.M = n * dm.Tq;
-            g.Wout = c->dp<__bf16>(c->lin_out.fr); g.bout = c->dp<float>(c->lin_out.b); g.F = c->F; g.nb_out = (c->F + 31) / 32;
-            g.Wx = c->dp<__bf16>(c->lin_x.fr); g.nkx = c->lin_x.Kp / 32;
-            g.c0 = c->c0h + row0 * c->d;
+            const bool f16 = c->phase_f16 && !eval_x3(c);
+            g.Wout = c->dp<__bf16>(f16 ? c->lin_out.fr16 : c->lin_out.fr); g.bout = c->dp<float>(c->lin_out.b); g.F = c->F; g.nb_out = (c->F + 31) / 32;
+            g.Wx = c->dp<__bf16>(f16 ? c->lin_x.fr16 : c->lin_x.fr); g.nkx = c->lin_x.Kp / 32;
+            g.c0 = (f16 ? reinterpret_cast<const __bf16*>(c->c0h16) : c->c0h) + row0 * c->d;
+            g.f16 = f16 ? 1 : 0;
             g.tab = c->d_tab; g.d_step = c->d_step; g.sp = c->d_sp;
             g.T = dm.T; g.B = dm.B; g.s0 = s_first; g.total_tiles = total_tiles; g.no_quads = c->step_no_quads;
             if (guided) { g.scale = c->scale; g.half = Mb; }  // x0 = x0_u + scale (x0_c - x0_u); rows [Mb, 2 Mb) are the unconditional half
@@ -1599,9 +1607,9 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
         // index lives on the device, so one instantiated graph serves any starting index. Long ranges replay the multi-step
         // graph (graph_steps iterations per host launch; a 4-branch launch costs the host ~1 ms, as much as the GPU needs for
         // a step at B = 256), the remainder single-step graphs.
-        auto graph_for = [&](bool x3, int steps, hipGraphExec_t* out) -> int {
+        auto graph_for = [&](bool x3, bool f16g, int steps, hipGraphExec_t* out) -> int {
             const uint64_t key = (uint64_t)c->B | ((uint64_t)(guided != 0) << 20) | ((uint64_t)sampler << 21) | ((uint64_t)x3 << 23) |
-                                 ((uint64_t)steps << 24);
+                                 ((uint64_t)steps << 24) | ((uint64_t)f16g << 40);
             auto it = c->graphs.find(key);
             if (it != c->graphs.end()) {
                 *out = it->second;
@@ -1610,6 +1618,7 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
             hipGraph_t graph = nullptr;
             hipGraphExec_t ge = nullptr;
             c->phase_x3 = x3;
+            c->phase_f16 = f16g;
             RGN_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             int r = RGN_OK;
             for (int k = 0; k < steps && r == RGN_OK; ++k) {
@@ -1651,7 +1660,7 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
                 if ((rc = embed_all(c, dm, s))) return rc;
                 planes_f16 = false;
             }
-            if (f16 && pl.steps && !planes_f16) {   // the fp16-operand form reads (and rewrites) the residual-stream planes as fp16: what the embedding or the bf16 launch left there is re-encoded
+            if (f16 && !planes_f16) {   // the fp16-operand forms read (and rewrite) the residual-stream planes as fp16: what the embedding or the bf16 steps left there is re-encoded
                 RGN_LAUNCH(c, KC_EMBED, s, launch_bf16_to_f16(c->h_hi, (size_t)dm.Bm * dm.Tq * c->d, s));
                 planes_f16 = true;
             }
@@ -1686,17 +1695,19 @@ int rgn_sample_range(rgn_handle h, int32_t sampler, int32_t guided, float eta, f
             if (graphs) {
                 const int steps = (multi > 1 && phase_left >= multi) ? multi : 1;
                 hipGraphExec_t ge = nullptr;
-                if ((rc = graph_for(x3, steps, &ge))) return rc;
+                if ((rc = graph_for(x3, f16, steps, &ge))) return rc;
                 RGN_HIP(c, hipGraphLaunch(ge, s));
                 k += steps;
             } else {
                 c->phase_x3 = x3;
+                c->phase_f16 = f16;
                 rc = run_eval(c, c->B, guided != 0, false, true, s);
                 if (rc) return rc;
                 k += 1;
             }
         }
         c->phase_x3 = true;
+        c->phase_f16 = false;
         return stream_exit(c, us);
     });
 }

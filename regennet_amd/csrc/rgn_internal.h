@@ -118,6 +118,7 @@ struct QkvAttnArgs {
     int Bm, Kp, d, H, Tq;
     float qscale;
     int Bm_eval;                                        // samples of the WHOLE evaluation (all kernel chains; 0: = Bm): what else runs beside this launch
+    int f16;                                            // k_qkv_attn_long only: Ahi, Wfr and the output plane hold IEEE fp16 (OpFmt<true>), not bf16
 };
 bool qkv_attn_supported(int Tq, int dh, int d);
 hipError_t configure_qkv_attn();
@@ -167,6 +168,7 @@ struct MlpArgs {
     const float* pervec; int ldper;       // + pervec[(row / Tq) * ldper + n]     (nullable)
     const float* stepvec; int ldstep; const int* d_step;   // + stepvec[(*d_step) * ldstep + n] (nullable)
     int Tq;
+    int f16;                              // k_mlp2<2> only: att / h / out planes and the three weight planes hold IEEE fp16 (OpFmt<true>)
 };
 bool mlp_supported(int d, int ff, int Tq);
 hipError_t configure_mlp();
@@ -263,6 +265,29 @@ bool sb_qkv_attn_supported(int d, int dh, int Tq);
 hipError_t configure_sb_qkv_attn();
 hipError_t launch_sb_qkv_attn(const SbArgs& g, int Bm, bool x3, hipStream_t s);
 
+// The 16-bit operand format of the plain phase's MFMAs (weights, activation images / planes, q / k / v / p): bf16 (8 mantissa bits) or IEEE fp16
+// (11). Both instructions are 8 passes of 4 cycles per 32 x 32 x 16 tile and take 16 bytes per lane and operand, so a kernel's structure - rings,
+// images, waits - does not depend on the format; what changes is every operand's rounding (2^-9 -> 2^-12 relative) and its range (fp16: 6.1e-5 ..
+// 65504 normal; LayerNorm outputs, GELU values, softmax probabilities and the weights of a transformer sit well inside, and rgn_finalize_weights
+// refuses a checkpoint that does not). Accumulation, LayerNorm statistics, softmax and the sampler update are fp32 either way. Nominally the same
+// rate - but the chip is power-managed under a matrix load and a pure f16 MFMA loop sustains 7.5 - 8 % less than the bf16 one
+// (tools/experiments/mfma_sustained.hip), which is why fp16 is a PHASE of the precision schedule (rgn_set_f16_steps), not its plain format.
+template <bool F16> struct OpFmt;
+template <> struct OpFmt<false> {
+    typedef __bf16 t;
+    typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 v4 __attribute__((ext_vector_type(4)));
+    typedef float acc16 __attribute__((ext_vector_type(16)));
+    static __device__ __forceinline__ acc16 mfma(v8 a, v8 b, acc16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct OpFmt<true> {
+    typedef _Float16 t;
+    typedef _Float16 v8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 v4 __attribute__((ext_vector_type(4)));
+    typedef float acc16 __attribute__((ext_vector_type(16)));
+    static __device__ __forceinline__ acc16 mfma(v8 a, v8 b, acc16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
 // XCD-affine workgroup order: the hardware places workgroup id b on XCD b % 8. Remapping the id so that every XCD gets one
 // CONTIGUOUS range of tiles / samples makes the rows a kernel reads the rows the previous kernel of the chain wrote on the
 // same XCD (k_qkv_attn -> k_mlp -> k_qkv_attn ...): they are still in that XCD's L2 instead of behind the fabric.
@@ -305,6 +330,7 @@ struct StepArgs {
     int no_quads;               // tests: draw the noise per element (philox_normal) instead of per quad of lanes (bit-identical)
     const float* scale; int half;   // guided sampling: scale[B] (nullptr: unguided) and the row distance B * T from a token's conditional
                                     // to its unconditional row (h / hout / c0 hold both halves; M counts the conditional rows)
+    int f16;                        // h / hout planes, Wout, Wx and c0 hold IEEE fp16 (OpFmt<true>)
 };
 bool step_fused_supported(int d, int F, int Kpx);
 hipError_t configure_step();

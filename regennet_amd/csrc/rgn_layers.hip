@@ -46,24 +46,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
-// The 16-bit operand format of the MFMAs (weights, activation images, q / k / v / p): bf16 (8 mantissa bits) or fp16 (11). Both instructions are
-// 8 passes of 4 cycles per 32 x 32 x 16 tile and take 16 bytes per lane and operand, so the kernel's structure - rings, images, waits - is the
-// same; what changes is the rounding of every operand (2^-9 -> 2^-12 relative) and the range (fp16: 6.1e-5 .. 65504 normal; activations behind
-// a LayerNorm, softmax probabilities and weights of a trained transformer sit well inside, the engine refuses a checkpoint that does not).
-// Accumulation, LayerNorm statistics, softmax and the sampler update are fp32 either way.
-template <bool F16> struct LyOp;
-template <> struct LyOp<false> {
-    typedef __bf16 t; typedef bf16x8 v8; typedef bf16x4 v4;
-    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-};
-template <> struct LyOp<true> {
-    typedef _Float16 t; typedef f16x8 v8; typedef f16x4 v4;
-    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-};
-
 #define RGN_AS1 __attribute__((address_space(1)))
 #define RGN_AS3 __attribute__((address_space(3)))
 #ifndef RGN_LY_ST_AUX
@@ -124,7 +106,7 @@ __device__ __forceinline__ void ly_static_for(F&& f) { ly_static_for_seq(std::ma
 template <bool STEPS, bool GUIDED = false, bool F16 = false>
 __global__ __launch_bounds__(LY_NTH, 2) void k_layers(LayersArgs g) {
     static_assert(STEPS || !GUIDED, "guidance inside the launch needs the step boundary");
-    using OP = LyOp<F16>;
+    using OP = OpFmt<F16>;
     using op_t = typename OP::t;
     using op8 = typename OP::v8;
     using op4 = typename OP::v4;

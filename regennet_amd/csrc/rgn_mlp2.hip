@@ -103,9 +103,13 @@ __device__ __forceinline__ f32x2 m2_gelu2(f32x2 x) {
     return x * __builtin_elementwise_fma(t, p, f32x2{0.5f, 0.5f});
 }
 
-template <int MT>
+template <int MT, bool F16 = false>
 __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
     using C = M2<MT>;
+    using OP = OpFmt<F16>;                // bf16 or fp16 operands (rgn_internal.h): planes in, planes out, weight planes
+    using op_t = typename OP::t;
+    using op8 = typename OP::v8;
+    using op4 = typename OP::v4;
     constexpr int NT = C::NT, NW = C::NW, R = C::R, CW = C::CW, RD = C::RD, KB = C::KB, NSAMP = C::NSAMP, VK = CW / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -136,14 +140,14 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
     //      [K/32][nb_all][2][64][8] (rgn_rowgemm.hip). Granule index hs = 2 kt + ks. Buffer loads: the resource (based at the wave's
     //      first column block) is scalar and every granule offset a compile-time constant, the lane contributes lane * 16
     struct Pass { __amdgpu_buffer_rsrc_t rs; int kstride, hs0; };   // kstride = nb_all * 2048 bytes per k-block
-    bf16x8 wf[RD][NT];
+    op8 wf[RD][NT];
     const int lane16 = lane * 16;
     auto load_g = [&](const Pass& ps, int hs_rel, int slot) {
         const int hs = ps.hs0 + hs_rel;
         const int soff = (hs >> 1) * ps.kstride + (hs & 1) * 1024;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            wf[slot][nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ps.rs, lane16, soff + nt * 2048, 0));
+            wf[slot][nt] = __builtin_bit_cast(op8, __builtin_amdgcn_raw_buffer_load_b128(ps.rs, lane16, soff + nt * 2048, 0));
     };
     // one GEMM pass over K = 512: acc[nt][mt] += A_image(16 k-blocks at img) . W[the wave's column blocks, granules hs0 .. hs0 + 31]^T.
     // The ring never drains between passes: the tail of a pass requests the first RD - 1 granules of the NEXT pass (chain). `extra`:
@@ -153,16 +157,16 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
         constexpr int EX = decltype(extra)::value, AH = RD - 1;
         constexpr bool CH = decltype(chain)::value;
         __builtin_amdgcn_sched_barrier(0);
-        bf16x8 af[MT];
+        op8 af[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(img + a_off[0] + mt * 2048);
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const op8*>(img + a_off[0] + mt * 2048);
 #pragma unroll
         for (int hs = 0; hs < 32; ++hs) {
-            bf16x8 afn[MT];
+            op8 afn[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 afn[mt] = af[mt];
-                if (hs + 1 < 32) afn[mt] = *reinterpret_cast<const bf16x8*>(img + ((hs + 1) >> 1) * KB + a_off[(hs + 1) & 1] + mt * 2048);   // one granule ahead
+                if (hs + 1 < 32) afn[mt] = *reinterpret_cast<const op8*>(img + ((hs + 1) >> 1) * KB + a_off[(hs + 1) & 1] + mt * 2048);   // one granule ahead
             }
             if (hs + AH < 32) load_g(cur, hs + AH, (hs + AH) % RD);
             else if (CH) load_g(nxt, hs + AH - 32, (hs + AH) % RD);
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[hs % RD][nt], af[mt], acc[nt][mt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = OP::mfma(wf[hs % RD][nt], af[mt], acc[nt][mt]);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) af[mt] = afn[mt];
         }
@@ -281,10 +285,10 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
             for (int i4 = 0; i4 < 4; ++i4)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    bf16x4 h;
+                    op4 h;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = (__bf16)acc[nt][mt][4 * i4 + e];
-                    *reinterpret_cast<bf16x4*>(img + img_off(nt, i4, mt)) = h;
+                    for (int e = 0; e < 4; ++e) h[e] = (op_t)acc[nt][mt][4 * i4 + e];
+                    *reinterpret_cast<op4*>(img + img_off(nt, i4, mt)) = h;
                 }
     };
 
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
     }
     asm volatile("" ::: "memory");
     // the residual tile straight into registers (needed after the loop: NOT waited for before the first MFMA), then phase B
-    bf16x4 hres[NT][MT][4];
+    op4 hres[NT][MT][4];
     auto load_hres = [&]() {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int i4 = 0; i4 < 4; ++i4)
-                    hres[nt][mt][i4] = *reinterpret_cast<const bf16x4*>(g.h + ((size_t)(NT * wave + nt) * g.rows + m) * 32 + 8 * i4 + 4 * kh);
+                    hres[nt][mt][i4] = *reinterpret_cast<const op4*>(g.h + ((size_t)(NT * wave + nt) * g.rows + m) * 32 + 8 * i4 + 4 * kh);
         }
     };
 #if RGN_M2_HRES == 0
@@ -439,13 +443,13 @@ __global__ __launch_bounds__(M2<MT>::NTH, 2) void k_mlp2(MlpArgs g) {
 
     // =============== stage 3: + residual h' + norm3 -> output planes =====================================================
     {
-        bf16x4 r[NT][MT][4];
+        op4 r[NT][MT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int i4 = 0; i4 < 4; ++i4) r[nt][mt][i4] = *reinterpret_cast<const bf16x4*>(smem + C::Y + img_off(nt, i4, mt));
+                for (int i4 = 0; i4 < 4; ++i4) r[nt][mt][i4] = *reinterpret_cast<const op4*>(smem + C::Y + img_off(nt, i4, mt));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -488,10 +492,13 @@ bool mlp2_supported(int rows, int d, int ff, int Tq) {
 }
 hipError_t configure_mlp2() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, M2<1>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp2<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, M2<2>::LDS);
     return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, M2<2>::LDS);
 }
 hipError_t launch_mlp2(int rows, const MlpArgs& g, hipStream_t s) {
+    if (g.f16 && rows != 64) return hipErrorInvalidValue;         // (fp16 operands: the 64-row form only)
     if (rows == 32) hipLaunchKernelGGL(k_mlp2<1>, dim3((g.M + 31) / 32), dim3(M2<1>::NTH), M2<1>::LDS, s, g);
+    else if (g.f16) hipLaunchKernelGGL((k_mlp2<2, true>), dim3((g.M + 63) / 64), dim3(M2<2>::NTH), M2<2>::LDS, s, g);
     else hipLaunchKernelGGL(k_mlp2<2>, dim3((g.M + 63) / 64), dim3(M2<2>::NTH), M2<2>::LDS, s, g);
     return hipGetLastError();
 }
@@ -505,7 +512,7 @@ hipError_t launch_mlp(const MlpArgs& g, hipStream_t s) {
         const char* e = getenv("REGENNET_MLP_ROWS");
         return e && atoi(e) == 32 ? 32 : 64;
     }();
-    return launch_mlp2(rows == 32 && mlp2_supported(32, 512, 1024, g.Tq) ? 32 : 64, g, s);
+    return launch_mlp2(rows == 32 && !g.f16 && mlp2_supported(32, 512, 1024, g.Tq) ? 32 : 64, g, s);
 }
 
 }  // namespace rgn

@@ -52,7 +52,12 @@ void ql_prof_read(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_
 #define RGN_LT(i)
 #endif
 
+template <bool F16>
 __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const __bf16* __restrict__ Wfr) {
+    using OP = OpFmt<F16>;                // bf16 or fp16 operands (rgn_internal.h): input plane, weight plane, q / k / v slabs, p, output plane
+    using op_t = typename OP::t;
+    using op8 = typename OP::v8;
+    using op4 = typename OP::v4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
     for (int t = 0; t < QL_TT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    bf16x8 wf[QL_RING][2];
+    op8 wf[QL_RING][2];
     u32x4 areg[QL_ARING];
     auto issue_a = [&](int kt) {
         areg[kt % QL_ARING] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_voff, kt * a_kbytes, 0));
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
     auto issue_w = [&](int kt) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            wf[kt % QL_RING][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_voff, (kt * nb_all * 1024 + ks * 512) * 2, 0));
+            wf[kt % QL_RING][ks] = __builtin_bit_cast(op8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_voff, (kt * nb_all * 1024 + ks * 512) * 2, 0));
     };
     char* abuf = smem + QL_A;
 #pragma unroll
@@ -121,8 +126,8 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int t = 0; t < QL_TT; ++t) {
-                const bf16x8 af = *reinterpret_cast<const bf16x8*>(sb + a_off[t][ks]);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kt % QL_RING][ks], af, acc[t], 0, 0, 0);   // transposed: lane = token, registers = columns
+                const op8 af = *reinterpret_cast<const op8*>(sb + a_off[t][ks]);
+                acc[t] = OP::mfma(wf[kt % QL_RING][ks], af, acc[t]);   // transposed: lane = token, registers = columns
             }
         if (kt + 1 < QL_NK) *reinterpret_cast<u32x4*>(abuf + ((kt + 1) & 1) * QL_ASTAGE + tid * 16) = areg[(kt + 1) % QL_ARING];
         __builtin_amdgcn_sched_barrier(0);
@@ -130,9 +135,9 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
 
     RGN_LT(1)
     // ---- accumulators -> the attention slabs (bf16) ---------------------------------------------------------------------
-    __bf16* sQ = reinterpret_cast<__bf16*>(smem + QL_Q);
-    __bf16* sK = reinterpret_cast<__bf16*>(smem + QL_K);
-    __bf16* sV = reinterpret_cast<__bf16*>(smem + QL_V);
+    op_t* sQ = reinterpret_cast<op_t*>(smem + QL_Q);
+    op_t* sK = reinterpret_cast<op_t*>(smem + QL_K);
+    op_t* sV = reinterpret_cast<op_t*>(smem + QL_V);
     // (q is stored UNSCALED: 1 / sqrt(dh) goes into the softmax's exponent, one FMA where the subtraction was. k is stored WITHOUT its bias:
     //  q . (k + b_k) = q . k + q . b_k adds the same number to every score of a query's row, which the softmax removes - exact in real arithmetic)
     if (which == 0) {
@@ -141,10 +146,10 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
             const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_s + wn * 32 + 8 * i4 + 4 * kh);
 #pragma unroll
             for (int t = 0; t < QL_TT; ++t) {
-                bf16x4 h;
+                op4 h;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (__bf16)(acc[t][4 * i4 + e] + bq[e]);
-                *reinterpret_cast<bf16x4*>(sQ + (t * 32 + l31) * QL_KLD + wn * 32 + 8 * i4 + 4 * kh) = h;
+                for (int e = 0; e < 4; ++e) h[e] = (op_t)(acc[t][4 * i4 + e] + bq[e]);
+                *reinterpret_cast<op4*>(sQ + (t * 32 + l31) * QL_KLD + wn * 32 + 8 * i4 + 4 * kh) = h;
             }
         }
     } else if (which == 1) {
@@ -152,10 +157,10 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
         for (int i4 = 0; i4 < 4; ++i4)
 #pragma unroll
             for (int t = 0; t < QL_TT; ++t) {
-                bf16x4 h;
+                op4 h;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = (__bf16)acc[t][4 * i4 + e];
-                *reinterpret_cast<bf16x4*>(sK + (t * 32 + l31) * QL_KLD + wn * 32 + 8 * i4 + 4 * kh) = h;
+                for (int e = 0; e < 4; ++e) h[e] = (op_t)acc[t][4 * i4 + e];
+                *reinterpret_cast<op4*>(sK + (t * 32 + l31) * QL_KLD + wn * 32 + 8 * i4 + 4 * kh) = h;
             }
     } else {   // v -> V^T[dh][token]: 2-byte writes, a wave's 32 lanes (consecutive tokens) fill one 64-byte run
 #pragma unroll
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
 #pragma unroll
             for (int t = 0; t < QL_TT; ++t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sV[(wn * 32 + 8 * i4 + 4 * kh + e) * QL_VLD + t * 32 + l31] = (__bf16)(acc[t][4 * i4 + e] + bv[e]);
+                for (int e = 0; e < 4; ++e) sV[(wn * 32 + 8 * i4 + 4 * kh + e) * QL_VLD + t * 32 + l31] = (op_t)(acc[t][4 * i4 + e] + bv[e]);
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -192,9 +197,9 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
     f32x16 oa[ND];
     float inv = 0.f, m_run = -INFINITY, l_run = 0.f;
     if (w < 9) {
-        bf16x8 qh[NS];
+        op8 qh[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) qh[s] = *reinterpret_cast<const bf16x8*>(sQ + qrow * QL_KLD + 16 * s + 8 * kh);
+        for (int s = 0; s < NS; ++s) qh[s] = *reinterpret_cast<const op8*>(sQ + qrow * QL_KLD + 16 * s + 8 * kh);
         // key tiles one at a time with a running maximum / sum (flash-style): one S^T tile of registers instead of five
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt)
@@ -208,8 +213,8 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
                 for (int i = 0; i < 16; ++i) st[i] = 0.f;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (32 * kj + l31) * QL_KLD + 16 * s + 8 * kh);
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qh[s], st, 0, 0, 0);
+                    const op8 kf = *reinterpret_cast<const op8*>(sK + (32 * kj + l31) * QL_KLD + 16 * s + 8 * kh);
+                    st = OP::mfma(kf, qh[s], st);
                 }
                 // key = 32 kj + (i&3) + 8 (i>>2) + 4 kh, query = qrow (a unit's first key tile holds a valid key for every real
                 // query - key 0, or the keys below the query's own tile, or the diagonal - so the maximum is finite)
@@ -239,9 +244,9 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
                     for (int i = 0; i < 16; ++i) oa[dt][i] *= alpha;
 #pragma unroll
                 for (int step = 0; step < 2; ++step) {
-                    bf16x8 ph;     // B operand: this lane's 8 keys = registers 8*step .. 8*step+7
+                    op8 ph;     // B operand: this lane's 8 keys = registers 8*step .. 8*step+7
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) ph[j] = (__bf16)st[8 * step + j];
+                    for (int j = 0; j < 8; ++j) ph[j] = (op_t)st[8 * step + j];
                     const int kb = 32 * kj + 16 * step + 4 * kh;      // keys kb..kb+3 and kb+8..kb+11
 #pragma unroll
                     for (int dt = 0; dt < ND; ++dt) {
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
                         u32x4 vh;
                         vh.lo = *reinterpret_cast<const u32x2*>(sV + o);
                         vh.hi = *reinterpret_cast<const u32x2*>(sV + o + 8);
-                        oa[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vh), ph, oa[dt], 0, 0, 0);
+                        oa[dt] = OP::mfma(__builtin_bit_cast(op8, vh), ph, oa[dt]);
                     }
                 }
             }
@@ -324,9 +329,9 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(&patch[r * QL_OLD + c + 4]);
                 const int col = hd * QL_DH + c;
                 const size_t o = ((size_t)(col >> 5) * g.out.rows + row0 + q) * 32 + (col & 31);
-                bf16x8 h;
+                op8 h;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v0[e]; h[4 + e] = (__bf16)v1[e]; }
+                for (int e = 0; e < 4; ++e) { h[e] = (op_t)v0[e]; h[4 + e] = (op_t)v1[e]; }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), o_rs, (int)(o * 2), 0, 16);
             }
         }
@@ -336,11 +341,13 @@ __global__ __launch_bounds__(QL_NT, 1) void k_qkv_attn_long(QkvAttnArgs g, const
 
 bool qkv_attn_long_supported(int Tq, int dh, int d) { return Tq > 64 && Tq <= QL_TQP && dh == QL_DH && d == 32 * QL_NK; }
 hipError_t configure_qkv_attn_long() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_long), hipFuncAttributeMaxDynamicSharedMemorySize, QL_LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_long<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QL_LDS);
+    return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_long<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QL_LDS);
 }
 hipError_t launch_qkv_attn_long(const QkvAttnArgs& g, hipStream_t s) {
     if (!g.Wfr || g.Kp != 32 * QL_NK || g.out.lo || (size_t)g.a_rows * g.Kp * 2 >= (1ull << 31)) return hipErrorInvalidValue;   // (32-bit buffer offsets)
-    hipLaunchKernelGGL(k_qkv_attn_long, dim3(g.Bm * g.H), dim3(QL_NT), QL_LDS, s, g, g.Wfr);
+    if (g.f16) hipLaunchKernelGGL(k_qkv_attn_long<true>, dim3(g.Bm * g.H), dim3(QL_NT), QL_LDS, s, g, g.Wfr);
+    else hipLaunchKernelGGL(k_qkv_attn_long<false>, dim3(g.Bm * g.H), dim3(QL_NT), QL_LDS, s, g, g.Wfr);
     return hipGetLastError();
 }
 

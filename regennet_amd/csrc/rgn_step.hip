@@ -59,8 +59,12 @@ constexpr int ST_LDS = ST_XIMG + 11 * 4096;
 static_assert(ST_BM * ST_XLD * 4 <= ST_XIMG && 16 * 4096 <= ST_XIMG && 2 * 65536 <= ST_LDS, "tile / images (guided: two 64 KiB input images)");
 }  // namespace
 
-template <int NKX, bool GUIDED>
+template <int NKX, bool GUIDED, bool F16 = false>
 __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
+    using OP = OpFmt<F16>;                // bf16 or fp16 operands (rgn_internal.h): h planes in and out, Wout / Wx, the x' image, c0
+    using op_t = typename OP::t;
+    using op8 = typename OP::v8;
+    using op4 = typename OP::v4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) a_off[mt][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
     }
-    bf16x8 wf[ST_PF + 1][2][2];
+    op8 wf[ST_PF + 1][2][2];
     const unsigned lane8 = (unsigned)lane * 8u;
     auto load_w = [&](const __bf16* W, int nb_all, int cb0, int kt, int slot) {
 #pragma unroll
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
             const int cb = cb0 + nt < nb_all ? cb0 + nt : nb_all - 1;
             const __bf16* base = W + ((size_t)kt * nb_all + cb) * 1024;   // wave-uniform: scalar base + the lane's 32-bit offset
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) wf[slot][ks][nt] = *reinterpret_cast<const bf16x8*>(base + ks * 512 + lane8);
+            for (int ks = 0; ks < 2; ++ks) wf[slot][ks][nt] = *reinterpret_cast<const op8*>(base + ks * 512 + lane8);
         }
     };
     auto prefetch = [&](const __bf16* W, int nb_all, int cb0) {
@@ -112,11 +116,11 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
 #pragma unroll
         for (int kt = 0; kt < NK; ++kt) {
             const char* sb = img + kt * 4096;
-            bf16x8 af[2][2];
+            op8 af[2][2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) af[ks][mt] = *reinterpret_cast<const bf16x8*>(sb + a_off[mt][ks]);
+                for (int mt = 0; mt < 2; ++mt) af[ks][mt] = *reinterpret_cast<const op8*>(sb + a_off[mt][ks]);
             asm volatile("" ::: "memory");
             if (kt + ST_PF < NK) {
                 load_w(W, nb_all, cb0, kt + ST_PF, (kt + ST_PF) & 3);
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kt & 3][ks][nt], af[ks][mt], acc[nt][mt], 0, 0, 0);
+                        acc[nt][mt] = OP::mfma(wf[kt & 3][ks][nt], af[ks][mt], acc[nt][mt]);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -162,13 +166,13 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
 #pragma unroll
         for (int kt = 0; kt < 16; ++kt) {
             const char* sb = smem + kt * 4096;
-            bf16x8 afc[2][2], afu[2][2];
+            op8 afc[2][2], afu[2][2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    afc[ks][mt] = *reinterpret_cast<const bf16x8*>(sb + a_off[mt][ks]);
-                    afu[ks][mt] = *reinterpret_cast<const bf16x8*>(sb + 65536 + a_off[mt][ks]);
+                    afc[ks][mt] = *reinterpret_cast<const op8*>(sb + a_off[mt][ks]);
+                    afu[ks][mt] = *reinterpret_cast<const op8*>(sb + 65536 + a_off[mt][ks]);
                 }
             asm volatile("" ::: "memory");
             if (kt + ST_PF < 16) {
@@ -181,8 +185,8 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kt & 3][ks][nt], afc[ks][mt], acc[nt][mt], 0, 0, 0);
-                        accu[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kt & 3][ks][nt], afu[ks][mt], accu[nt][mt], 0, 0, 0);
+                        acc[nt][mt] = OP::mfma(wf[kt & 3][ks][nt], afc[ks][mt], acc[nt][mt]);
+                        accu[nt][mt] = OP::mfma(wf[kt & 3][ks][nt], afu[ks][mt], accu[nt][mt]);
                     }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
             }
             // x' (0 in the K padding columns and the surplus rows) -> the K32-blocked image of GEMM 2's A operand
             const int r = lane, chunk = (f & 31) >> 3;
-            *reinterpret_cast<__bf16*>(ximg + (f >> 5) * 4096 + r * 64 + ((chunk ^ ((r >> 2) & 3)) << 4) + (f & 7) * 2) = (__bf16)nv;
+            *reinterpret_cast<op_t*>(ximg + (f >> 5) * 4096 + r * 64 + ((chunk ^ ((r >> 2) & 3)) << 4) + (f & 7) * 2) = (op_t)nv;
         };
         st_static_for<NKX>([&](auto IT) __attribute__((always_inline)) {   // groups of 4 features
             constexpr int it = decltype(IT)::value;
@@ -315,14 +319,14 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
 
     // ---- D: h' = x' . Wx'^T (+ c0 in the copy-out). The condition rows of the copy-out are requested NOW, ahead of the GEMM
     //      (in the copy-out loop each piece waited for its own two loads)
-    bf16x8 c0v[8];
+    op8 c0v[8];
     {
         const int r16 = lane >> 2, c = lane & 3;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int p = wave * 8 + j, blk = p >> 2, r = (p & 3) * 16 + r16;
             const int m = m0 + r < g.M ? m0 + r : g.M - 1;
-            c0v[j] = *reinterpret_cast<const bf16x8*>(g.c0 + (size_t)m * 512 + blk * 32 + c * 8);
+            c0v[j] = *reinterpret_cast<const op8*>(g.c0 + (size_t)m * 512 + blk * 32 + c * 8);
         }
     }
     asm volatile("" ::: "memory");
@@ -342,10 +346,10 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int r = 32 * mt + l31;
-                bf16x4 hv;
+                op4 hv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) hv[e] = (__bf16)acc[nt][mt][4 * i4 + e];
-                *reinterpret_cast<bf16x4*>(smem + (2 * wave + nt) * 4096 + r * 64 + ((i4 ^ ((r >> 2) & 3)) << 4) + 8 * kh) = hv;
+                for (int e = 0; e < 4; ++e) hv[e] = (op_t)acc[nt][mt][4 * i4 + e];
+                *reinterpret_cast<op4*>(smem + (2 * wave + nt) * 4096 + r * 64 + ((i4 ^ ((r >> 2) & 3)) << 4) + 8 * kh) = hv;
             }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -359,17 +363,17 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
             const int p = wave * 8 + j, blk = p >> 2, r = (p & 3) * 16 + r16;
             const int m = m0 + r;
             if (m < g.M) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + blk * 4096 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
+                const op8 v = *reinterpret_cast<const op8*>(smem + blk * 4096 + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
                 const __bf16* cp = g.c0 + (size_t)m * 512 + blk * 32 + c * 8;
-                bf16x8 o;
+                op8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)v[e] + (float)c0v[j][e]);
+                for (int e = 0; e < 8; ++e) o[e] = (op_t)((float)v[e] + (float)c0v[j][e]);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), h_rs, (int)((((size_t)blk * g.rows + m) * 32 + c * 8) * 2), 0, RGN_ST_ST_AUX);
                 if constexpr (GUIDED) {   // the unconditional evaluation sees the same x', with its own condition part
-                    const bf16x8 cu = *reinterpret_cast<const bf16x8*>(cp + (size_t)g.half * 512);
-                    bf16x8 ou;
+                    const op8 cu = *reinterpret_cast<const op8*>(cp + (size_t)g.half * 512);
+                    op8 ou;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) ou[e] = (__bf16)((float)v[e] + (float)cu[e]);
+                    for (int e = 0; e < 8; ++e) ou[e] = (op_t)((float)v[e] + (float)cu[e]);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ou), h_rs, (int)((((size_t)blk * g.rows + m + g.half) * 32 + c * 8) * 2), 0, RGN_ST_ST_AUX);
                 }
             }
@@ -387,15 +391,21 @@ __global__ __launch_bounds__(ST_NT, 2) void k_step(StepArgs g) {
 bool step_fused_supported(int d, int F, int Kpx) { return d == 512 && F % 4 == 0 && F <= 352 && Kpx == 352; }
 hipError_t configure_step() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<11, false>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<11, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<11, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<11, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
 }
 hipError_t launch_step(const StepArgs& g, hipStream_t s) {
     if (g.nkx != 11 || g.M <= 0) return hipErrorInvalidValue;
-    if (g.scale)   // guided: M = token rows of the conditional half; half = row distance to the unconditional half
-        hipLaunchKernelGGL((k_step<11, true>), dim3((g.M + ST_BM - 1) / ST_BM), dim3(ST_NT), ST_LDS, s, g);
-    else
-        hipLaunchKernelGGL((k_step<11, false>), dim3((g.M + ST_BM - 1) / ST_BM), dim3(ST_NT), ST_LDS, s, g);
+    const dim3 grid((g.M + ST_BM - 1) / ST_BM);
+    if (g.scale) {   // guided: M = token rows of the conditional half; half = row distance to the unconditional half
+        if (g.f16) hipLaunchKernelGGL((k_step<11, true, true>), grid, dim3(ST_NT), ST_LDS, s, g);
+        else hipLaunchKernelGGL((k_step<11, true>), grid, dim3(ST_NT), ST_LDS, s, g);
+    } else {
+        if (g.f16) hipLaunchKernelGGL((k_step<11, false, true>), grid, dim3(ST_NT), ST_LDS, s, g);
+        else hipLaunchKernelGGL((k_step<11, false>), grid, dim3(ST_NT), ST_LDS, s, g);
+    }
     return hipGetLastError();
 }
 

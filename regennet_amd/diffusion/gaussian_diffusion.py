@@ -423,16 +423,16 @@ class GaussianDiffusion:
         return chosen
 
     def _f32_run(self, inner, run, S):
-        """The calibration motions sampled in the engine's fp32 mode. The fp32 engine is built beside the model's engine cache (own cache, no
-        weight broadcast: every rank holds the checkpoint it loaded) and closed again."""
-        saved = (inner._engines, inner._engine, inner.precision, inner.weights_src, inner._ever_synced, inner._cond_key, inner._keep)
-        inner._engines, inner._engine, inner.precision, inner.weights_src, inner._ever_synced = {}, None, "f32", None, False
+        """The calibration motions sampled in the engine's fp32 mode. The fp32 engine is built beside the model's engine cache (own cache; packed locally
+        from the module's parameters like every engine) and closed again."""
+        saved = (inner._engines, inner._engine, inner.precision, inner._cond_key, inner._keep)
+        inner._engines, inner._engine, inner.precision = {}, None, "f32"
         try:
             return run(S)
         finally:
             for e in inner._engines.values():
                 e.close()
-            inner._engines, inner._engine, inner.precision, inner.weights_src, inner._ever_synced, inner._cond_key, inner._keep = saved
+            inner._engines, inner._engine, inner.precision, inner._cond_key, inner._keep = saved
 
     @staticmethod
     def _keyed_normal(eng, shape, seed, sample_offset, loop_index, dev):

@@ -150,10 +150,8 @@ class CMDM(nn.Module):
         # dict takes effect for engines built afterwards (model._engine_stale = True rebuilds)
         self.engine_options = dict(kargs.get("engine_options", None) or {})
         self._auto_tail, self._auto_tails = None, {}
-        # multi-GPU runs: rank `weights_src`'s packed blob is broadcast (one RCCL collective) into EVERY engine this model
-        # builds — also the ones built later for another length, a larger batch or after an eviction (None: single process)
-        self.weights_src = None
-        self._ever_synced = False        # an engine of this model has taken part in the start-up broadcast
+        # (multi-GPU runs: dist_util.sync_model_weights(model) synchronises THIS module's parameters once at start-up; every engine is then packed
+        #  locally from them, so building one - now or later, on one rank alone - is never a collective)
         self._engine = None
         self._engines = {}
         self._engine_stale = True
@@ -211,23 +209,18 @@ class CMDM(nn.Module):
             for e in self._engines.values():
                 e.close()
             self._engines.clear()
-            self._engine, self._engine_stale, self._ever_synced = None, False, False
+            self._engine, self._engine_stale = None, False
         T = int(T or (self._engine.cfg["num_frames"] if self._engine is not None else self.num_frames))
         eng = self._engines.pop(T, None)
         outgoing = None
         if eng is not None and (B > eng.max_batch or eng.precision != self.precision):
             dist_util.synchronize(dev)
             B = max(B, eng.max_batch)
-            outgoing, eng = eng, None            # (kept alive until the new engine is finalized: it may be the only holder of the synchronised blob)
+            outgoing, eng = eng, None            # (closed once the new engine stands: a failed build leaves the cache as it was)
         if eng is None:
             while len(self._engines) >= self.MAX_ENGINES:
                 dist_util.synchronize(dev)
-                victim = self._engines.pop(next(iter(self._engines)))
-                if outgoing is None and getattr(victim, "_blob_synced", False):
-                    outgoing = victim
-                else:
-                    victim.close()
-            eng = None
+                self._engines.pop(next(iter(self._engines))).close()
             try:
                 eng = _lib.Engine(self.engine_config(T), B, dev.index or 0, self.precision, **({"options": self.engine_options} if self.engine_options else {}))
                 for k, v in self.state_dict().items():
@@ -236,34 +229,12 @@ class CMDM(nn.Module):
                     eng.load_weight(k, v.detach().float().cpu().numpy())
                 eng.finalize()
             except BaseException:
-                # (out of memory, a refused checkpoint ...): nothing may leak and the engine this one was to replace - possibly this rank's only
-                # holder of the synchronised weight blob - goes back into the cache
+                # (out of memory, a refused checkpoint ...): nothing may leak, and the engine this one was to replace goes back into the cache
                 if eng is not None:
                     eng.close()
                 if outgoing is not None:
-                    self._engines[int(outgoing.cfg["num_frames"])] = outgoing
+                    self._engines[T] = outgoing
                 raise
-            if self.weights_src is not None:
-                # The RCCL broadcast is a collective: it may only run where EVERY rank builds an engine - the first one (the callers
-                # build it at start-up, whatever their shard size). Engines built later by one rank alone (a new sequence length, a
-                # larger batch, an evicted length) take the already-synchronised blob of a live engine of this model instead.
-                # Donors: the engine this one replaces (larger batch of the same length: same blob layout), then any other live engine.
-                donors = ([outgoing] if outgoing is not None and getattr(outgoing, "_blob_synced", False) else []) + \
-                         [e for e in self._engines.values() if getattr(e, "_blob_synced", False)]
-                copied = any(dist_util.copy_engine_weights(dn, eng, dev) for dn in donors)
-                if not copied:
-                    if self._ever_synced:
-                        # a lone broadcast would be a one-rank collective (the other ranks are not here): never issue it
-                        if outgoing is not None:
-                            outgoing.close()
-                        eng.close()
-                        raise RuntimeError("regennet_amd: this rank needs a new engine after start-up and holds no engine with the synchronised weight "
-                                           "blob to copy from (a blob's layout depends on the precision mode and the engine options: an engine rebuilt because "
-                                           "model.precision changed cannot take the old one's) - build every engine the run needs at start-up, where all ranks "
-                                           "take part in the RCCL broadcast (model._get_engine(B, T) on every rank)")
-                    dist_util.broadcast_engine_weights(eng, dev, int(self.weights_src))
-                eng._blob_synced = True
-                self._ever_synced = True
             if outgoing is not None:
                 outgoing.close()
         self._engines[T] = eng                                # (re)inserted last = most recently used

@@ -34,8 +34,8 @@ def _load_clips(args, cfg, n):
 def main(argv=None):
     """Single process: one GPU samples `num_samples` motions per repetition. Under torchrun
     (`python -m torch.distributed.run --nproc-per-node N -m regennet_amd.sample.cgenerate ...`): the `num_samples` of every
-    repetition are sharded over the N ranks (contiguous shards, `dist_util.shard_bounds`), rank 0's packed weights are
-    broadcast once over RCCL, every rank samples its shard with the Philox stream keyed by the GLOBAL sample index (so the
+    repetition are sharded over the N ranks (contiguous shards, `dist_util.shard_bounds`), rank 0's checkpoint is
+    broadcast once over RCCL (`dist_util.sync_model_weights`: one flat fp32 buffer), every rank samples its shard with the Philox stream keyed by the GLOBAL sample index (so the
     result does not depend on N), and rank 0 gathers and saves. No collective inside the sampling loop."""
     args = cgenerate_args(argv)
     fixseed(args.seed)
@@ -53,7 +53,7 @@ def main(argv=None):
     model, diffusion = create_model_and_diffusion(args, data)
     model.precision = args.precision
     if args.synthetic or not args.model_path:
-        # rank 0 owns "the checkpoint"; other ranks start from different values and receive rank 0's packed blob
+        # rank 0 owns "the checkpoint"; other ranks start from different values and receive rank 0's through the start-up broadcast
         sd = {k: torch.from_numpy(v) for k, v in
               synth.make_state_dict(model.engine_config() | {"layers": model.num_layers}, seed=0 if rank == 0 else 1000 + rank).items()}
     else:
@@ -65,6 +65,7 @@ def main(argv=None):
         model = ClassifierFreeSampleModel(model)
     model.to(dev)
     model.eval()
+    dist_util.sync_model_weights(model, 0)                  # THE collective of the run's start-up (none in a single process)
     clips, actions = _load_clips(args, cfg, args.num_samples)
     assert clips.shape[1:3] == (cfg["njoints"], cfg["nfeats"]) and clips.shape[3] >= n_frames, \
         f"actor clips {clips.shape} do not cover [N, {cfg['njoints']}, {cfg['nfeats']}, {n_frames}]"
@@ -74,7 +75,6 @@ def main(argv=None):
     Bl = hi - lo
     sample_fn = diffusion.p_sample_loop if not args.use_ddim else diffusion.ddim_sample_loop
     inner = model.model if isinstance(model, ClassifierFreeSampleModel) else model
-    inner.weights_src = 0 if world > 1 else None            # rank 0's packed blob -> every engine this model builds (one RCCL broadcast each)
     eng, _ = inner._get_engine(max(Bl, 1), n_frames)
     all_outputs, all_cmotions, time_all = [], [], 0.0
     shape = (Bl, inner.njoints, inner.nfeats, n_frames)

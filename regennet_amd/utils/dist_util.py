@@ -3,8 +3,9 @@
 The reference rendezvouses over mpi4py and pins 4 GPUs per node (dist_util.py:15-42). Here one process
 drives one GPU (8 per node), rendezvous comes from torchrun's environment, and the backend is
 `nccl` (= RCCL on ROCm, xGMI inside a node) or `gloo` on CPU-only hosts. Sampling shards only the
-batch axis: the single collective is ONE broadcast of the flat packed-weight buffer (replacing the
-per-tensor `sync_params`, dist_util.py:77-83) plus an optional all_gather of the outputs.
+batch axis: the single start-up collective is ONE broadcast of the module's parameters and buffers as a
+flat fp32 buffer (`sync_model_weights`, replacing the per-tensor `sync_params`, dist_util.py:77-83) plus an
+optional all_gather of the outputs; every rank then packs its engines from the synchronised module locally.
 """
 import os
 
@@ -90,35 +91,32 @@ def synchronize(device=None):
         torch.cuda.synchronize(device)
 
 
-def broadcast_engine_weights(engine, device, src=0):
-    """Start-up collective of a multi-GPU run: rank `src`'s packed weight blob (rgn_weight_blob: ONE flat device buffer)
-    is broadcast into every rank's blob over RCCL / xGMI — replaces the per-tensor `sync_params` of the reference
-    (utils/dist_util.py:77-83). Callers must re-derive everything computed FROM the weights afterwards (the per-schedule
-    tables: `engine.schedule_id = None`; the hoisted condition is rebound by every sampling call anyway)."""
+def sync_model_weights(model, src=0):
+    """THE start-up collective of a multi-GPU run: rank `src`'s checkpoint - every parameter and buffer of the module, flattened into one fp32
+    buffer on the device (115 MB for the shipped 8-layer model) - is broadcast over RCCL / xGMI and written back into every rank's module
+    (replaces the per-tensor `sync_params` of the reference, utils/dist_util.py:77-83; only rank `src` needs to have read the checkpoint file).
+    Every engine a rank builds afterwards - at start-up, or later and alone for another sequence length or a larger batch - packs its own blob
+    from the synchronised module (0.4 s of one host core), so nothing downstream of this call is a collective and no rank ever depends on another
+    rank having built the same engine. Rounds 1-5 broadcast the PACKED blob of one engine instead (fp32 + three 16-bit layouts: 204 MB, now 237)
+    and had to hand it from engine to engine on every rebuild. Returns the bytes broadcast (0 in a single process)."""
     if not collectives_active():
-        return
-    ptr, nbytes = engine.weight_blob()
-    view = ptr if torch.is_tensor(ptr) else device_view(ptr, nbytes, device)   # (a stub engine hands over a tensor)
-    synchronize(device)
-    dist.broadcast(view, src)
-    synchronize(device)
-    engine.schedule_id = None
-
-
-def copy_engine_weights(src_engine, dst_engine, device):
-    """Device-to-device copy of one engine's packed weight blob into another engine of the SAME model (same blob layout): what a
-    rank does for engines it builds alone after the start-up broadcast (no collective). False if the layouts differ."""
-    sp, sn = src_engine.weight_blob()
-    dp, dn = dst_engine.weight_blob()
-    if int(sn) != int(dn):
-        return False
-    sv = sp if torch.is_tensor(sp) else device_view(sp, sn, device)
-    dv = dp if torch.is_tensor(dp) else device_view(dp, dn, device)
-    synchronize(device)
-    dv.copy_(sv)
-    synchronize(device)
-    dst_engine.schedule_id = None
-    return True
+        return 0
+    inner = getattr(model, "model", model)                     # (a ClassifierFreeSampleModel wraps the module that owns the weights)
+    seen, tensors = set(), []
+    for t in inner.state_dict(keep_vars=True).values():       # parameters and buffers, deterministic order; shared storage (the two `pe` keys) once
+        if t.data_ptr() not in seen:
+            seen.add(t.data_ptr())
+            tensors.append(t)
+    flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
+    dist.broadcast(flat, src)
+    off = 0
+    with torch.no_grad():
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+    inner._engine_stale = True                                  # engines packed from the old values are obsolete
+    return flat.numel() * 4
 
 
 def sync_params(params):

@@ -157,7 +157,7 @@ def _cgen_worker(rank, world, port, out_dir):
 
 def test_cgenerate_entry_point_shards_broadcasts_and_gathers(tmp_path, monkeypatch):
     """`torchrun -m regennet_amd.sample.cgenerate` control flow on 2 gloo ranks: contiguous shards of num_samples, rank 0's
-    weight blob broadcast (rank 1 starts from a different checkpoint), per-rank sampling keyed by the global sample index,
+    checkpoint broadcast (rank 1 starts from a different one), per-rank sampling keyed by the global sample index,
     gather + save on rank 0 — and the saved result equals the single-process run (world-size invariance)."""
     from regennet_amd import _lib
     from regennet_amd.sample import cgenerate
@@ -195,31 +195,70 @@ def test_cgenerate_with_an_empty_shard_does_not_hang_in_the_calibration(tmp_path
     assert two["output"].shape == (2, 56, 6, 40) and two["world_size"] == 2
 
 
-def test_a_rebuilt_engine_takes_the_blob_of_the_engine_it_replaces(monkeypatch):
-    """Multi-rank run, ONE cached length (the normal cgenerate case), a larger batch arrives on this rank alone: the engine being replaced is
-    the only holder of the synchronised blob, so it must stay alive as the donor until the new engine is finalized - and where no donor is
-    left the model raises instead of issuing a one-rank broadcast (which would hang)."""
+def _sync_worker(rank, world, port):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from regennet_amd import _lib, synth
-    from regennet_amd.utils import dist_util as du
+    from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    _lib.Engine = FakeEngine
+    dev = dist_util.setup_dist()
+    cfg = synth.get_config("tiny")
+    model, _ = synth.build_model(cfg, synth.make_state_dict(cfg, seed=0 if rank == 0 else 77), precision="bf16_x3tail", device="cpu")
+    stale, _d = model._get_engine(2)                             # an engine packed BEFORE the synchronisation (from this rank's own values)
+    n_coll = []
+    real = dist.broadcast
+    dist.broadcast = lambda *a, **k: (n_coll.append(1), real(*a, **k))[1]
+    nbytes = dist_util.sync_model_weights(ClassifierFreeSampleModel(model), 0)   # (through the guidance wrapper: the inner module owns the weights)
+    ref = synth.make_state_dict(cfg, seed=0)
+    assert len(n_coll) == 1 and nbytes == 4 * sum(v.size for k, v in ref.items() if k != "sequence_pos_encoder.pe")   # ONE collective, `pe` once
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, torch.from_numpy(ref[k])), k       # every rank now holds rank 0's checkpoint, buffers included
+    # ... and everything a rank builds afterwards is local: a collective from here on would be a bug (the other rank is not there)
+    dist.broadcast = lambda *a, **k: (_ for _ in ()).throw(AssertionError("a collective behind the start-up synchronisation"))
+    e1, _d = model._get_engine(2)
+    assert e1 is not stale                                       # the pre-synchronisation engine was dropped
+    if rank == 1:                                                # one rank alone: a larger batch, another length
+        e2, _d = model._get_engine(5)
+        e3, _d = model._get_engine(5, T=cfg["num_frames"] - 2)
+        assert e2 is not e1 and e3 is not e2 and torch.equal(e3.blob, e1.blob)
+    dist.broadcast = real
+    blobs = [torch.zeros_like(e1.blob) for _ in range(world)]
+    dist.all_gather(blobs, e1.blob)
+    assert torch.equal(blobs[0], blobs[1])                       # the packed blobs agree across the ranks without ever having been exchanged
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_flat_broadcast_synchronises_the_module_and_every_later_engine_is_local():
+    """Multi-GPU start-up (utils/dist_util.py:54-83's counterpart): ONE collective - the module's parameters and buffers as a flat fp32 buffer
+    (dist_util.sync_model_weights) - after which every rank packs its engines locally; an engine a rank builds later and alone (larger batch,
+    another length) issues no collective and still agrees with the other ranks' engines."""
+    mp.spawn(_sync_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def test_a_failed_engine_build_leaves_the_cache_as_it_was(monkeypatch):
+    """The engine a rebuild was to replace goes back into the cache when the build throws (out of memory, a refused checkpoint), and the
+    half-built engine is closed."""
+    from regennet_amd import _lib, synth
     monkeypatch.setattr(_lib, "Engine", FakeEngine)
-    calls = []
-    monkeypatch.setattr(du, "broadcast_engine_weights", lambda eng, dev, src=0: calls.append("broadcast"))
-    real_copy = du.copy_engine_weights
-    monkeypatch.setattr(du, "copy_engine_weights", lambda a, b, dev: (calls.append("copy"), real_copy(a, b, dev))[1])
-    monkeypatch.setattr(du, "synchronize", lambda device=None: None)
     cfg = synth.get_config("tiny")
     model, _ = synth.build_model(cfg, synth.make_state_dict(cfg, seed=0), precision="bf16_x3tail", device="cpu")
-    model.weights_src = 0
     e1, _dev = model._get_engine(2)
-    assert calls == ["broadcast"] and e1._blob_synced
-    e2, _dev = model._get_engine(5)                             # larger batch, same length: rebuild
-    assert e2 is not e1 and calls == ["broadcast", "copy"] and e2._blob_synced and e2.max_batch == 5
-    e3, _dev = model._get_engine(5, T=cfg["num_frames"] - 2)    # another length: copies from the live engine
-    assert calls == ["broadcast", "copy", "copy"] and e3._blob_synced
-    monkeypatch.setattr(du, "copy_engine_weights", lambda a, b, dev: False)
-    with pytest.raises(RuntimeError, match="start-up"):
+    closed = []
+
+    class Refusing(FakeEngine):
+        def finalize(self):
+            raise RuntimeError("refused (test)")
+
+        def close(self):
+            closed.append(self)
+
+    monkeypatch.setattr(_lib, "Engine", Refusing)
+    with pytest.raises(RuntimeError, match="refused"):
         model._get_engine(9)
-    assert calls == ["broadcast", "copy", "copy"]               # no lone collective was issued
+    assert len(closed) == 1 and model._engines[cfg["num_frames"]] is e1
+    monkeypatch.setattr(_lib, "Engine", FakeEngine)
+    e2, _dev = model._get_engine(2)
+    assert e2 is e1
 
 
 def test_model_knobs_reach_the_engine(monkeypatch):
@@ -253,8 +292,8 @@ def _run_bench(extra_env, *flags):
 
 def test_bench_gpus_2_starts_two_ranks_by_itself():
     """`python bench.py --gpus 2` with no torchrun environment re-launches itself as 2 ranks (gloo here, the engine stubbed at
-    the _lib.Engine seam) and reports the line for 2 ranks; the weight blob of rank 0 reaches rank 1 through the model's
-    per-engine broadcast."""
+    the _lib.Engine seam) and reports the line for 2 ranks; rank 0's checkpoint reaches rank 1 through the start-up
+    broadcast (dist_util.sync_model_weights)."""
     rc, line, log = _run_bench({}, "--gpus", "2")
     assert rc == 0 and line is not None, log
     assert line["n_gpus"] == 2 and line["rccl_world_size"] == 2 and line["backend"] == "gloo", line

@@ -860,6 +860,95 @@ def test_text150_full_size_shard_is_row_independent():
         assert torch.allclose(full[b:b + 1], one, atol=2e-5), (b, (full[b:b + 1] - one).abs().max().item())
 
 
+def _redraw_tape(eng, shape, seed, S, idx):
+    """x_T and the S per-step draws of the fused loop's own Philox stream (rgn_randn_step), motions `idx`: the oracle's noise tape."""
+    st = torch.cuda.current_stream().cuda_stream
+    buf = torch.empty(shape, device="cuda")
+    tape = np.empty((S + 1, len(idx)) + tuple(shape[1:]), dtype=np.float32)
+    for k, loop_index in enumerate([-1] + list(range(S - 1, -1, -1))):     # draw order: x_T, then loop indices S-1 .. 0
+        eng.randn_step(buf, shape[0], seed, 0, loop_index, st)
+        tape[k] = buf[idx].cpu().numpy()
+    return tape
+
+
+def test_chi3d_full_size_shard_against_the_oracle_on_a_100_step_schedule():
+    """BASELINE configs[3]'s per-GPU shard at its real size - Chi3D, 150 frames, B = 128: 300 row tiles in four kernel chains of k_qkv_attn_long +
+    k_mlp2 + k_step per step - on a 100-step DDPM schedule (95 plain-bf16 + 5 split-bf16 steps), default engine, on-device Philox; every 16th motion
+    against the ORACLE on the very noise the kernels drew (re-drawn through rgn_randn_step). Bound: north_star's 1e-3.
+    Reference: utils/model_util.py:61-64 (num_frames = 150), diffusion/gaussian_diffusion.py:610-742."""
+    from oracle import regennet_oracle as orc
+    from regennet_amd import synth
+    cfg = synth.get_config("chi3d")
+    sd = synth.make_state_dict(cfg, seed=0)
+    B, S, seed = 128, 100, 79
+    y = {"cmotion": synth.make_cmotion(cfg, B, seed=71), "action": synth.make_actions(cfg, B, seed=72)}
+    model, diffusion = synth.build_model(cfg, sd, resp=str(S), precision="bf16_x3tail", device="cuda:0")
+    shape = (B, 56, 6, 150)
+    out = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": y_to_device(y)}, seed=seed, sample_offset=0)
+    assert torch.isfinite(out).all()
+    plan = model._engine.plan_query(B)
+    assert plan["qkv_attn"]["kernel"] == "k_qkv_attn_long" and plan["mlp"]["kernel"] == "k_mlp2" and "step_fused" in plan, plan
+    idx = np.arange(0, B, 16)
+    tape = _redraw_tape(model._engine, shape, seed, S, idx)
+    ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", str(S)), tape,
+                          {k: torch.from_numpy(np.ascontiguousarray(v[idx])) for k, v in y.items()}, mode="ddpm").numpy()
+    err = float(np.abs(out.cpu().numpy()[idx] - ref).max())
+    print(f"\n[cfg4 shard: chi3d B = 128, 150 frames, 95 + 5 steps, on-device Philox] every 16th motion vs oracle: {err:.2e}")
+    assert err < 1e-3, err
+    model._engine.close()
+
+
+def test_text150_full_size_shard_against_the_oracle_on_its_own_schedule():
+    """BASELINE configs[4]'s per-GPU shard EXACTLY: text-conditioned, 150 frames, B = 256, `ddim50` + guidance 2.5 (512 evaluations per step: 1200
+    row tiles; 45 plain-bf16 steps through k_qkv_attn_long + k_mlp2 + the guided k_step, 5 split-bf16 steps), default engine, on-device Philox;
+    every 16th motion against the ORACLE (cfg_forward, model/cfg_sampler.py:24-31) on the noise the kernels drew. Bound: 1e-3."""
+    from oracle import regennet_oracle as orc
+    from regennet_amd import synth
+    from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    cfg = synth.get_config("text150")
+    sd = synth.make_state_dict(cfg, seed=0)
+    B, S, seed = 256, 50, 83
+    y = {"cmotion": synth.make_cmotion(cfg, B, seed=71), "text_features": synth.make_text_features(cfg, B, seed=73), "scale": np.full((B,), 2.5, np.float32)}
+    model, diffusion = synth.build_model(cfg, sd, resp="ddim50", precision="bf16_x3tail", device="cuda:0")
+    shape = (B, 56, 6, 150)
+    out = diffusion.ddim_sample_loop(ClassifierFreeSampleModel(model), shape, clip_denoised=False, model_kwargs={"y": y_to_device(y)}, seed=seed, sample_offset=0)
+    assert torch.isfinite(out).all() and diffusion.num_timesteps == S
+    plan = model._engine.plan_query(B, guided=True)
+    assert plan["qkv_attn"]["kernel"] == "k_qkv_attn_long" and plan["step_fused"]["kernel"] == "k_step<guided>", plan
+    idx = np.arange(0, B, 16)
+    tape = _redraw_tape(model._engine, shape, seed, S, idx)
+    ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", "ddim50"), tape,
+                          {k: torch.from_numpy(np.ascontiguousarray(v[idx])) for k, v in y.items()}, mode="ddim", guided=True).numpy()
+    err = float(np.abs(out.cpu().numpy()[idx] - ref).max())
+    print(f"\n[cfg5 shard: text150 B = 256 + CFG, ddim50, on-device Philox] every 16th motion vs oracle: {err:.2e}")
+    assert err < 1e-3, err
+    model._engine.close()
+
+
+def test_chi3d_1000_step_launch_sequence_rows_equal_single_motion_runs():
+    """BASELINE configs[3]'s per-GPU call EXACTLY as bench.py issues it: Chi3D B = 128, the full 1000-step DDPM loop (99 ten-step graphs + 5 single
+    steps of the plain-bf16 phase in four chains, then the split-bf16 tail), on-device Philox. Rows {0, 31, 32, 127} against B = 1 runs of the same
+    kernels (throughput engine) with the motion's global Philox key - what bench.py's row check does on builder-run lines, inside the suite."""
+    from regennet_amd import synth
+    cfg = synth.get_config("chi3d")
+    sd = synth.make_state_dict(cfg, seed=0)
+    B = 128
+    y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1)).cuda(), "action": torch.from_numpy(synth.make_actions(cfg, B, seed=2)).cuda()}
+    model, diffusion = synth.build_model(cfg, sd, resp="", precision="bf16_x3tail", device="cuda:0")
+    full = diffusion.p_sample_loop(model, (B, 56, 6, 150), clip_denoised=False, model_kwargs={"y": y}, seed=100, sample_offset=0)
+    assert torch.isfinite(full).all() and diffusion.num_timesteps == 1000
+    model._engine.close()
+    model1, diffusion1 = build_hip(cfg, sd, resp="", precision="bf16_x3tail/throughput")
+    worst = 0.0
+    for b in (0, 31, 32, 127):
+        yb = {k: v[b:b + 1].contiguous() for k, v in y.items()}
+        one = diffusion1.p_sample_loop(model1, (1, 56, 6, 150), clip_denoised=False, model_kwargs={"y": yb}, seed=100, sample_offset=b)
+        worst = max(worst, (full[b:b + 1] - one).abs().max().item())
+    print(f"\n[cfg4 launch sequence, B = 128 x 1000 steps] rows (0, 31, 32, 127) vs single-motion runs: max |dev| = {worst:.1e}")
+    assert worst <= 2e-5, worst
+    model1._engine.close()
+
+
 @pytest.mark.parametrize("case", range(20))
 def test_fuzz_parity_case(case):
     """20 seeded cases of the randomised sweep (tests/fuzz_cases.py; `tools/fuzz_parity.py` runs any number): odd batch sizes,
@@ -1189,9 +1278,9 @@ def test_long_sequence_attention_units_against_the_unfused_path(T):
 
 def test_rccl_one_rank_group_takes_the_multi_gpu_code_paths():
     """utils/dist_util.py:20-83's counterpart on the pool's hardware, every round: a ONE-rank RCCL group (two ranks cannot share a GPU) in a
-    subprocess - backend init with the environment bench.py gives its ranks, the broadcast of the engine's packed weight blob through the
-    zero-copy view (rgn_weight_blob), the MAX all-reduce of the calibration agreement, a gather - and `bench.py --force-dist` end to end:
-    process-group init, blob broadcast into the engine, barriers around the timed region, MAX all-reduce of the time."""
+    subprocess - backend init with the environment bench.py gives its ranks, the start-up broadcast of the checkpoint as one flat fp32 buffer
+    (dist_util.sync_model_weights), the MAX all-reduce of the calibration agreement - and `bench.py --force-dist` end to end:
+    process-group init, checkpoint broadcast, local engine build, barriers around the timed region, MAX all-reduce of the time."""
     import json
     import subprocess
     import sys
@@ -1200,7 +1289,7 @@ def test_rccl_one_rank_group_takes_the_multi_gpu_code_paths():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_single_rank_check.py")], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0 and "[rccl] ok" in p.stdout and "bytes unchanged: True" in p.stdout, p.stdout + p.stderr
+    assert p.returncode == 0 and "[rccl] ok" in p.stdout and "values unchanged: True" in p.stdout, p.stdout + p.stderr
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "1", "--warmup", "1", "--respacing", "50", "--batch", "64",
                         "--no-cpu-baseline", "--profile-evals", "0"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
@@ -1209,6 +1298,7 @@ def test_rccl_one_rank_group_takes_the_multi_gpu_code_paths():
     line = json.loads(lines[-1])
     assert line["backend"] == "nccl" and line["rccl_world_size"] == 1 and line["value"] > 0, line
     assert line["headline_row_check_max_abs"] is not None and line["headline_row_check_max_abs"] <= 2e-5, line
+    assert 100e6 < line["weights_broadcast_bytes"] < 130e6, line            # the fp32 checkpoint once, not the packed blob
 
 
 def test_per_handle_kernel_switches():

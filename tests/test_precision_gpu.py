@@ -19,12 +19,13 @@ def _wrap(model, guided):
     return ClassifierFreeSampleModel(model)
 
 
-@pytest.mark.parametrize("name", ["ntu_ddpm1000", "ntu_action_ddim100_cfg", "ntu_eval_ddim5", "ntu_action_eval_ddim5"])
+@pytest.mark.parametrize("name", ["ntu_ddpm1000", "ntu_action_ddim100_cfg", "ntu_eval_ddim5", "ntu_action_eval_ddim5", "text150_ddim50_cfg", "chi3d_ddim20_cfg",
+                                  "chi3d_ddpm20"])
 def test_three_phase_precision_schedule_sweep(golden, name):
-    """Plain bf16 -> `f16_steps` plain fp16 steps -> split-bf16 tail, one-kernel decoder stack (the only form with the fp16 instantiation; forced
-    on for the goldens' B = 2), against the reference's own outputs: the engine's default plan (8 fp16 steps, 2 split-bf16 steps where the
-    stack runs the plain phase) and its neighbours keep the 3x margin; what other (f16_steps, tail) pairs cost is printed.
-    Reference: diffusion/gaussian_diffusion.py:508-560, model/cmdm.py:227."""
+    """Plain bf16 -> `f16_steps` plain fp16 steps -> split-bf16 tail, on the forms that have fp16 instantiations - the one-kernel decoder stack
+    (60 frames; forced on for the goldens' B = 2) and the kernel-per-stage chain of the 150-frame models (k_qkv_attn_long + k_mlp2 + k_step) -
+    against the reference's own outputs: the engine's default plan (8 fp16 steps, 2 split-bf16 steps) and its neighbours keep the 3x margin;
+    what other (f16_steps, tail) pairs cost is printed. Reference: diffusion/gaussian_diffusion.py:508-560, model/cmdm.py:227."""
     g = golden(name)
     cfg, sd, y, tape = fixture_inputs(g, loop=True)
     S, guided = int(g["S"]), bool(g["guided"])

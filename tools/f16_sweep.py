@@ -1,6 +1,6 @@
 """The operand-format axis of the precision schedule: error against the reference's goldens over (fp16 plain steps in front of the tail, split-bf16
-tail length). Every run forces the one-kernel decoder stack (k_layers<true>: LAYERS_MIN_B = 1, small-batch engine off) - the form with an fp16
-instantiation.      python tools/f16_sweep.py [golden ...]        (GPU box)"""
+tail length), on the forms with fp16 instantiations: the one-kernel decoder stack (k_layers<true>, forced on: LAYERS_MIN_B = 1, small-batch engine
+off) for 60 frames, k_qkv_attn_long + k_mlp2 + k_step for 150.      python tools/f16_sweep.py [golden ...]        (GPU box)"""
 import os
 import sys
 
@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests.helpers import build_hip, fixture_inputs, y_to_device  # noqa: E402
 
-NAMES = sys.argv[1:] or ["ntu_ddpm1000", "ntu_action_ddim100_cfg", "ntu_eval_ddim5", "ntu_eval_5", "ntu_action_eval_ddim5", "ntu_ddpm50"]
+NAMES = sys.argv[1:] or ["ntu_ddpm1000", "ntu_action_ddim100_cfg", "ntu_eval_ddim5", "ntu_eval_5", "ntu_action_eval_ddim5", "ntu_ddpm50", "text150_ddim50_cfg",
+                         "chi3d_ddim20_cfg", "chi3d_ddpm20"]
 TAILS = (0, 1, 2, 3, 5)
 N16 = (0, 2, 4, 8, 16, 10000)
 print("rows: fp16 plain steps in front of the tail (10000 = every plain step); columns: split-bf16 tail")

@@ -1,11 +1,9 @@
 mkdir -p gpurun_out/r06
-O=gpurun_out/r06/f16_speed.txt; : > $O
-run() { python bench.py --no-cpu-baseline --profile-evals 0 --no-row-check "$@" 2>/dev/null | python -c "import sys, json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])"; }
-for r in 1 2 3; do
-  for f in 0 1; do echo "cfg2 tail5 f16=$f $(run --steps 2 --warmup 1 --bulk-f16 $f)" >> $O; done
-done
-for f in 0 1; do for t in 5 2 1; do echo "cfg2 f16=$f tail=$t $(run --steps 2 --warmup 1 --bulk-f16 $f --x3-tail $t)" >> $O; done; done
-for f in 0 1; do for t in 5 2 1; do echo "cfg3 f16=$f tail=$t $(run --steps 3 --warmup 1 --bulk-f16 $f --x3-tail $t --config ntu_action --sampler ddim --respacing ddim100 --guided)" >> $O; done; done
-for f in 0 1; do for t in 3 2 1; do echo "eval_ddim5 f16=$f tail=$t $(run --steps 20 --warmup 3 --bulk-f16 $f --x3-tail $t --respacing ddim5)" >> $O; done; done
-cat $O
-bash tools/ab_trees.sh 3 build/r4_tree . -- --config chi3d --batch 128 --steps 2 --warmup 1 > gpurun_out/r06/cfg4_r4_vs_head.txt 2>&1; cat gpurun_out/r06/cfg4_r4_vs_head.txt
+python -m pytest tests -q -m gpu -x 2>&1 | grep -v amdgpu.ids | tail -30 > gpurun_out/r06/gpu_suite.txt; tail -5 gpurun_out/r06/gpu_suite.txt
+p() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['unit'], d['ms_per_step'], d['dtype'], d.get('headline_row_check_max_abs'))"; }
+python bench.py --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | p cfg2 | tee gpurun_out/r06/bench_quick.txt
+python bench.py --no-cpu-baseline --steps 3 --warmup 1 --f16-steps 0 2>/dev/null | p cfg2_bf16rule | tee -a gpurun_out/r06/bench_quick.txt
+python bench.py --config ntu_action --sampler ddim --respacing ddim100 --guided --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | p cfg3 | tee -a gpurun_out/r06/bench_quick.txt
+python bench.py --config ntu_action --sampler ddim --respacing ddim100 --guided --no-cpu-baseline --steps 3 --warmup 1 --f16-steps 0 2>/dev/null | p cfg3_bf16rule | tee -a gpurun_out/r06/bench_quick.txt
+python bench.py --respacing ddim5 --no-cpu-baseline --steps 20 --warmup 3 --profile-evals 0 2>/dev/null | p eval_ddim5 | tee -a gpurun_out/r06/bench_quick.txt
+python bench.py --respacing ddim5 --no-cpu-baseline --steps 20 --warmup 3 --profile-evals 0 --f16-steps 0 2>/dev/null | p eval_ddim5_bf16rule | tee -a gpurun_out/r06/bench_quick.txt
