@@ -256,6 +256,9 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=2, help="timed sampling calls")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=256, help="motions per GPU")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling: this many motions in total, sharded over the ranks like cgenerate shards num_samples (dist_util.shard_bounds); "
+                         "the line then says \"scaling\": \"strong\" and --batch is ignored (0: weak scaling, --batch motions per GPU)")
     ap.add_argument("--config", default="ntu")
     ap.add_argument("--respacing", default="", help="timestep_respacing ('' = 1000-step DDPM)")
     ap.add_argument("--sampler", default="ddpm", choices=["ddpm", "ddim"])
@@ -310,6 +313,12 @@ def main(argv=None):
 
     cfg = synth.get_config(a.config)
     B = a.batch
+    lo = rank * B                                           # global sample index of this rank's shard (weak scaling: every rank its own B motions)
+    if a.global_batch > 0:                                  # strong scaling: contiguous shards of ONE global batch (BASELINE configs[3] / [4]: 1024 / 2048 over 8)
+        if a.global_batch < world:
+            raise SystemExit(f"bench.py: --global-batch {a.global_batch} < {world} ranks: a rank would have nothing to sample")
+        lo, hi = dist_util.shard_bounds(a.global_batch, rank, world)
+        B = hi - lo
     # rank 0 owns the checkpoint; other ranks start from a different seed and receive rank 0's parameters via RCCL (dist_util.sync_model_weights)
     sd = synth.make_state_dict(cfg, seed=0 if rank == 0 else 1000 + rank)
     model, diffusion = synth.build_model(cfg, sd, resp=a.respacing, precision=a.precision, device=str(dev), x3_tail=a.x3_tail, f16_steps=a.f16_steps)
@@ -329,12 +338,19 @@ def main(argv=None):
     sync()
     build_s = time.perf_counter() - t_build
     fm = ClassifierFreeSampleModel(model) if a.guided else model
-    lo = rank * B                                           # global sample index of this rank's shard
-    y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1 + rank)).to(dev)}
-    if cfg["cond_mode"] == "action":
-        y["action"] = torch.from_numpy(synth.make_actions(cfg, B, seed=2 + rank)).to(dev)
-    if cfg["cond_mode"] == "text":
-        y["text_features"] = torch.from_numpy(synth.make_text_features(cfg, B, seed=3 + rank)).to(dev)
+    if a.global_batch > 0:     # the conditions of ONE global batch, this rank's slice: with the Philox key = global sample index a motion is the same at any N
+        cut = lambda arr: torch.from_numpy(np.ascontiguousarray(arr[lo:lo + B])).to(dev)
+        y = {"cmotion": cut(synth.make_cmotion(cfg, a.global_batch, seed=1))}
+        if cfg["cond_mode"] == "action":
+            y["action"] = cut(synth.make_actions(cfg, a.global_batch, seed=2))
+        if cfg["cond_mode"] == "text":
+            y["text_features"] = cut(synth.make_text_features(cfg, a.global_batch, seed=3))
+    else:
+        y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1 + rank)).to(dev)}
+        if cfg["cond_mode"] == "action":
+            y["action"] = torch.from_numpy(synth.make_actions(cfg, B, seed=2 + rank)).to(dev)
+        if cfg["cond_mode"] == "text":
+            y["text_features"] = torch.from_numpy(synth.make_text_features(cfg, B, seed=3 + rank)).to(dev)
     if a.guided:
         y["scale"] = torch.full((B,), 2.5, device=dev)
     shape = (B, cfg["njoints"], cfg["nfeats"], cfg["num_frames"])
@@ -489,7 +505,8 @@ def main(argv=None):
     if rank == 0:
         evals = S * (2 if a.guided else 1)
         algo = ALGO_GFLOP_PER_EVAL.get((cfg["dataset"], cfg["cm_mode"]), None)
-        value = a.steps * B * world / dt
+        total = a.global_batch if a.global_batch > 0 else B * world
+        value = a.steps * total / dt
         dtype = a.precision
         if a.precision == "bf16_x3tail":
             dtype = (f"bf16 MFMA operands, fp32 accumulate/LayerNorm/softmax, for {S - tail - n16} of {S} steps; " +
@@ -497,7 +514,7 @@ def main(argv=None):
         line = {
             "metric": "sampled motions/sec", "value": round(value, 3), "unit": "motions/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+            "scaling": "strong" if a.global_batch > 0 else "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic" if not a.engine_stub else f"STUB ENGINE {a.engine_stub}: launcher test, nothing measured",
             "engine_build_s": round(build_s, 2), "weights_broadcast_bytes": synced_bytes,
             "headline_row_check_max_abs": row_dev,
@@ -508,7 +525,8 @@ def main(argv=None):
             "config": {"workload": f"{a.config}: [B={B}/GPU,56,6,{cfg['num_frames']}] online/{cfg['cm_mode']}/{cfg['cond_mode']} "
                                    f"L{cfg['layers']} d{cfg['latent_dim']}, {S}-step {a.sampler.upper()}"
                                    f"{' + CFG 2.5' if a.guided else ''}, Philox noise, hipGraph={'off' if a.no_graph else 'on'}",
-                       "batch_per_gpu": B, "global_batch": B * world, "denoiser_evals_per_motion": evals,
+                       "batch_per_gpu": B if a.global_batch <= 0 else f"{a.global_batch // world}..{-(-a.global_batch // world)}", "global_batch": total,
+                       "denoiser_evals_per_motion": evals,
                        "parallelism": f"batch-shard x{world}"},
         }
         if algo is not None:

@@ -3,13 +3,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef RGN_PHILOX_ROUNDS
+#define RGN_PHILOX_ROUNDS 10
+#endif
+
 namespace rgn {
 
 // ---- Philox4x32-10 + Box-Muller: counter = (element/4, loop index, sample lo, sample hi), key = seed
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                               uint32_t out[4]) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < RGN_PHILOX_ROUNDS; ++r) {
         // one 32 x 32 -> 64 multiply (v_mad_u64_u32) per product instead of a v_mul_hi + v_mul_lo pair: the integer multiplies are
         // quarter-rate instructions and were most of the draw's cost
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;

@@ -312,6 +312,19 @@ def test_bench_gpus_2_chi3d_shard_and_serial_engine_build():
         assert "chi3d" in line["config"]["workload"] and line["scaling"] == "weak" and line["engine_build_s"] >= 0, line
 
 
+def test_bench_global_batch_is_the_strong_scaling_mode():
+    """`--global-batch N`: ONE batch of N motions sharded over the ranks (contiguous shards like cgenerate's, ragged when N % ranks != 0), reported
+    as "scaling": "strong" with value = N x steps / time - next to the weak mode, so that the first 8-GPU run can yield both curves
+    (BASELINE configs[3] / [4] are global batches of 1024 / 2048)."""
+    rc, line, log = _run_bench({}, "--gpus", "2", "--global-batch", "5")
+    assert rc == 0 and line is not None, log
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2 and line["config"]["global_batch"] == 5 and line["config"]["batch_per_gpu"] == "2..3", line
+    rc, line1, log = _run_bench({}, "--gpus", "1", "--global-batch", "5")
+    assert rc == 0 and line1["scaling"] == "strong" and line1["config"]["global_batch"] == 5, log
+    rc, _none, log = _run_bench({}, "--gpus", "2", "--global-batch", "1")
+    assert rc != 0 and "nothing to sample" in log
+
+
 class FailingEngine:
     """Engine stub whose construction fails on rank 0 (test_bench_rank_failure_is_a_nonzero_exit)."""
     requires_gpu = False
