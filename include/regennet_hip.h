@@ -220,7 +220,7 @@ RGN_API int rgn_profile_query(rgn_handle h, int32_t idx, const char** name, doub
  * phase of the precision schedule (split_phase = 0) or its split-bf16 tail (1): for kernel class idx (the classes of rgn_profile_query)
  * the concrete kernel, launches per evaluation (single kernel chain; 0 for k_layers<true>, which is ONE launch per run of steps),
  * the algorithmic FLOPs those launches carry (2 x MAC, full T x T scores) and, for the one-kernel forms, the weight
- * fragment bytes their workgroups stream from L2. Filled by the code that dispatches (plan_eval in rgn_api.cpp), so a benchmark prices
+ * fragment bytes their workgroups stream from L2. Filled by the code that dispatches (plan_eval in rgn_plan.cpp), so a benchmark prices
  * exactly what the engine launches. */
 RGN_API int rgn_plan_query(rgn_handle h, int32_t B, int32_t guided, int32_t split_phase, int32_t idx, const char** name,
                            const char** kernel, double* launches_per_eval, double* algo_flops_per_eval, double* l2_bytes_per_eval);

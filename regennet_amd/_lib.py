@@ -89,7 +89,7 @@ _lib = None
 
 
 def default_x3_tail(S, layers=8, etd=False):
-    """The engine's default split-bf16 tail where the plain phase has NO fp16 sub-phase (rgn_api.cpp default_tail(): kernel-per-stage forms,
+    """The engine's default split-bf16 tail where the plain phase has NO fp16 sub-phase (rgn_plan.cpp default_tail(): kernel-per-stage forms,
     150-frame models, batches below 64, "BULK_F16": 0): how many of the last loop indices run split-bf16. Host-side mirror for tests; what an
     engine will actually do for a batch on its bound schedule is Engine.precision_plan()."""
     if etd:

@@ -476,7 +476,7 @@ hipError_t configure_gemm_x3_sg() {
 
 // variant 0 = 128x128 / 4 waves (two workgroups per CU): the default. variant 1 = 256x256 / 8 waves / interleaved DMA (one
 // workgroup per CU): its loop is ~1.45x faster per output but it needs several tiles per CU to hide its 256 KiB-per-tile
-// epilogue, so the engine picks it only for launches of >= 7000 rows per chain (rgn_api.cpp). tools/gemm_bench builds
+// epilogue, so the engine picks it only for launches of >= 7000 rows per chain (rgn_plan.cpp). tools/gemm_bench builds
 // with RGN_GEMM_TOOLS and can also time 2 = 256x256 with the two-barrier loop, 3 = 128x128 with the interleaved loop,
 // 4 / 5 = 128x256 / 256x128 interleaved.
 hipError_t launch_gemm_x3(const GemmX3Args& g, bool x3, int variant, hipStream_t s) {

@@ -1,4 +1,4 @@
-// Internal declarations shared by rgn_api.cpp (host orchestration) and rgn_kernels.hip (device code).
+// Internal declarations shared by the host translation units (rgn_pack.cpp, rgn_plan.cpp, rgn_abi.cpp: rgn_host.h) and rgn_kernels.hip (device code).
 // Not part of the C-ABI (that is include/regennet_hip.h).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -14,7 +14,7 @@
 // norm3), 32 KiB each = 128 KiB, + statistics exchange + wave-private vectors = 144 KiB: one workgroup of 8 waves per CU, wave w = output columns
 // [64 w, 64 w + 64) (two accumulator tiles of 32 x 32). A weight fragment PAIR (2 KiB) feeds three MFMAs, so the L2 -> register weight stream
 // (4 B per weight per 32 rows) bounds the loops, not the matrix pipe; what the kernel removes is everything else the five launches carried.
-// Weights: fragment-ordered hi and lo planes [K/32][N/32][2][64][8] (rgn_api.cpp pack_linear), streamed through a register ring of RD granules
+// Weights: fragment-ordered hi and lo planes [K/32][N/32][2][64][8] (rgn_pack.cpp pack_linear), streamed through a register ring of RD granules
 // (half k-steps: 2 column blocks x (hi, lo) = 4 buffer loads) that never drains between the five GEMM passes.
 #include "rgn_internal.h"
 

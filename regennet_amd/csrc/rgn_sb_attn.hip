@@ -364,7 +364,7 @@ bool sb_qkv_attn_supported(int d, int dh, int Tq) {
     // column-split in_proj spreads 32 KB slices over 96 CUs - so 1000 steps at B = 1 take 0.294 s instead of 0.261 s; B = 4: 0.351 / 0.339 s;
     // it wins from B ~ 6 up (B = 8: 0.368 / 0.408 s). The two forms round differently and a motion must not depend on the batch it was
     // drawn in (test_small_batch_engine_is_bit_exact_under_batch_composition), so the choice cannot follow the batch size: off.
-    // (the switch is read when an engine is created: rgn_api.cpp)
+    // (the switch is read when an engine is created: rgn_pack.cpp)
     return d == SB_D && dh == SA_DH && Tq <= SA_ROWS;
 }
 hipError_t configure_sb_qkv_attn() {

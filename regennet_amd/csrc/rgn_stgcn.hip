@@ -401,7 +401,7 @@ int sg_boundary_error(rgn_stgcn_ctx* h, const char* fn, const char* what) noexce
     }
     return RGN_ERR_INTERNAL;
 }
-// no C++ exception crosses the C boundary (see rgn_guard in rgn_api.cpp)
+// no C++ exception crosses the C boundary (see rgn_guard in rgn_abi.cpp)
 template <class F>
 int sg_guard(rgn_stgcn_ctx* h, const char* fn, F&& body) noexcept {
     try {

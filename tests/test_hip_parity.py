@@ -32,7 +32,7 @@ LOOPS = ["tiny_ddpm10", "tiny_ddim10_cfg", "tiny_add_ddpm1000", "tiny_text_ddim2
 
 
 def default_tail(S, layers=8):
-    """rgn_api.cpp default_tail(): loop indices below this run split-bf16 under the precision schedule."""
+    """rgn_plan.cpp default_tail(): loop indices below this run split-bf16 under the precision schedule."""
     from regennet_amd._lib import default_x3_tail
     return default_x3_tail(S, layers)
 

@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
     std::mt19937 rng(1);
     std::normal_distribution<float> N01(0.f, 1.f);
     auto up = [&](const void* h, size_t bytes) { void* p; CK(hipMalloc(&p, bytes)); CK(hipMemcpy(p, h, bytes, hipMemcpyHostToDevice)); return p; };
-    auto wgt = [&](int N, int K, float gain) {   // fragment order [K / 32][N / 32][2][64][8] (rgn_api.cpp pack_linear)
+    auto wgt = [&](int N, int K, float gain) {   // fragment order [K / 32][N / 32][2][64][8] (rgn_pack.cpp pack_linear)
         std::vector<uint16_t> fr((size_t)N * K);
         const size_t nb = N / 32;
         for (int n = 0; n < N; ++n)

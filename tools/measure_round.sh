@@ -1,8 +1,9 @@
-# Round-5 measurement set (run on the GPU box): bench lines of the BASELINE configs + the evaluation setting + the recogniser, rocprofv3 kernel
+# A round's measurement set (run on the GPU box; tools/measure_round.sh TAG, e.g. r06): bench lines of the BASELINE configs + the evaluation setting + the recogniser, rocprofv3 kernel
 # stats of the default bench command and of the other configs, PMC passes (cfg2: counted on the FULL-LENGTH 995-step launch). Outputs under
-# gpurun_out/final5/; what should be judged is copied into profiles/r05_*.
+# gpurun_out/final_TAG/; what should be judged is copied into profiles/TAG_*.
 set -u
-R=$PWD; O=$R/gpurun_out/final5
+TAG=${1:-r06}
+R=$PWD; O=$R/gpurun_out/final_$TAG
 rm -rf $O; mkdir -p $O
 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err < /dev/null; echo bench rc=$?
 head -c 300 $O/bench_cfg2.json; echo
@@ -26,6 +27,6 @@ prof eval_ddim5 --steps 10 --warmup 2 --profile-evals 0 --respacing ddim5
 prof stgcn --config stgcn --steps 3 --warmup 1
 rm -f $O/*kernel_trace.csv $O/*agent_info.csv $O/*domain_stats.csv
 cd $R
-PMC_FULL=1 PMC_STEPS=995 bash tools/collect_pmc.sh gpurun_out/final5/pmc_bench.json ntu_B256_bf16_x3tail_plain 2>&1 | grep "rc="
+PMC_FULL=1 PMC_STEPS=990 bash tools/collect_pmc.sh gpurun_out/final_$TAG/pmc_bench.json ntu_B256_bf16_x3tail_plain 2>&1 | grep "rc="
 mkdir -p $O/pmc_raw && cp gpurun_out/pmc/*counter_collection.csv $O/pmc_raw/ 2>/dev/null
 ls $O

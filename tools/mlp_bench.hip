@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
             }
         return (__bf16*)up(pl.data(), pl.size() * 2);
     };
-    // weights: natural [N][K] values (bf16-rounded), stored in fragment order [K / 32][N / 32][2][64][8] (rgn_api.cpp pack_linear)
+    // weights: natural [N][K] values (bf16-rounded), stored in fragment order [K / 32][N / 32][2][64][8] (rgn_pack.cpp pack_linear)
     auto wgt = [&](std::vector<float>& nat, int N, int K, float gain) {
         nat.resize((size_t)N * K);
         std::vector<uint16_t> fr((size_t)N * K);
