@@ -118,7 +118,7 @@ struct QkvAttnArgs {
     int Bm, Kp, d, H, Tq;
     float qscale;
     int Bm_eval;                                        // samples of the WHOLE evaluation (all kernel chains; 0: = Bm): what else runs beside this launch
-    int f16;                                            // k_qkv_attn_long only: Ahi, Wfr and the output plane hold IEEE fp16 (OpFmt<true>), not bf16
+    int f16;                                            // k_qkv_attn_long / k_qkv_attn_rs<1>: Ahi, Wfr and the output plane hold IEEE fp16 (OpFmt<true>), not bf16
 };
 bool qkv_attn_supported(int Tq, int dh, int d);
 hipError_t configure_qkv_attn();

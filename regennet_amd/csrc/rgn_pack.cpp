@@ -370,7 +370,7 @@ int finalize_weights(rgn_ctx* c) {
         c->qkv_long = c->cfg.precision == RGN_PREC_BF16_X3TAIL && qkv_attn_long_supported(c->Tq, d / c->H, d) && !opt_flag(c, "NO_QKV_LONG");
         if (c->qkv_long) RGN_HIP(c, configure_qkv_attn_long());
         // the forms with fp16 instantiations: the multi-step one-kernel stack; k_qkv_attn_long + k_mlp2 + k_step (prec_plan decides per batch)
-        c->bulk_f16 = c->bulk_f16 && c->step_fused && (c->layers_steps || (c->qkv_long && c->mlp));
+        c->bulk_f16 = c->bulk_f16 && c->step_fused && (c->layers_steps || ((c->qkv_long || (c->fuse_qkv && c->qkv_rs && d == 512)) && c->mlp));
         c->sb = c->attn_x3 && sb_supported(d, ff, d / c->H);
         { int v; if (opt_get(c, "SB_FUSED_ATTN", &v)) c->sb_attn = v != 0; }
         { int v; if (opt_get(c, "SB_ROWS", &v)) c->sb_rows = c->sb_rows_default = v < 0 ? 0 : v; }

@@ -165,8 +165,10 @@ PrecPlan prec_plan(const rgn_ctx* c, const Dims& dm, bool guided) {
     if (c->cfg.precision != RGN_PREC_BF16_X3TAIL) return pp;
     const EvalPlan plain = plan_eval(c, dm, guided, false, true);
     // (the forms with an fp16 instantiation: the multi-step one-kernel stack, and the kernel-per-stage chain of 150-frame models -
-    //  k_qkv_attn_long + k_mlp2 + k_step, whose planes hand the residual stream from step to step)
-    const bool f16_ok = c->bulk_f16 && (plain.steps || (plain.step_fused && !plain.layers && plain.attn == AF_QKV_LONG && plain.tail == TF_MLP));
+    //  k_qkv_attn_long + k_mlp2 + k_step - and the same chain at <= 64 tokens below the one-kernel stack's batch threshold: k_qkv_attn_rs + k_mlp2 +
+    //  k_step - whose planes hand the residual stream from step to step)
+    const bool f16_ok = c->bulk_f16 && (plain.steps || (plain.step_fused && !plain.layers && plain.tail == TF_MLP &&
+                                                       (plain.attn == AF_QKV_LONG || (plain.attn == AF_QKV && c->qkv_rs && c->d == 512 && c->L > 0 && c->layers[0].qkv.fr16))));
     pp.n16 = !f16_ok ? 0 : (c->f16_steps >= 0 ? c->f16_steps : F16_STEPS_DEFAULT);
     if (c->x3_tail >= 0) pp.tail = c->x3_tail;
     else if (pp.n16 > 0 && c->L >= 8 && !c->etd) pp.tail = F16_TAIL < c->S ? F16_TAIL : c->S;
@@ -372,7 +374,8 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             QkvAttnArgs g{};
             g.Ahi = h_p.hi; g.Alo = h_p.lo; g.a_rows = h_p.rows;
             g.Whi = c->dp<__bf16>(w.qkv.hi); g.Wlo = c->dp<__bf16>(w.qkv.lo);
-            g.Wfr = (w.qkv.fr && c->qkv_rs) ? c->dp<__bf16>(w.qkv.fr) : nullptr;   // plain-bf16 phase: weights streamed to registers
+            g.Wfr = (w.qkv.fr && c->qkv_rs) ? c->dp<__bf16>(f16 ? w.qkv.fr16 : w.qkv.fr) : nullptr;   // plain phase: weights streamed to registers
+            g.f16 = f16 ? 1 : 0;
             g.bias = c->dp<float>(w.qkv.b);
             g.out = att_p;
             g.Bm = ns; g.Kp = w.qkv.Kp; g.d = d; g.H = c->H; g.Tq = dm.Tq;

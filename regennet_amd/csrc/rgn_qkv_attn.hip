@@ -57,9 +57,14 @@ __device__ long long g_qa_prof[64];   // tools only: phase cycle stamps of one w
 
 // Attention straight from the in_proj accumulators of one head (see the file header); shared by the DMA-fed and the
 // register-streamed GEMM phases. acc[token tile][q | k | v]; smem: the 96 KiB fp32 exchange buffer for the S^T partials.
-template <bool X3>
+template <bool X3, bool F16 = false>
 __device__ __forceinline__ void qa_attention(f32x16 (&acc)[2][3], const QkvAttnArgs& g, char* smem, const float* bias_h, int hd, int hslot,
                                              int wm, int wn, int nsamp, int b0, int lane, int tid) {
+    static_assert(!(X3 && F16), "the split form is bf16 (hi, lo) pairs");
+    using OP = OpFmt<F16>;                // plain form: bf16 or fp16 operands (rgn_internal.h)
+    using op_t = typename OP::t;
+    using op8 = typename OP::v8;
+    using op4 = typename OP::v4;
     const int l31 = lane & 31, kh = lane >> 5, Tq = g.Tq;
     (void)tid; (void)hslot;
     // ---------------- attention straight from the accumulators: q, k, v never leave the register file --------------
@@ -75,7 +80,7 @@ __device__ __forceinline__ void qa_attention(f32x16 (&acc)[2][3], const QkvAttnA
     // x 4 waves x 4 KiB). Both samples proceed at the same time on their own four waves.
     const bool live = wm < nsamp;                               // (an odd batch: the second sample of the last pair is a dummy)
     const size_t row0 = (size_t)(b0 + (live ? wm : 0)) * Tq;
-        bf16x8 qh[2][2], ql[2][2], kfh[2][2], kfl[2][2], vh[2][2], vl[2][2];   // [token tile][16-slice of the register index]
+        op8 qh[2][2], ql[2][2], kfh[2][2], kfl[2][2], vh[2][2], vl[2][2];   // [token tile][16-slice of the register index]
     {
         const float bv = bias_h[2 * QA_DH + l31];
         const float qs2 = g.qscale * 1.44269504088896340736f;   // scores in log2 units: softmax = exp2(s - max), one mul less per score
@@ -93,13 +98,13 @@ __device__ __forceinline__ void qa_attention(f32x16 (&acc)[2][3], const QkvAttnA
                     const float xq = (acc[ta][0][i] + (j < 4 ? bq0[j] : bq1[j - 4])) * qs2;
                     const float xk = acc[ta][1][i] + (j < 4 ? bk0[j] : bk1[j - 4]);
                     const float xv = acc[ta][2][i] + bv;
-                    qh[ta][sl][j] = (__bf16)xq;
-                    kfh[ta][sl][j] = (__bf16)xk;
-                    vh[ta][sl][j] = (__bf16)xv;
+                    qh[ta][sl][j] = (op_t)xq;
+                    kfh[ta][sl][j] = (op_t)xk;
+                    vh[ta][sl][j] = (op_t)xv;
                     if (X3) {
-                        ql[ta][sl][j] = (__bf16)(xq - (float)qh[ta][sl][j]);
-                        kfl[ta][sl][j] = (__bf16)(xk - (float)kfh[ta][sl][j]);
-                        vl[ta][sl][j] = (__bf16)(xv - (float)vh[ta][sl][j]);
+                        ql[ta][sl][j] = (op_t)(xq - (float)qh[ta][sl][j]);
+                        kfl[ta][sl][j] = (op_t)(xk - (float)kfh[ta][sl][j]);
+                        vl[ta][sl][j] = (op_t)(xv - (float)vh[ta][sl][j]);
                     }
                 }
             }
@@ -114,10 +119,10 @@ __device__ __forceinline__ void qa_attention(f32x16 (&acc)[2][3], const QkvAttnA
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
             if (X3) {
-                st[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl[kj][sl], qh[qtile][sl], st[tl], 0, 0, 0);
-                st[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh[kj][sl], ql[qtile][sl], st[tl], 0, 0, 0);
+                st[tl] = OP::mfma(kfl[kj][sl], qh[qtile][sl], st[tl]);
+                st[tl] = OP::mfma(kfh[kj][sl], ql[qtile][sl], st[tl]);
             }
-            st[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh[kj][sl], qh[qtile][sl], st[tl], 0, 0, 0);
+            st[tl] = OP::mfma(kfh[kj][sl], qh[qtile][sl], st[tl]);
         }
     }
     // sum the partials of the four dh tiles: [sample][tile][wave wn][i/4][lane] float4
@@ -192,18 +197,18 @@ __device__ __forceinline__ void qa_attention(f32x16 (&acc)[2][3], const QkvAttnA
             const int kj = tl >> 1;
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) {
-                bf16x8 ph, pl;
+                op8 ph, pl;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float x = st[tl][8 * sl + j];
-                    ph[j] = (__bf16)x;
-                    pl[j] = (__bf16)(x - (float)ph[j]);
+                    ph[j] = (op_t)x;
+                    pl[j] = (op_t)(x - (float)ph[j]);
                 }
                 if (X3) {
-                    oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl[kj][sl], ph, oa, 0, 0, 0);
-                    oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[kj][sl], pl, oa, 0, 0, 0);
+                    oa = OP::mfma(vl[kj][sl], ph, oa);
+                    oa = OP::mfma(vh[kj][sl], pl, oa);
                 }
-                oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh[kj][sl], ph, oa, 0, 0, 0);
+                oa = OP::mfma(vh[kj][sl], ph, oa);
             }
         }
         // O^T tile: lane = query (column), registers = 16 dh indices -> 4 runs of 4 consecutive dh = 8-byte plane
@@ -216,9 +221,9 @@ __device__ __forceinline__ void qa_attention(f32x16 (&acc)[2][3], const QkvAttnA
             u32x2 run[4];
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
-                bf16x4 hv;
+                op4 hv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) hv[e] = (__bf16)(oa[4 * i4 + e] * inv[qtile]);
+                for (int e = 0; e < 4; ++e) hv[e] = (op_t)(oa[4 * i4 + e] * inv[qtile]);
                 run[i4] = __builtin_bit_cast(u32x2, hv);
             }
             const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(g.out.hi, 0, (int)((size_t)g.out.rows * g.d * 2), 0x00020000);
@@ -239,15 +244,15 @@ __device__ __forceinline__ void qa_attention(f32x16 (&acc)[2][3], const QkvAttnA
             const size_t o = ((size_t)(hd * (QA_DH / 32) + wn) * g.out.rows + row0 + q) * 32 + 4 * kh;
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
-                bf16x4 hv, lv;
+                op4 hv, lv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float x = oa[4 * i4 + e] * inv[qtile];
-                    hv[e] = (__bf16)x;
-                    lv[e] = (__bf16)(x - (float)hv[e]);
+                    hv[e] = (op_t)x;
+                    lv[e] = (op_t)(x - (float)hv[e]);
                 }
-                *reinterpret_cast<bf16x4*>(g.out.hi + o + 8 * i4) = hv;
-                if (g.out.lo) *reinterpret_cast<bf16x4*>(g.out.lo + o + 8 * i4) = lv;
+                *reinterpret_cast<op4*>(reinterpret_cast<op_t*>(g.out.hi) + o + 8 * i4) = hv;
+                if (g.out.lo) *reinterpret_cast<op4*>(reinterpret_cast<op_t*>(g.out.lo) + o + 8 * i4) = lv;
             }
         }
     }
@@ -417,8 +422,10 @@ constexpr int QR_DA = 4, QR_ARING = QR_DA + 1;                // activation piec
 // workgroup (no MFMA work, no weight requests) then run under the other's k-loop.
 template <int NS> constexpr int qr_abuf() { return NS * 48 * 1024; }
 template <int NS> constexpr int qr_lds() { return qr_abuf<NS>() + 2 * NS * QA_ROWS * 64 + 8 * QA_WROWS * 4; }
-template <int NS>
+template <int NS, bool F16 = false>
 __global__ __launch_bounds__(NS * 256, 2 / NS) void k_qkv_attn_rs(QkvAttnArgs g, const __bf16* __restrict__ Wfr) {
+    using OP = OpFmt<F16>;                // bf16 or fp16 operands (rgn_internal.h): input plane, weight plane, q / k / v / p, output plane
+    using op8 = typename OP::v8;
     constexpr int NT = NS * 256, STAGE = NS * QA_ROWS * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -473,12 +480,12 @@ __global__ __launch_bounds__(NS * 256, 2 / NS) void k_qkv_attn_rs(QkvAttnArgs g,
         // Weight fragments: a ring of QR_WQ = 18 fragments (3 k-steps' worth) recycled ONE AT A TIME: fragment q = 6 kt + 3 ks + t
         // is consumed by two MFMAs and its registers immediately take fragment q + 18 - the same 72 VGPRs as three whole-step
         // slots, but every load is issued three k-steps (not two) ahead of its use and the loads are spread between the MFMAs.
-        bf16x8 wq[QR_WQ];
+        op8 wq[QR_WQ];
         u32x4 areg[QR_ARING];
         auto issue_a = [&](int kt) { areg[kt % QR_ARING] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_voff * 2, kt * a_kbytes, 0)); };
         auto issue_q = [&](int q) {                                  // q compile-time after unrolling
             const int kt = q / 6, ks = (q % 6) / 3, t = q % 3;
-            wq[q % QR_WQ] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, wofs[t] * 2, (kt * nb_all * 1024 + ks * 512) * 2, 0));
+            wq[q % QR_WQ] = __builtin_bit_cast(op8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, wofs[t] * 2, (kt * nb_all * 1024 + ks * 512) * 2, 0));
         };
 #pragma unroll
         for (int kt = 0; kt < QR_DA; ++kt) issue_a(kt);
@@ -492,11 +499,11 @@ __global__ __launch_bounds__(NS * 256, 2 / NS) void k_qkv_attn_rs(QkvAttnArgs g,
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                            // k-block kt is in its stage; everyone left stage (kt + 1) % 2
             const char* sb = abuf + (kt & 1) * STAGE;
-            bf16x8 af[2][2];
+            op8 af[2][2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int ta = 0; ta < 2; ++ta) af[ks][ta] = *reinterpret_cast<const bf16x8*>(sb + a_off[ta][ks]);
+                for (int ta = 0; ta < 2; ++ta) af[ks][ta] = *reinterpret_cast<const op8*>(sb + a_off[ta][ks]);
             __builtin_amdgcn_sched_barrier(0);
             if (kt + QR_DA < QR_NK) issue_a(kt + QR_DA);
             __builtin_amdgcn_sched_barrier(0);
@@ -509,9 +516,9 @@ __global__ __launch_bounds__(NS * 256, 2 / NS) void k_qkv_attn_rs(QkvAttnArgs g,
 #pragma unroll
                 for (int ta = 0; ta < 2; ++ta) {
                     if (t < 2)     // q, k tiles transposed (lane = token, registers = dh)
-                        acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[q % QR_WQ], af[ks][ta], acc[ta][t], 0, 0, 0);
+                        acc[ta][t] = OP::mfma(wq[q % QR_WQ], af[ks][ta], acc[ta][t]);
                     else           // v tile: lane = dh, registers = tokens
-                        acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][ta], wq[q % QR_WQ], acc[ta][t], 0, 0, 0);
+                        acc[ta][t] = OP::mfma(af[ks][ta], wq[q % QR_WQ], acc[ta][t]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (q + QR_WQ < 6 * QR_NK) issue_q(q + QR_WQ);
@@ -521,7 +528,7 @@ __global__ __launch_bounds__(NS * 256, 2 / NS) void k_qkv_attn_rs(QkvAttnArgs g,
             }
         }
         RGN_QT((hd - hd0) * 8 + 1)
-        qa_attention<false>(acc, g, smem, bias_s + (hd - hd0) * QA_WROWS + wn * 32, hd, hd - hd0, wm, wn, nsamp, b0, lane, tid);
+        qa_attention<false, F16>(acc, g, smem, bias_s + (hd - hd0) * QA_WROWS + wn * 32, hd, hd - hd0, wm, wn, nsamp, b0, lane, tid);
         RGN_QT((hd - hd0) * 8 + 6)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -540,6 +547,8 @@ hipError_t configure_qkv_attn() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_rs<2>), hipFuncAttributeMaxDynamicSharedMemorySize, qr_lds<2>());
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_rs<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, qr_lds<1>());
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_rs<1>), hipFuncAttributeMaxDynamicSharedMemorySize, qr_lds<1>());
 }
 hipError_t launch_qkv_attn(const QkvAttnArgs& g, bool x3, hipStream_t s) {
@@ -555,7 +564,9 @@ hipError_t launch_qkv_attn(const QkvAttnArgs& g, bool x3, hipStream_t s) {
         // 192 at 60 frames: 116.9 / 131.0 / 154.1 vs 135.6 / 139.7 / 158.0 ms per 250-step call; B = 256: 360 vs 369 motions/s the other way)
         const int beval = g.Bm_eval > 0 ? g.Bm_eval : g.Bm;
         const int hsplit = (hs_env > 0 && g.H % hs_env == 0) ? hs_env : (beval < 256 || g.H % 2) ? g.H : 2;
-        if (!two)
+        if (g.f16)     // fp16 operands (the schedule's fp16 sub-phase): the one-sample form
+            hipLaunchKernelGGL((k_qkv_attn_rs<1, true>), dim3(g.Bm, hsplit), dim3(256), qr_lds<1>(), s, g, g.Wfr);
+        else if (!two)
             hipLaunchKernelGGL(k_qkv_attn_rs<1>, dim3(g.Bm, hsplit), dim3(256), qr_lds<1>(), s, g, g.Wfr);
         else
             hipLaunchKernelGGL(k_qkv_attn_rs<2>, dim3(pairs, hsplit), dim3(512), qr_lds<2>(), s, g, g.Wfr);
@@ -563,6 +574,7 @@ hipError_t launch_qkv_attn(const QkvAttnArgs& g, bool x3, hipStream_t s) {
     }
     // heads per workgroup: half of them (the weight stream per sample is what bounds the kernel), but one head each while
     // the launch is small (<= 64 workgroups): a small batch is latency-bound and the heads of a workgroup run back to back
+    if (g.f16) return hipErrorInvalidValue;                         // (only the register-streamed plain form has the fp16 instantiation)
     const int pairs = (g.Bm + QA_NS - 1) / QA_NS;
     const int hsplit = (pairs * g.H <= 64) ? g.H : (g.H % 2 == 0 ? 2 : 1);
     const dim3 grid(pairs, hsplit);

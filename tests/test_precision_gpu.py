@@ -49,6 +49,28 @@ def test_three_phase_precision_schedule_sweep(golden, name):
     assert errs[(None, None)] == errs[(8, 2)]                              # the default IS (8, 2)
 
 
+@pytest.mark.parametrize("name", ["ntu_eval_ddim5", "ntu_ddpm50", "ntu_action_ddim100_cfg"])
+def test_three_phase_schedule_on_the_kernel_per_stage_chain_at_60_frames(golden, name):
+    """Below the one-kernel stack's batch threshold (64 motions) a 60-frame model runs k_qkv_attn_rs + k_mlp2 + k_step per step: the same three-phase
+    plan there (the reference's default batch is 64 and a strong-scaled shard is smaller: utils/parser_util.py:95), against the reference's outputs."""
+    g = golden(name)
+    cfg, sd, y, tape = fixture_inputs(g, loop=True)
+    S, guided = int(g["S"]), bool(g["guided"])
+    shape = (int(g["B"]), cfg["njoints"], cfg["nfeats"], cfg["num_frames"])
+    errs = {}
+    for n16 in (None, 0):
+        model, diffusion = build_hip(cfg, sd, resp=str(g["resp"]), precision="bf16_x3tail/throughput", f16_steps=n16, engine_options={"LAYERS": 0})
+        fn = diffusion.p_sample_loop if str(g["mode"]) == "ddpm" else diffusion.ddim_sample_loop
+        out = fn(_wrap(model, guided), shape, clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape))
+        errs[n16] = float(np.abs(out.cpu().numpy() - g["final"]).max())
+        plan, kern = model._engine.precision_plan(shape[0], guided), model._engine.plan_query(shape[0], guided)
+        assert kern["qkv_attn"]["kernel"] == "k_qkv_attn_rs" and kern["mlp"]["kernel"] == "k_mlp2" and "step_fused" in kern, kern
+        assert plan == ((min(8, S - 2), 2) if n16 is None else (0, 3 if S <= 10 else 5)), plan
+        model._engine.close()
+    print(f"\n[three-phase schedule, kernel per stage at 60 frames] {name}: default {errs[None]:.2e}, bf16 rule {errs[0]:.2e}")
+    assert errs[None] < MARGIN and errs[0] < MARGIN, errs
+
+
 def test_three_phase_schedule_is_invariant_under_range_cuts_and_batch_composition():
     """A call cut into ranges (the progressive API's shape of work) crosses the bf16 -> fp16 boundary at a different point of the launch
     sequence (planes re-encoded behind an embedding instead of behind a bf16 launch), and a motion's result may not depend on its batch:
