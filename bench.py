@@ -479,7 +479,7 @@ def main(argv=None):
         # MI355X guide's recipe) - read from the newest committed PMC summary (tools/collect_pmc.sh + tools/summarize_pmc.py) and
         # labelled as such
         key = f"{a.config}_B{B}_{a.precision}_{'cfg' if a.guided else 'plain'}"
-        for name in ("r05_pmc_bench.json", "r04_pmc_bench.json", "r03_pmc_bench.json", "r02_pmc_bench.json"):
+        for name in ("r06_pmc_bench.json", "r05_pmc_bench.json", "r04_pmc_bench.json", "r03_pmc_bench.json", "r02_pmc_bench.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
                 with open(pmc) as fh:

@@ -1,5 +1,5 @@
 # A round's measurement set (run on the GPU box; tools/measure_round.sh TAG, e.g. r06): bench lines of the BASELINE configs + the evaluation setting + the recogniser, rocprofv3 kernel
-# stats of the default bench command and of the other configs, PMC passes (cfg2: counted on the FULL-LENGTH 995-step launch). Outputs under
+# stats of the default bench command and of the other configs, PMC passes (cfg2: counted on the FULL-LENGTH launch of the plain-bf16 phase). Outputs under
 # gpurun_out/final_TAG/; what should be judged is copied into profiles/TAG_*.
 set -u
 TAG=${1:-r06}
@@ -14,6 +14,8 @@ python bench.py --config text150 --batch 256 --sampler ddim --respacing ddim50 -
 python bench.py --batch 1 --no-cpu-baseline --steps 3 --warmup 1 > $O/bench_cfg1_B1.json 2>/dev/null; head -c 160 $O/bench_cfg1_B1.json; echo
 python bench.py --respacing ddim5 --no-cpu-baseline --steps 20 --warmup 3 --profile-evals 0 > $O/bench_eval_ddim5.json 2>/dev/null; head -c 160 $O/bench_eval_ddim5.json; echo
 python bench.py --config stgcn --steps 10 --warmup 2 > $O/bench_stgcn.json 2>/dev/null; head -c 200 $O/bench_stgcn.json; echo
+python bench.py --config eval_pipeline --steps 10 --warmup 2 > $O/bench_eval_pipeline.json 2>/dev/null; head -c 200 $O/bench_eval_pipeline.json; echo
+bash tools/batch_sweep.sh > $O/batch_sweep.txt 2>&1; cat $O/batch_sweep.txt
 cd /tmp && export TMPDIR=/tmp
 prof() {  # name, bench flags...
   n=$1; shift

@@ -24,7 +24,8 @@ import os
 import sys
 
 # substring of the kernel name -> the name bench.py uses (first match wins)
-CLASSES = [("k_layers<true", "k_layers<steps>"), ("k_layers", "k_layers"), ("k_step", "k_step"), ("k_mlp", "k_mlp"), ("k_rowgemm<0", "k_rowgemm<LN>"), ("k_rowgemm<1", "k_rowgemm<ACT>"), ("k_gemm_x3", "k_gemm_x3"),
+CLASSES = [("k_layers<true, false, true>", "k_layers<steps, f16>"), ("k_layers<true, true, true>", "k_layers<steps, f16>"),   # the fp16 sub-phase's short launch: its own class
+           ("k_layers<true", "k_layers<steps>"), ("k_layers", "k_layers"), ("k_step", "k_step"), ("k_mlp", "k_mlp"), ("k_rowgemm<0", "k_rowgemm<LN>"), ("k_rowgemm<1", "k_rowgemm<ACT>"), ("k_gemm_x3", "k_gemm_x3"),
            ("k_qkv_attn_long", "k_qkv_attn_long"), ("k_qkv_attn", "k_qkv_attn"), ("k_attn_x3", "k_attn_x3"), ("k_sb_gemm", "k_sb_gemm"), ("k_layernorm", "k_layernorm"), ("k_update", "k_update"),
            ("k_gemm_bf16", "k_gemm_bf16"), ("k_gemm_f32", "k_gemm_f32"), ("k_attn_mfma", "k_attn_mfma")]
 N_SIMD = 1024          # 256 CUs x 4
