@@ -51,7 +51,7 @@ class STGCN(nn.Module):
             [_Block(c0 if ci is None else ci, co, K, s, residual=i > 0) for i, (ci, co, s) in enumerate(_BLOCKS)])
         self.edge_importance = nn.ParameterList([nn.Parameter(torch.ones(K, V, V)) for _ in _BLOCKS])
         self.fcn = nn.Conv2d(256, num_class, kernel_size=1)
-        self._engine, self._stale = None, True
+        self._engine, self._stale, self._applied_options = None, True, {}
         self.engine_options = {}                  # kernel-selection switches for this model's engine (rgn_stgcn_set_option; tools and tests)
         for p in self.parameters():
             p.requires_grad_(False)
@@ -81,7 +81,18 @@ class STGCN(nn.Module):
                     continue
                 eng.load_weight(k, v.detach().float().cpu().numpy())
             eng.finalize()
-            self._engine, self._stale = eng, False
+            self._engine, self._stale, self._applied_options = eng, False, dict(self.engine_options)
+        elif self.engine_options != self._applied_options:
+            # the recogniser's switches may be set at any time before a forward (rgn_stgcn_set_option): an edit of the dict reaches the live engine
+            torch.cuda.synchronize(dev)
+            for k, v in self.engine_options.items():
+                if self._applied_options.get(k) != v:
+                    eng.set_option(k, v)
+            for k in set(self._applied_options) - set(self.engine_options):
+                self._stale = True                                  # (a switch taken away: only a rebuild restores the environment's default)
+            self._applied_options = dict(self.engine_options)
+            if self._stale:
+                return self._get_engine(N, T)
         return eng, dev
 
     def forward(self, batch):
