@@ -316,7 +316,7 @@ int rgn_set_f16_steps(rgn_handle h, int32_t steps) {
     return rgn_guard(h, "rgn_set_f16_steps", [&]() -> int {
         if (!h) return RGN_ERR_INVALID_ARG;
         if (steps < -1) return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_f16_steps: steps < -1");
-        h->f16_steps = steps;
+        h->f16_steps = steps < 0 ? h->f16_steps_default : steps;
         return RGN_OK;
     });
 }

@@ -151,6 +151,7 @@ struct rgn_ctx {
     bool phase_x3 = true;
     bool phase_f16 = false;            // ... and, for a plain evaluation: fp16 operands (the fp16 sub-phase of the schedule, rgn_set_f16_steps)
     int x3_tail = -1;                  // -1: default_tail(S)
+    int f16_steps_default = -1;        // (REGENNET_F16_STEPS / rgn_set_option "F16_STEPS")
     int f16_steps = -1;                // rgn_set_f16_steps: plain-phase steps right in front of the split-bf16 tail that run on fp16 operands (-1: default)
     int const_noise = 0;               // rgn_set_const_noise
     bool bulk_resid_lo = false;        // bulk phase: residual stream as the hi plane only (REGENNET_BULK_RESID_LO=1: hi + lo; the switch-point

@@ -174,7 +174,7 @@ int finalize_weights(rgn_ctx* c) {
     // 2^-9 operand rounding - but a 5-bit exponent: a weight at or beyond fp16's range would become inf, so such a checkpoint is refused
     // here, with the key named (activations are LayerNorm outputs, probabilities and GELU values: O(1) by construction)
     { int v = 1; (void)opt_get(c, "BULK_F16", &v); c->bulk_f16 = c->cfg.precision == RGN_PREC_BF16_X3TAIL && v != 0; }
-    { int v; if (opt_get(c, "F16_STEPS", &v)) c->f16_steps = v < 0 ? -1 : v; }
+    { int v; if (opt_get(c, "F16_STEPS", &v)) c->f16_steps = c->f16_steps_default = v < 0 ? -1 : v; }
     auto f16_range = [&](const std::string& key, const float* w, size_t n) -> bool {
         for (size_t i = 0; i < n; ++i)
             if (!(std::fabs(w[i]) < 6.0e4f)) {
