@@ -46,6 +46,7 @@ struct Args {
     Ctrl* c;
     int layers;            // layers x steps to run
     int valu_attn, valu_ln12, valu_gelu, valu_ln3;   // dependent-FMA chain lengths of the stand-ins (per wave)
+    int xmask;             // bit 0: the attention-output exchange, bit 1: the all-reduce of the FFN partials (timing builds: parts removed)
 };
 constexpr size_t LAYER_BLOCKS = 16 * 48 + 16 * 16 + 16 * 32 + 32 * 16;   // 2 KiB each = 4 MiB
 
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(NTH, 2) void k_gcu(Args g) {
         }
         sink += valu_chain(g.valu_attn / G, sink);
         __syncthreads();
-        exchange(65536 / G, 65536, 65536, epoch, false);                                      // attention output slice -> image Y of every member
+        if (g.xmask & 1) exchange(65536 / G, 65536, 65536, epoch, false);                     // attention output slice -> image Y of every member
         // ---- out_proj (all 512 columns, redundant) + residual / norm1 / norm2
         pass(Wo, 16, 2 * wave, 0, K16{}, N2{}, 65536);
         sink += valu_chain(g.valu_ln12, sink);
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(NTH, 2) void k_gcu(Args g) {
             pass(W2, 16, 2 * wave, 8 * mem, std::integral_constant<int, 8>{}, N2{}, 65536);
         }
         __syncthreads();
-        exchange(131072, 0, 0, epoch, true);                                                  // all-reduce of the fp32 partials [64][512]
+        if (g.xmask & 2) exchange(131072, 0, 0, epoch, true);                                 // all-reduce of the fp32 partials [64][512]
         sink += valu_chain(g.valu_ln3, sink);
         __syncthreads();
     }
@@ -230,9 +231,11 @@ __global__ __launch_bounds__(NTH, 2) void k_gcu(Args g) {
 }
 
 template <int G>
-void run(int samples, int layers, const Args& a0, Ctrl* c) {
+void run(int samples, int layers, const Args& a0, Ctrl* c, int xmask = 3, bool valu = true) {
     Args a = a0;
     a.layers = layers;
+    a.xmask = xmask;
+    if (!valu) a.valu_attn = a.valu_ln12 = a.valu_gelu = a.valu_ln3 = 0;
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gcu<G>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     const int wgs = samples * G;
     if (wgs > 256 || wgs % (8 * G)) { printf("G = %d: %d samples -> %d workgroups: skipped (needs a multiple of %d, <= 256)\n", G, samples, wgs, 8 * G); return; }
@@ -257,8 +260,8 @@ void run(int samples, int layers, const Args& a0, Ctrl* c) {
         if ((double)mx / layers > worst) worst = (double)mx / layers;
         to += h.timeouts;
     }
-    printf("G = %d  %3d samples on %3d CUs: %7.2f us per layer (launch / layers), slowest workgroup %7.1f k cycles per layer -> 8 layers + 60 k boundary = %6.1f us per step at 1.95 GHz%s\n",
-           G, samples, wgs, best, worst / 1e3, (8 * worst + 60e3) / 1.95e3, to ? "   [BARRIER TIMEOUTS]" : "");
+    printf("G = %d  %3d samples on %3d CUs [%s%s%s]: %7.2f us per layer (launch / layers; slowest workgroup %6.1f k counter ticks) -> x 8 + 30 us boundary = %6.1f us per step%s\n",
+           G, samples, wgs, (xmask & 1) ? "X1 " : "", (xmask & 2) ? "X2 " : "", valu ? "VALU" : "", best, worst / 1e3, 8 * best + 30.0, to ? "   [BARRIER TIMEOUTS]" : "");
 }
 
 int main(int argc, char** argv) {
@@ -273,11 +276,18 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&c, sizeof(Ctrl)));
     // stand-ins, per wave and layer (k_layers' stamps, DESIGN.md 4.0d: VALU phases ~41 k of a layer's 112 k cycles with two waves per SIMD in the same
     // phase: 8 cycles of SIMD time per instruction pair): attention 2 x ~5 k, norm1 + norm2 + images 11.4 k, GELU ~11 k, norm3 6.3 k
-    Args a{W, xbuf, c, 0, 10000 / 8, 11400 / 8, 11000 / 8, 6300 / 8};
+    Args a{W, xbuf, c, 0, 10000 / 8, 11400 / 8, 11000 / 8, 6300 / 8, 3};
     printf("G-CUs-per-sample layer skeleton: %d samples, %d layers per launch (weights: 8 layers x 4 MiB, L2-resident per XCD like the real stream)\n", samples, layers);
-    run<1>(samples, layers, a, c);
-    run<2>(samples, layers, a, c);
-    run<4>(samples, layers, a, c);
-    if (samples != 32) { run<1>(32, layers, a, c); run<2>(32, layers, a, c); run<4>(32, layers, a, c); }
+    for (int smp : {samples, 32}) {
+        run<1>(smp, layers, a, c);
+        run<1>(smp, layers, a, c, 3, false);
+        run<2>(smp, layers, a, c);
+        run<2>(smp, layers, a, c, 0);
+        run<4>(smp, layers, a, c);
+        run<4>(smp, layers, a, c, 1);
+        run<4>(smp, layers, a, c, 2);
+        run<4>(smp, layers, a, c, 0);
+        run<4>(smp, layers, a, c, 0, false);
+    }
     return 0;
 }
