@@ -80,6 +80,38 @@ def test_stgcn_other_skeletons_match_the_oracle(V, hub, T, N):
     assert err_y < 1e-4 * max(1.0, float(ref_y.abs().max())), err_y
 
 
+@pytest.mark.parametrize("V,hub,T,N,opts", [(36, 2, 60, 40, {}), (52, 3, 48, 32, {}), (52, 3, 48, 32, {"SG_GCN_BN": 64}), (36, 2, 60, 40, {"SG_GCN_BN": 128}),
+                                             (52, 3, 48, 32, {"SG_TCONV_SMALL": 1})])
+def test_stgcn_many_tiles_on_skeletons_whose_vertex_count_is_not_a_multiple_of_8(V, hub, T, N, opts):
+    """V % 8 != 0 (36, 52: a frame is not a whole number of 8-row DMA groups, so tile and window boundaries fall mid-frame at different offsets from tile to
+    tile) on batches of hundreds of tiles - the persistent walk slot, slot + #CU, ... with windows in flight across tile boundaries - in the default
+    tile shapes and with the aggregation kernel capped at 64 / 128 columns and the temporal convolution at 256-row tiles: the whole batch against the same
+    motions four at a time (bit for bit) and against the CPU oracle on three motions."""
+    from oracle import stgcn_oracle
+    from regennet_amd.eval import STGCN
+    rng = np.random.Generator(np.random.PCG64(2000 + V + hub))
+    A = _tree_graph(V, hub, rng)
+    sd = synth.make_stgcn_state_dict(A, num_class=13, seed=V)
+    model = STGCN(in_channels=12, num_class=13, num_person=2, num_nodes=V, device="cuda:0")
+    model.engine_options = dict(opts)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model = model.to("cuda:0").eval()
+    x = rng.standard_normal((N, V, 12, T)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    big = model({"output": xd})
+    feats, yhat = big["features"].reshape(N, -1).clone(), big["yhat"].clone()
+    for i in range(0, N, 4):
+        part = model({"output": xd[i:i + 4]})
+        assert torch.equal(part["features"].reshape(-1, feats.shape[1]), feats[i:i + 4]), (i, opts)
+        assert torch.equal(part["yhat"], yhat[i:i + 4]), (i, opts)
+    sel = [0, N // 2, N - 1]
+    ref_f, ref_y = stgcn_oracle.stgcn_forward(sd, x[sel])
+    err = (feats[sel].cpu() - ref_f).abs().max().item()
+    print(f"\n[stgcn many tiles V={V} T={T} N={N} {opts}] max |features - oracle| = {err:.2e} (|ref| max {ref_f.abs().max():.2f})")
+    assert err < 1e-4 * max(1.0, float(ref_f.abs().max())), err
+    assert (yhat[sel].cpu() - ref_y).abs().max().item() < 1e-4 * max(1.0, float(ref_y.abs().max()))
+
+
 @pytest.mark.parametrize("opts", [{"SG_NO_WINDOW": 1}, {"SG_NO_GCN_FUSE": 1}, {"SG_NO_TAIL_FUSE": 1}, {"SG_NO_POLY_TAIL": 1}, {"SG_NO_S2_WINDOW": 1}, {"SG_TCONV_SMALL": 1},
                                   {"SG_GCN_BN": 64}, {"SG_GCN_BN": 64, "SG_GCN_STEP32": 1}, {"SG_NO_WINDOW": 1, "SG_NO_GCN_FUSE": 1, "SG_NO_TAIL_FUSE": 1}])
 def test_stgcn_every_kernel_form_matches_reference(golden, opts):
