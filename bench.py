@@ -47,6 +47,8 @@ def row_check(cfg, sd, a, dev, y, out, seed, lo, plan, fn_name, rows):
         model1.small_batch_rows = 0
     if any(k in plan for k in ("layers", "steps_fused")):
         model1.layers_min_b = 1
+        if a.guided:      # ... and the batch's guided form: a motion per workgroup (k_layers<true, true>) or an evaluation per workgroup and step
+            model1.layers_guided = 2 if "steps_fused" in plan else 0
     fm1 = ClassifierFreeSampleModel(model1) if a.guided else model1
     fn1 = getattr(diffusion1, fn_name)
     worst = 0.0

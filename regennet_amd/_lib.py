@@ -239,6 +239,11 @@ class Engine:
         """Evaluations of at most `rows` token rows run the small-batch (column-split) kernels; -1: default, 0: off."""
         self._ck(self.lib.rgn_set_small_batch_rows(self.h, int(rows)))
 
+    def set_option(self, key, value):
+        """rgn_set_option on the live handle: before finalize any switch; afterwards only the dispatch rules that may change between calls
+        ("LAYERS_GUIDED": 0 an evaluation per workgroup | 1 by batch size | 2 a motion per workgroup | -1 the engine's default)."""
+        self._ck(self.lib.rgn_set_option(self.h, str(key).encode(), int(value)))
+
     def set_layers_min_b(self, samples):
         """Evaluations of at least `samples` samples (<= 64 tokens) run the one-kernel decoder stack (k_layers); -1: default (64)."""
         self._ck(self.lib.rgn_set_layers_min_b(self.h, int(samples)))

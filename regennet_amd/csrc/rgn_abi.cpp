@@ -362,6 +362,16 @@ int rgn_set_option(rgn_handle h, const char* key, int32_t value) {
     return rgn_guard(h, "rgn_set_option", [&]() -> int {
         if (!h) return RGN_ERR_INVALID_ARG;
         if (!key || !*key) return h->fail(RGN_ERR_INVALID_ARG, "rgn_set_option: empty key");
+        if (h->finalized && strcmp(key, "LAYERS_GUIDED") == 0) {   // (a dispatch rule, not a packing decision: may change between calls; captured graphs hold the old form)
+            const int v = value < 0 ? h->layers_guided_default : (value > 2 ? 2 : value);
+            if (v != h->layers_guided) {
+                if (h->stream) RGN_HIP(h, hipStreamSynchronize(h->stream));
+                for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+                h->graphs.clear();
+                h->layers_guided = v;
+            }
+            return RGN_OK;
+        }
         if (h->finalized) return h->fail(RGN_ERR_STATE, "rgn_set_option: the switches select kernels when the weights are packed - set them before rgn_finalize_weights");
         static const char* known[] = {"NO_FUSED_QKV", "BIG_TILE_ROWS", "NO_ROWGEMM", "NO_MLP", "MLP_X3", "NO_QKV_RS", "NO_STEP_FUSION", "LAYERS_MIN_TQ", "LAYERS", "LAYERS_STEPS",
                                       "LAYERS_MIN_B", "LAYERS_GUIDED", "STEP_NO_QUADS", "NO_QKV_LONG", "SB_FUSED_ATTN", "SB_ROWS", "BULK_RESID_LO", "GRAPH_STEPS", "STREAMS", "SB_GRAPH",

@@ -124,7 +124,12 @@ struct rgn_ctx {
     int layers_min_b_default = 64;     // (REGENNET_LAYERS_MIN_B)
     int layers_min_b = 64;             // ... for evaluations of at least this many samples (REGENNET_LAYERS_MIN_B): one workgroup per sample is a latency chain of 8 layers (250-step calls: 114 ms at any B <= 256), the kernel-per-stage form spreads a sample over more CUs (B = 16 / 32 / 48: 110-111 ms; B = 64: 114.4 vs 113.6)
     bool layers_steps = false;         // ... and, unguided, whole runs of sampler steps in ONE launch (k_layers<true>: stack + step boundary per sample; REGENNET_LAYERS_STEPS=0: one k_layers + one k_step per step)
-    bool layers_guided = true;         // ... and guided runs too (a motion's two evaluations in one workgroup; REGENNET_LAYERS_GUIDED=0: k_layers per evaluation + the guided k_step)
+    // ... and guided runs: a MOTION per workgroup (its two evaluations back to back, x0_c parked meanwhile) or an EVALUATION per workgroup per step (k_layers<false>
+    // over the 2 B rows + the guided k_step). The first fills the chip only when B alone does: at 2 B <= #CUs the second runs a step in ONE evaluation's latency
+    // instead of two (cfg3's shape, same box: B = 64 1340 vs 786 motions/s, B = 128 2136 vs 1551; B = 160 1628 vs 1909, B = 256 2226 vs 2392).
+    // LAYERS_GUIDED: 0 never a motion per workgroup | 1 (default) when 2 B > #CUs | 2 always; rgn_set_option accepts it after finalize too (-1: the default again)
+    int layers_guided = 1, layers_guided_default = 1;
+    int num_cus = 256;
     bool skip_embed_out = false;       // (set by run_eval around run_layers while it enqueues a fused step)
     int step_no_quads = 0;             // REGENNET_STEP_NO_QUADS=1 (tests)
     bool qkv_rs = true;                // plain-bf16 phase: k_qkv_attn with register-streamed weights (REGENNET_NO_QKV_RS=1: the DMA-fed loop)

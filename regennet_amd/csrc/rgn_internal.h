@@ -222,7 +222,7 @@ struct LayersArgs {
     //      evaluation (planes rows of sample b) and its unconditional one (rows of sample B + b) run back to back in the same workgroup, the
     //      conditional x0 parked in `park` meanwhile; Bm = B motions; pervec / c0 / h hold both halves, `half` = row distance B * T
     const float* scale; int half; float* park;                // scale[B]; park: >= B * 6 * 4096 floats of scratch
-    // ---- f16 != 0 (steps > 0 only): every 16-bit operand is IEEE fp16 instead of bf16 - the weight planes (same fragment order), c0, and the
+    // ---- f16 != 0: every 16-bit operand is IEEE fp16 instead of bf16 - the weight planes (same fragment order), c0, and the
     //      residual-stream planes h / out (same K32-blocked layout): v_mfma_f32_32x32x16_f16 runs at the bf16 instruction's rate with 2^-12
     //      operand rounding instead of 2^-9 (rgn_set_option "BULK_F16")
     int f16;

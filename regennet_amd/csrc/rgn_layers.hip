@@ -954,17 +954,18 @@ hipError_t configure_layers() {
     if (e == hipSuccess) e = ly_lds(k_layers<true, true>);
     if (e == hipSuccess) e = ly_lds(k_layers<true, false, true>);
     if (e == hipSuccess) e = ly_lds(k_layers<true, true, true>);
+    if (e == hipSuccess) e = ly_lds(k_layers<false, false, true>);
     return e;
 }
 hipError_t launch_layers(const LayersArgs& g, hipStream_t s) {
-    if (g.f16 && g.steps <= 0) return hipErrorInvalidValue;      // fp16 operands: the multi-step forms only (the engine never asks for anything else)
     if (g.steps > 0 && g.scale) {
         if (g.f16) hipLaunchKernelGGL((k_layers<true, true, true>), dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
         else hipLaunchKernelGGL((k_layers<true, true>), dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
     } else if (g.steps > 0) {
         if (g.f16) hipLaunchKernelGGL((k_layers<true, false, true>), dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
         else hipLaunchKernelGGL(k_layers<true>, dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
-    } else hipLaunchKernelGGL(k_layers<false>, dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
+    } else if (g.f16) hipLaunchKernelGGL((k_layers<false, false, true>), dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
+    else hipLaunchKernelGGL(k_layers<false>, dim3(g.Bm), dim3(LY_NTH), LY_LDS, s, g);
     return hipGetLastError();
 }
 

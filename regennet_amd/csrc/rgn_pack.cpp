@@ -363,7 +363,8 @@ int finalize_weights(rgn_ctx* c) {
                           ly_on != 0;
         if (c->layers_fused) RGN_HIP(c, configure_layers());
         { int v; if (opt_get(c, "LAYERS_MIN_B", &v)) c->layers_min_b = c->layers_min_b_default = v < 1 ? 1 : v; }
-        { int v; if (opt_get(c, "LAYERS_GUIDED", &v)) c->layers_guided = v != 0; }
+        { int v; if (opt_get(c, "LAYERS_GUIDED", &v)) c->layers_guided = c->layers_guided_default = v < 0 ? 1 : (v > 2 ? 2 : v); }
+        { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->cfg.device) == hipSuccess && v > 0) c->num_cus = v; }
         c->layers_steps = c->layers_fused && c->step_fused && layers_steps_supported(d, F, c->lin_x.Kp) &&
                           ly_steps != 0;
         c->step_no_quads = opt_flag(c, "STEP_NO_QUADS");

@@ -130,7 +130,8 @@ EvalPlan plan_eval(const rgn_ctx* c, const Dims& dm, bool guided, bool x3, bool 
     }
     p.step_fused = sampling && step_fusable(c, x3, rows);
     p.layers = fast && !x3 && c->layers_fused && dm.Bm >= c->layers_min_b && !h_lo && all_frag(c);
-    p.steps = p.layers && p.step_fused && c->layers_steps && (!guided || (c->layers_guided && c->ffn_hi &&
+    const bool motion_per_wg = c->layers_guided == 2 || (c->layers_guided == 1 && dm.Bm > c->num_cus);   // (rgn_host.h: where a motion per workgroup pays)
+    p.steps = p.layers && p.step_fused && c->layers_steps && (!guided || (motion_per_wg && c->ffn_hi &&
               // the guided form parks a motion's conditional x0 (6 x 4096 floats) in the idle hidden-tensor planes: 2 max_batch Tq ffp bf16
               (size_t)2 * c->cfg.max_batch * c->Tq * align_up((size_t)c->ff, 32) * 2 >= (size_t)dm.B * 6 * 4096 * 4));
     if (p.layers) {
@@ -164,10 +165,10 @@ PrecPlan prec_plan(const rgn_ctx* c, const Dims& dm, bool guided) {
     PrecPlan pp;
     if (c->cfg.precision != RGN_PREC_BF16_X3TAIL) return pp;
     const EvalPlan plain = plan_eval(c, dm, guided, false, true);
-    // (the forms with an fp16 instantiation: the multi-step one-kernel stack, and the kernel-per-stage chain of 150-frame models -
+    // (the forms with an fp16 instantiation: the one-kernel stack - multi-step, or per evaluation in front of k_step - and the kernel-per-stage chain of 150-frame models -
     //  k_qkv_attn_long + k_mlp2 + k_step - and the same chain at <= 64 tokens below the one-kernel stack's batch threshold: k_qkv_attn_rs + k_mlp2 +
     //  k_step - whose planes hand the residual stream from step to step)
-    const bool f16_ok = c->bulk_f16 && (plain.steps || (plain.step_fused && !plain.layers && plain.tail == TF_MLP &&
+    const bool f16_ok = c->bulk_f16 && ((plain.layers && plain.step_fused) || (plain.step_fused && !plain.layers && plain.tail == TF_MLP &&
                                                        (plain.attn == AF_QKV_LONG || (plain.attn == AF_QKV && c->qkv_rs && c->d == 512 && c->L > 0 && c->layers[0].qkv.fr16))));
     pp.n16 = !f16_ok ? 0 : (c->f16_steps >= 0 ? c->f16_steps : F16_STEPS_DEFAULT);
     if (c->x3_tail >= 0) pp.tail = c->x3_tail;
@@ -363,7 +364,8 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
         // stream stays in LDS from the input embedding to the last norm3, only the weights stream (rgn_layers.hip)
         LayersArgs g{};
         g.h = h_p.hi; g.out = h_p.hi; g.rows = h_p.rows; g.Bm = ns;
-        fill_layers_args(c, g, dm, sampling, ccond_rows, s0);
+        fill_layers_args(c, g, dm, sampling, ccond_rows, s0, f16);
+        g.f16 = f16 ? 1 : 0;
         RGN_LAUNCH(c, KC_LAYERS, s, launch_layers(g, s));
         layers_done = true;
     }

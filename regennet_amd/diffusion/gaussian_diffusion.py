@@ -365,7 +365,7 @@ class GaussianDiffusion:
         B, nb, S = int(shape[0]), min(int(shape[0]), max_batch), self.num_timesteps
         ys = {k: (v[:nb].contiguous() if th.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B else (v[:nb] if isinstance(v, (list, tuple)) and len(v) == B else v))
               for k, v in y.items()}
-        saved, self._calibrating, self._last_calibration_dev = (inner.x3_tail, inner._auto_tail, inner.small_batch_rows, getattr(inner, "layers_min_b", None)), True, 0.0
+        saved, self._calibrating, self._last_calibration_dev = (inner.x3_tail, inner._auto_tail, inner.small_batch_rows, getattr(inner, "layers_min_b", None), getattr(inner, "layers_guided", None)), True, 0.0
         # calibrate on the kernels the CALLER's batch will run: the small-batch engine takes evaluations of at most sb token rows
         # (motions x tokens, doubled under guidance; rgn_set_small_batch_rows: the model's setting, else REGENNET_SB_ROWS, else 640)
         eo = getattr(inner, "engine_options", None) or {}      # (a handle's option takes precedence over the environment inside the engine: opt_get)
@@ -379,6 +379,12 @@ class GaussianDiffusion:
         lmb = inner.layers_min_b if getattr(inner, "layers_min_b", None) is not None else int(eo.get("LAYERS_MIN_B", os.environ.get("REGENNET_LAYERS_MIN_B", "64")))
         if int(eo.get("LAYERS", os.environ.get("REGENNET_LAYERS", "1"))) != 0 and B * (2 if inner is not model else 1) >= lmb:
             inner.layers_min_b = 1
+        # ... and, guided, in the caller's guided FORM: the engine runs a motion per workgroup only for batches of more evaluations than the chip has CUs
+        if inner is not model and getattr(inner, "layers_guided", None) is None:
+            dev0 = next(inner.parameters()).device
+            ncu = th.cuda.get_device_properties(dev0).multi_processor_count if dev0.type == "cuda" else 256
+            mode = int(eo.get("LAYERS_GUIDED", os.environ.get("REGENNET_LAYERS_GUIDED", "1")))
+            inner.layers_guided = 2 if (mode == 2 or (mode == 1 and 2 * B > ncu)) else 0
         fn = self.p_sample_loop if sampler == "ddpm" else self.ddim_sample_loop
         kw = dict(clip_denoised=False, model_kwargs={"y": ys}, seed=seed)
         if sampler == "ddim":
@@ -418,7 +424,7 @@ class GaussianDiffusion:
             if chosen == S:
                 self._last_calibration_dev = 0.0      # (no shorter tail passed: the schedule stays uniform split-bf16)
         finally:
-            inner.x3_tail, inner._auto_tail, inner.small_batch_rows, inner.layers_min_b = saved
+            inner.x3_tail, inner._auto_tail, inner.small_batch_rows, inner.layers_min_b, inner.layers_guided = saved
             self._calibrating = False
         return chosen
 

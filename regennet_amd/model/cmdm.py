@@ -146,6 +146,8 @@ class CMDM(nn.Module):
         self.small_batch_rows = kargs.get("small_batch_rows", None)
         # evaluations of at least this many samples run the one-kernel decoder stack (k_layers; None: engine default 64, 1: always)
         self.layers_min_b = kargs.get("layers_min_b", None)
+        # guided sampling on the one-kernel stack: a motion per workgroup (2) or an evaluation per workgroup and step (0); None: the engine's rule (by batch size)
+        self.layers_guided = kargs.get("layers_guided", None)
         # kernel-selection switches handed to every engine this model builds (rgn_set_option: {"LAYERS": 0, "STREAMS": 1, ...}); changing the
         # dict takes effect for engines built afterwards (model._engine_stale = True rebuilds)
         self.engine_options = dict(kargs.get("engine_options", None) or {})
@@ -247,6 +249,7 @@ class CMDM(nn.Module):
         eng.set_f16_steps(-1 if self.f16_steps is None else int(self.f16_steps))
         eng.set_small_batch_rows(-1 if self.small_batch_rows is None else int(self.small_batch_rows))
         eng.set_layers_min_b(-1 if self.layers_min_b is None else int(self.layers_min_b))
+        eng.set_option("LAYERS_GUIDED", -1 if self.layers_guided is None else int(self.layers_guided))
         return eng, dev
 
     def _rgn_bind(self, B, y, device=None, guided=False, T=None, cache=False):

@@ -53,7 +53,8 @@ def test_direct_to_lds_loads_find_their_m0_in_the_isa():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_m0.py"), "rgn_layers.hip"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "60 direct-to-LDS loads checked, 0 problem(s)" in r.stdout, r.stdout
+    m = re.search(r"(\d+) direct-to-LDS loads checked, 0 problem\(s\)", r.stdout)
+    assert m and int(m.group(1)) >= 60, r.stdout                          # (8 - 16 per instantiation of k_layers)
 
 
 def test_null_and_bad_arguments_return_status_codes():

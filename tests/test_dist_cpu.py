@@ -102,6 +102,9 @@ class FakeEngine:
     def set_f16_steps(self, n):
         self.knobs = dict(getattr(self, "knobs", {}), f16_steps=int(n))
 
+    def set_option(self, key, value):
+        self.options = dict(getattr(self, "options", {}), **{key: int(value)})
+
     def set_const_noise(self, on):
         self.const_noise = bool(on)
 

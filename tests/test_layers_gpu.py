@@ -11,7 +11,7 @@ from tests.helpers import build_hip, fixture_inputs, y_to_device
 pytestmark = pytest.mark.gpu
 
 # per evaluation: k_layers<false> + k_step / k_update per step; whole runs: k_layers<true> (unguided, no emb_trans_dec token)
-FORMS = {"per-step": {"REGENNET_LAYERS_MIN_B": "1", "REGENNET_LAYERS_STEPS": "0"}, "multi-step": {"REGENNET_LAYERS_MIN_B": "1"},   # (guided: a motion per workgroup)
+FORMS = {"per-step": {"REGENNET_LAYERS_MIN_B": "1", "REGENNET_LAYERS_STEPS": "0"}, "multi-step": {"REGENNET_LAYERS_MIN_B": "1", "REGENNET_LAYERS_GUIDED": "2"},   # (guided: a motion per workgroup - forced: the engine's rule takes it only for 2 B > #CUs)
          "kernel-per-stage": {"REGENNET_LAYERS": "0"}}
 
 
@@ -221,3 +221,57 @@ def test_headline_launch_shape_against_the_oracle_on_a_100_step_schedule():
     print(f"\n[headline launch shape, 95 + 5 steps, B = 256, on-device Philox] every 16th motion vs oracle: {err:.2e}")
     assert err < 1e-3, err
     model._engine.close()
+
+
+def test_guided_batches_that_do_not_fill_the_chip_run_an_evaluation_per_workgroup():
+    """Guided sampling on the one-kernel stack has two forms: a MOTION per workgroup (k_layers<true, true>: its two evaluations back to back inside
+    whole runs of steps) and an EVALUATION per workgroup and step (k_layers<false> over the 2 B rows + the guided k_step, hipGraph replays). The first
+    fills the chip only when B alone does; at 2 B <= #CUs the second runs a step in one evaluation's latency instead of two (cfg3's shape at B = 64:
+    1340 vs 786 motions/s same-box), so the engine picks by batch size (rgn_host.h; LAYERS_GUIDED = 0 / 1 / 2, settable per call). Checked: the plan
+    the engine reports for B = 64 and B = 256, the three-phase precision plan on both, B = 64 against the ORACLE on the kernels' own Philox draws,
+    rows against single-motion runs of the same form, and the two forms against each other.
+    Reference: model/cfg_sampler.py:24-31, utils/parser_util.py:95 (--batch_size 64)."""
+    from oracle import regennet_oracle as orc
+    from regennet_amd import synth
+    from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    cfg = synth.get_config("ntu_action")
+    sd = synth.make_state_dict(cfg, seed=0)
+    B, S, seed = 64, 20, 91
+    y = {"cmotion": synth.make_cmotion(cfg, B, seed=71), "action": synth.make_actions(cfg, B, seed=72), "scale": np.full((B,), 2.5, np.float32)}
+    model, diffusion = synth.build_model(cfg, sd, resp="ddim20", precision="bf16_x3tail", device="cuda:0")
+    fm = ClassifierFreeSampleModel(model)
+    shape = (B, 56, 6, 60)
+    out = diffusion.ddim_sample_loop(fm, shape, clip_denoised=False, model_kwargs={"y": y_to_device(y)}, seed=seed)
+    eng = model._engine
+    plan = eng.plan_query(B, guided=True)
+    assert plan.get("layers", {}).get("kernel") == "k_layers<false>" and plan["step_fused"]["kernel"] == "k_step<guided>" and "steps_fused" not in plan, plan
+    assert eng.precision_plan(B, True) == (8, 2)
+    assert "steps_fused" in eng.plan_query(256, guided=True) if eng.max_batch >= 256 else True
+    # against the oracle on the very noise the kernels drew
+    idx = np.arange(0, B, 8)
+    st = torch.cuda.current_stream().cuda_stream
+    buf = torch.empty(shape, device="cuda")
+    tape = np.empty((S + 1, len(idx)) + shape[1:], dtype=np.float32)
+    for k, loop_index in enumerate([-1] + list(range(S - 1, -1, -1))):
+        eng.randn_step(buf, B, seed, 0, loop_index, st)
+        tape[k] = buf[idx].cpu().numpy()
+    ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", "ddim20"), tape, {k: torch.from_numpy(np.ascontiguousarray(v[idx])) for k, v in y.items()},
+                          mode="ddim", guided=True).numpy()
+    err = float(np.abs(out.cpu().numpy()[idx] - ref).max())
+    # rows against single-motion runs of the same form (LAYERS_MIN_B = 1, an evaluation per workgroup), and the other form on the whole batch
+    model1, diffusion1 = build_hip(cfg, sd, resp="ddim20", precision="bf16_x3tail/throughput", engine_options={"LAYERS_MIN_B": 1})
+    model1.layers_guided = 0
+    fm1 = ClassifierFreeSampleModel(model1)
+    worst = 0.0
+    for b in (0, 31, 63):
+        yb = {k: torch.from_numpy(v[b:b + 1]).cuda() for k, v in y.items()}
+        one = diffusion1.ddim_sample_loop(fm1, (1, 56, 6, 60), clip_denoised=False, model_kwargs={"y": yb}, seed=seed, sample_offset=b)
+        worst = max(worst, float((one - out[b:b + 1]).abs().max()))
+    model.layers_guided = 2
+    other = diffusion.ddim_sample_loop(fm, shape, clip_denoised=False, model_kwargs={"y": y_to_device(y)}, seed=seed)
+    assert "steps_fused" in eng.plan_query(B, guided=True)
+    dev = float((other - out).abs().max())
+    print(f"\n[guided B = 64, ddim20] evaluation per workgroup vs oracle {err:.2e}; rows vs single-motion runs {worst:.1e}; vs a motion per workgroup {dev:.2e}")
+    assert err < 1e-3 and worst <= 2e-5 and dev < 5e-4, (err, worst, dev)
+    model._engine.close()
+    model1._engine.close()
