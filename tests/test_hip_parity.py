@@ -1325,11 +1325,12 @@ def test_per_handle_kernel_switches():
 
 
 @pytest.mark.parametrize("cfg_name,B,guided,opts", [("ntu", 64, False, {}), ("ntu", 64, False, {"LAYERS_STEPS": 0}), ("ntu", 64, False, {"LAYERS": 0}),
-                                                  ("ntu_action", 64, True, {}), ("chi3d", 8, False, {}), ("ntu", 4, False, {})])
+                                                  ("ntu_action", 64, True, {}), ("ntu_action", 64, True, {"LAYERS_GUIDED": 2}), ("chi3d", 8, False, {}), ("ntu", 4, False, {})])
 def test_the_reported_plan_is_what_the_engine_launches(cfg_name, B, guided, opts):
     """rgn_plan_query (what bench.py prices) against rgn_profile_query (what was launched): one eager, profiled, plain-bf16 sampling step per
     configuration - the kernel classes with launches and their launch counts per evaluation must agree with the plan, for the one-kernel stack, its
-    per-step form, the kernel-per-stage chain, guidance, 150 frames and the small-batch engine."""
+    per-step form, the kernel-per-stage chain, guidance (an evaluation per workgroup: the engine's choice at 2 B <= #CUs; a motion per workgroup: forced),
+    150 frames and the small-batch engine."""
     from regennet_amd import synth
     cfg = synth.get_config(cfg_name)
     sd = synth.make_state_dict(cfg, seed=0)

@@ -1,2 +1,3 @@
 mkdir -p gpurun_out/r06
-for B in 128 160 256; do python bench.py --config ntu_action --sampler ddim --respacing ddim100 --guided --batch $B --no-cpu-baseline --profile-evals 0 --steps 3 --warmup 1 2>/dev/null | python -c "import sys, json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cfg3 shape B=$B engine rule', d['value'], 'motions/s', d['ms_per_step'], 'ms per call, row check', d['headline_row_check_max_abs'])"; done | tee -a gpurun_out/r06/layers_guided_sweep2.txt
+python -m pytest tests -q -m gpu 2>&1 | grep -v amdgpu.ids | tail -25 > gpurun_out/r06/gpu_suite_full2.txt; tail -8 gpurun_out/r06/gpu_suite_full2.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep smoke | tee gpurun_out/r06/smoke.txt
