@@ -52,16 +52,17 @@ class STGCN(nn.Module):
         self.edge_importance = nn.ParameterList([nn.Parameter(torch.ones(K, V, V)) for _ in _BLOCKS])
         self.fcn = nn.Conv2d(256, num_class, kernel_size=1)
         self._engine, self._stale, self._applied_options = None, True, {}
+        self._stale_person = {}
         self.engine_options = {}                  # kernel-selection switches for this model's engine (rgn_stgcn_set_option; tools and tests)
         for p in self.parameters():
             p.requires_grad_(False)
 
     def load_state_dict(self, state_dict, strict=True):
-        self._stale = True
+        self._stale, self._stale_person = True, {}
         return super().load_state_dict(state_dict, strict=strict)
 
     def _apply(self, fn, *a, **k):
-        self._stale = True
+        self._stale, self._stale_person = True, {}
         return super()._apply(fn, *a, **k)
 
     def _get_engine(self, N, T):
@@ -109,6 +110,50 @@ class STGCN(nn.Module):
         batch["features"] = feats.squeeze()
         batch["yhat"] = yhat
         return batch
+
+    # ---- per-person evaluation (not in the reference: an evaluation loop that shows the recogniser the SAME actor clip again and again - every
+    #      repetition / seed of eval/a2m/stgcn/evaluate.py re-samples the reactor for the same actors - can keep the actor's half) -------------------
+    def person_features(self, x, person=0):
+        """Pooled features [N, 256] of ONE person's motion x [N, V, C, T] (slot `person` of batch['output']'s channel axis): stgcn.py:96-113 for that
+        person alone. In eval mode the persons of a clip never meet before the final mean (data_bn is a per-channel affine, every st_gcn block runs
+        on the (N M) sequences independently, stgcn.py:99-114), so `features_from_persons` reproduces `forward` from per-person results."""
+        N, V, C, T = x.shape
+        M = self.num_person
+        assert (V, C * M) == (self.A.shape[1], self.in_channels) and 0 <= person < M, f"x {tuple(x.shape)} is not one person of this model's input"
+        dev = self.A.device
+        if dev.type != "cuda":
+            raise RuntimeError("regennet_amd STGCN runs on an AMD GPU only: call model.to(device) first (no CPU fallback)")
+        engs = self.__dict__.setdefault("_person_engines", {})
+        eng = engs.get(person)
+        if eng is None or self._stale_person.get(person, True) or N > eng.max_batch or eng.shape != (V, C, T):
+            if eng is not None:
+                torch.cuda.synchronize(dev)
+                eng.close()
+            eng = _lib.StgcnEngine(C, self.num_class, 1, V, T, max(N, eng.max_batch if eng and eng.shape == (V, C, T) else 0), dev.index or 0, options=self.engine_options)
+            lo, hi = person * V * C, (person + 1) * V * C               # BatchNorm1d channel (m V + v) C + c (stgcn.py:96-101): person m's slice
+            for k, v in self.state_dict().items():
+                if k.endswith("num_batches_tracked"):
+                    continue
+                if k.startswith("data_bn."):
+                    v = v[lo:hi]
+                eng.load_weight(k, v.detach().float().cpu().numpy())
+            eng.finalize()
+            engs[person] = eng
+            self._stale_person[person] = False
+        xc = x.to(device=dev, dtype=torch.float32).contiguous()
+        feats = torch.empty(N, 256, device=dev)
+        eng.forward(N, xc, feats, None, torch.cuda.current_stream(dev).cuda_stream)
+        return feats
+
+    def features_from_persons(self, persons):
+        """`persons`: one entry per person slot, each either that person's motion [N, V, C, T] (evaluated now) or its pooled features [N, 256] from an
+        earlier `person_features` call (reused). Returns {'features', 'yhat'} as `forward` does for the concatenated clip: the mean over the persons
+        (stgcn.py:114) and the 256 -> classes layer (stgcn.py:117-119)."""
+        assert len(persons) == self.num_person
+        fs = [p if p.dim() == 2 else self.person_features(p, m) for m, p in enumerate(persons)]
+        f = torch.stack(fs).mean(dim=0)
+        w = self.fcn.weight.reshape(self.num_class, 256).to(f.device)
+        return {"features": f.squeeze(), "yhat": f @ w.t() + self.fcn.bias.to(f.device)}
 
     def compute_accuracy(self, batch):
         """stgcn.py:125-132."""

@@ -159,6 +159,31 @@ def test_stgcn_many_tiles_per_workgroup(golden, T, N):
     assert (yhat[sel].cpu() - ref_y).abs().max().item() < 1e-4 * max(1.0, float(ref_y.abs().max()))
 
 
+def test_stgcn_per_person_features_reproduce_the_two_person_forward(golden):
+    """The persons of a clip never meet before the final mean (eval-mode data_bn is a per-channel affine, the st_gcn blocks run on the N M sequences
+    independently, stgcn.py:99-114): the actor's pooled features can be computed once and reused for every re-sampled reactor of the same actor clip
+    (each repetition / seed of evaluate.py). `person_features` + `features_from_persons` against `forward` on the reference's golden input, and against
+    the reference's own features: same bound as the two-person forward."""
+    g = golden("stgcn")
+    model, sd = _model(g)
+    x = torch.from_numpy(g["x_ntu"]).cuda()
+    C = x.shape[2] // 2
+    full = model({"output": x})
+    fa = model.person_features(x[:, :, :C], person=0)                       # the actor half, once
+    two = model.features_from_persons([fa, x[:, :, C:].contiguous()])       # ... reused; the reactor half evaluated now
+    both = model.features_from_persons([x[:, :, :C].contiguous(), x[:, :, C:].contiguous()])
+    ref = torch.from_numpy(g["features_ntu"]).reshape(x.shape[0], -1)
+    scale = max(1.0, float(ref.abs().max()))
+    d_full = float((two["features"].reshape(ref.shape) - full["features"].reshape(ref.shape)).abs().max())
+    d_ref = float((two["features"].reshape(ref.shape).cpu() - ref).abs().max())
+    print(f"\n[stgcn per person] cached actor + reactor vs two-person forward {d_full:.2e}, vs the reference {d_ref:.2e} (|ref| max {scale:.1f})")
+    assert torch.equal(two["features"], both["features"]) and d_full < 2e-6 * scale and d_ref < 1e-4 * scale
+    assert float((two["yhat"] - full["yhat"]).abs().max()) < 1e-5 * max(1.0, float(full["yhat"].abs().max()))
+    assert torch.equal(two["yhat"].argmax(1), full["yhat"].argmax(1))
+    with pytest.raises(AssertionError):
+        model.person_features(x, person=0)                                  # (a two-person clip is not one person)
+
+
 def test_stgcn_batching_and_errors(golden):
     """A batch evaluated at once equals its samples evaluated one by one (rows are independent); a checkpoint with a
     missing key is refused with the key named."""
