@@ -78,6 +78,19 @@ class Evaluation:
                 labels.append(torch.as_tensor(batch["y"]).to(activations[-1].device))
         return torch.cat(activations, dim=0), torch.cat(labels, dim=0)
 
+    def compute_features_and_accuracy(self, motionloader):
+        """evaluate.py:41-52 and accuracy.py:4-14 from one forward per batch: (activations [N, 256], labels [N], accuracy)."""
+        activations, labels = [], []
+        confusion = torch.zeros(self.num_classes, self.num_classes, dtype=torch.long)
+        with torch.no_grad():
+            for batch in motionloader:
+                out = self.model(batch)
+                activations.append(out["features"].reshape(-1, 256))
+                y = torch.as_tensor(batch["y"])
+                labels.append(y.to(activations[-1].device))
+                confusion.index_put_((y.cpu().long(), out["yhat"].max(dim=1).indices.cpu()), torch.ones_like(y.cpu().long()), accumulate=True)
+        return torch.cat(activations, dim=0), torch.cat(labels, dim=0), (torch.trace(confusion) / torch.sum(confusion)).item()
+
     @staticmethod
     def calculate_activation_statistics(activations):
         from .fid import calculate_activation_statistics
@@ -89,8 +102,9 @@ class Evaluation:
             computedfeats, metrics = {}, {}
             for key, loader_sets in loaders.items():
                 loader = loader_sets[sets]
-                metrics[f"accuracy_{key}"], _ = calculate_accuracy(model, loader, self.num_classes, self.model, self.device)
-                feats, labels = self.compute_features(model, loader)
+                # ONE pass of the recogniser per loader: the reference runs it twice over the same batches - once for yhat (accuracy.py:4-14), once for
+                # the features (evaluate.py:41-52) - and both come out of the same forward
+                feats, labels, metrics[f"accuracy_{key}"] = self.compute_features_and_accuracy(loader)
                 computedfeats[key] = {"feats": feats, "labels": labels, "stats": self.calculate_activation_statistics(feats)}
                 ret = calculate_diversity_multimodality(feats, labels, self.num_classes, seed=self.seed,
                                                         unconstrained=(getattr(model, "cond_mode", None) == "no_cond"))

@@ -235,8 +235,8 @@ def test_fid_on_device(golden):
 
 
 def test_evaluation_pipeline_end_to_end(golden):
-    """Evaluation.evaluate (evaluate.py:55-124) over synthetic 'gt' and 'gen' loaders: every metric is produced and the
-    ground truth's FID against itself is zero."""
+    """Evaluation.evaluate (evaluate.py:55-124) over synthetic 'gt' and 'gen' loaders: every metric is produced, the
+    ground truth's FID against itself is zero, the accuracies equal those of the reference-shaped two-pass `calculate_accuracy`."""
     from regennet_amd.eval import Evaluation
     g = golden("stgcn")
     sd = synth.make_stgcn_state_dict(g["A"], num_class=26, seed=0)
@@ -249,7 +249,11 @@ def test_evaluation_pipeline_end_to_end(golden):
                  "y": torch.from_numpy(rng.integers(0, 26, 16))} for _ in range(3)]
 
     loaders = {"gt": {"train": loader(0.0), "test": loader(0.0)}, "gen": {"train": loader(0.3), "test": loader(0.3)}}
+    calls, fwd = [], ev.model.forward
+    ev.model.forward = lambda b: (calls.append(1), fwd(b))[1]
     m = ev.evaluate(type("M", (), {"cond_mode": "action"})(), loaders, "cmdm")
+    ev.model.forward = fwd
+    assert len(calls) == 12          # ONE recogniser forward per batch (4 loaders x 3 batches): accuracy and features share it (the reference runs two)
     for sets in ("train", "test"):
         assert abs(m[f"fid_gt_{sets}"]) < 1e-6 and m[f"fid_gen_{sets}"] > 0
         for key in ("accuracy", "diversity", "multimodality"):
