@@ -33,7 +33,7 @@ import torch.distributed as dist  # noqa: E402
 
 # minimal algorithmic work of ONE denoiser evaluation for ONE sample (FLOP = 2*MAC)
 ALGO_GFLOP_PER_EVAL = {("ntu", "concat"): 2.154, ("ntu", "add"): 2.123, ("chi3d", "concat"): 5.593, ("chi3d", "add"): 5.514}
-PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "bf16_x3tail": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "bf16_x3tail": 2500.0, "f16": 2500.0}   # MI355X_MICROARCH.md dense MFMA peaks
 
 
 def row_check(cfg, sd, a, dev, y, out, seed, lo, plan, fn_name, rows):
@@ -85,6 +85,13 @@ def bench_stgcn(a):
     model = STGCN(in_channels=M * C, num_class=26, num_person=M, graph_args={"layout": "smplx", "strategy": "spatial"}, device=str(dev))
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     model.to(dev).eval()
+    ref_model = None
+    if a.recogniser_f16:
+        # the fp16 form next to the default arithmetic: same checkpoint, same input, feature / logit differences reported with the line
+        ref_model = STGCN(in_channels=M * C, num_class=26, num_person=M, graph_args={"layout": "smplx", "strategy": "spatial"}, device=str(dev))
+        ref_model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        ref_model.to(dev).eval()
+        model.engine_options["SG_F16"] = 1
     blocks = [(C, 64, 1, False), (64, 64, 1, False), (64, 64, 1, False), (64, 64, 1, False), (64, 128, 2, True), (128, 128, 1, False),
               (128, 128, 1, False), (128, 256, 2, True), (256, 256, 1, False), (256, 256, 1, False)]
     lines = []
@@ -115,16 +122,25 @@ def bench_stgcn(a):
         dt = time.perf_counter() - t0
         ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
         tf = flops / (ms * 1e-3) / 1e12
+        vs_x3 = None
+        if ref_model is not None:
+            o16, o3 = model({"output": x}), ref_model({"output": x})
+            f16_, f3 = o16["features"].reshape(N, -1), o3["features"].reshape(N, -1)
+            vs_x3 = {"features_max_abs": float((f16_ - f3).abs().max()), "features_abs_max_of_default": float(f3.abs().max()),
+                     "features_rms_rel": float(((f16_ - f3).pow(2).mean() / f3.pow(2).mean()).sqrt()), "logits_max_abs": float((o16["yhat"] - o3["yhat"]).abs().max()),
+                     "argmax_agree": float((o16["yhat"].argmax(1) == o3["yhat"].argmax(1)).float().mean())}
         lines.append({"T": T, "N": N, "ms_per_forward": round(ms, 3), "wall_ms_per_forward": round(1e3 * dt / a.steps, 3),
                       "motions_per_s": round(N / (ms * 1e-3), 1), "algo_gflop_per_forward": round(flops / 1e9, 2),
-                      "gflop_per_forward_dense_aggregation": round(flops_dense / 1e9, 2),
+                      "gflop_per_forward_dense_aggregation": round(flops_dense / 1e9, 2), **({"fp16_form_vs_default_arithmetic": vs_x3} if vs_x3 else {}),
                       "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_TFLOPS["bf16x3"], "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS["bf16x3"], 4),
-                                   "traffic": None, "note": "FLOPs of one forward (all its launches; graph aggregation counted over the adjacency's nonzeros, as executed - the dense reference count "
+                                   "traffic": None, "note": ("SG_F16: ONE fp16 MFMA per product in blocks 1-9 (ceiling for algorithmic FLOPs = peak); otherwise as the default's note: " if a.recogniser_f16 else "") +
+                                                            "FLOPs of one forward (all its launches; graph aggregation counted over the adjacency's nonzeros, as executed - the dense reference count "
                                                             "is gflop_per_forward_dense_aggregation) / its duration; split-bf16 GEMMs: three MFMAs per product, "
                                                             "ceiling for algorithmic FLOPs = peak / 3; the 4 shared zero pad frames per sequence are computed too (not counted)"}})
     print(json.dumps({"metric": "ST-GCN recogniser forward (evaluation harness, SURVEY 8f next-4)", "value": lines[0]["motions_per_s"], "unit": "motions/s",
                       "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": lines[0]["ms_per_forward"], "higher_is_better": True,
-                      "scaling": "weak", "vs_baseline": None, "dtype": "split-bf16 (x3) MFMA, fp32 accumulate", "data": "synthetic", "config": {"workload": f"stgcn: N={a.batch} x [56, 12, 60 | 150]"},
+                      "scaling": "weak", "vs_baseline": None, "dtype": "fp16 MFMA (block 0's graph convolution split-bf16), fp32 accumulate" if a.recogniser_f16 else "split-bf16 (x3) MFMA, fp32 accumulate",
+                      "data": "synthetic", "config": {"workload": f"stgcn: N={a.batch} x [56, 12, 60 | 150]" + (" (SG_F16)" if a.recogniser_f16 else "")},
                       "roofline": lines[0]["roofline"], "per_length": lines}), flush=True)
 
 
@@ -143,6 +159,8 @@ def bench_eval_pipeline(a):
     rec = STGCN(in_channels=12, num_class=26, num_person=2, graph_args={"layout": "smplx", "strategy": "spatial"}, device=str(dev))
     rec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_stgcn_state_dict(A, num_class=26, seed=0).items()}, strict=True)
     rec.to(dev).eval()
+    if a.recogniser_f16:
+        rec.engine_options["SG_F16"] = 1
     B = a.batch
     y = {"cmotion": torch.from_numpy(synth.make_cmotion(cfg, B, seed=1)).to(dev), "action": torch.from_numpy(synth.make_actions(cfg, B, seed=2)).to(dev)}
     shape = (B, 56, 6, 60)
@@ -199,7 +217,7 @@ def bench_eval_pipeline(a):
     ms_s = float(np.mean([e[0].elapsed_time(e[1]) for e in evs])), float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
     print(json.dumps({"metric": "evaluation batches of eval_cmdm's hot loop (sample ddim5 + ST-GCN features)", "value": round(a.steps * B / dt, 1), "unit": "motions/s", "n_gpus": 1,
                       "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                      "dtype": "sampler: bf16 / split-bf16 schedule; recogniser: split-bf16", "data": "synthetic",
+                      "dtype": "sampler: bf16 / fp16 / split-bf16 schedule; recogniser: " + ("fp16 (SG_F16)" if a.recogniser_f16 else "split-bf16"), "data": "synthetic",
                       "config": {"workload": f"ntu_action B={B}: p_sample_loop(ddim5) -> cat(cmotion, sample) -> STGCN features; FID statistics over {a.steps * B} motions once"},
                       "actor_features_cached": {"ms_per_step": round(1e3 * dtc / a.steps, 3), "motions_per_s": round(a.steps * B / dtc, 1),
                                                 "recogniser_ms": round(float(np.mean([e[1].elapsed_time(e[2]) for e in evc])), 3),
@@ -300,6 +318,8 @@ def main(argv=None):
     ap.add_argument("--f16-steps", type=int, default=None,
                     help="precision schedule: fp16 MFMA operands for the N plain steps in front of the split-bf16 tail (default: the engine's 8 where the one-kernel "
                          "decoder stack runs the plain phase; 0: none, and the bf16 rule's tail)")
+    ap.add_argument("--recogniser-f16", action="store_true",
+                    help="--config stgcn / eval_pipeline: the recogniser on single fp16 operand planes (SG_F16: one MFMA per product instead of the split-bf16 three)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", default=bool(os.environ.get("REGENNET_FORCE_DIST")),

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libregennet_hip.so")
 
 RGN_OK = 0
+RGN_ERR_UNSUPPORTED = -7
 ERR_NAMES = {-1: "INVALID_ARG", -2: "BAD_KEY", -3: "BAD_SHAPE", -4: "MISSING_KEY", -5: "STATE", -6: "HIP", -7: "UNSUPPORTED", -8: "INTERNAL"}
 CM = {"add": 0, "concat": 1}
 COND = {"no_cond": 0, "action": 1, "text": 2}

@@ -99,6 +99,8 @@ struct GemmX3Args {
     // the 256-channel blocks fetched 32 GB per forward over the fabric (L2 hit rate 0.61). The addend row is (row % add_mod) when add_mod > 0; act 3 = ReLU
     int a_taps, add_mod;
     long long a_tap[9];
+    int f16;                                            // launch_sg_gcn / launch_sg_tconv(_s2) only: the single-plane fp16 form (rgn_sg_kernels.hip) - Ahi, Whi, Rhi,
+                                                        // A2hi, W2hi and Chi hold IEEE fp16, the lo pointers are not used
 };
 
 // Split-bf16 activation planes in the K32-blocked layout; hi == nullptr means "not requested".

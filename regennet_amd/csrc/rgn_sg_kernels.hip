@@ -17,6 +17,12 @@ namespace rgn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// F16 (every kernel of this file): the SINGLE-PLANE fp16 form - the hi planes of activations, residual, weights and output hold IEEE fp16, the lo planes
+// are neither read nor written (their LDS images stay unused), one v_mfma_f32_32x32x16_f16 per product instead of three bf16 ones: 2^-12 per operand
+// instead of ~2^-16 per product at a third of the matrix work and half the bytes (rgn_stgcn.hip: SG_F16).
+__device__ __forceinline__ float f16_bits_to_float(unsigned b) { return (float)__builtin_bit_cast(_Float16, (unsigned short)b); }
 
 #define RGN_AS1 __attribute__((address_space(1)))
 #define RGN_AS3 __attribute__((address_space(3)))
@@ -35,7 +41,7 @@ __device__ __forceinline__ void wait_vmcnt() {   // at most N vector-memory oper
 // What a 32 x 32 tile needs from memory is requested one tile AHEAD of its use: vmcnt retires in order, so a load queued behind the previous tile's
 // stores would wait for their acknowledgements - 2 TM TN round trips to memory per workgroup tile in x3_epilogue's order.
 enum { SGE_VERTEX_BIAS = 1, SGE_RELU = 2, SGE_PLANES = 4, SGE_RES_PLANES = 8, SGE_POLY = 16 };
-template <int TM, int TN, bool CHECK, int MODE>
+template <int TM, int TN, bool CHECK, int MODE, bool F16 = false>
 __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[TM][TN], int mw, int nw, int lane) {
     const int l31 = lane & 31, kh = lane >> 5;
     const bool odd = lane & 1;
@@ -61,7 +67,7 @@ __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
                 const int ii = odd ? i + 8 : i, ro = (ii & 3) + 8 * (ii >> 2);
                 const bool ok = !CHECK || (n_ok && mb + ro < g.M);
                 f[i] = ok ? *reinterpret_cast<const unsigned*>(g.Rhi + o + ro * 32) : 0u;
-                f[8 + i] = ok ? *reinterpret_cast<const unsigned*>(g.Rlo + o + ro * 32) : 0u;
+                if constexpr (!F16) f[8 + i] = ok ? *reinterpret_cast<const unsigned*>(g.Rlo + o + ro * 32) : 0u;
             }
         } else {
             f[0] = (g.bias && n_ok) ? __builtin_bit_cast(unsigned, g.bias[n]) : 0u;
@@ -83,11 +89,19 @@ __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 // the partner lane (lane ^ 1) holds this column's values for the other eight rows
-                const unsigned ph = nxt[i], pl = nxt[8 + i];
-                const unsigned qh = (unsigned)__builtin_amdgcn_mov_dpp((int)ph, 0xB1, 0xf, 0xf, true), ql = (unsigned)__builtin_amdgcn_mov_dpp((int)pl, 0xB1, 0xf, 0xf, true);
-                const unsigned mh = odd ? (ph & 0xffff0000u) : (ph << 16), ml = odd ? (pl & 0xffff0000u) : (pl << 16);   // own rows: register ii = odd ? i + 8 : i
-                const unsigned oh = odd ? (qh & 0xffff0000u) : (qh << 16), ol = odd ? (ql & 0xffff0000u) : (ql << 16);   // the partner's rows
-                const float mine = __builtin_bit_cast(float, mh) + __builtin_bit_cast(float, ml), other = __builtin_bit_cast(float, oh) + __builtin_bit_cast(float, ol);
+                float mine, other;
+                if constexpr (F16) {
+                    const unsigned ph = nxt[i], qh = (unsigned)__builtin_amdgcn_mov_dpp((int)ph, 0xB1, 0xf, 0xf, true);
+                    mine = f16_bits_to_float(odd ? (ph >> 16) : (ph & 0xffffu));
+                    other = f16_bits_to_float(odd ? (qh >> 16) : (qh & 0xffffu));
+                } else {
+                    const unsigned ph = nxt[i], pl = nxt[8 + i];
+                    const unsigned qh = (unsigned)__builtin_amdgcn_mov_dpp((int)ph, 0xB1, 0xf, 0xf, true), ql = (unsigned)__builtin_amdgcn_mov_dpp((int)pl, 0xB1, 0xf, 0xf, true);
+                    const unsigned mh = odd ? (ph & 0xffff0000u) : (ph << 16), ml = odd ? (pl & 0xffff0000u) : (pl << 16);   // own rows: register ii = odd ? i + 8 : i
+                    const unsigned oh = odd ? (qh & 0xffff0000u) : (qh << 16), ol = odd ? (ql & 0xffff0000u) : (ql << 16);   // the partner's rows
+                    mine = __builtin_bit_cast(float, mh) + __builtin_bit_cast(float, ml);
+                    other = __builtin_bit_cast(float, oh) + __builtin_bit_cast(float, ol);
+                }
                 r[i] = (acc[ta][tb][i] + b) + (odd ? other : mine);          // (static register indices: a lane-dependent index is a 16-way select chain)
                 r[i + 8] = (acc[ta][tb][i + 8] + b) + (odd ? mine : other);
             }
@@ -125,11 +139,16 @@ __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
                 if (t >= Tp) { t -= Tp; ++nm; }
                 if (t < Tr && (!CHECK || mb + ro < g.M)) {
                     const size_t o = (cb + (size_t)(t & 1) * g.poly_region + ((size_t)nm * Tpo + (t >> 1)) * Vv + v) * 32 + (n & 30);
-                    const __bf16 h0 = (__bf16)c0, h1 = (__bf16)c1;
-                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                    bf16x2 hv = {h0, h1}, lv = {(__bf16)(c0 - (float)h0), (__bf16)(c1 - (float)h1)};
-                    *reinterpret_cast<bf16x2*>(g.Chi + o) = hv;
-                    *reinterpret_cast<bf16x2*>(g.Clo + o) = lv;
+                    if constexpr (F16) {
+                        f16x2 hv = {(_Float16)c0, (_Float16)c1};
+                        *reinterpret_cast<f16x2*>(g.Chi + o) = hv;
+                    } else {
+                        const __bf16 h0 = (__bf16)c0, h1 = (__bf16)c1;
+                        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                        bf16x2 hv = {h0, h1}, lv = {(__bf16)(c0 - (float)h0), (__bf16)(c1 - (float)h1)};
+                        *reinterpret_cast<bf16x2*>(g.Chi + o) = hv;
+                        *reinterpret_cast<bf16x2*>(g.Clo + o) = lv;
+                    }
                 }
             }
         } else if constexpr (!CHECK) {   // K32-blocked planes [N/32][c_rows][32]: a 32-column tile is one contiguous run of rows
@@ -141,11 +160,16 @@ __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
                 const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xf, 0xf, true));   // lane ^ 1
                 const float c0 = odd ? got : mine, c1 = odd ? mine : got;
                 const int ii = odd ? i + 8 : i, ro = (ii & 3) + 8 * (ii >> 2);
-                const __bf16 h0 = (__bf16)c0, h1 = (__bf16)c1;
-                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                bf16x2 hv = {h0, h1}, lv = {(__bf16)(c0 - (float)h0), (__bf16)(c1 - (float)h1)};
-                *reinterpret_cast<bf16x2*>(g.Chi + o + ro * 32) = hv;
-                *reinterpret_cast<bf16x2*>(g.Clo + o + ro * 32) = lv;
+                if constexpr (F16) {
+                    f16x2 hv = {(_Float16)c0, (_Float16)c1};
+                    *reinterpret_cast<f16x2*>(g.Chi + o + ro * 32) = hv;
+                } else {
+                    const __bf16 h0 = (__bf16)c0, h1 = (__bf16)c1;
+                    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                    bf16x2 hv = {h0, h1}, lv = {(__bf16)(c0 - (float)h0), (__bf16)(c1 - (float)h1)};
+                    *reinterpret_cast<bf16x2*>(g.Chi + o + ro * 32) = hv;
+                    *reinterpret_cast<bf16x2*>(g.Clo + o + ro * 32) = lv;
+                }
             }
         } else {
             const size_t o = ((size_t)(n >> 5) * g.c_rows + mb) * 32 + (n & 31);
@@ -153,9 +177,12 @@ __device__ __forceinline__ void sg_epilogue(const GemmX3Args& g, f32x16 (&acc)[T
             for (int i = 0; i < 16; ++i) {
                 const int ro = (i & 3) + 8 * (i >> 2);
                 if (n_ok && mb + ro < g.M) {
-                    const __bf16 h = (__bf16)r[i];
-                    g.Chi[o + ro * 32] = h;
-                    g.Clo[o + ro * 32] = (__bf16)(r[i] - (float)h);
+                    if constexpr (F16) reinterpret_cast<_Float16*>(g.Chi)[o + ro * 32] = (_Float16)r[i];
+                    else {
+                        const __bf16 h = (__bf16)r[i];
+                        g.Chi[o + ro * 32] = h;
+                        g.Clo[o + ro * 32] = (__bf16)(r[i] - (float)h);
+                    }
                 }
             }
         }
@@ -187,10 +214,11 @@ static int sg_cu_count() {
 // window are fetched during its own taps 0-3 (first needed by tap 4). K order: k-block kt = (channel block kt / 9, tap kt % 9).
 // PERSISTENT over tiles (slot, + gridDim, ...) like k_sg_gcn: no launch / first-window / store-acknowledgement gap between tiles. The epilogue (MODE,
 // sg_epilogue) writes the fp32 convolution, or - the block's whole tail in place - relu(conv + b2' [+ identity residual]) as the next block's planes.
-template <int BM, int BN, int WM, int MODE>
+template <int BM, int BN, int WM, int MODE, bool F16 = false>
 __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int ntiles, int V) {
     constexpr int NT = 512, TAPS = 9;
-    [[maybe_unused]] constexpr bool PROF = BM == 256 && BN == 256 && MODE == (SGE_RELU | SGE_PLANES | SGE_RES_PLANES);   // (tools: SG_STAMP)
+    [[maybe_unused]] constexpr bool PROF = !F16 && BM == 256 && BN == 256 && MODE == (SGE_RELU | SGE_PLANES | SGE_RES_PLANES);   // (tools: SG_STAMP)
+    constexpr int ST_PER = (F16 && (MODE & SGE_PLANES)) ? 8 : 16;   // stores per 32 x 32 tile of the epilogue (planes: hi [+ lo] of 8 column pairs)
     constexpr int WN = 8 / WM;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int W_BYTES = BN * 64, W_STAGE = 2 * W_BYTES;      // one plane tile; a stage = hi | lo
@@ -220,6 +248,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
     // one 16-row piece (1 KiB per plane) of the window of (tile rows m0t, channel block cb), rows [r0, r0 + 16) limited to rows < rend, into its place in plane pl
     // ws = the window's first physical row (0 unless CIRC)
     auto a_piece = [&](int m0t, int cb, int pl, int r0, int rend, int ws) {
+        if (F16 && pl) return;                                   // (wave-uniform)
         const int r = r0 + (lane >> 2);
         if (r < rend) {
             long long gr = (long long)m0t - 4LL * V + r;
@@ -239,6 +268,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int pl = (it * NT + (tid & ~63)) / (BN * 4);
+            if (F16 && pl) continue;
             __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(w_pl[pl] + ((size_t)kt * g.N + n0t) * 64 + w_lane[it]),
                                              (RGN_AS3 void*)(stage + pl * W_BYTES + (it * NT + (tid & ~63) - pl * (BN * 4)) * 16), 16, 0, 0);
         }
@@ -252,9 +282,12 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
     }
     const int arow0 = wm * (BM / WM) + l31;
     auto mma3 = [&](f32x16& c, const bf16x8& a_h, const bf16x8& a_l, const bf16x8& w_h, const bf16x8& w_l) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, w_h, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_l, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_h, c, 0, 0, 0);
+        if constexpr (F16) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_h), __builtin_bit_cast(f16x8, w_h), c, 0, 0, 0);
+        else {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, w_h, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_l, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_h, c, 0, 0, 0);
+        }
     };
 
     int tile = slot;
@@ -284,7 +317,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
 #pragma unroll 1
             for (int dt = 0; dt < TAPS; ++dt, ++gstep) {
                 SG_STAMP(0)
-                if (stores_behind) wait_vmcnt<16 * TM * TN>();   // this k-step's DMA is older than the 16 TM TN stores of the tile just written
+                if (stores_behind) wait_vmcnt<ST_PER * TM * TN>();   // this k-step's DMA is older than the 16 (F16: 8) TM TN stores of the tile just written
                 else wait_vmcnt<0>();                            // everything this thread requested up to the last k-step has landed ...
                 stores_behind = false;
                 SG_STAMP(1)
@@ -301,11 +334,11 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
                             const int rl = arow0 + t * 32 + dt * V, rr = CIRC ? ((ws + rl) & RMASK) : rl;
                             const int o = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
                             ah[ks][t] = *reinterpret_cast<const bf16x8*>(smem + o);
-                            al[ks][t] = *reinterpret_cast<const bf16x8*>(smem + A_PLANE + o);
+                            if constexpr (!F16) al[ks][t] = *reinterpret_cast<const bf16x8*>(smem + A_PLANE + o);
                         }
                     }
                     wh[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + w_off[tb][ks]);
-                    wl[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + W_BYTES + w_off[tb][ks]);
+                    if constexpr (!F16) wl[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + W_BYTES + w_off[tb][ks]);
                 };
                 fetch(0);
 #pragma unroll
@@ -351,20 +384,20 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
         }
         const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
         if (interior) {
-            sg_epilogue<TM, TN, false, MODE>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+            sg_epilogue<TM, TN, false, MODE, F16>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
             stores_behind = true;
-        } else sg_epilogue<TM, TN, true, MODE>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+        } else sg_epilogue<TM, TN, true, MODE, F16>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
         if (!more) break;
         tile = tnext; m0 = m0n; n0 = n0n;
     }
 }
 static int tconv_lds_bytes(int BM, int BN, int V) { return 2 * (BM > 256 ? 2 * BM : BM + 8 * V) * 64 + 2 * 2 * BN * 64; }
-template <int BM, int BN, int WM, int MODE>
+template <int BM, int BN, int WM, int MODE, bool F16 = false>
 static hipError_t tconv_launch(const GemmX3Args& g, int V, hipStream_t s, bool configure_only) {
     if (configure_only)
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_tconv<BM, BN, WM, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, std::min(160 * 1024, tconv_lds_bytes(BM, BN, 64)));
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_tconv<BM, BN, WM, MODE, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, std::min(160 * 1024, tconv_lds_bytes(BM, BN, 64)));
     const int nbx = (g.N + BN - 1) / BN, ntiles = nbx * ((g.M + BM - 1) / BM);
-    hipLaunchKernelGGL((k_sg_tconv<BM, BN, WM, MODE>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), tconv_lds_bytes(BM, BN, V), s, g, nbx, ntiles, V);
+    hipLaunchKernelGGL((k_sg_tconv<BM, BN, WM, MODE, F16>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), tconv_lds_bytes(BM, BN, V), s, g, nbx, ntiles, V);
     return hipGetLastError();
 }
 // (8 V >= 256: tap 0 reads window rows [0, 256), and only the first 8 V rows of a window are in place before its own taps run)
@@ -377,7 +410,16 @@ static hipError_t tconv_dispatch(const GemmX3Args& g, int V, int tail, hipStream
         if (e != hipSuccess) return e;
         e = tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES>(g, V, s, true);
         if (e == hipSuccess) e = tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES | SGE_RES_PLANES>(g, V, s, true);
-        return e != hipSuccess ? e : tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES | SGE_RES_PLANES | SGE_POLY>(g, V, s, true);
+        if (e == hipSuccess) e = tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES | SGE_RES_PLANES | SGE_POLY>(g, V, s, true);
+        if (e == hipSuccess) e = tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES, true>(g, V, s, true);
+        if (e == hipSuccess) e = tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES | SGE_RES_PLANES, true>(g, V, s, true);
+        return e != hipSuccess ? e : tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES | SGE_RES_PLANES | SGE_POLY, true>(g, V, s, true);
+    }
+    if (g.f16) {                                                 // the fp16 form exists for the plane tails only (rgn_stgcn.hip refuses the rest)
+        if (tail == 1) return tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES, true>(g, V, s, false);
+        if (tail == 2) return tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES | SGE_RES_PLANES, true>(g, V, s, false);
+        if (tail == 3) return tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES | SGE_RES_PLANES | SGE_POLY, true>(g, V, s, false);
+        return hipErrorInvalidValue;
     }
     if (tail == 0) return tconv_launch<BM, BN, WM, 0>(g, V, s, false);
     if (tail == 1) return tconv_launch<BM, BN, WM, SGE_RELU | SGE_PLANES>(g, V, s, false);
@@ -396,7 +438,7 @@ hipError_t launch_sg_tconv(const GemmX3Args& g, int V, int tail, bool small, hip
     if (g.N == 256 && !small && tconv_lds_bytes(256, 256, V) <= 160 * 1024) return tconv_dispatch<256, 256, 8>(g, V, tail, s, false);
     return tconv_dispatch<256, 128, 4>(g, V, tail, s, false);
 }
-template <int MODE>
+template <int MODE, bool F16 = false>
 __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, int ntiles, int V, long long o_rows);
 hipError_t configure_sg_tconv() {
     GemmX3Args g{};
@@ -406,6 +448,7 @@ hipError_t configure_sg_tconv() {
     if (e == hipSuccess) e = tconv_dispatch<512, 64, 8>(g, 0, 0, nullptr, true);
     if (e == hipSuccess) e = tconv_dispatch<512, 128, 8>(g, 0, 0, nullptr, true);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_tconv_s2<SGE_RELU | SGE_PLANES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_tconv_s2<SGE_RELU | SGE_PLANES, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;
 }
 
@@ -417,9 +460,10 @@ hipError_t configure_sg_tconv() {
 // k-step the L2 -> LDS path carries the weight tile + V rows + 64 rows (31 KB; 48 KB as a row-shifted GEMM). The strided 1 x 1 shortcut (BN folded)
 // is k2 more k-steps on the same accumulators: its operand fragments come straight from the block's input planes (region E = the even frames)
 // into registers, requested one k-step ahead. Epilogue: planes relu(acc + bias), bias = b2' + br'. Persistent over tiles like k_sg_tconv.
-template <int MODE>
+template <int MODE, bool F16>
 __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, int ntiles, int V, long long o_rows) {
     constexpr int BM = 256, BN = 128, NT = 512, WM = 4, WN = 2, TM = 2, TN = 2;
+    constexpr int ST_PER = (F16 && (MODE & SGE_PLANES)) ? 8 : 16;
     constexpr int W_BYTES = BN * 64, W_STAGE = 2 * W_BYTES, W_IT = BN * 8 / NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -438,6 +482,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
     const char* const a_pl[2] = {reinterpret_cast<const char*>(g.Ahi), reinterpret_cast<const char*>(g.Alo)};
     // one 16-row piece of a window: `first` = the global row of window row 0, rows [r0, r0 + 16) below rend, plane pl of the buffer at `buf` (`pb` bytes per plane)
     auto a_piece = [&](long long first, int cb, int pl, int r0, int rend, char* buf, int pb) {
+        if (F16 && pl) return;                                   // (wave-uniform)
         const int r = r0 + (lane >> 2);
         if (r < rend) {
             long long gr = first + r;
@@ -456,6 +501,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int pl = (it * NT + (tid & ~63)) / (BN * 4);
+            if (F16 && pl) continue;
             const char* base = reinterpret_cast<const char*>(pl ? wlo : whi);
             __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(base + ((size_t)kt * g.N + n0t) * 64 + w_lane[it]),
                                              (RGN_AS3 void*)(stage + pl * W_BYTES + (it * NT + (tid & ~63) - pl * (BN * 4)) * 16), 16, 0, 0);
@@ -470,9 +516,12 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
     }
     const int arow0 = wm * (BM / WM) + l31;
     auto mma3 = [&](f32x16& c, const bf16x8& a_h, const bf16x8& a_l, const bf16x8& w_h, const bf16x8& w_l) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, w_h, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_l, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_h, c, 0, 0, 0);
+        if constexpr (F16) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_h), __builtin_bit_cast(f16x8, w_h), c, 0, 0, 0);
+        else {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, w_h, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_l, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_h, c, 0, 0, 0);
+        }
     };
     // the shortcut's operand fragments of this lane's rows, k-block cr (straight from the input planes, region E)
     bf16x8 sh[2][TM], sl[2][TM];
@@ -485,7 +534,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 sh[ks][t] = *reinterpret_cast<const bf16x8*>(g.A2hi + o + 16 * ks);
-                sl[ks][t] = *reinterpret_cast<const bf16x8*>(g.A2lo + o + 16 * ks);
+                if constexpr (!F16) sl[ks][t] = *reinterpret_cast<const bf16x8*>(g.A2lo + o + 16 * ks);
             }
         }
     };
@@ -517,7 +566,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
             const int cb = shortcut ? ncb - 1 : st / 9, i9 = shortcut ? 9 : st - cb * 9;      // i9: 0..4 E taps, 5..8 O taps
             const bool isE = i9 < 5;
             const int j = isE ? i9 : i9 - 5;
-            if (stores_behind) wait_vmcnt<16 * TM * TN>();
+            if (stores_behind) wait_vmcnt<ST_PER * TM * TN>();
             else wait_vmcnt<0>();
             stores_behind = false;
             __builtin_amdgcn_s_barrier();
@@ -531,7 +580,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
 #pragma unroll
                     for (int t = 0; t < TM; ++t) {
                         ah[ks][t] = sh[ks][t];
-                        al[ks][t] = sl[ks][t];
+                        if constexpr (!F16) al[ks][t] = sl[ks][t];
                     }
             }
             auto fetch = [&](int grp) {                          // grp = ks * TN + tb
@@ -542,11 +591,11 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
                         const int rr = arow0 + t * 32 + j * V;
                         const int o = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
                         ah[ks][t] = *reinterpret_cast<const bf16x8*>(abuf + o);
-                        al[ks][t] = *reinterpret_cast<const bf16x8*>(abuf + apl + o);
+                        if constexpr (!F16) al[ks][t] = *reinterpret_cast<const bf16x8*>(abuf + apl + o);
                     }
                 }
                 wh[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + w_off[tb][ks]);
-                wl[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + W_BYTES + w_off[tb][ks]);
+                if constexpr (!F16) wl[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + W_BYTES + w_off[tb][ks]);
             };
             fetch(0);
 #pragma unroll
@@ -585,9 +634,9 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
         }
         const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
         if (interior) {
-            sg_epilogue<TM, TN, false, MODE>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+            sg_epilogue<TM, TN, false, MODE, F16>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
             stores_behind = true;
-        } else sg_epilogue<TM, TN, true, MODE>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+        } else sg_epilogue<TM, TN, true, MODE, F16>(g, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
         if (!more) break;
         tile = tnext; m0 = m0n; n0 = n0n;
     }
@@ -596,7 +645,8 @@ static int tconv_s2_lds_bytes(int V) { return 2 * (256 + 4 * V) * 64 + 2 * (256 
 bool sg_tconv_s2_supported(int N, int Kp, int V) { return (N == 128 || N == 256) && Kp == 9 * N && V % 4 == 0 && V >= 16 && V <= 64 && tconv_s2_lds_bytes(V) <= 160 * 1024; }
 hipError_t launch_sg_tconv_s2(const GemmX3Args& g, int V, long long o_rows, hipStream_t s) {
     const int nbx = g.N / 128, ntiles = nbx * ((g.M + 255) / 256);
-    hipLaunchKernelGGL((k_sg_tconv_s2<SGE_RELU | SGE_PLANES>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), tconv_s2_lds_bytes(V), s, g, nbx, ntiles, V, o_rows);
+    if (g.f16) hipLaunchKernelGGL((k_sg_tconv_s2<SGE_RELU | SGE_PLANES, true>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), tconv_s2_lds_bytes(V), s, g, nbx, ntiles, V, o_rows);
+    else hipLaunchKernelGGL((k_sg_tconv_s2<SGE_RELU | SGE_PLANES>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), tconv_s2_lds_bytes(V), s, g, nbx, ntiles, V, o_rows);
     return hipGetLastError();
 }
 
@@ -613,9 +663,10 @@ hipError_t launch_sg_tconv_s2(const GemmX3Args& g, int V, long long o_rows, hipS
 // launch + first window + store acknowledgements were 25 - 45 % of the kernel with the matrix pipe and the fabric taking turns idling).
 // ALLK: one barrier per CHANNEL BLOCK - a weight stage holds the tiles of all KP <= 4 partitions (narrow tiles only: 3 x 8 KB at BN = 64): the k-step's fixed
 // costs (DMA wait, barrier, DMA issue; ~1950 cycles in k_sg_tconv's stamps) are paid once per 96-deep step instead of once per 32.
-template <int BN, bool ALLK>
+template <int BN, bool ALLK, bool F16 = false>
 __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int ntiles, int V, int KP, unsigned slot_k, const int* __restrict__ sl_v, const float* __restrict__ sl_a) {
     constexpr int BM = 256, NT = 512, TN = BN / 32, NS = 8;
+    constexpr int ST_PER = F16 ? 8 : 16;                         // plane stores per 32 x 32 tile of the epilogue
     constexpr int W_BYTES = BN * 64, W_STAGE = 2 * W_BYTES * (ALLK ? 4 : 1);
     constexpr int W_IT = BN * 8 / NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -639,6 +690,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
     const int ppk = (npieces + 8 * KP - 1) / (8 * KP);           // pieces per wave per k-step
     auto x_piece = [&](int m0t, int cb, int p, int buf) {        // piece p of the window of (tile rows m0t, channel block cb) into window buffer buf
         const int pl = p >= npc ? 1 : 0, r0 = (p - pl * npc) * 16, r = r0 + (lane >> 2);
+        if (F16 && pl) return;                                   // (wave-uniform)
         if (r < WRX) {
             long long gr = (long long)m0t - V + r;
             gr = gr > row_hi ? row_hi : gr;
@@ -650,6 +702,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int q = it * NT + tid, pl = (it * NT + (tid & ~63)) / (BN * 4), qq = q - pl * (BN * 4), r = qq >> 2, c = (qq & 3) ^ ((r >> 2) & 3);
+            if (F16 && pl) continue;
             int n = n0t + r;
             n = n < g.N ? n : g.N - 1;
             __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(w_pl[pl] + ((size_t)kb * g.N + n) * 64 + c * 16),
@@ -704,7 +757,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
             const bool wlast = cb + 1 == ncb;
             for (int k = 0; k < KP; ++k) {
                 if (!ALLK || k == 0) {
-                    if (stores_behind) wait_vmcnt<16 * TN>();    // the DMA of this step is older than the 16 TN stores of the tile just written
+                    if (stores_behind) wait_vmcnt<ST_PER * TN>();    // the DMA of this step is older than the 16 (F16: 8) TN stores of the tile just written
                     else wait_vmcnt<0>();
                     stores_behind = false;
                     __builtin_amdgcn_s_barrier();                // the tile(s) of this step (and, at k = 0, the window) are in LDS; the previous step is read out
@@ -734,26 +787,43 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks) {
                             const int o = so[s] ^ (32 * ks);
-                            const bf16x8 h = *reinterpret_cast<const bf16x8*>(xw + o), l = *reinterpret_cast<const bf16x8*>(xw + XP + o);
+                            if constexpr (F16) {
+                                const f16x8 h = *reinterpret_cast<const f16x8*>(xw + o);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) z[ks][e] = fmaf(sa[s], (float)h[e] + (float)l[e], z[ks][e]);
+                                for (int e = 0; e < 8; ++e) z[ks][e] = fmaf(sa[s], (float)h[e], z[ks][e]);
+                            } else {
+                                const bf16x8 h = *reinterpret_cast<const bf16x8*>(xw + o), l = *reinterpret_cast<const bf16x8*>(xw + XP + o);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) z[ks][e] = fmaf(sa[s], (float)h[e] + (float)l[e], z[ks][e]);
+                            }
                         }
                     }
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 ah, al;
+                    if constexpr (F16) {
+                        f16x8 af;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        ah[e] = (__bf16)z[ks][e];
-                        al[e] = (__bf16)(z[ks][e] - (float)ah[e]);
-                    }
+                        for (int e = 0; e < 8; ++e) af[e] = (_Float16)z[ks][e];
 #pragma unroll
-                    for (int tb = 0; tb < TN; ++tb) {
-                        const int o = w_off[tb] ^ (32 * ks);
-                        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wsb + o), wl = *reinterpret_cast<const bf16x8*>(wsb + W_BYTES + o);
-                        acc[0][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[0][tb], 0, 0, 0);
-                        acc[0][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[0][tb], 0, 0, 0);
-                        acc[0][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[0][tb], 0, 0, 0);
+                        for (int tb = 0; tb < TN; ++tb) {
+                            const f16x8 wf = *reinterpret_cast<const f16x8*>(wsb + (w_off[tb] ^ (32 * ks)));
+                            acc[0][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wf, acc[0][tb], 0, 0, 0);
+                        }
+                    } else {
+                        bf16x8 ah, al;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            ah[e] = (__bf16)z[ks][e];
+                            al[e] = (__bf16)(z[ks][e] - (float)ah[e]);
+                        }
+#pragma unroll
+                        for (int tb = 0; tb < TN; ++tb) {
+                            const int o = w_off[tb] ^ (32 * ks);
+                            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wsb + o), wl = *reinterpret_cast<const bf16x8*>(wsb + W_BYTES + o);
+                            acc[0][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh, acc[0][tb], 0, 0, 0);
+                            acc[0][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl, acc[0][tb], 0, 0, 0);
+                            acc[0][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc[0][tb], 0, 0, 0);
+                        }
                     }
                 }
                 if (!ALLK || k + 1 == KP) ++gstep;
@@ -761,9 +831,9 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
         }
         const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
         if (interior) {
-            sg_epilogue<1, TN, false, SGE_VERTEX_BIAS | SGE_RELU | SGE_PLANES>(g, acc, m0 + wave * 32, n0, lane);
+            sg_epilogue<1, TN, false, SGE_VERTEX_BIAS | SGE_RELU | SGE_PLANES, F16>(g, acc, m0 + wave * 32, n0, lane);
             stores_behind = true;                                // (exactly 16 TN stores, all issued after the next k-step's DMA)
-        } else sg_epilogue<1, TN, true, SGE_VERTEX_BIAS | SGE_RELU | SGE_PLANES>(g, acc, m0 + wave * 32, n0, lane);
+        } else sg_epilogue<1, TN, true, SGE_VERTEX_BIAS | SGE_RELU | SGE_PLANES, F16>(g, acc, m0 + wave * 32, n0, lane);
         if (!more) break;
         tile = tnext; m0 = m0n; n0 = n0n;
     }
@@ -775,7 +845,8 @@ bool sg_gcn_supported(int N, int Kp, int V, int KP) {
 template <int BN, bool ALLK>
 static hipError_t gcn_launch(const GemmX3Args& g, int V, int KP, unsigned slot_k, const int* sl_v, const float* sl_a, hipStream_t s) {
     const int nbx = (g.N + BN - 1) / BN, ntiles = nbx * ((g.M + 255) / 256);
-    hipLaunchKernelGGL((k_sg_gcn<BN, ALLK>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), gcn_lds_bytes(BN, V, ALLK), s, g, nbx, ntiles, V, KP, slot_k, sl_v, sl_a);
+    if (g.f16) hipLaunchKernelGGL((k_sg_gcn<BN, ALLK, true>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), gcn_lds_bytes(BN, V, ALLK), s, g, nbx, ntiles, V, KP, slot_k, sl_v, sl_a);
+    else hipLaunchKernelGGL((k_sg_gcn<BN, ALLK>), dim3(std::min(ntiles, sg_cu_count())), dim3(512), gcn_lds_bytes(BN, V, ALLK), s, g, nbx, ntiles, V, KP, slot_k, sl_v, sl_a);
     return hipGetLastError();
 }
 hipError_t launch_sg_gcn(const GemmX3Args& g, int V, int KP, unsigned slot_k, const int* sl_v, const float* sl_a, int cap, bool per_block_barrier, hipStream_t s) {   // cap: widest tile (tools / tests)
@@ -789,6 +860,10 @@ hipError_t configure_sg_gcn() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<64, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<64, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<128, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sg_gcn<256, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return e;
 }
 

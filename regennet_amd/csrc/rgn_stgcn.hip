@@ -53,6 +53,7 @@ struct SgBlock {
     int *nz_ptr = nullptr, *nz_v = nullptr;          // nonzeros of A'_k[:, w]: list (k V + w) = [nz_ptr[k V + w], nz_ptr[k V + w + 1])
     float* nz_a = nullptr;
     __bf16 *W1h = nullptr, *W1l = nullptr, *W2h = nullptr, *W2l = nullptr, *Wrh = nullptr, *Wrl = nullptr;   // K32-blocked weight planes [Kp/32][co][32]
+    __bf16 *W1f = nullptr, *W2f = nullptr, *Wrf = nullptr;   // the same planes as ONE IEEE fp16 plane each (SG_F16: the single-plane form, rgn_sg_kernels.hip)
     float *b1 = nullptr, *b2 = nullptr, *br = nullptr, *b2r = nullptr;   // b2r = b2' + br' (the stride-2 kernel adds the shortcut into the same accumulators)
 };
 
@@ -71,6 +72,7 @@ struct rgn_stgcn_ctx {
     std::map<std::string, std::vector<float>> sd;
     std::map<std::string, std::vector<int64_t>> shapes;
     bool finalized = false;
+    std::string f16_refused;                     // why SG_F16 cannot be served by this checkpoint (a folded weight beyond the fp16 range); empty: it can
     std::map<std::string, int> opts;             // rgn_stgcn_set_option: kernel-selection switches of this handle (they take precedence over REGENNET_<KEY>)
     int V = 0, K = 0, C0 = 0;
     std::vector<SgBlock> blocks;
@@ -98,7 +100,10 @@ thread_local std::string g_sg_create_error;
     } while (0)
 
 // The kernel-selection switches (rgn_stgcn_set_option; every selectable form meets the same parity bound - tests/test_eval_gpu.py runs them all):
-const char* const kSgOptions[] = {"SG_NO_WINDOW", "SG_NO_GCN_FUSE", "SG_NO_TAIL_FUSE", "SG_NO_POLY_TAIL", "SG_NO_S2_WINDOW", "SG_TCONV_SMALL", "SG_GCN_BN", "SG_GCN_STEP32"};
+// SG_F16 selects the ARITHMETIC, not a kernel form: blocks 1-9 (and block 0's temporal convolution) on single fp16 operand planes, one MFMA per product instead of
+// three - 2^-12 per operand (the level of the TF32 convolutions the reference's own GPU run uses by default) instead of ~2^-16 per product; measured 1e-3-class
+// relative feature differences instead of 1e-5-class (tests/test_eval_gpu.py states both bounds). Off unless asked for.
+const char* const kSgOptions[] = {"SG_NO_WINDOW", "SG_NO_GCN_FUSE", "SG_NO_TAIL_FUSE", "SG_NO_POLY_TAIL", "SG_NO_S2_WINDOW", "SG_TCONV_SMALL", "SG_GCN_BN", "SG_GCN_STEP32", "SG_F16"};
 // value of a switch: the handle's option if given, else the environment variable REGENNET_<KEY>, else `dflt`
 int sg_opt(const rgn_stgcn_ctx* c, const char* key, int dflt) {
     auto it = c->opts.find(key);
@@ -109,6 +114,7 @@ int sg_opt(const rgn_stgcn_ctx* c, const char* key, int dflt) {
 }
 
 typedef __bf16 sg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sg_f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void sg_split8(const float (&v)[8], sg_bf16x8& h, sg_bf16x8& l) {
 #pragma unroll
@@ -245,6 +251,20 @@ __global__ void k_sg_zero(SgPl g, long long base, int NM, int Tr, int Tp, int V,
     *reinterpret_cast<sg_bf16x8*>(g.lo + o) = zero;
 }
 
+// split-bf16 planes -> the single fp16 plane of SG_F16, in place in the hi plane (block 0's graph convolution stays on the split GEMM: K = 32, 2 % of the forward):
+// one thread per run of 8 channels of `cb` channel blocks x `rows` rows
+__global__ void k_sg_to_f16(SgPl g, size_t rows, int cb) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cb * 4) return;
+    const size_t row = (idx >> 2) % rows;
+    const size_t o = ((idx >> 2) / rows * (size_t)g.R + row) * 32 + 8 * (idx & 3);
+    const sg_bf16x8 h = *reinterpret_cast<const sg_bf16x8*>(g.hi + o), l = *reinterpret_cast<const sg_bf16x8*>(g.lo + o);
+    sg_f16x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (_Float16)((float)h[e] + (float)l[e]);
+    *reinterpret_cast<sg_f16x8*>(g.hi + o) = f;
+}
+
 // x'[nm][t'][v][co] = relu(conv[nm][t'][v][co] + b2[co] + res) as planes, pads of x' zero. conv / rfull rows run (nm, frame < Tpi, v): the block's own
 // rate (a stride-2 block computes its convolution at the OUTPUT rate from polyphase planes: nothing is subsampled here).
 //   res: none | identity x[nm][t'][v][co] (planes, same geometry) | rfull[nm][t'][v][co] + br[co] (the strided 1x1 convolution + BN)
@@ -296,6 +316,7 @@ __global__ void k_sg_post(const float* __restrict__ conv, const float* __restric
 
 // global average pool over (t, v) and mean over the M persons (stgcn.py:113-114): pooled[n][c]. One workgroup per motion: thread = (run of 8 channels,
 // slice of the rows), 16-byte plane loads, the slices summed through LDS
+template <bool F16>
 __global__ __launch_bounds__(256) void k_sg_pool(SgPl x, float* __restrict__ pooled, int M, int T, int V, int C) {
     __shared__ float part[8][256];
     const int n = blockIdx.x, Tp = T + SG_PAD, c8n = C / 8;                      // C <= 256: c8n <= 32
@@ -305,9 +326,15 @@ __global__ __launch_bounds__(256) void k_sg_pool(SgPl x, float* __restrict__ poo
         for (int m = 0; m < M; ++m) {
             const size_t o = ((size_t)(c8 >> 2) * x.R + ((size_t)(n * M + m) * Tp) * V) * 32 + 8 * (c8 & 3);
             for (int i = sl; i < T * V; i += 8) {
-                const sg_bf16x8 h = *reinterpret_cast<const sg_bf16x8*>(x.hi + o + (size_t)i * 32), l = *reinterpret_cast<const sg_bf16x8*>(x.lo + o + (size_t)i * 32);
+                if constexpr (F16) {
+                    const sg_f16x8 h = *reinterpret_cast<const sg_f16x8*>(x.hi + o + (size_t)i * 32);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += (float)h[e] + (float)l[e];
+                    for (int e = 0; e < 8; ++e) acc[e] += (float)h[e];
+                } else {
+                    const sg_bf16x8 h = *reinterpret_cast<const sg_bf16x8*>(x.hi + o + (size_t)i * 32), l = *reinterpret_cast<const sg_bf16x8*>(x.lo + o + (size_t)i * 32);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += (float)h[e] + (float)l[e];
+                }
             }
         }
 #pragma unroll
@@ -351,19 +378,29 @@ inline float sg_bf2f(uint16_t h) {
     return f;
 }
 // W [N][Kp] (row-major fp32, Kp % 32 == 0) -> split-bf16 weight planes [Kp/32][N][32] (the B operand layout of k_gemm_x3)
-int sg_upload_planes(rgn_stgcn_ctx* c, const std::vector<float>& W, int N, int Kp, __bf16** hi, __bf16** lo) {
-    std::vector<uint16_t> h((size_t)N * Kp), l((size_t)N * Kp);
+// ... and, with `f16`, the same layout as one IEEE fp16 plane (rne); a weight beyond the fp16 range is recorded in c->f16_refused under `name`
+int sg_upload_planes(rgn_stgcn_ctx* c, const std::vector<float>& W, int N, int Kp, __bf16** hi, __bf16** lo, __bf16** f16 = nullptr, const char* name = "") {
+    std::vector<uint16_t> h((size_t)N * Kp), l((size_t)N * Kp), f(f16 ? (size_t)N * Kp : 0);
     for (int n = 0; n < N; ++n)
         for (int k = 0; k < Kp; ++k) {
             const float v = W[(size_t)n * Kp + k];
             const size_t o = ((size_t)(k / 32) * N + n) * 32 + k % 32;
             h[o] = sg_f2bf(v);
             l[o] = sg_f2bf(v - sg_bf2f(h[o]));
+            if (f16) {
+                if (!(std::fabs(v) < 6.0e4f) && c->f16_refused.empty()) c->f16_refused = std::string(name) + " (folded with its BatchNorm) holds " + std::to_string(v);
+                const _Float16 hv = (_Float16)v;
+                memcpy(&f[o], &hv, 2);
+            }
         }
     int rc;
     if ((rc = sg_alloc(c, hi, h.size())) || (rc = sg_alloc(c, lo, l.size()))) return rc;
     SG_HIP(c, hipMemcpy(*hi, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     SG_HIP(c, hipMemcpy(*lo, l.data(), l.size() * 2, hipMemcpyHostToDevice));
+    if (f16) {
+        if ((rc = sg_alloc(c, f16, f.size()))) return rc;
+        SG_HIP(c, hipMemcpy(*f16, f.data(), f.size() * 2, hipMemcpyHostToDevice));
+    }
     return RGN_OK;
 }
 int sg_upload_ints(rgn_stgcn_ctx* c, int** p, const std::vector<int>& v) {
@@ -608,8 +645,8 @@ int rgn_stgcn_finalize(rgn_stgcn_handle h) {
                 }
             }
             if ((rc = sg_upload_ints(c, &b.nz_ptr, nzp)) || (rc = sg_upload_ints(c, &b.nz_v, nzv)) || (rc = sg_upload(c, &b.nz_a, nza)) ||
-                (rc = sg_upload_planes(c, W1, co, b.kp1, &b.W1h, &b.W1l)) || (rc = sg_upload(c, &b.b1, b1)) ||
-                (rc = sg_upload_planes(c, W2, co, 9 * co, &b.W2h, &b.W2l)) || (rc = sg_upload(c, &b.b2, b2)))
+                (rc = sg_upload_planes(c, W1, co, b.kp1, &b.W1h, &b.W1l, &b.W1f, (p + "gcn.conv.weight").c_str())) || (rc = sg_upload(c, &b.b1, b1)) ||
+                (rc = sg_upload_planes(c, W2, co, 9 * co, &b.W2h, &b.W2l, &b.W2f, (p + "tcn.2.weight").c_str())) || (rc = sg_upload(c, &b.b2, b2)))
                 return rc;
             if (b.res_conv) {
                 b.kpr = (int)up32((size_t)ci);
@@ -620,7 +657,7 @@ int rgn_stgcn_finalize(rgn_stgcn_handle h) {
                 }
                 std::vector<float> b2r(co);
                 for (int o = 0; o < co; ++o) b2r[o] = b2[o] + br[o];
-                if ((rc = sg_upload_planes(c, Wr, co, b.kpr, &b.Wrh, &b.Wrl)) || (rc = sg_upload(c, &b.br, br)) || (rc = sg_upload(c, &b.b2r, b2r))) return rc;
+                if ((rc = sg_upload_planes(c, Wr, co, b.kpr, &b.Wrh, &b.Wrl, &b.Wrf, (p + "residual.0.weight").c_str())) || (rc = sg_upload(c, &b.br, br)) || (rc = sg_upload(c, &b.b2r, b2r))) return rc;
             }
         }
         {
@@ -718,6 +755,12 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
         const bool small_tiles = sg_opt(c, "SG_TCONV_SMALL", 0) != 0;    // 256-row, <= 128-wide temporal-convolution tiles
         const int gcn_bn = sg_opt(c, "SG_GCN_BN", 256);                  // widest k_sg_gcn tile
         const bool gcn_step32 = sg_opt(c, "SG_GCN_STEP32", 0) != 0;      // 64-wide k_sg_gcn: one barrier per 32-deep k-block (default: per channel block)
+        const bool f16 = sg_opt(c, "SG_F16", 0) != 0;                    // single fp16 operand planes (above): the fused kernels only
+        if (f16 && !c->f16_refused.empty()) return c->fail(RGN_ERR_UNSUPPORTED, "rgn_stgcn_forward: SG_F16 - a weight lies beyond the fp16 range: " + c->f16_refused);
+        auto f16_unserved = [&](int blk, const char* what) {
+            return c->fail(RGN_ERR_UNSUPPORTED, std::string("rgn_stgcn_forward: SG_F16 exists for the fused kernels only; block ") + std::to_string(blk) + " would take " + what +
+                                                    " (this graph / shape, or an SG_NO_* switch)");
+        };
         __bf16 *(*x)[2] = &c->xa, *(*xn)[2] = &c->xb;
         auto phys = [&](int Tf, bool poly) { return (size_t)NM * (poly ? 2 * ((size_t)(Tf + 1) / 2 + SG_PAD) : (size_t)Tf + SG_PAD) * V; };
         for (int i = 0; i < 10; ++i) {
@@ -731,14 +774,18 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
             const SgPl xp = planes(*x, rows), zp = planes(c->z, rows), gp = planes(c->g, rows), xo = planes(*xn, rows_o);
             // graph aggregation on the input channels (sparse A'), then the 1x1 convolution over K C_in (+ folded BN, vertex bias, ReLU): frame-local, any row order
             const bool fused = !no_fuse && b.sl_v && b.ci % 32 == 0 && b.kp1 == K * b.ci && sg_gcn_supported(b.co, b.kp1, V, K);
-            GemmX3Args g1 = sg_gemm_x3(fused ? xp : zp, b.W1h, b.W1l, (int)rows, b.co, b.kp1);
+            if (f16 && !fused && i > 0) return f16_unserved(i, "the two-launch graph convolution");
+            const bool gf16 = f16 && fused;                      // (block 0, K C_in = 18 of one 32-deep k-block, keeps the split GEMM: its planes come from k_sg_in)
+            GemmX3Args g1 = sg_gemm_x3(fused ? xp : zp, gf16 ? b.W1f : b.W1h, b.W1l, (int)rows, b.co, b.kp1);
             g1.add = b.b1; g1.ldadd = b.co; g1.add_mod = V; g1.act = 3;                          // + b1'[row % V], ReLU
             g1.Chi = gp.hi; g1.Clo = gp.lo; g1.c_rows = (int)gp.R;
+            g1.f16 = gf16 ? 1 : 0;
             if (fused) SG_HIP(c, launch_sg_gcn(g1, V, K, b.slot_k, b.sl_v, b.sl_a, gcn_bn, gcn_step32, s));   // z is formed in registers, fragment by fragment
             else {
                 if (b.ci % 32 == 0) hipLaunchKernelGGL(k_sg_agg, dim3((unsigned)((rows * 4 + 255) / 256), (unsigned)(K * (b.ci / 32))), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
                 else hipLaunchKernelGGL(k_sg_agg_small, blocks1d(rows), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
                 SG_HIP(c, launch_gemm_x3_sg(g1, s));
+                if (f16) hipLaunchKernelGGL(k_sg_to_f16, blocks1d(rows * (b.co / 32) * 4), dim3(256), 0, s, gp, rows, b.co / 32);
             }
             // pad frames and guard rows back to zero: what the temporal taps read beyond a sequence
             auto zero = [&](const SgPl& pl, long long base, int Tr, int Tp, int lead, int trail) {
@@ -751,8 +798,9 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
                 zero(gp, (long long)rows_c, T / 2, Te + SG_PAD, 0, guard);
             }
             // 9x1 temporal convolution: ONE GEMM over K = 9 C_out; tap dt of k-block (channel block, dt) is a byte offset into g
-            GemmX3Args g2 = sg_gemm_x3(gp, b.W2h, b.W2l, (int)rows_c, b.co, 9 * b.co);
+            GemmX3Args g2 = sg_gemm_x3(gp, f16 ? b.W2f : b.W2h, b.W2l, (int)rows_c, b.co, 9 * b.co);
             g2.a_taps = 9;
+            g2.f16 = f16 ? 1 : 0;
             for (int dt = 0; dt < 9; ++dt) {
                 if (!ipoly) g2.a_tap[dt] = (long long)(dt - 4) * V * 64;                                  // frame t + dt - 4
                 else if ((dt & 1) == 0) g2.a_tap[dt] = (long long)((dt - 4) / 2) * V * 64;                  // frame 2 t' + dt - 4 = even frame t' + (dt - 4) / 2
@@ -764,7 +812,7 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
                 g2.bias = b.b2r;
                 g2.Chi = xo.hi; g2.Clo = xo.lo; g2.c_rows = (int)xo.R;
                 g2.A2hi = xp.hi; g2.A2lo = xp.lo; g2.a2_rows = (int)xp.R;
-                g2.W2hi = b.Wrh; g2.W2lo = b.Wrl; g2.k2 = b.kpr / 32;
+                g2.W2hi = f16 ? b.Wrf : b.Wrh; g2.W2lo = b.Wrl; g2.k2 = b.kpr / 32;
                 SG_HIP(c, launch_sg_tconv_s2(g2, V, (long long)rows_c, s));
                 zero(xo, 0, To, To + SG_PAD, guard, guard);
             } else if (window && opoly && b.res_id && !no_tail && !no_poly) {
@@ -785,6 +833,7 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
                 SG_HIP(c, launch_sg_tconv(g2, V, b.res_id ? 2 : 1, small_tiles, s));
                 zero(xo, 0, To, To + SG_PAD, guard, guard);
             } else {
+                if (f16) return f16_unserved(i, "the unfused temporal convolution + k_sg_post");
                 g2.C = c->conv; g2.ldc = b.co;
                 if (window) SG_HIP(c, launch_sg_tconv(g2, V, 0, small_tiles, s));
                 else SG_HIP(c, launch_gemm_x3_sg(g2, s));
@@ -799,7 +848,8 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
             std::swap(x, xn);
             T = To;
         }
-        hipLaunchKernelGGL(k_sg_pool, dim3(N), dim3(256), 0, s, planes(*x, (size_t)NM * (T + SG_PAD) * V), c->pooled, M, T, V, 256);
+        if (f16) hipLaunchKernelGGL(k_sg_pool<true>, dim3(N), dim3(256), 0, s, planes(*x, (size_t)NM * (T + SG_PAD) * V), c->pooled, M, T, V, 256);
+        else hipLaunchKernelGGL(k_sg_pool<false>, dim3(N), dim3(256), 0, s, planes(*x, (size_t)NM * (T + SG_PAD) * V), c->pooled, M, T, V, 256);
         if (features) SG_HIP(c, hipMemcpyAsync(features, c->pooled, (size_t)N * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (yhat) {
             GemmArgs gf = sg_gemm(c->pooled, 256, c->Wf, 256, 256, c->bf, yhat, c->cfg.num_class, N, c->cfg.num_class);

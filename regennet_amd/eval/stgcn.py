@@ -53,7 +53,8 @@ class STGCN(nn.Module):
         self.fcn = nn.Conv2d(256, num_class, kernel_size=1)
         self._engine, self._stale, self._applied_options = None, True, {}
         self._stale_person = {}
-        self.engine_options = {}                  # kernel-selection switches for this model's engine (rgn_stgcn_set_option; tools and tests)
+        self.engine_options = {}                  # switches of this model's engine (rgn_stgcn_set_option): kernel forms (tools and tests) and "SG_F16": 1 - the
+                                                  # recogniser on single fp16 operand planes (one MFMA per product; features 4e-4 of the largest instead of 5e-6)
         for p in self.parameters():
             p.requires_grad_(False)
 
@@ -124,7 +125,17 @@ class STGCN(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("regennet_amd STGCN runs on an AMD GPU only: call model.to(device) first (no CPU fallback)")
         engs = self.__dict__.setdefault("_person_engines", {})
+        popts = self.__dict__.setdefault("_person_options", {})
         eng = engs.get(person)
+        if eng is not None and popts.get(person) != self.engine_options:        # an edit of the switches reaches the live per-person engines too
+            torch.cuda.synchronize(dev)
+            if set(popts.get(person, {})) - set(self.engine_options):
+                self._stale_person[person] = True                               # (a switch taken away: only a rebuild restores the environment's default)
+            else:
+                for k, v in self.engine_options.items():
+                    if popts[person].get(k) != v:
+                        eng.set_option(k, v)
+                popts[person] = dict(self.engine_options)
         if eng is None or self._stale_person.get(person, True) or N > eng.max_batch or eng.shape != (V, C, T):
             if eng is not None:
                 torch.cuda.synchronize(dev)
@@ -139,6 +150,7 @@ class STGCN(nn.Module):
                 eng.load_weight(k, v.detach().float().cpu().numpy())
             eng.finalize()
             engs[person] = eng
+            popts[person] = dict(self.engine_options)
             self._stale_person[person] = False
         xc = x.to(device=dev, dtype=torch.float32).contiguous()
         feats = torch.empty(N, 256, device=dev)

@@ -14,7 +14,10 @@ import numpy as np
 import torch
 
 
-def run(n_motions=1024, chunk=256, threads=32, seed=0, verbose=False):
+def run(n_motions=1024, chunk=256, threads=32, seed=0, verbose=False, recogniser_f16=False):
+    """recogniser_f16: additionally pass every set through a second recogniser engine on single fp16 operand planes (SG_F16) and report what THAT
+    arithmetic is worth in FID units: FID(features of the default recogniser, features of the fp16 one) on the HIP-sampled set, and the change of
+    FID(gt*, HIP set) when the whole evaluation (both sets) runs on the fp16 recogniser."""
     from oracle import regennet_oracle as orc
     from regennet_amd import synth
     from regennet_amd.eval import STGCN
@@ -30,10 +33,16 @@ def run(n_motions=1024, chunk=256, threads=32, seed=0, verbose=False):
     rec = STGCN(in_channels=12, num_class=26, num_person=2, graph_args={"layout": "smplx", "strategy": "spatial"}, device="cuda:0")
     rec.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in rec_sd.items()}, strict=True)
     rec.to("cuda:0").eval()
+    rec16 = None
+    if recogniser_f16:
+        rec16 = STGCN(in_channels=12, num_class=26, num_person=2, graph_args={"layout": "smplx", "strategy": "spatial"}, device="cuda:0")
+        rec16.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in rec_sd.items()}, strict=True)
+        rec16.to("cuda:0").eval()
+        rec16.engine_options["SG_F16"] = 1
     old_threads = torch.get_num_threads()
     torch.set_num_threads(min(threads, old_threads))
-    feats = {"hip": [], "oracle": [], "gt": []}
-    preds = {"hip": [], "oracle": []}
+    feats = {"hip": [], "oracle": [], "gt": [], "hip_f16": [], "gt_f16": []}
+    preds = {"hip": [], "oracle": [], "hip_f16": []}
     worst = 0.0
     try:
         for c0 in range(0, n_motions, chunk):
@@ -51,16 +60,28 @@ def run(n_motions=1024, chunk=256, threads=32, seed=0, verbose=False):
                 feats[name].append(batch["features"].reshape(nb, 256).clone())
                 if name in preds:
                     preds[name].append(batch["yhat"].max(dim=1).indices.clone())
+                if rec16 is not None and name != "oracle":
+                    b16 = rec16({"output": torch.cat((y["cmotion"], other), dim=2)})
+                    feats[name + "_f16"].append(b16["features"].reshape(nb, 256).clone())
+                    if name == "hip":
+                        preds["hip_f16"].append(b16["yhat"].max(dim=1).indices.clone())
             if verbose:
                 print(f"[fid proxy] motions {c0 + nb}/{n_motions}, max |hip - oracle| so far {worst:.2e}", flush=True)
     finally:
         torch.set_num_threads(old_threads)
-    st = {k: calculate_activation_statistics(torch.cat(v)) for k, v in feats.items()}
+    st = {k: calculate_activation_statistics(torch.cat(v)) for k, v in feats.items() if v}
     fid_gt_hip, fid_gt_orc = float(calculate_fid(st["gt"], st["hip"])), float(calculate_fid(st["gt"], st["oracle"]))
     out = {"n": n_motions, "max_abs_motion_dev": worst, "fid_oracle_hip": float(calculate_fid(st["oracle"], st["hip"])),
            "fid_gt_hip": fid_gt_hip, "fid_gt_oracle": fid_gt_orc, "delta_vs_gt": abs(fid_gt_hip - fid_gt_orc),
            "argmax_agree": float((torch.cat(preds["hip"]) == torch.cat(preds["oracle"])).float().mean()),
            "feature_scale": float(torch.cat(feats["oracle"]).abs().mean())}
+    if rec16 is not None:
+        f3, f16 = torch.cat(feats["hip"]), torch.cat(feats["hip_f16"])
+        fid16 = float(calculate_fid(st["gt_f16"], st["hip_f16"]))
+        out["recogniser_f16"] = {"fid_default_vs_f16_features": float(calculate_fid(st["hip"], st["hip_f16"])), "fid_gt_hip_on_f16": fid16,
+                                 "delta_of_fid_gt_hip": abs(fid16 - fid_gt_hip), "features_max_abs": float((f3 - f16).abs().max()),
+                                 "features_abs_max": float(f3.abs().max()), "features_rms_rel": float(((f3 - f16).pow(2).mean() / f3.pow(2).mean()).sqrt()),
+                                 "argmax_agree": float((torch.cat(preds["hip"]) == torch.cat(preds["hip_f16"])).float().mean())}
     model._engine.close()
     return out
 
@@ -71,5 +92,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--threads", type=int, default=32)
+    ap.add_argument("--recogniser-f16", action="store_true")
     a = ap.parse_args()
-    print(json.dumps(run(a.n, threads=a.threads, verbose=True)))
+    print(json.dumps(run(a.n, threads=a.threads, verbose=True, recogniser_f16=a.recogniser_f16)))

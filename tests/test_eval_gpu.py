@@ -159,6 +159,165 @@ def test_stgcn_many_tiles_per_workgroup(golden, T, N):
     assert (yhat[sel].cpu() - ref_y).abs().max().item() < 1e-4 * max(1.0, float(ref_y.abs().max()))
 
 
+F16_BOUND = 1.5e-3     # the single-plane fp16 form (SG_F16): max |features - reference| relative to the largest feature. Measured 3.5e-4 ... 4e-4 on the
+                       # reference's goldens, <= 6e-4 on the other skeletons below; the default split-bf16 arithmetic measures 5e-6 and is held to 1e-4.
+
+
+@pytest.mark.parametrize("tag", ["ntu", "chi3d", "one"])
+def test_stgcn_fp16_form_against_the_reference(golden, tag):
+    """SG_F16 (rgn_stgcn_set_option / STGCN.engine_options): blocks 1-9 and block 0's temporal convolution on single fp16 operand planes, one MFMA per
+    product - the operand precision of the TF32 convolutions the reference's own GPU run uses by default. Against the reference's outputs: features and
+    logits inside F16_BOUND, the predicted classes unchanged; and the switch reaches a LIVE engine in both directions (the default arithmetic again
+    meets its own 1e-4 bound afterwards, bit-equal to an engine that never left it)."""
+    g = golden("stgcn")
+    model, _ = _model(g)
+    x = torch.from_numpy(g[f"x_{tag}"]).cuda()
+    ref_f, ref_y = g[f"features_{tag}"], g[f"yhat_{tag}"]
+    base = model({"output": x})
+    f3, y3 = base["features"].clone(), base["yhat"].clone()
+    model.engine_options["SG_F16"] = 1
+    b16 = model({"output": x})
+    f16 = b16["features"].reshape(x.shape[0], -1).cpu().numpy()
+    err_f, err_y = np.abs(f16 - ref_f).max(), np.abs(b16["yhat"].cpu().numpy() - ref_y).max()
+    print(f"\n[stgcn fp16 form {tag}] max |features - reference| = {err_f:.2e} (|ref| max {np.abs(ref_f).max():.2f}), logits {err_y:.2e} (|ref| max {np.abs(ref_y).max():.2f})")
+    assert err_f < F16_BOUND * max(1.0, np.abs(ref_f).max()) and err_y < F16_BOUND * max(1.0, np.abs(ref_y).max())
+    assert err_f > 1e-4 * np.abs(ref_f).max()                   # (it IS the other arithmetic: the default never differs by this much)
+    assert torch.equal(b16["yhat"].max(dim=1).indices.cpu(), torch.from_numpy(ref_y).max(dim=1).indices)
+    model.engine_options["SG_F16"] = 0
+    again = model({"output": x})
+    assert torch.equal(again["features"], f3) and torch.equal(again["yhat"], y3)
+
+
+@pytest.mark.parametrize("T,N", [(60, 48), (150, 20)])
+def test_stgcn_fp16_form_many_tiles_per_workgroup(golden, T, N):
+    """The fp16 form through the persistent tile walk (several hundred to a thousand tiles; its counted waits differ from the default's: half the plane
+    stores per tile): the whole batch against the same motions four at a time, bit for bit, and against the CPU oracle on three motions inside F16_BOUND."""
+    from oracle import stgcn_oracle
+    g = golden("stgcn")
+    model, sd = _model(g)
+    model.engine_options["SG_F16"] = 1
+    rng = np.random.Generator(np.random.PCG64(4242 + T))
+    x = rng.standard_normal((N, 56, 12, T)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    big = model({"output": xd})
+    feats, yhat = big["features"].clone(), big["yhat"].clone()
+    for i in range(0, N, 4):
+        part = model({"output": xd[i:i + 4]})
+        assert torch.equal(part["features"], feats[i:i + 4]), (i, (part["features"] - feats[i:i + 4]).abs().max().item())
+        assert torch.equal(part["yhat"], yhat[i:i + 4]), i
+    sel = [0, N // 2, N - 1]
+    ref_f, ref_y = stgcn_oracle.stgcn_forward(sd, x[sel])
+    err = (feats[sel].cpu() - ref_f).abs().max().item()
+    print(f"\n[stgcn fp16 form, many tiles T={T} N={N}] max |features - oracle| = {err:.2e} (|ref| max {ref_f.abs().max():.2f})")
+    assert err < F16_BOUND * max(1.0, float(ref_f.abs().max())), err
+    assert (yhat[sel].cpu() - ref_y).abs().max().item() < F16_BOUND * max(1.0, float(ref_y.abs().max()))
+
+
+@pytest.mark.parametrize("V,hub,T,N,opts", [(56, 5, 24, 3, {}), (32, 3, 24, 2, {}), (40, 6, 30, 2, {}), (64, 4, 20, 2, {}), (36, 2, 60, 40, {}), (52, 3, 48, 32, {}),
+                                             (52, 3, 48, 32, {"SG_GCN_BN": 64}), (36, 2, 60, 40, {"SG_GCN_BN": 128}), (52, 3, 48, 32, {"SG_TCONV_SMALL": 1}),
+                                             (52, 3, 48, 32, {"SG_GCN_BN": 64, "SG_GCN_STEP32": 1})])
+def test_stgcn_fp16_form_on_other_skeletons(V, hub, T, N, opts):
+    """The fp16 form on every graph / shape the fused kernels take (V % 4 == 0, 32 <= V <= 64, lists inside the 8 register slots), with the tile-shape switches,
+    against the CPU oracle; batches of many tiles also against themselves four motions at a time (bit for bit)."""
+    from oracle import stgcn_oracle
+    from regennet_amd.eval import STGCN
+    rng = np.random.Generator(np.random.PCG64(3000 + V + hub))
+    A = _tree_graph(V, hub, rng)
+    sd = synth.make_stgcn_state_dict(A, num_class=13, seed=V)
+    model = STGCN(in_channels=12, num_class=13, num_person=2, num_nodes=V, device="cuda:0")
+    model.engine_options = dict(opts, SG_F16=1)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model = model.to("cuda:0").eval()
+    x = rng.standard_normal((N, V, 12, T)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    big = model({"output": xd})
+    feats, yhat = big["features"].reshape(N, -1).clone(), big["yhat"].clone()
+    if N > 4:
+        for i in range(0, N, 4):
+            part = model({"output": xd[i:i + 4]})
+            assert torch.equal(part["features"].reshape(-1, feats.shape[1]), feats[i:i + 4]), (i, opts)
+    sel = sorted({0, N // 2, N - 1})
+    ref_f, ref_y = stgcn_oracle.stgcn_forward(sd, x[sel])
+    err_f, err_y = (feats[sel].cpu() - ref_f).abs().max().item(), (yhat[sel].cpu() - ref_y).abs().max().item()
+    print(f"\n[stgcn fp16 form V={V} hub={hub} T={T} N={N} {opts}] max |features - oracle| = {err_f:.2e} (|ref| max {ref_f.abs().max():.2f}), logits {err_y:.2e}")
+    assert err_f < F16_BOUND * max(1.0, float(ref_f.abs().max())), err_f
+    assert err_y < F16_BOUND * max(1.0, float(ref_y.abs().max())), err_y
+
+
+def test_stgcn_fp16_form_is_refused_where_it_does_not_exist(golden):
+    """SG_F16 exists for the fused kernels only and for weights inside the fp16 range; everything else is an error that says why (RGN_ERR_UNSUPPORTED),
+    never a silent change of arithmetic: a graph outside the LDS-window kernels' shapes (V = 30), a hub beyond the 8 aggregation slots, an SG_NO_* switch
+    that selects an unfused form, and a checkpoint whose folded temporal-convolution weight overflows fp16 (the key is named). The default arithmetic serves all four."""
+    from regennet_amd import _lib
+    from regennet_amd.eval import STGCN
+    rng = np.random.Generator(np.random.PCG64(77))
+    for V, hub in ((30, 4), (56, 12)):
+        A = _tree_graph(V, hub, rng)
+        sd = synth.make_stgcn_state_dict(A, num_class=13, seed=V)
+        model = STGCN(in_channels=12, num_class=13, num_person=2, num_nodes=V, device="cuda:0")
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        model = model.to("cuda:0").eval()
+        x = torch.from_numpy(rng.standard_normal((2, V, 12, 24)).astype(np.float32)).cuda()
+        model({"output": x})
+        model.engine_options["SG_F16"] = 1
+        with pytest.raises(_lib.RgnError) as e:
+            model({"output": x})
+        assert e.value.code == _lib.RGN_ERR_UNSUPPORTED and "SG_F16" in str(e.value) and "fused kernels only" in str(e.value), str(e.value)
+    g = golden("stgcn")
+    model, sd = _model(g)
+    x = torch.from_numpy(g["x_ntu"]).cuda()
+    for sw in ("SG_NO_WINDOW", "SG_NO_GCN_FUSE", "SG_NO_TAIL_FUSE", "SG_NO_POLY_TAIL", "SG_NO_S2_WINDOW"):
+        model.engine_options = {"SG_F16": 1, sw: 1}
+        with pytest.raises(_lib.RgnError) as e:
+            model({"output": x})
+        assert e.value.code == _lib.RGN_ERR_UNSUPPORTED and "fused kernels only" in str(e.value), (sw, str(e.value))
+    model.engine_options = {"SG_F16": 1}
+    model({"output": x})                                         # (and without the switch the same engine serves it)
+    big = {k: np.array(v, copy=True) for k, v in sd.items()}
+    big["st_gcn_networks.6.tcn.2.weight"][3, 5, 4, 0] = 3.0e5
+    m2 = STGCN(in_channels=12, num_class=26, num_person=2, graph_args={"layout": "smplx", "strategy": "spatial"}, device="cuda:0")
+    m2.load_state_dict({k: torch.from_numpy(v) for k, v in big.items()}, strict=True)
+    m2 = m2.to("cuda:0").eval()
+    m2({"output": x})
+    m2.engine_options["SG_F16"] = 1
+    with pytest.raises(_lib.RgnError) as e:
+        m2({"output": x})
+    assert e.value.code == _lib.RGN_ERR_UNSUPPORTED and "st_gcn_networks.6.tcn.2.weight" in str(e.value) and "fp16 range" in str(e.value), str(e.value)
+
+
+def test_stgcn_fp16_form_per_person_features(golden):
+    """person_features / features_from_persons under SG_F16: the per-person engines take the model's switches (also when they change after the engines were
+    built), and cached actor + reactor reproduces the two-person fp16 forward."""
+    g = golden("stgcn")
+    model, _ = _model(g)
+    x = torch.from_numpy(g["x_ntu"]).cuda()
+    C = x.shape[2] // 2
+    fa3 = model.person_features(x[:, :, :C], person=0)
+    model.engine_options["SG_F16"] = 1
+    full = model({"output": x})
+    fa = model.person_features(x[:, :, :C], person=0)
+    assert not torch.equal(fa, fa3)                              # (the live per-person engine changed arithmetic with the model)
+    two = model.features_from_persons([fa, x[:, :, C:].contiguous()])
+    ref = torch.from_numpy(g["features_ntu"]).reshape(x.shape[0], -1)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((two["features"].reshape(ref.shape) - full["features"].reshape(ref.shape)).abs().max()) < 2e-6 * scale
+    assert float((two["features"].reshape(ref.shape).cpu() - ref).abs().max()) < F16_BOUND * scale
+
+
+def test_fid_proxy_with_the_fp16_recogniser():
+    """What SG_F16 is worth in the harness's own units (tests/fid_proxy.py, recogniser_f16): 512 HIP-sampled motions through the default and the fp16
+    recogniser - FID between the two feature sets, the change of FID(gt*, HIP set) when the whole evaluation runs on the fp16 recogniser, predicted classes."""
+    from tests.fid_proxy import run
+    r = run(512, recogniser_f16=True)
+    print(f"\n[fid proxy, fp16 recogniser] {r['recogniser_f16']} (FID(gt*, HIP) {r['fid_gt_hip']:.2f})")
+    q = r["recogniser_f16"]
+    # measured: FID(default features, fp16 features) 0.005 and |delta FID(gt*, HIP)| 0.16 at an FID scale of 2153 (7e-5 of it; the sampler's own arithmetic difference
+    # measures 3e-9 / 0.002 in the test above - the fp16 recogniser is NOT free, which is why it is a switch and not the default)
+    assert q["fid_default_vs_f16_features"] < 2e-2, q
+    assert q["delta_of_fid_gt_hip"] < max(0.01, 2e-4 * r["fid_gt_hip"]), q
+    assert q["argmax_agree"] >= 0.998, q
+
+
 def test_stgcn_per_person_features_reproduce_the_two_person_forward(golden):
     """The persons of a clip never meet before the final mean (eval-mode data_bn is a per-channel affine, the st_gcn blocks run on the N M sequences
     independently, stgcn.py:99-114): the actor's pooled features can be computed once and reused for every re-sampled reactor of the same actor clip
