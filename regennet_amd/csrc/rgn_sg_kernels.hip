@@ -20,8 +20,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // F16 (every kernel of this file): the SINGLE-PLANE fp16 form - the hi planes of activations, residual, weights and output hold IEEE fp16, the lo planes
-// are neither read nor written (their LDS images stay unused), one v_mfma_f32_32x32x16_f16 per product instead of three bf16 ones: 2^-12 per operand
-// instead of ~2^-16 per product at a third of the matrix work and half the bytes (rgn_stgcn.hip: SG_F16).
+// are neither read nor written, one v_mfma_f32_32x32x16_f16 per product instead of three bf16 ones: 2^-12 per operand instead of ~2^-16 per product
+// (rgn_stgcn.hip: SG_F16). The LDS images, the DMA schedule and every hazard stay those of the split form: what was the lo plane of channel block cb
+// (window and weight tile) is the fp16 plane of channel block cb + 1 - a k-step is 64 channels deep (two MFMAs per fragment pair instead of three),
+// there are half as many of them, and the per-step costs that bound these kernels (DMA wait, barrier, DMA issue) are paid half as often. Channel
+// block counts are even (64 / 128 / 256 channels).
 __device__ __forceinline__ float f16_bits_to_float(unsigned b) { return (float)__builtin_bit_cast(_Float16, (unsigned short)b); }
 
 #define RGN_AS1 __attribute__((address_space(1)))
@@ -240,21 +243,22 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
     const int WR = BM + 8 * V, A_PLANE = (CIRC ? 2 * BM : WR) * 64;   // window rows (a multiple of 16: V even); bytes per plane
     const int SP = CIRC ? BM - 8 * V : 0;
     char* const wst = smem + 2 * A_PLANE;                        // weight stages behind the two window planes
-    const int ncb = g.Kp / (32 * TAPS);
+    constexpr int CBS = F16 ? 2 : 1;                             // channel blocks per k-step (F16: the "lo" images hold the next channel block)
+    const int ncb = g.Kp / (32 * TAPS * CBS);
     const long long row_lo = -4LL * V, row_hi = (long long)g.M + 4LL * V - 1;   // the planes' zero guard rows bound what a window may touch
-    const char* const a_pl[2] = {reinterpret_cast<const char*>(g.Ahi), reinterpret_cast<const char*>(g.Alo)};
-    const char* const w_pl[2] = {reinterpret_cast<const char*>(g.Whi), reinterpret_cast<const char*>(g.Wlo)};
+    const char* const a_pl[2] = {reinterpret_cast<const char*>(g.Ahi), F16 ? reinterpret_cast<const char*>(g.Ahi) + (long long)g.a_rows * 64 : reinterpret_cast<const char*>(g.Alo)};
+    const char* const w_pl[2] = {reinterpret_cast<const char*>(g.Whi), F16 ? reinterpret_cast<const char*>(g.Whi) + (size_t)TAPS * g.N * 64 : reinterpret_cast<const char*>(g.Wlo)};
+    auto wk = [&](int cb, int dt) { return CBS * cb * TAPS + dt; };   // weight k-block of (channel block [pair], tap)
 
     // one 16-row piece (1 KiB per plane) of the window of (tile rows m0t, channel block cb), rows [r0, r0 + 16) limited to rows < rend, into its place in plane pl
     // ws = the window's first physical row (0 unless CIRC)
     auto a_piece = [&](int m0t, int cb, int pl, int r0, int rend, int ws) {
-        if (F16 && pl) return;                                   // (wave-uniform)
         const int r = r0 + (lane >> 2);
         if (r < rend) {
             long long gr = (long long)m0t - 4LL * V + r;
             gr = gr < row_lo ? row_lo : (gr > row_hi ? row_hi : gr);
             const int p0 = CIRC ? ((ws + r0) & RMASK) : r0, pr = p0 + (lane >> 2);   // (pieces start on multiples of 16: they never wrap)
-            const char* src = a_pl[pl] + ((long long)cb * g.a_rows + gr) * 64 + (((lane & 3) ^ ((pr >> 2) & 3)) << 4);
+            const char* src = a_pl[pl] + ((long long)(CBS * cb) * g.a_rows + gr) * 64 + (((lane & 3) ^ ((pr >> 2) & 3)) << 4);
             __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)src, (RGN_AS3 void*)(smem + pl * A_PLANE + p0 * 64), 16, 0, 0);
         }
     };
@@ -268,7 +272,6 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int pl = (it * NT + (tid & ~63)) / (BN * 4);
-            if (F16 && pl) continue;
             __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(w_pl[pl] + ((size_t)kt * g.N + n0t) * 64 + w_lane[it]),
                                              (RGN_AS3 void*)(stage + pl * W_BYTES + (it * NT + (tid & ~63) - pl * (BN * 4)) * 16), 16, 0, 0);
         }
@@ -282,8 +285,10 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
     }
     const int arow0 = wm * (BM / WM) + l31;
     auto mma3 = [&](f32x16& c, const bf16x8& a_h, const bf16x8& a_l, const bf16x8& w_h, const bf16x8& w_l) {
-        if constexpr (F16) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_h), __builtin_bit_cast(f16x8, w_h), c, 0, 0, 0);
-        else {
+        if constexpr (F16) {                                     // (a_l, w_l: the next channel block's fragments)
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_h), __builtin_bit_cast(f16x8, w_h), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_l), __builtin_bit_cast(f16x8, w_l), c, 0, 0, 0);
+        } else {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, w_h, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_l, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_h, c, 0, 0, 0);
@@ -334,11 +339,11 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
                             const int rl = arow0 + t * 32 + dt * V, rr = CIRC ? ((ws + rl) & RMASK) : rl;
                             const int o = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
                             ah[ks][t] = *reinterpret_cast<const bf16x8*>(smem + o);
-                            if constexpr (!F16) al[ks][t] = *reinterpret_cast<const bf16x8*>(smem + A_PLANE + o);
+                            al[ks][t] = *reinterpret_cast<const bf16x8*>(smem + A_PLANE + o);
                         }
                     }
                     wh[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + w_off[tb][ks]);
-                    if constexpr (!F16) wl[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + W_BYTES + w_off[tb][ks]);
+                    wl[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + W_BYTES + w_off[tb][ks]);
                 };
                 fetch(0);
 #pragma unroll
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv(GemmX3Args g, int nbx, int 
                     if (grp == 0) {
                         // the path's load for this k-step, behind the first MFMA group: next weight tile, the dead strip's successor, the window's top quarter
                         const bool klast = wlast && dt == TAPS - 1;
-                        if (!klast) w_tile(n0, cb * TAPS + dt + 1, wst + ((gstep + 1) & 1) * W_STAGE);
+                        if (!klast) w_tile(n0, dt + 1 < TAPS ? wk(cb, dt + 1) : wk(cb + 1, 0), wst + ((gstep + 1) & 1) * W_STAGE);
                         else if (more) w_tile(n0n, 0, wst + ((gstep + 1) & 1) * W_STAGE);
                         if (!wlast || more) {
                             const int m0w = wlast ? m0n : m0, cbw = wlast ? 0 : cb + 1;
@@ -477,17 +482,20 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
     char* const ebuf = smem;                                     // E hi | E lo
     char* const obuf = smem + 2 * EP;                            // O hi | O lo
     char* const wst = obuf + 2 * OP;
-    const int ncb = g.Kp / (32 * 9);
+    constexpr int CBS = F16 ? 2 : 1;                             // channel blocks per k-step (F16: the "lo" images hold the next channel block)
+    const int ncb = g.Kp / (32 * 9 * CBS), k2 = g.k2 / CBS;
     const long long row_lo = -4LL * V, row_hi = o_rows + (long long)g.M + 4LL * V - 1;   // guard rows in front of E and behind O
-    const char* const a_pl[2] = {reinterpret_cast<const char*>(g.Ahi), reinterpret_cast<const char*>(g.Alo)};
+    const char* const a_pl[2] = {reinterpret_cast<const char*>(g.Ahi), F16 ? reinterpret_cast<const char*>(g.Ahi) + (long long)g.a_rows * 64 : reinterpret_cast<const char*>(g.Alo)};
+    const __bf16* const w1lo = F16 ? g.Whi + (size_t)9 * g.N * 32 : g.Wlo;      // (the same tap of the next channel block: 9 k-blocks of N x 32 further on)
+    const __bf16* const w2lo = F16 ? g.W2hi + (size_t)g.N * 32 : g.W2lo;
+    const __bf16* const a2lo = F16 ? g.A2hi + (size_t)g.a2_rows * 32 : g.A2lo;
     // one 16-row piece of a window: `first` = the global row of window row 0, rows [r0, r0 + 16) below rend, plane pl of the buffer at `buf` (`pb` bytes per plane)
     auto a_piece = [&](long long first, int cb, int pl, int r0, int rend, char* buf, int pb) {
-        if (F16 && pl) return;                                   // (wave-uniform)
         const int r = r0 + (lane >> 2);
         if (r < rend) {
             long long gr = first + r;
             gr = gr < row_lo ? row_lo : (gr > row_hi ? row_hi : gr);
-            const char* src = a_pl[pl] + ((long long)cb * g.a_rows + gr) * 64 + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+            const char* src = a_pl[pl] + ((long long)(CBS * cb) * g.a_rows + gr) * 64 + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
             __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)src, (RGN_AS3 void*)(buf + pl * pb + r0 * 64), 16, 0, 0);
         }
     };
@@ -501,7 +509,6 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int pl = (it * NT + (tid & ~63)) / (BN * 4);
-            if (F16 && pl) continue;
             const char* base = reinterpret_cast<const char*>(pl ? wlo : whi);
             __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(base + ((size_t)kt * g.N + n0t) * 64 + w_lane[it]),
                                              (RGN_AS3 void*)(stage + pl * W_BYTES + (it * NT + (tid & ~63) - pl * (BN * 4)) * 16), 16, 0, 0);
@@ -516,8 +523,10 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
     }
     const int arow0 = wm * (BM / WM) + l31;
     auto mma3 = [&](f32x16& c, const bf16x8& a_h, const bf16x8& a_l, const bf16x8& w_h, const bf16x8& w_l) {
-        if constexpr (F16) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_h), __builtin_bit_cast(f16x8, w_h), c, 0, 0, 0);
-        else {
+        if constexpr (F16) {                                     // (a_l, w_l: the next channel block's fragments)
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_h), __builtin_bit_cast(f16x8, w_h), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_l), __builtin_bit_cast(f16x8, w_l), c, 0, 0, 0);
+        } else {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, w_h, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_l, c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, w_h, c, 0, 0, 0);
@@ -530,11 +539,11 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
         for (int t = 0; t < TM; ++t) {
             long long row = (long long)m0t + arow0 + t * 32;
             row = row > row_hi ? row_hi : row;
-            const size_t o = ((size_t)cr * g.a2_rows + (size_t)row) * 32 + 8 * kh;
+            const size_t o = ((size_t)(CBS * cr) * g.a2_rows + (size_t)row) * 32 + 8 * kh;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 sh[ks][t] = *reinterpret_cast<const bf16x8*>(g.A2hi + o + 16 * ks);
-                if constexpr (!F16) sl[ks][t] = *reinterpret_cast<const bf16x8*>(g.A2lo + o + 16 * ks);
+                sl[ks][t] = *reinterpret_cast<const bf16x8*>(a2lo + o + 16 * ks);
             }
         }
     };
@@ -545,7 +554,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
         const int ne = (WE + 15) / 16, no = (3 * V + 15) / 16;
         for (int q = wave; q < 2 * ne; q += 8) a_piece((long long)m0 - 2 * V, 0, q / ne, (q % ne) * 16, WE, ebuf, EP);
         for (int q = wave; q < 2 * no; q += 8) a_piece(o_rows + m0 - 2 * V, 0, q / no, (q % no) * 16, 3 * V, obuf, OP);
-        w_tile(g.Whi, g.Wlo, n0, 0, wst);
+        w_tile(g.Whi, w1lo, n0, 0, wst);
     }
     unsigned gstep = 0;
     bool stores_behind = false;
@@ -560,7 +569,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
             for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-        const int nsteps = ncb * 9 + g.k2;
+        const int nsteps = ncb * 9 + k2;
         for (int st = 0; st < nsteps; ++st, ++gstep) {
             const bool shortcut = st >= ncb * 9;
             const int cb = shortcut ? ncb - 1 : st / 9, i9 = shortcut ? 9 : st - cb * 9;      // i9: 0..4 E taps, 5..8 O taps
@@ -580,7 +589,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
 #pragma unroll
                     for (int t = 0; t < TM; ++t) {
                         ah[ks][t] = sh[ks][t];
-                        if constexpr (!F16) al[ks][t] = sl[ks][t];
+                        al[ks][t] = sl[ks][t];
                     }
             }
             auto fetch = [&](int grp) {                          // grp = ks * TN + tb
@@ -591,11 +600,11 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
                         const int rr = arow0 + t * 32 + j * V;
                         const int o = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
                         ah[ks][t] = *reinterpret_cast<const bf16x8*>(abuf + o);
-                        if constexpr (!F16) al[ks][t] = *reinterpret_cast<const bf16x8*>(abuf + apl + o);
+                        al[ks][t] = *reinterpret_cast<const bf16x8*>(abuf + apl + o);
                     }
                 }
                 wh[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + w_off[tb][ks]);
-                if constexpr (!F16) wl[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + W_BYTES + w_off[tb][ks]);
+                wl[grp & 1] = *reinterpret_cast<const bf16x8*>(wsb + W_BYTES + w_off[tb][ks]);
             };
             fetch(0);
 #pragma unroll
@@ -610,9 +619,9 @@ __global__ __launch_bounds__(512, 1) void k_sg_tconv_s2(GemmX3Args g, int nbx, i
                         const int s1 = st + 1;
                         if (s1 < ncb * 9) {
                             const int c1 = s1 / 9, i1 = s1 - c1 * 9;
-                            w_tile(g.Whi, g.Wlo, n0, c1 * 9 + (i1 < 5 ? 2 * i1 : 2 * (i1 - 5) + 1), nstage);
-                        } else w_tile(g.W2hi, g.W2lo, n0, s1 - ncb * 9, nstage);
-                    } else if (more) w_tile(g.Whi, g.Wlo, n0n, 0, nstage);
+                            w_tile(g.Whi, w1lo, n0, CBS * c1 * 9 + (i1 < 5 ? 2 * i1 : 2 * (i1 - 5) + 1), nstage);
+                        } else w_tile(g.W2hi, w2lo, n0, CBS * (s1 - ncb * 9), nstage);
+                    } else if (more) w_tile(g.Whi, w1lo, n0n, 0, nstage);
                     if (!shortcut) {
                         const bool wlast = cb + 1 == ncb;
                         const bool nextw = !wlast || more;       // a next pair of windows exists: (this tile, cb + 1) or (next tile, 0)
@@ -682,19 +691,20 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
         t_a[i] = sl_a[i];
     }
     __syncthreads();
-    const int ncb = g.Kp / (32 * KP);
+    constexpr int CBS = F16 ? 2 : 1;                             // channel blocks per window (F16: the "lo" images hold the next channel block)
+    const int ncbf = g.Kp / (32 * KP), ncb = ncbf / CBS;         // channel blocks, windows
     const long long row_hi = (long long)g.M + 4LL * V - 1;       // (the planes carry 4 V guard rows at both ends)
-    const char* const a_pl[2] = {reinterpret_cast<const char*>(g.Ahi), reinterpret_cast<const char*>(g.Alo)};
-    const char* const w_pl[2] = {reinterpret_cast<const char*>(g.Whi), reinterpret_cast<const char*>(g.Wlo)};
+    const char* const a_pl[2] = {reinterpret_cast<const char*>(g.Ahi), F16 ? reinterpret_cast<const char*>(g.Ahi) + (long long)g.a_rows * 64 : reinterpret_cast<const char*>(g.Alo)};
+    const char* const w_pl[2] = {reinterpret_cast<const char*>(g.Whi), F16 ? reinterpret_cast<const char*>(g.Whi) + (size_t)g.N * 64 : reinterpret_cast<const char*>(g.Wlo)};
+    auto wkb = [&](int cb, int k) { return k * ncbf + CBS * cb; };   // weight k-block of (window, partition)
     const int npc = (WRX + 15) / 16, npieces = 2 * npc;          // 16-row pieces of a window: hi plane, then lo plane
     const int ppk = (npieces + 8 * KP - 1) / (8 * KP);           // pieces per wave per k-step
     auto x_piece = [&](int m0t, int cb, int p, int buf) {        // piece p of the window of (tile rows m0t, channel block cb) into window buffer buf
         const int pl = p >= npc ? 1 : 0, r0 = (p - pl * npc) * 16, r = r0 + (lane >> 2);
-        if (F16 && pl) return;                                   // (wave-uniform)
         if (r < WRX) {
             long long gr = (long long)m0t - V + r;
             gr = gr > row_hi ? row_hi : gr;
-            const char* src = a_pl[pl] + ((long long)cb * g.a_rows + gr) * 64 + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+            const char* src = a_pl[pl] + ((long long)(CBS * cb) * g.a_rows + gr) * 64 + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
             __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)src, (RGN_AS3 void*)(smem + buf * XW + pl * XP + r0 * 64), 16, 0, 0);
         }
     };
@@ -702,7 +712,6 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int q = it * NT + tid, pl = (it * NT + (tid & ~63)) / (BN * 4), qq = q - pl * (BN * 4), r = qq >> 2, c = (qq & 3) ^ ((r >> 2) & 3);
-            if (F16 && pl) continue;
             int n = n0t + r;
             n = n < g.N ? n : g.N - 1;
             __builtin_amdgcn_global_load_lds((const RGN_AS1 void*)(w_pl[pl] + ((size_t)kb * g.N + n) * 64 + c * 16),
@@ -723,7 +732,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
     int m0 = (tile / nbx) * BM, n0 = (tile % nbx) * BN;
     for (int p = wave; p < npieces; p += 8) x_piece(m0, 0, p, 0);
     if constexpr (ALLK) {
-        for (int kk = 0; kk < KP; ++kk) w_tile(n0, kk * ncb, wst + kk * 2 * W_BYTES);
+        for (int kk = 0; kk < KP; ++kk) w_tile(n0, wkb(0, kk), wst + kk * 2 * W_BYTES);
     } else w_tile(n0, 0, wst);
     unsigned gstep = 0, widx = 0;                                // k-steps / windows consumed so far: stage gstep & 1, window buffer widx & 1
     bool stores_behind = false;                                  // the previous tile's stores were issued after everything the next wait is for
@@ -763,7 +772,7 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
                     __builtin_amdgcn_s_barrier();                // the tile(s) of this step (and, at k = 0, the window) are in LDS; the previous step is read out
                     if constexpr (!ALLK) {
                         const bool klast = k + 1 == KP;
-                        if (!(klast && wlast)) w_tile(n0, klast ? cb + 1 : (k + 1) * ncb + cb, wst + ((gstep + 1) & 1) * W_STAGE);
+                        if (!(klast && wlast)) w_tile(n0, klast ? wkb(cb + 1, 0) : wkb(cb, k + 1), wst + ((gstep + 1) & 1) * W_STAGE);
                         else if (more) w_tile(n0n, 0, wst + ((gstep + 1) & 1) * W_STAGE);
                         if (!wlast || more)
                             for (int i = 0; i < ppk; ++i) {
@@ -771,16 +780,23 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
                                 if (p < npieces) x_piece(wlast ? m0n : m0, wlast ? 0 : cb + 1, p, (widx + 1) & 1);
                             }
                     } else if (!wlast || more) {                 // every partition's tile of the next channel block, and its whole window
-                        for (int kk = 0; kk < KP; ++kk) w_tile(wlast ? n0n : n0, kk * ncb + (wlast ? 0 : cb + 1), wst + ((gstep + 1) & 1) * W_STAGE + kk * 2 * W_BYTES);
+                        for (int kk = 0; kk < KP; ++kk) w_tile(wlast ? n0n : n0, wkb(wlast ? 0 : cb + 1, kk), wst + ((gstep + 1) & 1) * W_STAGE + kk * 2 * W_BYTES);
                         for (int p = wave; p < npieces; p += 8) x_piece(wlast ? m0n : m0, wlast ? 0 : cb + 1, p, (widx + 1) & 1);
                     }
                 }
                 const char* wsb = wst + (gstep & 1) * W_STAGE + (ALLK ? k * 2 * W_BYTES : 0);
                 float z[2][8];
+                // F16: the sums of the window's two channel blocks, formed in PACKED fp16 (v_pk_fma_f16: 4 instructions per slot and fragment where the fp32
+                // sums take 8 conversions + 8 fmas - this aggregation, not the MFMAs, bounds the narrow tiles): <= 6 terms with |coefficient| <= 1, one
+                // fp16 rounding per term where the fp32 form rounds once at the end (stated with SG_F16's bound, tests/test_eval_gpu.py)
+                [[maybe_unused]] f16x8 zf[2], zf2[2];
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) z[ks][e] = 0.f;
+                    for (int e = 0; e < 8; ++e) {
+                        z[ks][e] = 0.f;
+                        zf[ks][e] = zf2[ks][e] = (_Float16)0.f;
+                    }
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
                     if ((int)((slot_k >> (4 * s)) & 15u) == k && ((live >> s) & 1u)) {     // (uniform)
@@ -788,9 +804,11 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
                         for (int ks = 0; ks < 2; ++ks) {
                             const int o = so[s] ^ (32 * ks);
                             if constexpr (F16) {
-                                const f16x8 h = *reinterpret_cast<const f16x8*>(xw + o);
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) z[ks][e] = fmaf(sa[s], (float)h[e], z[ks][e]);
+                                const f16x8 h = *reinterpret_cast<const f16x8*>(xw + o), h2 = *reinterpret_cast<const f16x8*>(xw + XP + o);
+                                const _Float16 c16 = (_Float16)sa[s];
+                                const f16x8 cv = {c16, c16, c16, c16, c16, c16, c16, c16};
+                                zf[ks] = __builtin_elementwise_fma(cv, h, zf[ks]);
+                                zf2[ks] = __builtin_elementwise_fma(cv, h2, zf2[ks]);
                             } else {
                                 const bf16x8 h = *reinterpret_cast<const bf16x8*>(xw + o), l = *reinterpret_cast<const bf16x8*>(xw + XP + o);
 #pragma unroll
@@ -801,13 +819,13 @@ __global__ __launch_bounds__(512, 1) void k_sg_gcn(GemmX3Args g, int nbx, int nt
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     if constexpr (F16) {
-                        f16x8 af;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) af[e] = (_Float16)z[ks][e];
+                        const f16x8 af = zf[ks], af2 = zf2[ks];
 #pragma unroll
                         for (int tb = 0; tb < TN; ++tb) {
-                            const f16x8 wf = *reinterpret_cast<const f16x8*>(wsb + (w_off[tb] ^ (32 * ks)));
+                            const int o = w_off[tb] ^ (32 * ks);
+                            const f16x8 wf = *reinterpret_cast<const f16x8*>(wsb + o), wf2 = *reinterpret_cast<const f16x8*>(wsb + W_BYTES + o);
                             acc[0][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wf, acc[0][tb], 0, 0, 0);
+                            acc[0][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af2, wf2, acc[0][tb], 0, 0, 0);
                         }
                     } else {
                         bf16x8 ah, al;

@@ -224,6 +224,39 @@ __global__ void k_sg_agg_small(SgPl x, SgPl z, const int* __restrict__ nz_ptr, c
     }
 }
 
+// ... and for the shapes the evaluation uses (C = 6 rot6d channels per person, K = 3 partitions; any C <= 8) with everything static: the sums stay in
+// registers (the form above indexes val[k C + c] with run-time C: private memory) and a neighbour's channels are ONE 16-byte load per plane
+template <int C, int K>
+__global__ __launch_bounds__(256) void k_sg_agg_small_t(SgPl x, SgPl z, const int* __restrict__ nz_ptr, const int* __restrict__ nz_v, const float* __restrict__ nz_a, size_t rows, int V) {
+    static_assert(C <= 8 && K * C <= 32, "one 16-byte chunk per neighbour, one 32-channel block out");
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const size_t frame = row / V;
+    const int w = (int)(row - frame * V);
+    float val[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) val[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        for (int j = nz_ptr[k * V + w]; j < nz_ptr[k * V + w + 1]; ++j) {
+            const size_t src = (frame * V + nz_v[j]) * 32;
+            const float a = nz_a[j];
+            const sg_bf16x8 h = *reinterpret_cast<const sg_bf16x8*>(x.hi + src), l = *reinterpret_cast<const sg_bf16x8*>(x.lo + src);
+#pragma unroll
+            for (int c = 0; c < C; ++c) val[k * C + c] = fmaf(a, (float)h[c] + (float)l[c], val[k * C + c]);
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = val[8 * q + j];
+        sg_bf16x8 h, l;
+        sg_split8(v8, h, l);
+        *reinterpret_cast<sg_bf16x8*>(z.hi + row * 32 + 8 * q) = h;
+        *reinterpret_cast<sg_bf16x8*>(z.lo + row * 32 + 8 * q) = l;
+    }
+}
+
 // zero the pad frames and the guard rows of padded planes with `cb` channel blocks: sequences of Tr real + (Tp - Tr) pad frames starting at row
 // `base` of every plane block, `lead` / `trail` guard rows in front of / behind the NM sequences (0: that side borders another region)
 __global__ void k_sg_zero(SgPl g, long long base, int NM, int Tr, int Tp, int V, int cb, int lead, int trail) {
@@ -783,6 +816,7 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
             if (fused) SG_HIP(c, launch_sg_gcn(g1, V, K, b.slot_k, b.sl_v, b.sl_a, gcn_bn, gcn_step32, s));   // z is formed in registers, fragment by fragment
             else {
                 if (b.ci % 32 == 0) hipLaunchKernelGGL(k_sg_agg, dim3((unsigned)((rows * 4 + 255) / 256), (unsigned)(K * (b.ci / 32))), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
+                else if (b.ci == 6 && K == 3) hipLaunchKernelGGL((k_sg_agg_small_t<6, 3>), blocks1d(rows), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V);
                 else hipLaunchKernelGGL(k_sg_agg_small, blocks1d(rows), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
                 SG_HIP(c, launch_gemm_x3_sg(g1, s));
                 if (f16) hipLaunchKernelGGL(k_sg_to_f16, blocks1d(rows * (b.co / 32) * 4), dim3(256), 0, s, gp, rows, b.co / 32);
