@@ -255,7 +255,11 @@ RGN_API int rgn_stgcn_finalize(rgn_stgcn_handle h);
  * LDS-window temporal convolutions), "SG_NO_GCN_FUSE" (aggregation and 1x1 convolution as two launches), "SG_NO_TAIL_FUSE" (k_sg_post for every block), "SG_NO_POLY_TAIL" (... for the two blocks with polyphase output),
  * "SG_NO_S2_WINDOW" (stride-2 blocks as row-shifted GEMM + shortcut GEMM), "SG_TCONV_SMALL" (256-row tiles), "SG_GCN_BN" (widest aggregation tile: 64 |
  * 128 | 256), "SG_GCN_STEP32" (64-wide aggregation tiles: one barrier per 32-deep k-block). A handle's option takes precedence over REGENNET_<KEY> in the environment; unknown names are RGN_ERR_BAD_KEY. Every form meets the same
- * parity bound (tests/test_eval_gpu.py runs each against the reference's outputs). */
+ * parity bound (tests/test_eval_gpu.py runs each against the reference's outputs).
+ * "SG_F16" (0 | 1, default 0) is not a kernel form but the ARITHMETIC: blocks 1-9 and block 0's temporal convolution on single IEEE fp16 operand planes, one MFMA per
+ * product instead of the split-bf16 three (features within 1.5e-3 of the largest feature - measured 4e-4 - instead of 1e-4 / 5e-6; about twice the speed). It exists
+ * for the fused kernels only: rgn_stgcn_forward returns RGN_ERR_UNSUPPORTED, with the reason in rgn_stgcn_last_error, for a graph / shape / SG_NO_* selection they do
+ * not cover or a checkpoint with a folded weight of magnitude >= 6e4 (key named) - never a silent change of arithmetic. */
 RGN_API int rgn_stgcn_set_option(rgn_stgcn_handle h, const char* key, int32_t value);
 /* STGCN.forward (stgcn.py:76-123): output_dev fp32 [N, num_nodes, in_channels, T] (batch['output']) ->
  * features_dev fp32 [N, 256] (batch['features'], nullable) and yhat_dev fp32 [N, num_class] (batch['yhat'], nullable) */

@@ -15,6 +15,8 @@ python bench.py --batch 1 --no-cpu-baseline --steps 3 --warmup 1 > $O/bench_cfg1
 python bench.py --respacing ddim5 --no-cpu-baseline --steps 20 --warmup 3 --profile-evals 0 > $O/bench_eval_ddim5.json 2>/dev/null; head -c 160 $O/bench_eval_ddim5.json; echo
 python bench.py --config stgcn --steps 10 --warmup 2 > $O/bench_stgcn.json 2>/dev/null; head -c 200 $O/bench_stgcn.json; echo
 python bench.py --config eval_pipeline --steps 10 --warmup 2 > $O/bench_eval_pipeline.json 2>/dev/null; head -c 200 $O/bench_eval_pipeline.json; echo
+python bench.py --config stgcn --recogniser-f16 --steps 10 --warmup 2 > $O/bench_stgcn_fp16_form.json 2>/dev/null; head -c 200 $O/bench_stgcn_fp16_form.json; echo
+python bench.py --config eval_pipeline --recogniser-f16 --steps 10 --warmup 2 > $O/bench_eval_pipeline_fp16_recogniser.json 2>/dev/null; head -c 200 $O/bench_eval_pipeline_fp16_recogniser.json; echo
 bash tools/batch_sweep.sh > $O/batch_sweep.txt 2>&1; cat $O/batch_sweep.txt
 cd /tmp && export TMPDIR=/tmp
 prof() {  # name, bench flags...
@@ -27,6 +29,7 @@ prof cfg4 --steps 1 --warmup 1 --profile-evals 0 --config chi3d --batch 128 --re
 prof cfg5 --steps 1 --warmup 1 --profile-evals 0 --config text150 --batch 256 --sampler ddim --respacing ddim50 --guided
 prof eval_ddim5 --steps 10 --warmup 2 --profile-evals 0 --respacing ddim5
 prof stgcn --config stgcn --steps 3 --warmup 1
+prof stgcn_fp16_form --config stgcn --recogniser-f16 --steps 3 --warmup 1
 rm -f $O/*kernel_trace.csv $O/*agent_info.csv $O/*domain_stats.csv
 cd $R
 PMC_FULL=1 PMC_STEPS=990 bash tools/collect_pmc.sh gpurun_out/final_$TAG/pmc_bench.json ntu_B256_bf16_x3tail_plain 2>&1 | grep "rc="
