@@ -67,6 +67,8 @@ class Evaluation:
         model.load_state_dict(state_dict)
         model = model.to(device)
         model.eval()
+        if parameters.get("recogniser_f16"):        # not in the reference: the recogniser's opt-in fp16 arithmetic (STGCN.engine_options["SG_F16"])
+            model.engine_options["SG_F16"] = 1
         self.num_classes, self.model = parameters["num_classes"], model
         self.dataname, self.device, self.seed = dataname, device, seed
 

@@ -447,6 +447,35 @@ def test_evaluation_pipeline_end_to_end(golden):
     assert all(acc[k] == m[k] for k in acc)
 
 
+def test_evaluation_with_the_fp16_recogniser(golden):
+    """parameters["recogniser_f16"]: the whole Evaluation on the recogniser's fp16 form - the same loaders through both arithmetics: accuracies equal, FIDs and
+    diversities within 1e-3 relative of the default's (measured 1e-4-class)."""
+    from regennet_amd.eval import Evaluation
+    g = golden("stgcn")
+    sd = synth.make_stgcn_state_dict(g["A"], num_class=26, seed=0)
+    params = {"nfeats": 12, "num_classes": 26, "num_person": 2, "state_dict": {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}}
+    rng = np.random.Generator(np.random.PCG64(3))
+
+    def loader(shift):
+        return [{"output": torch.from_numpy((rng.standard_normal((16, 56, 12, 60)) + shift).astype(np.float32)).cuda(),
+                 "y": torch.from_numpy(rng.integers(0, 26, 16))} for _ in range(3)]
+
+    loaders = {"gt": {"train": loader(0.0), "test": loader(0.0)}, "gen": {"train": loader(0.3), "test": loader(0.3)}}
+    ms = []
+    for f16 in (0, 1):
+        ev = Evaluation("ntu", "smplx", dict(params, recogniser_f16=f16), "cuda:0", seed=7)
+        assert ev.model.engine_options.get("SG_F16", 0) == f16
+        ms.append(ev.evaluate(type("M", (), {"cond_mode": "action"})(), loaders, "cmdm"))
+    for k, v in ms[0].items():
+        if k.startswith("accuracy"):
+            assert ms[1][k] == v, k
+        elif k.startswith("fid_gt"):
+            assert abs(ms[1][k]) < 1e-6
+        else:
+            assert abs(ms[1][k] - v) < 1e-3 * max(1.0, abs(v)), (k, v, ms[1][k])
+    print("\n[evaluation, fp16 recogniser] " + ", ".join(f"{k} {ms[0][k]:.4f} -> {ms[1][k]:.4f}" for k in sorted(ms[0]) if k.startswith(("fid_gen", "diversity_gen"))))
+
+
 def test_fid_delta_proxy_of_hip_sampled_against_oracle_sampled_motions():
     """north_star: "FID within +-0.1 of reference". 1024 action-conditioned NTU motions, the reference's shipped evaluation setting (ddim5
     through p_sample_loop), default precision schedule, HIP vs the oracle on the same noise tape, through the same recogniser

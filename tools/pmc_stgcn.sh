@@ -1,5 +1,7 @@
 # PMC passes over the recogniser bench (run on the GPU box): what bounds its GEMMs? -> gpurun_out/pmc_stgcn/summary.json
+# PMC_STGCN_FLAGS="--recogniser-f16": the fp16 form (its kernels are the <..., true> instantiations; the bench's comparison forward adds the default's once)
 set -u
+FLAGS=${PMC_STGCN_FLAGS:-}
 R=${GRAFT_REPO_ROOT:-$PWD}
 rm -rf "$R/gpurun_out/pmc_stgcn"; mkdir -p "$R/gpurun_out/pmc_stgcn"
 cd /tmp && export TMPDIR=/tmp
@@ -7,7 +9,7 @@ i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY GRBM_GUI_ACTIVE"; do
     i=$((i + 1))
-    timeout 300 rocprofv3 --pmc $grp --output-format csv -d "$R/gpurun_out/pmc_stgcn" -o "pass$i" -- python "$R/bench.py" --config stgcn --steps 1 --warmup 0 > "$R/gpurun_out/pmc_stgcn/pass$i.log" 2>&1 < /dev/null
+    timeout 300 rocprofv3 --pmc $grp --output-format csv -d "$R/gpurun_out/pmc_stgcn" -o "pass$i" -- python "$R/bench.py" --config stgcn $FLAGS --steps 1 --warmup 0 > "$R/gpurun_out/pmc_stgcn/pass$i.log" 2>&1 < /dev/null
     echo "pass $i ($grp): rc=$?"
 done
 python - <<PY
