@@ -41,6 +41,11 @@ __device__ __forceinline__ void wait_vmcnt() {   // at most N vector-memory oper
 //   SGE_RELU | SGE_PLANES (output as split planes, else fp32)
 //   SGE_POLY         the planes are written POLYPHASE for a stride-2 consumer: input row (sequence, frame t < T of T + 4, vertex) -> region t & 1 (poly_region
 //                    rows each), frame t >> 1 of ceil(T / 2) + 4; the input's pad frames are not written (the consumer's pads are zeroed by the host's k_sg_zero)
+// The callers' counted wait behind an epilogue (`stores_behind`: vmcnt <= the stores of one tile) is an upper bound on what may stay outstanding, not the
+// guarantee that the next k-step's DMA has landed: a wave whose 32 rows are all pad rows SKIPS its polyphase stores (s_cbranch_execz in the ISA). The guarantee
+// there is the in-order retirement of vmcnt: SGE_POLY (the only mode with conditional stores on the counted path) always comes with SGE_RES_PLANES, whose residual
+// loads are issued AFTER that DMA and consumed BEFORE the first store - the DMA has retired by then whatever the number of stores. The other modes issue
+// exactly the counted stores on the interior path (CHECK = false); edge tiles (CHECK = true) are followed by a full wait.
 // What a 32 x 32 tile needs from memory is requested one tile AHEAD of its use: vmcnt retires in order, so a load queued behind the previous tile's
 // stores would wait for their acknowledgements - 2 TM TN round trips to memory per workgroup tile in x3_epilogue's order.
 enum { SGE_VERTEX_BIAS = 1, SGE_RELU = 2, SGE_PLANES = 4, SGE_RES_PLANES = 8, SGE_POLY = 16 };
