@@ -254,7 +254,7 @@ RGN_API int rgn_stgcn_finalize(rgn_stgcn_handle h);
 /* Kernel-selection switches of ONE recogniser handle (like rgn_set_option; any time before a forward): "SG_NO_WINDOW" (row-shifted GEMMs instead of the
  * LDS-window temporal convolutions), "SG_NO_GCN_FUSE" (aggregation and 1x1 convolution as two launches), "SG_NO_TAIL_FUSE" (k_sg_post for every block), "SG_NO_POLY_TAIL" (... for the two blocks with polyphase output),
  * "SG_NO_S2_WINDOW" (stride-2 blocks as row-shifted GEMM + shortcut GEMM), "SG_TCONV_SMALL" (256-row tiles), "SG_GCN_BN" (widest aggregation tile: 64 |
- * 128 | 256), "SG_GCN_STEP32" (64-wide aggregation tiles: one barrier per 32-deep k-block). A handle's option takes precedence over REGENNET_<KEY> in the environment; unknown names are RGN_ERR_BAD_KEY. Every form meets the same
+ * 128 | 256), "SG_GCN_STEP32" (64-wide aggregation tiles: one barrier per 32-deep k-block), "SG_NO_BLOCK0_FUSE" (the first block's graph convolution as aggregation + split GEMM instead of one fp32 kernel). A handle's option takes precedence over REGENNET_<KEY> in the environment; unknown names are RGN_ERR_BAD_KEY. Every form meets the same
  * parity bound (tests/test_eval_gpu.py runs each against the reference's outputs).
  * "SG_F16" (0 | 1, default 0) is not a kernel form but the ARITHMETIC: blocks 1-9 and block 0's temporal convolution on single IEEE fp16 operand planes, one MFMA per
  * product instead of the split-bf16 three (features within 1.5e-3 of the largest feature - measured 4e-4 - instead of 1e-4 / 5e-6; about twice the speed). It exists

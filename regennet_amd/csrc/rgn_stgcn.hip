@@ -54,6 +54,7 @@ struct SgBlock {
     float* nz_a = nullptr;
     __bf16 *W1h = nullptr, *W1l = nullptr, *W2h = nullptr, *W2l = nullptr, *Wrh = nullptr, *Wrl = nullptr;   // K32-blocked weight planes [Kp/32][co][32]
     __bf16 *W1f = nullptr, *W2f = nullptr, *Wrf = nullptr;   // the same planes as ONE IEEE fp16 plane each (SG_F16: the single-plane form, rgn_sg_kernels.hip)
+    float* W1s = nullptr;                                    // first block only: W1' dense fp32 [co][K ci] (k_sg_block0)
     float *b1 = nullptr, *b2 = nullptr, *br = nullptr, *b2r = nullptr;   // b2r = b2' + br' (the stride-2 kernel adds the shortcut into the same accumulators)
 };
 
@@ -103,7 +104,7 @@ thread_local std::string g_sg_create_error;
 // SG_F16 selects the ARITHMETIC, not a kernel form: blocks 1-9 (and block 0's temporal convolution) on single fp16 operand planes, one MFMA per product instead of
 // three - 2^-12 per operand (the level of the TF32 convolutions the reference's own GPU run uses by default) instead of ~2^-16 per product; measured 1e-3-class
 // relative feature differences instead of 1e-5-class (tests/test_eval_gpu.py states both bounds). Off unless asked for.
-const char* const kSgOptions[] = {"SG_NO_WINDOW", "SG_NO_GCN_FUSE", "SG_NO_TAIL_FUSE", "SG_NO_POLY_TAIL", "SG_NO_S2_WINDOW", "SG_TCONV_SMALL", "SG_GCN_BN", "SG_GCN_STEP32", "SG_F16"};
+const char* const kSgOptions[] = {"SG_NO_WINDOW", "SG_NO_GCN_FUSE", "SG_NO_TAIL_FUSE", "SG_NO_POLY_TAIL", "SG_NO_S2_WINDOW", "SG_TCONV_SMALL", "SG_GCN_BN", "SG_GCN_STEP32", "SG_F16", "SG_NO_BLOCK0_FUSE"};
 // value of a switch: the handle's option if given, else the environment variable REGENNET_<KEY>, else `dflt`
 int sg_opt(const rgn_stgcn_ctx* c, const char* key, int dflt) {
     auto it = c->opts.find(key);
@@ -254,6 +255,56 @@ __global__ __launch_bounds__(256) void k_sg_agg_small_t(SgPl x, SgPl z, const in
         sg_split8(v8, h, l);
         *reinterpret_cast<sg_bf16x8*>(z.hi + row * 32 + 8 * q) = h;
         *reinterpret_cast<sg_bf16x8*>(z.lo + row * 32 + 8 * q) = l;
+    }
+}
+
+// The whole graph convolution of the FIRST block for the evaluation's shapes (C = 6 channels per person, K = 3 partitions, 64 output channels) as one kernel: the
+// aggregation above, then g = relu(z . W1'^T + b1'[w]) on the VALU in fp32 - 18 x 64 fmas per row with the weights as scalar operands (uniform addresses: s_load) -
+// written as the temporal convolution's operand planes, split bf16 or (F16) one fp16 plane. Replaces k_sg_agg_small_t + k_gemm_x3<256, 64> (K = 18 padded to a
+// 32-deep k-block, three MFMAs per product, z written and read back) [+ k_sg_to_f16]: 0.28 (0.39) -> 0.1 ms per 256 motions, and exact fp32 products.
+template <int C, int K, int CO, bool F16>
+__global__ __launch_bounds__(256) void k_sg_block0(SgPl x, SgPl g, const int* __restrict__ nz_ptr, const int* __restrict__ nz_v, const float* __restrict__ nz_a,
+                                                   const float* __restrict__ W, const float* __restrict__ b1, size_t rows, int V) {
+    static_assert(C <= 8 && CO % 32 == 0, "one 16-byte chunk per neighbour, whole 32-channel output blocks");
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const size_t frame = row / V;
+    const int w = (int)(row - frame * V);
+    float z[K * C];
+#pragma unroll
+    for (int q = 0; q < K * C; ++q) z[q] = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        for (int j = nz_ptr[k * V + w]; j < nz_ptr[k * V + w + 1]; ++j) {
+            const size_t src = (frame * V + nz_v[j]) * 32;
+            const float a = nz_a[j];
+            const sg_bf16x8 h = *reinterpret_cast<const sg_bf16x8*>(x.hi + src), l = *reinterpret_cast<const sg_bf16x8*>(x.lo + src);
+#pragma unroll
+            for (int c = 0; c < C; ++c) z[k * C + c] = fmaf(a, (float)h[c] + (float)l[c], z[k * C + c]);
+        }
+    const float* bw = b1 + (size_t)w * CO;
+#pragma unroll
+    for (int og = 0; og < CO / 8; ++og) {
+        const float4 ba = *reinterpret_cast<const float4*>(bw + 8 * og), bb = *reinterpret_cast<const float4*>(bw + 8 * og + 4);
+        float acc[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int q = 0; q < K * C; ++q) acc[j] = fmaf(z[q], W[(og * 8 + j) * (K * C) + q], acc[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+        const size_t o = ((size_t)(og >> 2) * g.R + row) * 32 + 8 * (og & 3);
+        if constexpr (F16) {
+            sg_f16x8 f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (_Float16)acc[j];
+            *reinterpret_cast<sg_f16x8*>(g.hi + o) = f;
+        } else {
+            sg_bf16x8 h, l;
+            sg_split8(acc, h, l);
+            *reinterpret_cast<sg_bf16x8*>(g.hi + o) = h;
+            *reinterpret_cast<sg_bf16x8*>(g.lo + o) = l;
+        }
     }
 }
 
@@ -681,6 +732,12 @@ int rgn_stgcn_finalize(rgn_stgcn_handle h) {
                 (rc = sg_upload_planes(c, W1, co, b.kp1, &b.W1h, &b.W1l, &b.W1f, (p + "gcn.conv.weight").c_str())) || (rc = sg_upload(c, &b.b1, b1)) ||
                 (rc = sg_upload_planes(c, W2, co, 9 * co, &b.W2h, &b.W2l, &b.W2f, (p + "tcn.2.weight").c_str())) || (rc = sg_upload(c, &b.b2, b2)))
                 return rc;
+            if (i == 0) {
+                std::vector<float> Ws((size_t)co * K1);
+                for (int o = 0; o < co; ++o)
+                    for (int q = 0; q < K1; ++q) Ws[(size_t)o * K1 + q] = W1[(size_t)o * b.kp1 + q];
+                if ((rc = sg_upload(c, &b.W1s, Ws))) return rc;
+            }
             if (b.res_conv) {
                 b.kpr = (int)up32((size_t)ci);
                 std::vector<float> Wr((size_t)co * b.kpr, 0.f), br(co);
@@ -789,6 +846,7 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
         const int gcn_bn = sg_opt(c, "SG_GCN_BN", 256);                  // widest k_sg_gcn tile
         const bool gcn_step32 = sg_opt(c, "SG_GCN_STEP32", 0) != 0;      // 64-wide k_sg_gcn: one barrier per 32-deep k-block (default: per channel block)
         const bool f16 = sg_opt(c, "SG_F16", 0) != 0;                    // single fp16 operand planes (above): the fused kernels only
+        const bool no_block0 = sg_opt(c, "SG_NO_BLOCK0_FUSE", 0) != 0;   // first block's graph convolution as aggregation + split GEMM (+ conversion)
         if (f16 && !c->f16_refused.empty()) return c->fail(RGN_ERR_UNSUPPORTED, "rgn_stgcn_forward: SG_F16 - a weight lies beyond the fp16 range: " + c->f16_refused);
         auto f16_unserved = [&](int blk, const char* what) {
             return c->fail(RGN_ERR_UNSUPPORTED, std::string("rgn_stgcn_forward: SG_F16 exists for the fused kernels only; block ") + std::to_string(blk) + " would take " + what +
@@ -814,7 +872,10 @@ int rgn_stgcn_forward(rgn_stgcn_handle h, int32_t N, const float* output, float*
             g1.Chi = gp.hi; g1.Clo = gp.lo; g1.c_rows = (int)gp.R;
             g1.f16 = gf16 ? 1 : 0;
             if (fused) SG_HIP(c, launch_sg_gcn(g1, V, K, b.slot_k, b.sl_v, b.sl_a, gcn_bn, gcn_step32, s));   // z is formed in registers, fragment by fragment
-            else {
+            else if (i == 0 && !no_block0 && b.ci == 6 && K == 3 && b.co == 64 && b.W1s) {
+                if (f16) hipLaunchKernelGGL((k_sg_block0<6, 3, 64, true>), blocks1d(rows), dim3(256), 0, s, xp, gp, b.nz_ptr, b.nz_v, b.nz_a, b.W1s, b.b1, rows, V);
+                else hipLaunchKernelGGL((k_sg_block0<6, 3, 64, false>), blocks1d(rows), dim3(256), 0, s, xp, gp, b.nz_ptr, b.nz_v, b.nz_a, b.W1s, b.b1, rows, V);
+            } else {
                 if (b.ci % 32 == 0) hipLaunchKernelGGL(k_sg_agg, dim3((unsigned)((rows * 4 + 255) / 256), (unsigned)(K * (b.ci / 32))), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);
                 else if (b.ci == 6 && K == 3) hipLaunchKernelGGL((k_sg_agg_small_t<6, 3>), blocks1d(rows), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V);
                 else hipLaunchKernelGGL(k_sg_agg_small, blocks1d(rows), dim3(256), 0, s, xp, zp, b.nz_ptr, b.nz_v, b.nz_a, rows, V, K, b.ci);

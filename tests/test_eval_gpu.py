@@ -113,7 +113,8 @@ def test_stgcn_many_tiles_on_skeletons_whose_vertex_count_is_not_a_multiple_of_8
 
 
 @pytest.mark.parametrize("opts", [{"SG_NO_WINDOW": 1}, {"SG_NO_GCN_FUSE": 1}, {"SG_NO_TAIL_FUSE": 1}, {"SG_NO_POLY_TAIL": 1}, {"SG_NO_S2_WINDOW": 1}, {"SG_TCONV_SMALL": 1},
-                                  {"SG_GCN_BN": 64}, {"SG_GCN_BN": 64, "SG_GCN_STEP32": 1}, {"SG_NO_WINDOW": 1, "SG_NO_GCN_FUSE": 1, "SG_NO_TAIL_FUSE": 1}])
+                                  {"SG_GCN_BN": 64}, {"SG_GCN_BN": 64, "SG_GCN_STEP32": 1}, {"SG_NO_WINDOW": 1, "SG_NO_GCN_FUSE": 1, "SG_NO_TAIL_FUSE": 1},
+                                  {"SG_NO_BLOCK0_FUSE": 1}, {"SG_NO_BLOCK0_FUSE": 1, "SG_NO_WINDOW": 1, "SG_NO_GCN_FUSE": 1, "SG_NO_TAIL_FUSE": 1, "SG_NO_S2_WINDOW": 1}])
 def test_stgcn_every_kernel_form_matches_reference(golden, opts):
     """rgn_stgcn_set_option: each selectable kernel form (the fused kernels one at a time switched back to the form they replaced, the narrow / small
     tiles, and the first split-bf16 build as a whole) against the reference's outputs, per handle and without touching the environment."""
@@ -240,7 +241,7 @@ def test_stgcn_fp16_form_many_tiles_per_workgroup(golden, T, N):
 
 @pytest.mark.parametrize("V,hub,T,N,opts", [(56, 5, 24, 3, {}), (32, 3, 24, 2, {}), (40, 6, 30, 2, {}), (64, 4, 20, 2, {}), (36, 2, 60, 40, {}), (52, 3, 48, 32, {}),
                                              (52, 3, 48, 32, {"SG_GCN_BN": 64}), (36, 2, 60, 40, {"SG_GCN_BN": 128}), (52, 3, 48, 32, {"SG_TCONV_SMALL": 1}),
-                                             (52, 3, 48, 32, {"SG_GCN_BN": 64, "SG_GCN_STEP32": 1})])
+                                             (52, 3, 48, 32, {"SG_GCN_BN": 64, "SG_GCN_STEP32": 1}), (56, 5, 24, 3, {"SG_NO_BLOCK0_FUSE": 1})])
 def test_stgcn_fp16_form_on_other_skeletons(V, hub, T, N, opts):
     """The fp16 form on every graph / shape the fused kernels take (V % 4 == 0, 32 <= V <= 64, lists inside the 8 register slots), with the tile-shape switches,
     against the CPU oracle; batches of many tiles also against themselves four motions at a time (bit for bit)."""
