@@ -181,7 +181,7 @@ RGN_API int rgn_set_small_batch_rows(rgn_handle h, int32_t rows);
 /* Kernel-selection switches of ONE handle, set between rgn_create and rgn_finalize_weights (afterwards: RGN_ERR_STATE, except "LAYERS_GUIDED" - a dispatch rule,
  * not a packing decision: 0 an evaluation per workgroup and step | 1 a motion per workgroup when 2 B > #CUs (default) | 2 always | -1 the default again): the names of the
  * REGENNET_<KEY> environment variables without the prefix - "LAYERS" (0: kernel per stage instead of the one-kernel decoder stack), "LAYERS_STEPS",
- * "LAYERS_GUIDED", "LAYERS_MIN_B", "LAYERS_MIN_TQ", "NO_STEP_FUSION", "NO_MLP", "MLP_X3", "NO_ROWGEMM", "NO_FUSED_QKV", "NO_QKV_RS", "NO_QKV_LONG",
+ * "LAYERS_GUIDED", "LAYERS_MIN_B", "LAYERS_MIN_TQ", "NO_STEP_FUSION", "NO_MLP", "MLP_X3", "NO_ROWGEMM", "NO_FUSED_QKV", "NO_QKV_RS", "QKV_X3_DMA", "NO_QKV_LONG",
  * "SB_ROWS", "SB_FUSED_ATTN", "SB_GRAPH", "STREAMS", "GRAPH_STEPS", "BIG_TILE_ROWS", "BULK_RESID_LO", "STEP_NO_QUADS", "BULK_F16" (0: no fp16
  * weight planes, no fp16 phase), "F16_STEPS"; an unknown name is
  * RGN_ERR_BAD_KEY. A handle's option takes precedence over the environment, which remains the process-wide default (tools, A/B runs): tests and

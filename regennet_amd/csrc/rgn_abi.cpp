@@ -375,7 +375,7 @@ int rgn_set_option(rgn_handle h, const char* key, int32_t value) {
         if (h->finalized) return h->fail(RGN_ERR_STATE, "rgn_set_option: the switches select kernels when the weights are packed - set them before rgn_finalize_weights");
         static const char* known[] = {"NO_FUSED_QKV", "BIG_TILE_ROWS", "NO_ROWGEMM", "NO_MLP", "MLP_X3", "NO_QKV_RS", "NO_STEP_FUSION", "LAYERS_MIN_TQ", "LAYERS", "LAYERS_STEPS",
                                       "LAYERS_MIN_B", "LAYERS_GUIDED", "STEP_NO_QUADS", "NO_QKV_LONG", "SB_FUSED_ATTN", "SB_ROWS", "BULK_RESID_LO", "GRAPH_STEPS", "STREAMS", "SB_GRAPH",
-                                      "BULK_F16", "F16_STEPS"};
+                                      "BULK_F16", "F16_STEPS", "QKV_X3_DMA"};
         bool ok = false;
         for (const char* k : known) ok = ok || strcmp(k, key) == 0;
         if (!ok) return h->fail(RGN_ERR_BAD_KEY, std::string("rgn_set_option: unknown switch '") + key + "'");

@@ -133,6 +133,7 @@ struct rgn_ctx {
     bool skip_embed_out = false;       // (set by run_eval around run_layers while it enqueues a fused step)
     int step_no_quads = 0;             // REGENNET_STEP_NO_QUADS=1 (tests)
     bool qkv_rs = true;                // plain-bf16 phase: k_qkv_attn with register-streamed weights (REGENNET_NO_QKV_RS=1: the DMA-fed loop)
+    bool qkv_x3_dma = false;           // split-bf16 phase: keep the direct-to-LDS k_qkv_attn<true> (REGENNET_QKV_X3_DMA=1) instead of k_qkv_attn_rs_x3
     bool qkv_long = false;             // plain-bf16 phase, 65 .. 160 tokens: fused in_proj + attention per (sample, head) (REGENNET_NO_QKV_LONG=1: in_proj GEMM + k_attn_x3)
     bool sb = false;                   // small-batch engine: column-split GEMMs with consumer-side LayerNorm (k_sb_gemm)
     bool sb_attn = false;              // small-batch engine: in_proj + attention as one launch per layer (k_sb_qkv_attn; REGENNET_SB_FUSED_ATTN=1: it loses below B ~ 6)

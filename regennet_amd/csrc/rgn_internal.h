@@ -115,6 +115,7 @@ struct QkvAttnArgs {
     const __bf16* Ahi; const __bf16* Alo; int a_rows;   // layer input planes [Kp/32][a_rows][32] (advanced to the first sample)
     const __bf16* Whi; const __bf16* Wlo;               // in_proj weight planes [Kp/32][3d][32]
     const __bf16* Wfr;                                  // the hi plane in MFMA-fragment order [Kp/32][3d/32][2][64][8] (plain-bf16 phase, d = 512), nullable
+    const __bf16* Wfr_lo;                               // split phase, register-streamed form (k_qkv_attn_rs_x3): the lo plane in the same order, with Wfr = the bf16 hi plane; nullable
     const float* bias;                                  // in_proj bias [3d]
     Planes out;                                         // attention output planes (advanced to the first sample's row)
     int Bm, Kp, d, H, Tq;

@@ -241,7 +241,9 @@ int finalize_weights(rgn_ctx* c) {
             for (const char* nm : {"self_attn.in_proj_weight", "self_attn.out_proj.weight", "linear1.weight", "linear2.weight"})
                 if (!f16_range(p + nm, W(p + nm), c->sd[p + nm].v.size())) return RGN_ERR_UNSUPPORTED;
         lw.qkv = pack_linear(c, W(p + "self_attn.in_proj_weight"), W(p + "self_attn.in_proj_bias"), 3 * d, d, true,
-                             c->cfg.precision == RGN_PREC_BF16_X3TAIL, false, c->bulk_f16);   // fragment order: k_rowgemm (long sequences) / k_qkv_attn_rs
+                             c->cfg.precision == RGN_PREC_BF16_X3TAIL || c->cfg.precision == RGN_PREC_BF16X3,
+                             c->cfg.precision == RGN_PREC_BF16_X3TAIL || c->cfg.precision == RGN_PREC_BF16X3,
+                             c->bulk_f16);   // fragment order: k_rowgemm (long sequences) / k_qkv_attn_rs; + the lo plane: k_qkv_attn_rs_x3 (split phase)
         const bool fr = c->cfg.precision == RGN_PREC_BF16_X3TAIL;   // k_rowgemm operands (plain-bf16 phase)
         // (+ lo fragment planes: the operand pairs of k_mlp_x3, the split-bf16 layer tail, in every mode that has a split-bf16 phase)
         const bool frx = c->cfg.precision == RGN_PREC_BF16_X3TAIL || c->cfg.precision == RGN_PREC_BF16X3;
@@ -350,6 +352,7 @@ int finalize_weights(rgn_ctx* c) {
         }
         if (c->fuse_qkv) RGN_HIP(c, configure_qkv_attn());
         c->qkv_rs = !opt_flag(c, "NO_QKV_RS");
+        c->qkv_x3_dma = opt_flag(c, "QKV_X3_DMA");
         c->step_fused = c->rowgemm && !c->etd && c->lin_x.fr && c->lin_out.fr && c->lin_out.has_bias && !c->lin_x.has_bias &&
                         step_fused_supported(d, F, c->lin_x.Kp) && !opt_flag(c, "NO_STEP_FUSION");
         if (c->step_fused) RGN_HIP(c, configure_step());

@@ -377,6 +377,7 @@ int run_layers(rgn_ctx* c, const Dims& dmf, bool guided, bool sampling, const fl
             g.Ahi = h_p.hi; g.Alo = h_p.lo; g.a_rows = h_p.rows;
             g.Whi = c->dp<__bf16>(w.qkv.hi); g.Wlo = c->dp<__bf16>(w.qkv.lo);
             g.Wfr = (w.qkv.fr && c->qkv_rs) ? c->dp<__bf16>(f16 ? w.qkv.fr16 : w.qkv.fr) : nullptr;   // plain phase: weights streamed to registers
+            g.Wfr_lo = (x3 && w.qkv.fr && w.qkv.fr_lo && c->qkv_rs && !c->qkv_x3_dma) ? c->dp<__bf16>(w.qkv.fr_lo) : nullptr;   // ... and the split phase's (k_qkv_attn_rs_x3)
             g.f16 = f16 ? 1 : 0;
             g.bias = c->dp<float>(w.qkv.b);
             g.out = att_p;
@@ -853,7 +854,7 @@ int plan_query(rgn_ctx* c, int32_t B, int32_t guided, int32_t split_phase, int32
                 l2[KC_LAYERS] = (double)dm.Bm * wl * 2.0;
             } else {
                 switch (pl.attn) {
-                case AF_QKV: mac[KC_QKV] = qkv + attn; n[KC_QKV] = L; kn[KC_QKV] = (x3 || !c->qkv_rs) ? "k_qkv_attn" : "k_qkv_attn_rs"; break;
+                case AF_QKV: mac[KC_QKV] = qkv + attn; n[KC_QKV] = L; kn[KC_QKV] = !c->qkv_rs ? "k_qkv_attn" : x3 ? (c->qkv_x3_dma || c->d != 512 ? "k_qkv_attn" : "k_qkv_attn_rs_x3") : "k_qkv_attn_rs"; break;
                 case AF_QKV_LONG: mac[KC_QKV] = qkv + attn; n[KC_QKV] = L; kn[KC_QKV] = "k_qkv_attn_long"; break;
                 case AF_ROWGEMM_ATTN: mac[KC_ROWACT] += qkv; n[KC_ROWACT] += L; mac[KC_ATTN] = attn; n[KC_ATTN] = L; kn[KC_ATTN] = "k_attn_x3"; break;
                 case AF_GEMM_ATTN: mac[KC_GEMM] += qkv; n[KC_GEMM] += L; mac[KC_ATTN] = attn; n[KC_ATTN] = L; kn[KC_ATTN] = "k_attn_x3"; break;

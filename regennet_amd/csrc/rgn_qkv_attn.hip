@@ -537,6 +537,133 @@ __global__ __launch_bounds__(NS * 256, 2 / NS) void k_qkv_attn_rs(QkvAttnArgs g,
     RGN_QL(2)
 }
 
+// ---- split-bf16 phase, d = 512: the register-streamed form of the SPLIT arithmetic (round 6) ---------------------------------------
+// k_qkv_attn<true> above moves 64 KiB of operands per k-step through the ~20 B/clk direct-to-LDS path against 2304 cycles of MFMA (3400 measured):
+// the same weight stream through the vector-memory path into register rings, hi and lo fragment planes side by side, leaves only the activation tile
+// (hi | lo, 16 KiB per k-step pair of stages) in LDS. One sample (4 waves) per workgroup, two workgroups per CU like k_qkv_attn_rs<1>. Every accumulator
+// sees the MFMAs of k_qkv_attn<true> in the same order (k-block, k half; lo x hi, hi x lo, hi x hi): the two forms agree bit for bit
+// (tests/test_hip_parity.py), "QKV_X3_DMA" = 1 keeps the direct-to-LDS form. The kernel itself runs 53 us where the direct-to-LDS form ran 73 (rocprofv3, the
+// evaluation schedule at B = 256) - and the CALL gains 1 - 3 %: the split steps run three kernel chains side by side and are short of L2 bandwidth chip-wide
+// (k_mlp_x3 streams 5.2 MB of weight fragments per 32-row tile), so time a chain's in_proj gives back is taken by its neighbours' layer tails.
+constexpr int QX_WQ = 9, QX_DA = 2, QX_ARING = QX_DA + 1;        // ring depths: 1.5 k-steps of (hi, lo) weight fragment pairs, activation pieces 2 ahead
+template <int NS> constexpr int qx_lds() { return qr_abuf<NS>() + 2 * 2 * NS * QA_ROWS * 64 + 8 * QA_WROWS * 4; }
+// NS = samples per workgroup (4 waves each): 2 = one 8-wave workgroup per CU whose sample halves request the SAME weight fragments at the same time (one L2
+// read serves both: half the L2 weight traffic per sample, which is what a full chip of concurrent chains is short of); 1 = two independent workgroups per CU.
+template <int NS>
+__global__ __launch_bounds__(NS * 256, 2 / NS) void k_qkv_attn_rs_x3(QkvAttnArgs g) {
+    constexpr int NT = NS * 256, STAGE = NS * QA_ROWS * 64;          // one plane of one stage; a stage = hi | lo
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int b0 = xcd_affine(blockIdx.x, gridDim.x) * NS, Tq = g.Tq, d = g.d;
+    const int hpb = g.H / (int)gridDim.y, hd0 = blockIdx.y * hpb;
+    const int nsamp = g.Bm - b0 < NS ? g.Bm - b0 : NS;
+    constexpr int nb_all = 3 * 512 / 32;
+    unsigned a_voff;
+    {
+        const int r = tid >> 2, c = (tid & 3) ^ ((r >> 2) & 3);      // tile row r: sample r / 64, token r % 64
+        const int sm = (r >> 6) < nsamp ? (r >> 6) : 0, tk = r & 63;
+        const int rr = tk < Tq ? tk : Tq - 1;                        // padding rows replicate the last token (masked later)
+        a_voff = (unsigned)((b0 + sm) * Tq + rr) * 32u + c * 8;
+    }
+    const __amdgpu_buffer_rsrc_t ah_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(g.Ahi), 0, (int)((size_t)g.a_rows * g.Kp * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t al_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(g.Alo), 0, (int)((size_t)g.a_rows * g.Kp * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wh_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(g.Wfr), 0, 3 * d * g.Kp * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wl_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(g.Wfr_lo), 0, 3 * d * g.Kp * 2, 0x00020000);
+    const unsigned a_kbytes = (unsigned)g.a_rows * 64u;
+    int a_off[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int rr = wm * 64 + t * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a_off[t][ks] = rr * 64 + (((2 * ks + kh) ^ ((rr >> 2) & 3)) << 4);
+    }
+    char* abuf = smem + qr_abuf<NS>();                               // [stage 2][plane 2][NS x 64 rows][64 B]
+    float* bias_s = reinterpret_cast<float*>(abuf + 4 * STAGE);
+    for (int i = tid; i < hpb * QA_WROWS; i += NT) {
+        const int hh = i / QA_WROWS, r = i - hh * QA_WROWS;
+        bias_s[i] = g.bias[(r >> 7) * d + (hd0 + hh) * QA_DH + (r & 127)];
+    }
+    for (int hd = hd0; hd < hd0 + hpb; ++hd) {
+        unsigned wofs[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) wofs[t] = (unsigned)((t * d + hd * QA_DH) / 32 + wn) * 1024u + lane * 8;
+        f32x16 acc[2][3];
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[ta][t][i] = 0.f;
+        bf16x8 wqh[QX_WQ], wql[QX_WQ];
+        u32x4 arh[QX_ARING], arl[QX_ARING];
+        auto issue_a = [&](int kt) {
+            arh[kt % QX_ARING] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ah_rs, a_voff * 2, kt * a_kbytes, 0));
+            arl[kt % QX_ARING] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(al_rs, a_voff * 2, kt * a_kbytes, 0));
+        };
+        auto issue_q = [&](int q) {                                  // q compile-time after unrolling
+            const int kt = q / 6, ks = (q % 6) / 3, t = q % 3;
+            wqh[q % QX_WQ] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wh_rs, wofs[t] * 2, (kt * nb_all * 1024 + ks * 512) * 2, 0));
+            wql[q % QX_WQ] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wl_rs, wofs[t] * 2, (kt * nb_all * 1024 + ks * 512) * 2, 0));
+        };
+#pragma unroll
+        for (int kt = 0; kt < QX_DA; ++kt) issue_a(kt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < QX_WQ; ++q) issue_q(q);
+        __builtin_amdgcn_sched_barrier(0);
+        *reinterpret_cast<u32x4*>(abuf + tid * 16) = arh[0];         // stage 0 <- k-block 0
+        *reinterpret_cast<u32x4*>(abuf + STAGE + tid * 16) = arl[0];
+#pragma unroll
+        for (int kt = 0; kt < QR_NK; ++kt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                            // k-block kt is in its stage; everyone left stage (kt + 1) % 2
+            const char* sb = abuf + (kt & 1) * 2 * STAGE;
+            bf16x8 ah[2][2], al[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta) {
+                    ah[ks][ta] = *reinterpret_cast<const bf16x8*>(sb + a_off[ta][ks]);
+                    al[ks][ta] = *reinterpret_cast<const bf16x8*>(sb + STAGE + a_off[ta][ks]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + QX_DA < QR_NK) issue_a(kt + QX_DA);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int grp = 0; grp < 6; ++grp) {
+                const int ks = grp / 3, t = grp % 3, q = kt * 6 + grp;
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta) {
+                    if (t < 2) {   // q, k tiles transposed (lane = token, registers = dh)
+                        acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wqh[q % QX_WQ], al[ks][ta], acc[ta][t], 0, 0, 0);
+                        acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wql[q % QX_WQ], ah[ks][ta], acc[ta][t], 0, 0, 0);
+                        acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wqh[q % QX_WQ], ah[ks][ta], acc[ta][t], 0, 0, 0);
+                    } else {       // v tile: lane = dh, registers = tokens
+                        acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][ta], wqh[q % QX_WQ], acc[ta][t], 0, 0, 0);
+                        acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][ta], wql[q % QX_WQ], acc[ta][t], 0, 0, 0);
+                        acc[ta][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][ta], wqh[q % QX_WQ], acc[ta][t], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + QX_WQ < 6 * QR_NK) issue_q(q + QX_WQ);
+                if (grp == 2 && kt + 1 < QR_NK) {                    // next k-block of the activation tile -> the other stage
+                    *reinterpret_cast<u32x4*>(abuf + ((kt + 1) & 1) * 2 * STAGE + tid * 16) = arh[(kt + 1) % QX_ARING];
+                    *reinterpret_cast<u32x4*>(abuf + ((kt + 1) & 1) * 2 * STAGE + STAGE + tid * 16) = arl[(kt + 1) % QX_ARING];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // (the exchange buffer does not alias the ring, but every wave must have left the k-loop's last stage reads)
+        qa_attention<true>(acc, g, smem, bias_s + (hd - hd0) * QA_WROWS + wn * 32, hd, hd - hd0, wm, wn, nsamp, b0, lane, tid);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 bool qkv_attn_supported(int Tq, int dh, int d) { return Tq <= QA_ROWS && dh == QA_DH && d % 32 == 0 && d / dh <= 8 && d >= 128; }
 static int qa_lds(bool x3) { return 2 * (x3 ? 2 : 1) * (QA_NS * QA_ROWS * 64 + QA_WROWS * 64) + 8 * QA_WROWS * 4 /* biases of <= 8 heads (odd H: one workgroup runs them all) */; }
 hipError_t configure_qkv_attn() {
@@ -548,6 +675,10 @@ hipError_t configure_qkv_attn() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_rs<2>), hipFuncAttributeMaxDynamicSharedMemorySize, qr_lds<2>());
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_rs<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, qr_lds<1>());
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_rs_x3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, qx_lds<1>());
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_rs_x3<2>), hipFuncAttributeMaxDynamicSharedMemorySize, qx_lds<2>());
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_qkv_attn_rs<1>), hipFuncAttributeMaxDynamicSharedMemorySize, qr_lds<1>());
 }
@@ -575,6 +706,16 @@ hipError_t launch_qkv_attn(const QkvAttnArgs& g, bool x3, hipStream_t s) {
     // heads per workgroup: half of them (the weight stream per sample is what bounds the kernel), but one head each while
     // the launch is small (<= 64 workgroups): a small batch is latency-bound and the heads of a workgroup run back to back
     if (g.f16) return hipErrorInvalidValue;                         // (only the register-streamed plain form has the fp16 instantiation)
+    if (x3 && g.Wfr && g.Wfr_lo && g.Alo && g.Kp == 32 * QR_NK && g.d == 512 && (size_t)g.a_rows * g.Kp * 2 < (1ull << 31)) {   // split phase, weights streamed to registers
+        const int beval = g.Bm_eval > 0 ? g.Bm_eval : g.Bm;
+        const int hsplit = (beval < 256 || g.H % 2) ? g.H : 2;      // (the plain form's rule)
+        // one sample per workgroup: 5.71 ms per ddim5 call at B = 256 against 5.79 with two (and 5.78 with the direct-to-LDS form), 3.04 / 3.06 / 3.14 at B = 64
+        // (tools/ab_qkv_x3.sh, profiles/r06_qkv_x3_forms.txt; REGENNET_QKV_X3_NS=2 keeps the two-sample build for that comparison)
+        static const bool two = getenv("REGENNET_QKV_X3_NS") && atoi(getenv("REGENNET_QKV_X3_NS")) == 2;
+        if (!two) hipLaunchKernelGGL(k_qkv_attn_rs_x3<1>, dim3(g.Bm, hsplit), dim3(256), qx_lds<1>(), s, g);
+        else hipLaunchKernelGGL(k_qkv_attn_rs_x3<2>, dim3((g.Bm + 1) / 2, hsplit), dim3(512), qx_lds<2>(), s, g);
+        return hipGetLastError();
+    }
     const int pairs = (g.Bm + QA_NS - 1) / QA_NS;
     const int hsplit = (pairs * g.H <= 64) ? g.H : (g.H % 2 == 0 ? 2 : 1);
     const dim3 grid(pairs, hsplit);

@@ -840,6 +840,45 @@ def test_split_bf16_layer_tail_kernel_matches_the_five_kernel_form(cfg_name, B, 
     assert e1 < 1e-3 and e0 < 1e-3 and d < 2e-4 and e1 < 2.0 * e0 + 2e-5
 
 
+@pytest.mark.parametrize("cfg_name,B,guided,frames,precision", [("ntu", 16, False, None, "bf16x3/throughput"), ("ntu", 3, False, None, "bf16x3/throughput"),
+                                                                ("ntu_action", 5, True, None, "bf16x3/throughput"), ("ntu", 7, False, 40, "bf16x3/throughput"),
+                                                                ("ntu", 300, False, None, "bf16_x3tail/throughput"), ("ntu_action", 140, True, None, "bf16_x3tail/throughput")])
+def test_split_bf16_qkv_attention_register_streamed_form_equals_the_dma_form(cfg_name, B, guided, frames, precision):
+    """k_qkv_attn_rs_x3 (round 6: the split phase's in_proj + attention with the hi and lo weight fragment planes streamed into register rings, one sample per
+    four-wave workgroup) against k_qkv_attn<true> (direct-to-LDS operands, two samples per workgroup; engine option QKV_X3_DMA = 1): every accumulator sees
+    the same MFMAs in the same order, so the two forms agree BIT FOR BIT - odd batches (the DMA form pads its last pair), 40-frame motions, guidance, one and
+    two heads per workgroup (B < / >= 256 evaluations), the uniform split mode and the tail of the default schedule - and against the oracle."""
+    from oracle import regennet_oracle as orc
+    from regennet_amd import synth
+    from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
+    cfg = synth.get_config(cfg_name)
+    sd = synth.make_state_dict(cfg, seed=9)
+    if frames:
+        cfg = dict(cfg, num_frames=frames)
+    T = cfg["num_frames"]
+    y = {"cmotion": synth.make_cmotion(cfg, B, seed=71)}
+    if cfg["cond_mode"] == "action":
+        y["action"] = synth.make_actions(cfg, B, seed=72)
+    if guided:
+        y["scale"] = np.linspace(1.0, 3.0, B).astype(np.float32)
+    resp, mode = ("ddim3", "ddim") if guided else ("3", "ddpm")
+    tape = synth.make_noise_tape(cfg, B, 3, seed=73)
+    outs, names = {}, {}
+    for dma in (0, 1):
+        model, diffusion = build_hip(cfg, sd, resp=resp, precision=precision, x3_tail=2 if "tail" in precision else None, f16_steps=0 if "tail" in precision else None,
+                                     engine_options={"QKV_X3_DMA": dma, "LAYERS": 0})
+        fm = ClassifierFreeSampleModel(model) if guided else model
+        fn = diffusion.p_sample_loop if mode == "ddpm" else diffusion.ddim_sample_loop
+        outs[dma] = fn(fm, (B, cfg["njoints"], cfg["nfeats"], T), clip_denoised=False, model_kwargs={"y": y_to_device(y)}, noise_tape=torch.from_numpy(tape)).cpu().numpy()
+        model._engine.close()
+    assert np.array_equal(outs[0], outs[1]), float(np.abs(outs[0] - outs[1]).max())
+    if B <= 16:
+        ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", resp), tape, {k: torch.from_numpy(v) for k, v in y.items()}, mode=mode, guided=guided).numpy()
+        err = float(np.abs(outs[0] - ref).max())
+        print(f"\n[k_qkv_attn_rs_x3] {cfg_name} B={B} guided={guided}: vs oracle {err:.2e}, the two forms are bit-equal")
+        assert err < 1e-3
+
+
 def test_text150_full_size_shard_is_row_independent():
     """BASELINE configs[4] per-GPU shard at FULL size (text-conditioned, T=150, B=256 = 2048 / 8, CFG: 76 800 token rows, 1200 row
     tiles, four kernel chains, the guided fused step at 150 frames): rows of the batch against the same motion drawn alone
