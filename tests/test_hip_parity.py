@@ -786,9 +786,9 @@ def test_bench_shape_bulk_phase_against_the_oracle():
             y["action"] = synth.make_actions(cfg, B, seed=52)
             y["scale"] = np.full((B,), 2.5, dtype=np.float32)
         tape = synth.make_noise_tape(cfg, B, 16, seed=53)
-        # the oracle (host CPU) runs every 4th motion - motions are independent, 64 of them sit on 64 different workgroups of all 8 XCDs -
-        # the HIP path runs the full bench batch
-        idx = np.arange(0, B, 4)
+        # the oracle (host CPU) runs every 8th motion - motions are independent, 32 of them sit on 32 different workgroups of all 8 XCDs
+        # (every 4th until round 6: the oracle's seconds are most of this suite's wall time) - the HIP path runs the full bench batch
+        idx = np.arange(0, B, 8)
         ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", resp), np.ascontiguousarray(tape[:, idx]),
                               {k: torch.from_numpy(np.ascontiguousarray(v[idx])) for k, v in y.items()}, mode=mode, guided=guided).numpy()
         model, diffusion = build_hip(cfg, sd, resp=resp, precision="bf16_x3tail")
@@ -912,8 +912,8 @@ def _redraw_tape(eng, shape, seed, S, idx):
 
 def test_chi3d_full_size_shard_against_the_oracle_on_a_100_step_schedule():
     """BASELINE configs[3]'s per-GPU shard at its real size - Chi3D, 150 frames, B = 128: 300 row tiles in four kernel chains of k_qkv_attn_long +
-    k_mlp2 + k_step per step - on a 100-step DDPM schedule (95 plain-bf16 + 5 split-bf16 steps), default engine, on-device Philox; every 16th motion
-    against the ORACLE on the very noise the kernels drew (re-drawn through rgn_randn_step). Bound: north_star's 1e-3.
+    k_mlp2 + k_step per step - on a 100-step DDPM schedule (95 plain-bf16 + 5 split-bf16 steps), default engine, on-device Philox; motions 0, 24, 48, ... 120 and the
+    last (every chain, both ends of the batch) against the ORACLE on the very noise the kernels drew (re-drawn through rgn_randn_step). Bound: north_star's 1e-3.
     Reference: utils/model_util.py:61-64 (num_frames = 150), diffusion/gaussian_diffusion.py:610-742."""
     from oracle import regennet_oracle as orc
     from regennet_amd import synth
@@ -927,12 +927,12 @@ def test_chi3d_full_size_shard_against_the_oracle_on_a_100_step_schedule():
     assert torch.isfinite(out).all()
     plan = model._engine.plan_query(B)
     assert plan["qkv_attn"]["kernel"] == "k_qkv_attn_long" and plan["mlp"]["kernel"] == "k_mlp2" and "step_fused" in plan, plan
-    idx = np.arange(0, B, 16)
+    idx = np.r_[np.arange(0, B, 24), B - 1]
     tape = _redraw_tape(model._engine, shape, seed, S, idx)
     ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", str(S)), tape,
                           {k: torch.from_numpy(np.ascontiguousarray(v[idx])) for k, v in y.items()}, mode="ddpm").numpy()
     err = float(np.abs(out.cpu().numpy()[idx] - ref).max())
-    print(f"\n[cfg4 shard: chi3d B = 128, 150 frames, 95 + 5 steps, on-device Philox] every 16th motion vs oracle: {err:.2e}")
+    print(f"\n[cfg4 shard: chi3d B = 128, 150 frames, 95 + 5 steps, on-device Philox] a subset of the motions vs oracle: {err:.2e}")
     assert err < 1e-3, err
     model._engine.close()
 
@@ -940,7 +940,7 @@ def test_chi3d_full_size_shard_against_the_oracle_on_a_100_step_schedule():
 def test_text150_full_size_shard_against_the_oracle_on_its_own_schedule():
     """BASELINE configs[4]'s per-GPU shard EXACTLY: text-conditioned, 150 frames, B = 256, `ddim50` + guidance 2.5 (512 evaluations per step: 1200
     row tiles; 45 plain-bf16 steps through k_qkv_attn_long + k_mlp2 + the guided k_step, 5 split-bf16 steps), default engine, on-device Philox;
-    every 16th motion against the ORACLE (cfg_forward, model/cfg_sampler.py:24-31) on the noise the kernels drew. Bound: 1e-3."""
+    every 32nd motion and the last against the ORACLE (cfg_forward, model/cfg_sampler.py:24-31) on the noise the kernels drew. Bound: 1e-3."""
     from oracle import regennet_oracle as orc
     from regennet_amd import synth
     from regennet_amd.model.cfg_sampler import ClassifierFreeSampleModel
@@ -954,12 +954,12 @@ def test_text150_full_size_shard_against_the_oracle_on_its_own_schedule():
     assert torch.isfinite(out).all() and diffusion.num_timesteps == S
     plan = model._engine.plan_query(B, guided=True)
     assert plan["qkv_attn"]["kernel"] == "k_qkv_attn_long" and plan["step_fused"]["kernel"] == "k_step<guided>", plan
-    idx = np.arange(0, B, 16)
+    idx = np.r_[np.arange(0, B, 32), B - 1]
     tape = _redraw_tape(model._engine, shape, seed, S, idx)
     ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", "ddim50"), tape,
                           {k: torch.from_numpy(np.ascontiguousarray(v[idx])) for k, v in y.items()}, mode="ddim", guided=True).numpy()
     err = float(np.abs(out.cpu().numpy()[idx] - ref).max())
-    print(f"\n[cfg5 shard: text150 B = 256 + CFG, ddim50, on-device Philox] every 16th motion vs oracle: {err:.2e}")
+    print(f"\n[cfg5 shard: text150 B = 256 + CFG, ddim50, on-device Philox] every 32nd motion + the last vs oracle: {err:.2e}")
     assert err < 1e-3, err
     model._engine.close()
 

@@ -193,7 +193,7 @@ def test_headline_launch_at_its_real_shape_rows_equal_single_sample_runs(monkeyp
 
 def test_headline_launch_shape_against_the_oracle_on_a_100_step_schedule():
     """The same launch shape (256 workgroups, default engine, default precision schedule, on-device Philox) on a 100-step DDPM schedule,
-    every 16th motion (two workgroups of every XCD) against the ORACLE on the very noise the kernel drew: x_T and the 100 per-step draws
+    every 32nd motion and the last (one workgroup of every XCD) against the ORACLE on the very noise the kernel drew: x_T and the 100 per-step draws
     are re-drawn through rgn_randn_step - the fused loop's own Philox stream, element for element
     (test_model_kwargs_the_fused_loop_does_not_read) - and handed to the oracle as its tape. Bound: north_star's 1e-3."""
     from oracle import regennet_oracle as orc
@@ -207,7 +207,7 @@ def test_headline_launch_shape_against_the_oracle_on_a_100_step_schedule():
     shape = (B, 56, 6, 60)
     out = diffusion.p_sample_loop(model, shape, clip_denoised=False, model_kwargs={"y": yd}, seed=seed, sample_offset=0)
     assert torch.isfinite(out).all()
-    idx = np.arange(0, B, 16)
+    idx = np.r_[np.arange(0, B, 32), B - 1]
     eng = model._engine
     st = torch.cuda.current_stream().cuda_stream
     buf = torch.empty(shape, device="cuda")
@@ -218,7 +218,7 @@ def test_headline_launch_shape_against_the_oracle_on_a_100_step_schedule():
     ref = orc.sample_loop(sd, cfg, orc.make_schedule("cosine", str(S)), tape,
                           {k: torch.from_numpy(np.ascontiguousarray(v[idx])) for k, v in y.items()}, mode="ddpm").numpy()
     err = float(np.abs(out.cpu().numpy()[idx] - ref).max())
-    print(f"\n[headline launch shape, 95 + 5 steps, B = 256, on-device Philox] every 16th motion vs oracle: {err:.2e}")
+    print(f"\n[headline launch shape, 95 + 5 steps, B = 256, on-device Philox] a subset of the motions vs oracle: {err:.2e}")
     assert err < 1e-3, err
     model._engine.close()
 
